@@ -1,0 +1,327 @@
+/*
+ * sim5gpu.h -- C-ABI of the MI355X (gfx950) Kerr ray tracer.
+ *
+ * Plain C: pointers, sizes and POD structs only; no HIP, torch or C++ types cross this
+ * boundary.  Implemented by sim5_amd/lib/libsim5gpu.so (hand-written HIP kernels).
+ * There is NO CPU fallback behind these entry points: without a usable GPU every
+ * compute call returns SIM5GPU_E_NO_DEVICE / SIM5GPU_E_HIP and writes nothing.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) Batch forms of the SIM5 per-ray functions ("sim5gpu_<sim5 name>").  Each mirrors
+ *      the argument meaning, output struct layout and error behaviour of the SIM5
+ *      function it replaces, for n independent rays held in caller-owned HOST arrays.
+ *      A reference-side binding (cgo/ctypes/plain C) calls these in place of its
+ *      per-ray loop; sim5_amd/host/sim5lib.c implements the unchanged SIM5 scalar API
+ *      on top of them (n = 1).
+ *
+ *  (2) Whole-job kernels working on DEVICE buffers (pointers from hipMalloc, from
+ *      sim5gpu_malloc below, or from torch tensors' data_ptr()), asynchronous on a
+ *      caller-supplied stream: the thin-disk image loop, the polarized image and the
+ *      step-wise (Verlet) ray tracer with radiative transfer.
+ *
+ * Citations "ref:" are file:line in the reference tree (mbursa/sim5).
+ */
+#ifndef SIM5GPU_H
+#define SIM5GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------- */
+#define SIM5GPU_OK            0
+#define SIM5GPU_E_NO_DEVICE  -1   /* no HIP device visible                          */
+#define SIM5GPU_E_HIP        -2   /* a HIP runtime call failed (see last_error)     */
+#define SIM5GPU_E_ARG        -3   /* invalid argument (NULL pointer, bad size, ...)  */
+#define SIM5GPU_E_NOT_SETUP  -4   /* disk model used before sim5gpu_disk_nt_setup   */
+
+/* ---- geodesic classes and per-ray status: ref src/sim5kerr-geod.h:19-37 -------- */
+#define SIM5GPU_GEOD_TYPE_RR      40
+#define SIM5GPU_GEOD_TYPE_RR_DBL  41
+#define SIM5GPU_GEOD_TYPE_RR_BH   42
+#define SIM5GPU_GEOD_TYPE_RC       2
+#define SIM5GPU_GEOD_TYPE_CC       0
+
+#define SIM5GPU_GD_OK                      0
+#define SIM5GPU_GD_ERROR_Q_ZERO            1
+#define SIM5GPU_GD_ERROR_BOUND_GEODESIC    2
+#define SIM5GPU_GD_ERROR_UNKNOWN_SOLUTION  3
+#define SIM5GPU_GD_ERROR_TYPE_RR_DOUBLE    4
+#define SIM5GPU_GD_ERROR_TYPE_CC           5
+#define SIM5GPU_GD_ERROR_Q_RANGE           7
+#define SIM5GPU_GD_ERROR_MUPLUS_RANGE      8
+#define SIM5GPU_GD_ERROR_MU0_RANGE         9
+#define SIM5GPU_GD_ERROR_MM_RANGE         10
+#define SIM5GPU_GD_ERROR_INCL_RANGE       11
+#define SIM5GPU_GD_ERROR_SPIN_RANGE       12
+
+/* ---- options of the step-wise integrator: ref src/sim5raytrace.h:21-23 --------- */
+#define SIM5GPU_RTOPT_NONE          0
+#define SIM5GPU_RTOPT_FLAT          1
+#define SIM5GPU_RTOPT_POLARIZATION  2
+
+/* ---- POD records with the reference layouts ------------------------------------- */
+
+/* 240 B; byte-compatible with `struct geodesic` (ref src/sim5kerr-geod.h:42-68).
+ * The four roots are C99 `double _Complex` there; {re, im} pairs here. */
+typedef struct sim5gpu_geodesic {
+    double a, alpha, beta, incl, cos_i;
+    double l, q;
+    double r1[2], r2[2], r3[2], r4[2];
+    int    nrr, type;
+    double m2p, m2m, mm, mK;
+    double rp, dmdp_inf;
+    double Rpc, Tpp, Tip;
+    double k[4];
+    double p;
+} sim5gpu_geodesic;
+
+/* 64 B; `struct sim5metric` (ref src/sim5kerr.h:18-25) */
+typedef struct sim5gpu_metric { double a, r, m, g00, g11, g22, g33, g03; } sim5gpu_metric;
+
+/* 192 B; `struct sim5tetrad` (ref src/sim5kerr.h:27-31) */
+typedef struct sim5gpu_tetrad { double e[4][4]; sim5gpu_metric metric; } sim5gpu_tetrad;
+
+/* 144 B; `struct raytrace_data` (ref src/sim5raytrace.h:26-43) */
+typedef struct sim5gpu_raytrace_data {
+    int    opt_gr, opt_pol;
+    double step_epsilon;
+    double bh_spin, E, Q;
+    double WP[2];
+    int    pass, refines;
+    double dk[4], df[4];
+    double kt;
+    float  error;
+} sim5gpu_raytrace_data;
+
+/* 40 B; `struct stokes_params` (ref src/sim5radiation.h:19-25) */
+typedef struct sim5gpu_stokes { double i, q, u, v, tau; } sim5gpu_stokes;
+
+/* ---- runtime ---------------------------------------------------------------------- */
+int         sim5gpu_device_count(void);            /* 0 when no GPU is visible       */
+int         sim5gpu_set_device(int device);
+const char *sim5gpu_last_error(void);              /* text of the last failure        */
+const char *sim5gpu_version(void);
+int         sim5gpu_malloc(void **dptr, size_t bytes);
+int         sim5gpu_free(void *dptr);
+int         sim5gpu_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int         sim5gpu_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int         sim5gpu_memset(void *dst, int value, size_t bytes);
+int         sim5gpu_synchronize(void *stream);     /* stream == NULL: default stream  */
+
+/* ==================================================================================== */
+/* (1) batch forms of the SIM5 per-ray API (HOST arrays, synchronous)                   */
+/* ==================================================================================== */
+
+/* geodesic_init_inf (ref src/sim5kerr-geod.c:42-100) for n rays.
+ * ok[i] = TRUE/FALSE return value, error[i] = GD_* code (either may be NULL). */
+int sim5gpu_geodesic_init_inf(size_t n, const double *incl, const double *a,
+                              const double *alpha, const double *beta,
+                              sim5gpu_geodesic *g, int *error, int *ok);
+
+/* geodesic_init_src (ref src/sim5kerr-geod.c:106-173); k is n x 4 */
+int sim5gpu_geodesic_init_src(size_t n, const double *a, const double *r, const double *m,
+                              const double *k, const int *ppc,
+                              sim5gpu_geodesic *g, int *error, int *ok);
+
+/* geodesic_find_midplane_crossing (ref src/sim5kerr-geod.c:846-885); NaN = no crossing */
+int sim5gpu_geodesic_find_midplane_crossing(size_t n, const sim5gpu_geodesic *g,
+                                            const int *order, double *P);
+
+/* geodesic_P_int (ref src/sim5kerr-geod.c:179-263) */
+int sim5gpu_geodesic_P_int(size_t n, const sim5gpu_geodesic *g, const double *r,
+                           const int *ppc, double *P);
+
+/* geodesic_position_rad / _pol (ref src/sim5kerr-geod.c:291-357, 363-407) */
+int sim5gpu_geodesic_position_rad(size_t n, const sim5gpu_geodesic *g, const double *P, double *r);
+int sim5gpu_geodesic_position_pol(size_t n, const sim5gpu_geodesic *g, const double *P, double *m);
+
+/* geodesic_dm_sign (ref src/sim5kerr-geod.c:737-781) */
+int sim5gpu_geodesic_dm_sign(size_t n, const sim5gpu_geodesic *g, const double *P, double *sign);
+
+/* geodesic_momentum (ref src/sim5kerr-geod.c:787-840); r = m = 0 means "derive from P";
+ * k is n x 4 */
+int sim5gpu_geodesic_momentum(size_t n, const sim5gpu_geodesic *g, const double *P,
+                              const double *r, const double *m, double *k);
+
+/* geodesic_follow (ref src/sim5kerr-geod.c:891-925); P, r, m are in/out */
+int sim5gpu_geodesic_follow(size_t n, const sim5gpu_geodesic *g, const double *step,
+                            double *P, double *r, double *m, int *status);
+
+/* photon_momentum (ref src/sim5kerr.c:1151-1213); k is n x 4 */
+int sim5gpu_photon_momentum(size_t n, const double *a, const double *r, const double *m,
+                            const double *l, const double *q,
+                            const double *r_sign, const double *m_sign, double *k);
+
+/* photon_motion_constants / photon_carter_const (ref src/sim5kerr.c:1217-1269) */
+int sim5gpu_photon_motion_constants(size_t n, const double *a, const double *r, const double *m,
+                                    const double *k, double *L, double *Q);
+int sim5gpu_photon_carter_const(size_t n, const double *k, const sim5gpu_metric *metric, double *Q);
+
+/* gfactorK (ref src/sim5kerr.c:1128-1141) */
+int sim5gpu_gfactorK(size_t n, const double *r, const double *a, const double *l, double *g);
+
+/* kerr_metric / kerr_connection (ref src/sim5kerr.c:75-101, 233-316); G is n x 64 */
+int sim5gpu_kerr_metric(size_t n, const double *a, const double *r, const double *m,
+                        sim5gpu_metric *metric);
+int sim5gpu_kerr_connection(size_t n, const double *a, const double *r, const double *m, double *G);
+
+/* tetrad_zamo / tetrad_azimuthal / tetrad_surface (ref src/sim5kerr.c:678, 766, 818) */
+int sim5gpu_tetrad_zamo(size_t n, const sim5gpu_metric *metric, sim5gpu_tetrad *t);
+int sim5gpu_tetrad_azimuthal(size_t n, const sim5gpu_metric *metric, const double *Omega,
+                             sim5gpu_tetrad *t);
+int sim5gpu_tetrad_surface(size_t n, const sim5gpu_metric *metric, const double *Omega,
+                           const double *V, const double *dhdr, sim5gpu_tetrad *t);
+
+/* bl2on / on2bl (ref src/sim5kerr.c:926-970); vectors are n x 4 */
+int sim5gpu_bl2on(size_t n, const double *vin, double *vout, const sim5gpu_tetrad *t);
+int sim5gpu_on2bl(size_t n, const double *vin, double *vout, const sim5gpu_tetrad *t);
+
+/* Carlson R_F and the Jacobi inverses built on it (ref src/sim5elliptic.c:19-52, 218-225,
+ * 481-528, 536-598).  which: 0 = rf(x,y,z), 1 = elliptic_k(x), 2 = jacobi_isn(x,y),
+ * 3 = jacobi_icn(x,y), 4 = jacobi_itn(x,y), 5 = jacobi_sn(x,y), 6 = jacobi_cn(x,y),
+ * 7 = jacobi_dn(x,y), 8 = rd(x,y,z), 9 = rc(x,y), 10 = rj(x,y,z,w) */
+int sim5gpu_elliptic(int which, size_t n, const double *x, const double *y, const double *z,
+                     const double *w, double *out);
+
+/* Novikov-Thorne disk (ref src/sim5disk-nt.c:37-146, 260-266).  As in SIM5 the disk model
+ * is process-global state set once by disk_nt_setup; options must be 0 (mdot-parametrised). */
+int sim5gpu_disk_nt_setup(double M, double a, double mdot, double alpha, int options);
+int sim5gpu_disk_nt_r_min(double *r_min);
+int sim5gpu_disk_nt_flux(size_t n, const double *r, double *flux);
+int sim5gpu_disk_nt_ell(size_t n, const double *r, double *ell);
+
+/* raytrace_prepare / raytrace / raytrace_error (ref src/sim5raytrace.c:44-94, 109-245,
+ * 328-343).  x, k are n x 4 and in/out; step is in/out.  sim5gpu_raytrace makes `nsteps`
+ * consecutive calls of raytrace() per ray with the same *step cap re-applied each call
+ * (nsteps = 1 is exactly one SIM5 raytrace() call). */
+int sim5gpu_raytrace_prepare(size_t n, const double *bh_spin, const double *x, const double *k,
+                             const double *precision, const int *options,
+                             sim5gpu_raytrace_data *rtd);
+int sim5gpu_raytrace(size_t n, double *x, double *k, double *step, sim5gpu_raytrace_data *rtd,
+                     int nsteps);
+int sim5gpu_raytrace_error(size_t n, const double *x, const double *k,
+                           const sim5gpu_raytrace_data *rtd, double *err);
+
+/* polarization_constant / _vector / _constant_infinity / _angle_rotation
+ * (ref src/sim5polarization.c:145-158, 14-105, 249-258, 272-285); wp is n x 2 {re, im} */
+int sim5gpu_polarization_constant(size_t n, const double *k, const double *f,
+                                  const sim5gpu_metric *metric, double *wp);
+int sim5gpu_polarization_vector(size_t n, const double *k, const double *wp,
+                                const sim5gpu_metric *metric, double *f);
+int sim5gpu_polarization_constant_infinity(size_t n, const double *a, const double *alpha,
+                                           const double *beta, const double *incl, double *wp);
+int sim5gpu_polarization_angle_rotation(size_t n, const double *a, const double *inc,
+                                        const double *alpha, const double *beta,
+                                        const double *wp, double *angle);
+
+/* blackbody_Iv (ref src/sim5radiation.c:27-49) */
+int sim5gpu_blackbody_Iv(size_t n, const double *T, const double *hardf, const double *cos_mu,
+                         const double *E, double *Iv);
+
+/* ==================================================================================== */
+/* (2) whole-job kernels (DEVICE buffers, asynchronous on `stream`)                     */
+/* ==================================================================================== */
+
+/* per-pixel outcome of the thin-disk loop; the numbering is this project's own
+ * bookkeeping of the branches of ref examples/04-disk-image-eqplane/disk-image.c:53-105 */
+#define SIM5GPU_PX_ERROR 0   /* geodesic_init_inf rejected the ray       (:66-69)  */
+#define SIM5GPU_PX_NAN0  1   /* no first equatorial crossing              (:74)     */
+#define SIM5GPU_PX_HIT0  2   /* first crossing on the disk, r >= r_ms     (:83-89)  */
+#define SIM5GPU_PX_NAN1  3   /* first inside r_ms, no second crossing     (:94)     */
+#define SIM5GPU_PX_HIT1  4   /* second crossing on the disk               (:98-103) */
+#define SIM5GPU_PX_MISS  5   /* both crossings inside r_ms                          */
+
+/* Job description of one thin-disk image (or a row tile of it).  The pixel -> impact
+ * parameter map is the one of ref disk-image.c:57-58 for an nx x ny image whose
+ * half-width is rmax.  Rows [y0, y1) are traced; outputs are packed row-major arrays of
+ * (y1-y0) x nx elements (tile-local), so a row-tile shard is contiguous in the full image. */
+typedef struct sim5gpu_image_desc {
+    int    nx, ny;          /* full image size in pixels                               */
+    int    y0, y1;          /* row range traced by this call, 0 <= y0 < y1 <= ny        */
+    double a;               /* black-hole spin                                           */
+    double incl;            /* observer inclination [rad]                                */
+    double rmax;            /* half-width of the view [GM/c^2]; <= 0: r_ms(a) + 8       */
+    double rms;             /* inner disk edge used for the r >= rms test; <= 0: r_ms(a) */
+    double bh_mass;         /* disk_nt_setup arguments (M [Msun], mdot [Edd], alpha)     */
+    double mdot;
+    double alpha_visc;
+    int    max_order;       /* number of equatorial crossings tried (reference: 2)       */
+    int    flags;           /* SIM5GPU_IMG_*                                             */
+    double pol_degree;      /* polarization degree delta of the disk emission (polarized) */
+} sim5gpu_image_desc;
+
+#define SIM5GPU_IMG_DEFAULT 0
+
+/* optional full-precision outputs (any pointer may be NULL) */
+typedef struct sim5gpu_image_aux {
+    uint8_t *cls;           /* SIM5GPU_PX_*                         */
+    int8_t  *gtype;         /* geodesic type, -1 if rejected        */
+    double  *r;             /* radius of the accepted crossing, NaN */
+    double  *g;             /* g-factor (0 if no hit)               */
+    double  *flux;          /* local disk flux F(r) (0 if no hit)   */
+} sim5gpu_image_aux;
+
+/* The caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105 as one kernel:
+ * image_f = (float)(F g^4), image_g = (float)g, zero where the ray does not hit the disk. */
+int sim5gpu_disk_image(const sim5gpu_image_desc *desc, float *d_image_f, float *d_image_g,
+                       const sim5gpu_image_aux *d_aux, void *stream);
+
+/* Same job on caller-owned HOST buffers (allocates, launches, copies back, frees). */
+int sim5gpu_disk_image_host(const sim5gpu_image_desc *desc, float *h_image_f, float *h_image_g,
+                            const sim5gpu_image_aux *h_aux);
+
+/* Same per-ray work for an explicit list of n rays (alpha[], beta[] in DEVICE memory,
+ * SoA, read coalesced) instead of the implicit pixel grid. */
+int sim5gpu_disk_rays(const sim5gpu_image_desc *desc, size_t n, const double *d_alpha,
+                      const double *d_beta, float *d_image_f, float *d_image_g,
+                      const sim5gpu_image_aux *d_aux, void *stream);
+
+/* Thin-disk image with Walker-Penrose polarization transport: Stokes I = F g^4,
+ * Q = delta I cos 2chi, U = delta I sin 2chi with chi from polarization_angle_rotation of the
+ * Walker-Penrose constant of the local polarization vector at the emitter (recipe built from
+ * ref src/sim5kerr-geod.c:787, src/sim5kerr.c:766,926,948,553, src/sim5polarization.c:145,272).
+ * d_stokes: 3 planes [I | Q | U], each (y1-y0) x nx doubles; d_chi optional. */
+int sim5gpu_disk_image_polarized(const sim5gpu_image_desc *desc, double *d_stokes,
+                                 double *d_chi, const sim5gpu_image_aux *d_aux, void *stream);
+
+/* Step-wise (Verlet) ray tracer with radiative transfer through an optically thin torus.
+ * Rays start on the incoming branch at radius r0 (geodesic_init_inf -> geodesic_P_int ->
+ * geodesic_position_pol -> geodesic_momentum), are advanced by raytrace() until they leave
+ * [r_stop_in * r_bh, r_stop_out * r0], exceed max_steps or rtd.error > max_error, and
+ * accumulate dI = g^4 j e^-tau dl, dtau = kappa_abs j-weighted dl in the torus. */
+typedef struct sim5gpu_torus_desc {
+    sim5gpu_image_desc img;       /* image geometry (disk fields unused)                */
+    double r0;                    /* starting radius of the integration [GM/c^2]        */
+    double dl_max;                /* cap handed to raytrace() in *step (<= 0: 1e9)       */
+    double precision;             /* raytrace_prepare precision factor                   */
+    int    options;               /* SIM5GPU_RTOPT_*                                      */
+    int    max_steps;
+    double max_error;             /* stop when rtd.error exceeds this (reference: 1e-2)  */
+    double r_stop_in, r_stop_out; /* in units of r_bh and r0                              */
+    int    shape;                 /* 0: Gaussian torus; 1: uniform sphere of radius torus_w */
+    double torus_r, torus_w;      /* centre radius and Gaussian width of the torus        */
+    double torus_l;               /* specific angular momentum of the torus fluid         */
+    double emis0, absorb0;        /* emissivity and absorption normalisations             */
+} sim5gpu_torus_desc;
+
+typedef struct sim5gpu_torus_aux {
+    int    *steps;           /* raytrace() calls made                        */
+    float  *max_step_error;  /* largest rtd.error seen                       */
+    double *carter_error;    /* raytrace_error() at the end                  */
+    double *x_end;           /* n x 4 final position                         */
+    double *k_end;           /* n x 4 final momentum                         */
+} sim5gpu_torus_aux;
+
+/* d_stokes: (y1-y0) x nx records of sim5gpu_stokes */
+int sim5gpu_torus_image(const sim5gpu_torus_desc *desc, sim5gpu_stokes *d_stokes,
+                        const sim5gpu_torus_aux *d_aux, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIM5GPU_H */

@@ -174,3 +174,161 @@ int cpu_disk_image(const char *libpath, int kind, int nx, int ny, double a, doub
     if (seconds) *seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     return 0;
 }
+
+/* ====================================================================================== */
+/*  Recipes assembled from public SIM5 routines, run through either checker library        */
+/*  (prefix "" = reference symbols, "orc_" = our restatement; same signatures).            */
+/* ====================================================================================== */
+typedef struct { double a, r, m, g00, g11, g22, g33, g03; } metric_t;
+typedef struct { double e[4][4]; metric_t metric; } tetrad_t;
+typedef struct { double re, im; } cplx_t;
+typedef struct {
+    int opt_gr, opt_pol; double step_epsilon, bh_spin, E, Q; cplx_t WP;
+    int pass, refines; double dk[4], df[4], kt; float error;
+} rtd_t;
+
+typedef struct {
+    int (*init_inf)(double, double, double, double, geod_t *, int *);
+    double (*midplane)(geod_t *, int);
+    double (*pos_rad)(geod_t *, double);
+    double (*pos_pol)(geod_t *, double);
+    double (*P_int)(geod_t *, double, int);
+    void (*momentum)(geod_t *, double, double, double, double *);
+    void (*kerr_metric)(double, double, double, metric_t *);
+    void (*tetrad_azimuthal)(metric_t *, double, tetrad_t *);
+    void (*bl2on)(double *, double *, tetrad_t *);
+    void (*on2bl)(double *, double *, tetrad_t *);
+    void (*norm_to)(double *, double, metric_t *);
+    double (*OmegaK)(double, double);
+    double (*gfac)(double, double, double);
+    double _Complex (*pol_const)(double *, double *, metric_t *);
+    double (*pol_rot)(double, double, double, double, double _Complex);
+    void (*rt_prepare)(double, double *, double *, double, int, rtd_t *);
+    void (*rt_step)(double *, double *, double *, rtd_t *);
+    double (*rt_error)(double *, double *, rtd_t *);
+    double (*r_ms)(double);
+} api_t;
+
+static void *sym(void *h, const char *prefix, const char *name)
+{
+    char buf[128];
+    snprintf(buf, sizeof buf, "%s%s", prefix, name);
+    return dlsym(h, buf);
+}
+
+static int load_api(const char *libpath, const char *prefix, api_t *A, void **hout)
+{
+    void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "cpu_driver: %s\n", dlerror()); return -1; }
+    A->init_inf = sym(h, prefix, "geodesic_init_inf");
+    A->midplane = sym(h, prefix, "geodesic_find_midplane_crossing");
+    A->pos_rad = sym(h, prefix, "geodesic_position_rad");
+    A->pos_pol = sym(h, prefix, "geodesic_position_pol");
+    A->P_int = sym(h, prefix, "geodesic_P_int");
+    A->momentum = sym(h, prefix, "geodesic_momentum");
+    A->kerr_metric = sym(h, prefix, "kerr_metric");
+    A->tetrad_azimuthal = sym(h, prefix, "tetrad_azimuthal");
+    A->bl2on = sym(h, prefix, "bl2on");
+    A->on2bl = sym(h, prefix, "on2bl");
+    A->norm_to = sym(h, prefix, "vector_norm_to");
+    A->OmegaK = sym(h, prefix, "OmegaK");
+    A->gfac = sym(h, prefix, "gfactorK");
+    A->pol_const = sym(h, prefix, "polarization_constant");
+    A->pol_rot = sym(h, prefix, "polarization_angle_rotation");
+    A->rt_prepare = sym(h, prefix, "raytrace_prepare");
+    A->rt_step = sym(h, prefix, "raytrace");
+    A->rt_error = sym(h, prefix, "raytrace_error");
+    A->r_ms = sym(h, prefix, "r_ms");
+    void **p = (void **)A;
+    for (size_t i = 0; i < sizeof(api_t) / sizeof(void *); i++)
+        if (!p[i]) { fprintf(stderr, "cpu_driver: missing symbol #%zu in %s\n", i, libpath); return -2; }
+    *hout = h;
+    return 0;
+}
+
+/*
+ * Polarization angle at infinity for thin-disk pixels (SURVEY.md 3.4 recipe; the routines are
+ * ref src/sim5kerr-geod.c:787, src/sim5kerr.c:75,766,926,948,553,1037, src/sim5polarization.c:145,272).
+ * For each of n rays (alpha[i], beta[i]): chi[i] (NaN if the ray does not hit the disk), r, g,
+ * and the Walker-Penrose constant (2 doubles).
+ */
+int cpu_polarized_rays(const char *libpath, const char *prefix, double a, double inc_rad, double rms,
+                       int n, const double *alpha, const double *beta,
+                       double *chi, double *r_out, double *g_out, double *wp_out)
+{
+    api_t A; void *h;
+    int rc = load_api(libpath, prefix, &A, &h);
+    if (rc) return rc;
+    if (rms <= 0) rms = A.r_ms(a);
+    for (int i = 0; i < n; i++) {
+        geod_t gd; int err = 0;
+        chi[i] = NAN; r_out[i] = NAN; g_out[i] = 0.0; wp_out[2 * i] = wp_out[2 * i + 1] = NAN;
+        A.init_inf(inc_rad, a, alpha[i], beta[i], &gd, &err);
+        if (err) continue;
+        for (int order = 0; order < 2; order++) {
+            double P = A.midplane(&gd, order);
+            if (isnan(P)) break;
+            double r = A.pos_rad(&gd, P);
+            if (r >= rms) {
+                double k[4], nloc[4], floc[4], f[4];
+                metric_t mt; tetrad_t t;
+                A.momentum(&gd, P, r, 0.0, k);
+                A.kerr_metric(a, r, 0.0, &mt);
+                A.tetrad_azimuthal(&mt, A.OmegaK(r, a), &t);
+                A.bl2on(k, nloc, &t);
+                floc[0] = 0.0; floc[1] = nloc[3]; floc[2] = 0.0; floc[3] = -nloc[1];
+                A.on2bl(floc, f, &t);
+                A.norm_to(f, 1.0, &mt);
+                double _Complex wp = A.pol_const(k, f, &mt);
+                chi[i] = A.pol_rot(a, inc_rad, alpha[i], beta[i], wp);
+                r_out[i] = r;
+                g_out[i] = A.gfac(r, a, gd.l);
+                wp_out[2 * i] = __real__ wp; wp_out[2 * i + 1] = __imag__ wp;
+                break;
+            }
+        }
+    }
+    return 0;
+}
+
+/*
+ * Step-wise integration of one ray from radius r0 on the incoming branch (SURVEY.md 8(d) C4
+ * start-up: geodesic_init_inf -> geodesic_P_int -> geodesic_position_pol -> geodesic_momentum ->
+ * raytrace_prepare), recording after every raytrace() call: x[4], k[4], dl, rtd.error, rtd.kt.
+ * trace is nmax x 11 doubles; returns the number of steps made (or <0 on error) and the final
+ * raytrace_error() in *carter.  Stops when r <= r_in, r >= r_out, error > max_error or nmax steps.
+ */
+int cpu_verlet_trace(const char *libpath, const char *prefix, double a, double inc_rad,
+                     double alpha, double beta, double r0, double precision, int options,
+                     double dl_max, double r_in, double r_out, double max_error, int nmax,
+                     double *trace, double *x_start, double *k_start, double *carter)
+{
+    api_t A; void *h;
+    int rc = load_api(libpath, prefix, &A, &h);
+    if (rc) return rc;
+    geod_t gd; int err = 0;
+    A.init_inf(inc_rad, a, alpha, beta, &gd, &err);
+    if (err) return -10 - err;
+    if (!(r0 > gd.rp)) return -3;
+    double P0 = A.P_int(&gd, r0, 0);
+    double x[4] = { 0.0, r0, 0.0, 0.0 }, k[4];
+    x[2] = A.pos_pol(&gd, P0);
+    A.momentum(&gd, P0, r0, x[2], k);
+    if (isnan(k[0])) return -4;
+    for (int c = 0; c < 4; c++) { x_start[c] = x[c]; k_start[c] = k[c]; }
+    rtd_t rtd;
+    memset(&rtd, 0, sizeof rtd);
+    A.rt_prepare(a, x, k, precision, options, &rtd);
+    int n = 0;
+    while (n < nmax) {
+        double dl = dl_max;
+        A.rt_step(x, k, &dl, &rtd);
+        double *row = trace + (size_t)n * 11;
+        for (int c = 0; c < 4; c++) { row[c] = x[c]; row[4 + c] = k[c]; }
+        row[8] = dl; row[9] = rtd.error; row[10] = rtd.kt;
+        n++;
+        if (!(x[1] > r_in) || !(x[1] < r_out) || (rtd.error > max_error)) break;
+    }
+    if (carter) *carter = A.rt_error(x, k, &rtd);
+    return n;
+}

@@ -1,0 +1,439 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the UNMODIFIED reference.
+
+Runs only in the build container: it needs oracle/_ref/libsim5ref.so, which oracle/Makefile
+compiles from /root/reference/src/sim5lib.c.  Every fixture stores the inputs next to the
+reference's outputs, so the tests never need the reference itself.
+
+    make -C oracle && python oracle/gen_golden.py
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import ctypes as C
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oraclelib as ol  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+NTHREADS = os.cpu_count() or 1
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print("%-24s %8.1f KiB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def deg(x):
+    return x / 180.0 * math.pi          # deg2rad macro, ref src/sim5math.h:50
+
+
+# ------------------------------------------------------------------------------------------
+def kat_elliptic(ref, rng):
+    n = 1500
+    out = {}
+    # Carlson: broad log-uniform arguments plus near-degenerate ones
+    x = 10.0 ** rng.uniform(-6, 3, n); y = 10.0 ** rng.uniform(-6, 3, n); z = 10.0 ** rng.uniform(-6, 3, n)
+    x[:50] = 0.0                                   # one argument may be zero
+    y[50:100] = x[50:100] * (1 + 1e-9)             # nearly equal
+    p = 10.0 ** rng.uniform(-3, 2, n) * np.where(rng.random(n) < 0.3, -1.0, 1.0)
+    out.update(c_x=x, c_y=y, c_z=z, c_p=p)
+    out["rf"] = np.array([ref.rf(a, b, c) for a, b, c in zip(x, y, z)])
+    zz = np.maximum(z, 1e-6)
+    out["rd_z"] = zz
+    out["rd"] = np.array([ref.rd(a, b, c) for a, b, c in zip(x, y, zz)])
+    yc = np.where(rng.random(n) < 0.3, -y, y) + 1e-9
+    out["rc_y"] = yc
+    out["rc"] = np.array([ref.rc(a, b) for a, b in zip(np.maximum(x, 1e-9), yc)])
+    out["rc_x"] = np.maximum(x, 1e-9)
+    xs, ys, zs = np.maximum(x, 1e-5), np.maximum(y, 1e-5), np.maximum(z, 1e-5)
+    out.update(rj_x=xs, rj_y=ys, rj_z=zs)
+    out["rj"] = np.array([ref.rj(a, b, c, d) for a, b, c, d in zip(xs, ys, zs, p)])
+    # Legendre / Jacobi: modulus incl. the special-cased neighbourhoods of 0 and 1
+    m = rng.uniform(0, 1, n)
+    m[:40] = 0.0; m[40:80] = 10.0 ** rng.uniform(-12, -7, 40); m[80:120] = 1.0 - 10.0 ** rng.uniform(-12, -7, 40)
+    m[120:160] = 1.0 - 10.0 ** rng.uniform(-6, -2, 40)
+    zq = rng.uniform(-1, 1, n)
+    zq[160:200] = 0.0; zq[200:230] = 1.0; zq[230:260] = 1.0 + 5e-9; zq[260:290] = -1.0 - 5e-9
+    out.update(j_m=m, j_z=zq)
+    mk = np.minimum(m, 1.0 - 1e-12)
+    out["k_m"] = mk
+    out["elliptic_k"] = np.array([ref.elliptic_k(v) for v in mk])
+    zs_ = np.clip(np.abs(zq), 0, 1 - 1e-12)
+    out["isn_z"] = zs_
+    out["jacobi_isn"] = np.array([ref.jacobi_isn(a, b) for a, b in zip(zs_, mk)])
+    zc = np.where(np.abs(zq) > 1.0 + 1e-8, np.sign(zq), zq)
+    out["icn_z"] = zc
+    out["jacobi_icn"] = np.array([ref.jacobi_icn(a, b) for a, b in zip(zc, mk)])
+    zt = rng.uniform(-20, 20, n)
+    out["itn_z"] = zt
+    out["jacobi_itn"] = np.array([ref.jacobi_itn(a, b) for a, b in zip(zt, mk)])
+    # sn, cn, dn: u within [0, 2K(m)], also the negative-complement branch m > 1 is not used by sim5
+    K = out["elliptic_k"]
+    u = rng.uniform(0, 1, n) * 2.0 * np.where(np.isfinite(K), K, 1.0) * 0.999
+    u[:30] = 0.0
+    out["sn_u"] = u
+    sn, cn, dn = np.empty(n), np.empty(n), np.empty(n)
+    s_, c_, d_ = C.c_double(), C.c_double(), C.c_double()
+    for i in range(n):
+        ref.jacobi_sncndn(u[i], mk[i], C.byref(s_), C.byref(c_), C.byref(d_))
+        sn[i], cn[i], dn[i] = s_.value, c_.value, d_.value
+    out.update(sn=sn, cn=cn, dn=dn)
+    save("kat_elliptic.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+def kat_geodesic(ref, rng):
+    """geodesic_init_inf struct dumps + everything derived from them, ~4k rays over all classes."""
+    spins = [0.0, 1e-5, 0.3, 0.9, 0.998, 0.999999]
+    incs = [deg(5.0), deg(30.0), deg(60.0), deg(70.0), deg(85.0), deg(89.0)]
+    rows = []
+    for a in spins:
+        for inc in incs:
+            lim = ref.r_ms(a) + 8.0
+            for _ in range(110):
+                # concentrate near the shadow where RC/CC and the second crossing occur
+                rad = lim * rng.random() ** 2
+                ang = rng.uniform(0, 2 * math.pi)
+                rows.append((inc, a, rad * math.cos(ang), rad * math.sin(ang)))
+    # rejected inputs: spin / inclination out of range, beta == 0, q == 0
+    rows += [(deg(60.0), -0.1, 1.0, 1.0), (deg(60.0), 1.0, 1.0, 1.0), (0.0, 0.5, 1.0, 1.0),
+             (1.58, 0.5, 1.0, 1.0), (deg(60.0), 0.5, 3.0, 0.0), (deg(60.0), 0.5, -4.0, 0.0)]
+    inp = np.array(rows)
+    n = len(inp)
+    dump = np.zeros((n, 240), np.uint8)
+    err = np.zeros(n, np.int32); ok = np.zeros(n, np.int32)
+    P0 = np.full(n, np.nan); P1 = np.full(n, np.nan); r0 = np.full(n, np.nan); r1 = np.full(n, np.nan)
+    rq = np.full(n, np.nan); Pq0 = np.full(n, np.nan); Pq1 = np.full(n, np.nan)
+    Pm = np.full(n, np.nan); mpol = np.full(n, np.nan); dms = np.full(n, np.nan)
+    kmom = np.full((n, 4), np.nan); rmom = np.full(n, np.nan)
+    for i, (inc, a, al, be) in enumerate(inp):
+        g = ol.Geodesic()
+        C.memset(C.byref(g), 0, 240)
+        e = C.c_int(-1)
+        ok[i] = ref.geodesic_init_inf(inc, a, al, be, C.byref(g), C.byref(e))
+        err[i] = e.value
+        dump[i] = np.frombuffer(ol.struct_bytes(g), np.uint8)
+        if not ok[i]:
+            continue
+        P0[i] = ref.geodesic_find_midplane_crossing(C.byref(g), 0)
+        P1[i] = ref.geodesic_find_midplane_crossing(C.byref(g), 1)
+        if not math.isnan(P0[i]):
+            r0[i] = ref.geodesic_position_rad(C.byref(g), P0[i])
+        if not math.isnan(P1[i]):
+            r1[i] = ref.geodesic_position_rad(C.byref(g), P1[i])
+        # P_int at a radius above pericentre, both branches
+        rq[i] = max(g.rp, 0.0) * (1.0 + rng.random()) + 0.5 + 30.0 * rng.random()
+        if g.type in (40, 2, 0) and rq[i] > g.rp:
+            Pq0[i] = ref.geodesic_P_int(C.byref(g), rq[i], 0)
+            if g.type == 40:
+                Pq1[i] = ref.geodesic_P_int(C.byref(g), rq[i], 1)
+        # polar coordinate, dm sign and momentum at a point of the trajectory
+        if g.type in (40, 2) and g.Rpc == g.Rpc:
+            hi = 2.0 * g.Rpc if g.type == 40 else g.Rpc
+            Pm[i] = hi * (0.02 + 0.96 * rng.random())
+            mpol[i] = ref.geodesic_position_pol(C.byref(g), Pm[i])
+            dms[i] = ref.geodesic_dm_sign(C.byref(g), Pm[i])
+            rmom[i] = ref.geodesic_position_rad(C.byref(g), Pm[i])
+            k = ol.D4()
+            ref.geodesic_momentum(C.byref(g), Pm[i], rmom[i], mpol[i], k)
+            kmom[i] = list(k)
+    save("kat_geodesic.npz", inp=inp, dump=dump, err=err, ok=ok, P0=P0, P1=P1, r0=r0, r1=r1,
+         rq=rq, Pq0=Pq0, Pq1=Pq1, Pm=Pm, mpol=mpol, dms=dms, kmom=kmom, rmom=rmom)
+
+
+# ------------------------------------------------------------------------------------------
+def kat_kerr(ref, rng):
+    n = 600
+    a = rng.choice([0.0, 0.1, 0.5, 0.9, 0.998], n)
+    r = (1.0 + np.sqrt(1 - a * a)) * (1.02 + 30.0 * rng.random(n) ** 2)
+    m = rng.uniform(-0.98, 0.98, n)
+    m[:40] = 0.0
+    met = np.zeros((n, 8)); con = np.zeros((n, 64)); metc = np.zeros((n, 8))
+    zamo = np.zeros((n, 24)); azim = np.zeros((n, 24)); surf = np.zeros((n, 24))
+    Om = np.zeros(n); V = rng.uniform(-0.3, 0.3, n); dh = rng.uniform(-0.2, 0.2, n)
+    vin = rng.normal(size=(n, 4)); v_on = np.zeros((n, 4)); v_bl = np.zeros((n, 4))
+    l = rng.uniform(-4, 4, n); q = rng.uniform(0.1, 30, n)
+    kph = np.zeros((n, 4)); Lc = np.zeros(n); Qc = np.zeros(n); Qcar = np.zeros(n)
+    gK = np.zeros(n); OmK = np.zeros(n); ellK = np.zeros(n)
+    rs = np.where(rng.random(n) < 0.5, -1.0, 1.0); ms = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    for i in range(n):
+        g = ol.Metric(); gc = ol.Metric(); t = ol.Tetrad(); G = ol.G444()
+        ref.kerr_metric(a[i], r[i], m[i], C.byref(g))
+        ref.kerr_metric_contravariant(a[i], r[i], m[i], C.byref(gc))
+        ref.kerr_connection(a[i], r[i], m[i], G)
+        met[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        metc[i] = np.frombuffer(ol.struct_bytes(gc), np.float64)
+        con[i] = np.frombuffer(bytes(memoryview(G)), np.float64)
+        ref.tetrad_zamo(C.byref(g), C.byref(t)); zamo[i] = np.frombuffer(ol.struct_bytes(t), np.float64)
+        OmK[i] = ref.OmegaK(r[i], a[i]); ellK[i] = ref.ellK(r[i], a[i])
+        Om[i] = OmK[i] * rng.uniform(0.5, 1.0)
+        ref.tetrad_azimuthal(C.byref(g), Om[i], C.byref(t)); azim[i] = np.frombuffer(ol.struct_bytes(t), np.float64)
+        ref.tetrad_surface(C.byref(g), Om[i], V[i], dh[i], C.byref(t)); surf[i] = np.frombuffer(ol.struct_bytes(t), np.float64)
+        vi = ol.D4(*vin[i]); vo = ol.D4()
+        ref.bl2on(vi, vo, C.byref(t)); v_on[i] = list(vo)
+        ref.on2bl(vi, vo, C.byref(t)); v_bl[i] = list(vo)
+        kk = ol.D4()
+        ref.photon_momentum(a[i], r[i], m[i], l[i], q[i], rs[i], ms[i], kk); kph[i] = list(kk)
+        if not math.isnan(kph[i, 0]):
+            L_, Q_ = C.c_double(), C.c_double()
+            ref.photon_motion_constants(a[i], r[i], m[i], kk, C.byref(L_), C.byref(Q_))
+            Lc[i], Qc[i] = L_.value, Q_.value
+            Qcar[i] = ref.photon_carter_const(kk, C.byref(g))
+        else:
+            Lc[i] = Qc[i] = Qcar[i] = np.nan
+        gK[i] = ref.gfactorK(max(r[i], ref.r_ms(a[i])), a[i], l[i] * 0.5)
+    save("kat_kerr.npz", a=a, r=r, m=m, metric=met, metric_contra=metc, connection=con, zamo=zamo,
+         azim=azim, surf=surf, Omega=Om, V=V, dhdr=dh, vin=vin, v_on=v_on, v_bl=v_bl, l=l, q=q,
+         r_sign=rs, m_sign=ms, kph=kph, L=Lc, Q=Qc, Qcarter=Qcar, gK=gK, gK_r=np.maximum(r, [ref.r_ms(x) for x in a]),
+         gK_l=l * 0.5, OmegaK=OmK, ellK=ellK,
+         r_ms_a=np.array([0.0, 0.1, 0.5, 0.9, 0.998, 0.999]),
+         r_ms=np.array([ref.r_ms(x) for x in [0.0, 0.1, 0.5, 0.9, 0.998, 0.999]]),
+         r_bh=np.array([ref.r_bh(x) for x in [0.0, 0.1, 0.5, 0.9, 0.998, 0.999]]))
+
+
+# ------------------------------------------------------------------------------------------
+def kat_disk(ref, rng):
+    out = {}
+    spins = [0.0, 0.5, 0.9, 0.998]
+    out["spins"] = np.array(spins)
+    for j, a in enumerate(spins):
+        ref.disk_nt_setup(10.0, a, 0.1, 0.1, 0)
+        rmin = ref.disk_nt_r_min()
+        rms = ref.r_ms(a)
+        # the thin band rms <= r <= rms_disk where g != 0 but F == 0, then a log grid outwards
+        r = np.concatenate([np.linspace(rms - 1e-3, rmin + 2e-3, 200),
+                            rmin * 10.0 ** np.linspace(1e-6, 2.5, 400)])
+        out["r_%d" % j] = r
+        out["rmin_%d" % j] = np.array([rmin])
+        out["flux_%d" % j] = np.array([ref.disk_nt_flux(v) for v in r])
+        out["ell_%d" % j] = np.array([ref.disk_nt_ell(v) for v in r])
+    # a second mass / accretion rate
+    ref.disk_nt_setup(3.7e6, 0.7, 0.31, 0.05, 0)
+    r = ref.disk_nt_r_min() * 10.0 ** np.linspace(0, 2, 100)
+    out.update(r_x=r, flux_x=np.array([ref.disk_nt_flux(v) for v in r]), rmin_x=np.array([ref.disk_nt_r_min()]))
+    save("kat_disk.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+def kat_polar(ref, rng):
+    n = 400
+    a = rng.choice([0.1, 0.5, 0.9, 0.998], n)
+    r = (1.0 + np.sqrt(1 - a * a)) * (1.05 + 20.0 * rng.random(n) ** 2)
+    m = rng.uniform(-0.95, 0.95, n)
+    l = rng.uniform(-3, 3, n); q = rng.uniform(0.5, 25, n)
+    kk = np.zeros((n, 4)); ff = np.zeros((n, 4)); wp = np.zeros((n, 2)); f2 = np.zeros((n, 4)); met = np.zeros((n, 8))
+    for i in range(n):
+        g = ol.Metric(); t = ol.Tetrad()
+        ref.kerr_metric(a[i], r[i], m[i], C.byref(g))
+        met[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        k = ol.D4()
+        ref.photon_momentum(a[i], r[i], m[i], l[i], q[i], 1.0, 1.0, k)
+        if math.isnan(k[0]):
+            # not a valid photon at this point: use a ZAMO-frame null direction instead
+            ref.tetrad_zamo(C.byref(g), C.byref(t))
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            ref.on2bl(ol.D4(1.0, *d), k, C.byref(t))
+        kk[i] = list(k)
+        # a unit space-like vector orthogonal to k: build in the ZAMO frame
+        ref.tetrad_zamo(C.byref(g), C.byref(t))
+        kl = ol.D4(); ref.bl2on(k, kl, C.byref(t))
+        nv = np.array(list(kl)[1:]) / kl[0]
+        e = np.cross(nv, rng.normal(size=3)); e /= np.linalg.norm(e)
+        f = ol.D4(); ref.on2bl(ol.D4(0.0, *e), f, C.byref(t))
+        ff[i] = list(f)
+        w = ref.polarization_constant(k, f, C.byref(g))
+        wp[i] = (w.re, w.im)
+        fo = ol.D4(); ref.polarization_vector(k, w, C.byref(g), fo); f2[i] = list(fo)
+    al = rng.uniform(-10, 10, n); be = rng.uniform(-10, 10, n); inc = rng.uniform(0.1, 1.5, n)
+    winf = np.zeros((n, 2)); rot = np.zeros(n)
+    for i in range(n):
+        w = ref.polarization_constant_infinity(a[i], al[i], be[i], inc[i]); winf[i] = (w.re, w.im)
+        rot[i] = ref.polarization_angle_rotation(a[i], inc[i], al[i], be[i], ol.Cplx(wp[i, 0], wp[i, 1]))
+    T = 10.0 ** rng.uniform(5, 8, n); hf = rng.uniform(1.0, 2.0, n); cm = rng.uniform(-1, 1, n); E = 10.0 ** rng.uniform(-2, 2, n)
+    T[:10] = 0.0
+    Iv = np.array([ref.blackbody_Iv(T[i], hf[i], cm[i], E[i]) for i in range(n)])
+    save("kat_polar.npz", a=a, metric=met, k=kk, f=ff, wp=wp, f_back=f2, alpha=al, beta=be, incl=inc,
+         wp_inf=winf, rot=rot, T=T, hardf=hf, cos_mu=cm, E=E, Iv=Iv)
+
+
+# ------------------------------------------------------------------------------------------
+def _driver():
+    drv = C.CDLL(ol.DRIVER_SO)
+    VP, D, I = C.c_void_p, C.c_double, C.c_int
+    drv.cpu_polarized_rays.argtypes = [C.c_char_p, C.c_char_p, D, D, D, I, VP, VP, VP, VP, VP, VP]
+    drv.cpu_polarized_rays.restype = I
+    drv.cpu_verlet_trace.argtypes = [C.c_char_p, C.c_char_p, D, D, D, D, D, D, I, D, D, D, D, I, VP, VP, VP, VP]
+    drv.cpu_verlet_trace.restype = I
+    return drv
+
+
+def verlet_traces(lib, prefix, cases, nmax):
+    drv = _driver()
+    out = []
+    for (a, inc, al, be, r0, prec, opt) in cases:
+        tr = np.zeros((nmax, 11)); xs = np.zeros(4); ks = np.zeros(4); car = C.c_double(np.nan)
+        rbh = 1.0 + math.sqrt(1.0 - a * a)
+        n = drv.cpu_verlet_trace(lib.encode(), prefix.encode(), a, inc, al, be, r0, prec, opt, 1e9,
+                                 1.05 * rbh, 1.01 * r0, 1e-2, nmax, tr.ctypes.data, xs.ctypes.data,
+                                 ks.ctypes.data, C.byref(car))
+        out.append((n, tr, xs, ks, car.value))
+    return out
+
+
+def kat_raytrace(ref, rng):
+    """Verlet step sequences (G5): 32 rays x 2 precisions in Kerr (a=0.998, 0.9) + flat-space rays."""
+    cases = []
+    for a, inc in ((0.998, deg(70.0)), (0.9, deg(60.0))):
+        lim = ref.r_ms(a) + 8.0
+        for j in range(8):
+            rad = lim * (0.15 + 0.85 * rng.random()); ang = rng.uniform(0, 2 * math.pi)
+            for prec in (1.0, 0.01):
+                cases.append((a, inc, rad * math.cos(ang), rad * math.sin(ang), 100.0, prec, 0))
+    for j in range(6):
+        cases.append((0.5, deg(50.0), rng.uniform(-9, 9), rng.uniform(-9, 9), 60.0, 1.0, 1))   # RTOPT_FLAT
+    nmax = 6000
+    res = verlet_traces(ol.REF_SO, "", cases, nmax)
+    keep = {"cases": np.array(cases)}
+    for i, (n, tr, xs, ks, car) in enumerate(res):
+        assert n > 0, (i, n)
+        # first 64 steps, every 64th afterwards, and the last one
+        idx = sorted(set(list(range(min(64, n))) + list(range(0, n, 64)) + [n - 1]))
+        keep["n_%d" % i] = np.array([n]); keep["idx_%d" % i] = np.array(idx)
+        keep["tr_%d" % i] = tr[idx]; keep["x0_%d" % i] = xs; keep["k0_%d" % i] = ks
+        keep["carter_%d" % i] = np.array([car])
+    save("kat_raytrace.npz", **keep)
+    # single-call API KAT: raytrace_prepare + first raytrace() on independent states
+    n = 300
+    a = rng.choice([0.0, 0.5, 0.998], n)
+    rr = (1.0 + np.sqrt(1 - a * a)) * (1.3 + 40.0 * rng.random(n) ** 2)
+    mm = rng.uniform(-0.9, 0.9, n)
+    xin = np.zeros((n, 4)); kin = np.zeros((n, 4)); prec = rng.choice([1.0, 0.1, 0.01], n)
+    opt = (rng.random(n) < 0.2).astype(np.int32)
+    rtd0 = np.zeros((n, 144), np.uint8); rtd1 = np.zeros((n, 144), np.uint8)
+    x1 = np.zeros((n, 4)); k1 = np.zeros((n, 4)); st = np.zeros(n); cerr = np.zeros(n)
+    stepcap = rng.choice([1e9, 0.5, 0.05], n)
+    for i in range(n):
+        g = ol.Metric(); t = ol.Tetrad()
+        if opt[i]:
+            ref.flat_metric(rr[i], mm[i], C.byref(g))
+        else:
+            ref.kerr_metric(a[i], rr[i], mm[i], C.byref(g))
+        ref.tetrad_zamo(C.byref(g), C.byref(t))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        k = ol.D4(); ref.on2bl(ol.D4(1.0, *d), k, C.byref(t))
+        x = ol.D4(0.0, rr[i], mm[i], 0.3)
+        xin[i] = list(x); kin[i] = list(k)
+        rtd = ol.RaytraceData(); C.memset(C.byref(rtd), 0, 144)
+        ref.raytrace_prepare(a[i], x, k, prec[i], int(opt[i]), C.byref(rtd))
+        rtd0[i] = np.frombuffer(ol.struct_bytes(rtd), np.uint8)
+        s = C.c_double(stepcap[i])
+        ref.raytrace(x, k, C.byref(s), C.byref(rtd))
+        rtd1[i] = np.frombuffer(ol.struct_bytes(rtd), np.uint8)
+        x1[i] = list(x); k1[i] = list(k); st[i] = s.value
+        cerr[i] = ref.raytrace_error(x, k, C.byref(rtd))
+    save("kat_raytrace_api.npz", a=a, x=xin, k=kin, precision=prec, options=opt, stepcap=stepcap,
+         rtd_prepared=rtd0, rtd_stepped=rtd1, x1=x1, k1=k1, step=st, carter=cerr)
+
+
+# ------------------------------------------------------------------------------------------
+def image_fixture(name, n, a, inc_deg, dec):
+    """Full class map + every dec-th pixel at full precision + counts and sums."""
+    o = ol.cpu_disk_image("reference", n, n, a, inc_deg, nthreads=NTHREADS, full=True)
+    cls = o["cls"]
+    counts = np.bincount(cls.ravel(), minlength=6)
+    gt = o["gtype"]
+    tcounts = np.array([(gt == 40).sum(), (gt == 2).sum(), (gt == 0).sum(), (gt == -1).sum()])
+    sl = (slice(dec // 2, None, dec), slice(dec // 2, None, dec))
+    save(name, n=np.array([n]), a=np.array([a]), inc_deg=np.array([inc_deg]), dec=np.array([dec]),
+         cls=cls, counts=counts, type_counts=tcounts,
+         sum_g=np.array([o["g"].sum(dtype=np.float64)]),
+         sum_fg4=np.array([(o["flux"] * o["g"] ** 4).sum(dtype=np.float64)]),
+         sum_image_g=np.array([o["image_g"].astype(np.float64).sum()]),
+         sum_image_f=np.array([o["image_f"].astype(np.float64).sum()]),
+         d_r=o["r"][sl], d_g=o["g"][sl], d_flux=o["flux"][sl], d_gtype=gt[sl],
+         d_image_f=o["image_f"][sl], d_image_g=o["image_g"][sl])
+    print("   counts", counts.tolist(), "types RR/RC/CC/err", tcounts.tolist(),
+          "%.2fs" % o["seconds"])
+    return o
+
+
+def images():
+    # C1: the reference's own CPU-runnable case, complete at full precision
+    o = ol.cpu_disk_image("reference", 64, 64, 0.0, 60.0, nthreads=1, full=True)
+    save("img_c1_64_a0_i60.npz", **{k: v for k, v in o.items() if k not in ("seconds", "rays")})
+    image_fixture("img_c2_1024_a0998_i70.npz", 1024, 0.998, 70.0, 16)
+    image_fixture("img_c3_2048_a09_i70.npz", 2048, 0.9, 70.0, 32)
+    image_fixture("img_head_4096_a0998_i70.npz", 4096, 0.998, 70.0, 64)
+    # boundary band (G3): all pixels of C2 whose 4-neighbourhood has a different class
+    o = ol.cpu_disk_image("reference", 1024, 1024, 0.998, 70.0, nthreads=NTHREADS, full=True)
+    c = o["cls"].astype(np.int16)
+    edge = np.zeros_like(c, bool)
+    edge[1:, :] |= c[1:, :] != c[:-1, :]; edge[:-1, :] |= c[1:, :] != c[:-1, :]
+    edge[:, 1:] |= c[:, 1:] != c[:, :-1]; edge[:, :-1] |= c[:, 1:] != c[:, :-1]
+    iy, ix = np.nonzero(edge)
+    save("img_c2_band.npz", iy=iy.astype(np.int32), ix=ix.astype(np.int32), cls=o["cls"][edge],
+         r=o["r"][edge], g=o["g"][edge], flux=o["flux"][edge])
+    # C5: 8192^2 x 8 inclinations, every 64th pixel in x and y (row-tile sharding is checked on these)
+    recs = {}
+    for inc in range(10, 90, 10):
+        s = ol.cpu_disk_image("reference", 8192, 8192, 0.998, float(inc), y0=32, ystride=64, xstride=64,
+                              nthreads=NTHREADS, full=True)
+        # xstride samples columns 0, 64, ...: keep as is (the GPU test samples the same pixels)
+        for k in ("cls", "r", "g", "flux", "image_f", "image_g"):
+            recs["%s_%d" % (k, inc)] = s[k]
+    save("img_c5_8192_sampled.npz", **recs)
+
+
+def polarized():
+    """G6: polarization recipe on the C3 grid (2048^2, a=0.9, i=70), every 32nd pixel."""
+    drv = _driver()
+    n, a, inc, dec = 2048, 0.9, deg(70.0), 32
+    ref = ol.Reference()
+    rms = ref.r_ms(a); rmax = rms + 8.0
+    idx = np.arange(dec // 2, n, dec)
+    ix, iy = np.meshgrid(idx, idx)
+    alpha = ((ix + .5) / n - 0.5) * 2.0 * rmax
+    beta = ((iy + .5) / n - 0.5) * 2.0 * rmax * (float(n) / float(n))
+    al = np.ascontiguousarray(alpha.ravel()); be = np.ascontiguousarray(beta.ravel())
+    m = al.size
+    chi = np.zeros(m); r = np.zeros(m); g = np.zeros(m); wp = np.zeros((m, 2))
+    rc = drv.cpu_polarized_rays(ol.REF_SO.encode(), b"", a, inc, -1.0, m, al.ctypes.data, be.ctypes.data,
+                                chi.ctypes.data, r.ctypes.data, g.ctypes.data, wp.ctypes.data)
+    assert rc == 0
+    save("img_c3_polarized.npz", n=np.array([n]), a=np.array([a]), inc_deg=np.array([70.0]), dec=np.array([dec]),
+         ix=ix.ravel().astype(np.int32), iy=iy.ravel().astype(np.int32), alpha=al, beta=be,
+         chi=chi, r=r, g=g, wp=wp)
+
+
+def main():
+    if not ol.have_reference():
+        sys.exit("oracle/_ref/libsim5ref.so missing: run `make -C oracle` in the build container")
+    ol.build_oracle()
+    ref = ol.Reference()
+    rng = np.random.default_rng(20261003)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(2)
+    os.dup2(devnull, 2)          # the reference prints diagnostics for out-of-range KAT inputs
+    try:
+        kat_elliptic(ref, rng)
+        kat_geodesic(ref, rng)
+        kat_kerr(ref, rng)
+        kat_disk(ref, rng)
+        kat_polar(ref, rng)
+        kat_raytrace(ref, rng)
+        polarized()
+        images()
+    finally:
+        os.dup2(saved, 2)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,540 @@
+"""ctypes binding of include/sim5gpu.h (the C-ABI of libsim5gpu.so).
+
+Fails loudly: a missing library raises ImportError at import; any non-zero status from the
+library raises Sim5GpuError with the library's own message.  Nothing here computes rays.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsim5gpu.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sim5gpu.h")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "sim5_amd: %s is missing -- build it with `python -m sim5_amd.build` "
+        "(there is no CPU fallback)" % LIB_PATH)
+
+_lib = C.CDLL(LIB_PATH)
+
+D = C.c_double
+I = C.c_int
+SZ = C.c_size_t
+VP = C.c_void_p
+
+
+class Sim5GpuError(RuntimeError):
+    pass
+
+
+class Geodesic(C.Structure):
+    _fields_ = [("a", D), ("alpha", D), ("beta", D), ("incl", D), ("cos_i", D),
+                ("l", D), ("q", D),
+                ("r1", D * 2), ("r2", D * 2), ("r3", D * 2), ("r4", D * 2),
+                ("nrr", I), ("type", I),
+                ("m2p", D), ("m2m", D), ("mm", D), ("mK", D),
+                ("rp", D), ("dmdp_inf", D),
+                ("Rpc", D), ("Tpp", D), ("Tip", D),
+                ("k", D * 4), ("p", D)]
+
+
+class Metric(C.Structure):
+    _fields_ = [("a", D), ("r", D), ("m", D), ("g00", D), ("g11", D), ("g22", D),
+                ("g33", D), ("g03", D)]
+
+
+class Tetrad(C.Structure):
+    _fields_ = [("e", (D * 4) * 4), ("metric", Metric)]
+
+
+class RaytraceData(C.Structure):
+    _fields_ = [("opt_gr", I), ("opt_pol", I), ("step_epsilon", D),
+                ("bh_spin", D), ("E", D), ("Q", D), ("WP", D * 2),
+                ("pass_", I), ("refines", I), ("dk", D * 4), ("df", D * 4),
+                ("kt", D), ("error", C.c_float)]
+
+
+class Stokes(C.Structure):
+    _fields_ = [("i", D), ("q", D), ("u", D), ("v", D), ("tau", D)]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [("nx", I), ("ny", I), ("y0", I), ("y1", I),
+                ("a", D), ("incl", D), ("rmax", D), ("rms", D),
+                ("bh_mass", D), ("mdot", D), ("alpha_visc", D),
+                ("max_order", I), ("flags", I), ("pol_degree", D)]
+
+
+class ImageAux(C.Structure):
+    _fields_ = [("cls", VP), ("gtype", VP), ("r", VP), ("g", VP), ("flux", VP)]
+
+
+class TorusDesc(C.Structure):
+    _fields_ = [("img", ImageDesc), ("r0", D), ("dl_max", D), ("precision", D),
+                ("options", I), ("max_steps", I), ("max_error", D),
+                ("r_stop_in", D), ("r_stop_out", D), ("shape", I),
+                ("torus_r", D), ("torus_w", D), ("torus_l", D),
+                ("emis0", D), ("absorb0", D)]
+
+
+class TorusAux(C.Structure):
+    _fields_ = [("steps", VP), ("max_step_error", VP), ("carter_error", VP),
+                ("x_end", VP), ("k_end", VP)]
+
+
+assert C.sizeof(Geodesic) == 240 and C.sizeof(Metric) == 64 and C.sizeof(Tetrad) == 192
+assert C.sizeof(RaytraceData) == 144 and C.sizeof(Stokes) == 40
+
+GEODESIC_DTYPE = np.dtype(Geodesic)
+METRIC_DTYPE = np.dtype(Metric)
+TETRAD_DTYPE = np.dtype(Tetrad)
+RAYTRACE_DTYPE = np.dtype(RaytraceData)
+STOKES_DTYPE = np.dtype(Stokes)
+
+PX_ERROR, PX_NAN0, PX_HIT0, PX_NAN1, PX_HIT1, PX_MISS = range(6)
+
+_lib.sim5gpu_last_error.restype = C.c_char_p
+_lib.sim5gpu_version.restype = C.c_char_p
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _lib.sim5gpu_last_error().decode(errors="replace")
+        raise Sim5GpuError("%s failed (status %d): %s" % (what, rc, msg))
+
+
+def _f64(x, n=None, cols=None):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if n is not None:
+        a = np.ascontiguousarray(np.broadcast_to(a, (n,) if cols is None else (n, cols)))
+    return a
+
+
+def _i32(x, n):
+    return np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.int32), (n,)))
+
+
+def _p(a):
+    return a.ctypes.data_as(VP)
+
+
+def device_count():
+    _lib.sim5gpu_device_count.restype = I
+    return _lib.sim5gpu_device_count()
+
+
+def set_device(dev):
+    _check(_lib.sim5gpu_set_device(I(dev)), "sim5gpu_set_device")
+
+
+def version():
+    return _lib.sim5gpu_version().decode()
+
+
+def synchronize(stream=None):
+    _check(_lib.sim5gpu_synchronize(VP(stream or 0)), "sim5gpu_synchronize")
+
+
+# ---- raw device memory (for hosts that do not use torch) -----------------------------------
+class DeviceBuffer:
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = VP()
+        _check(_lib.sim5gpu_malloc(C.byref(p), SZ(self.nbytes)), "sim5gpu_malloc")
+        self.ptr = p.value
+
+    def to_numpy(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _check(_lib.sim5gpu_memcpy_d2h(_p(out), VP(self.ptr), SZ(out.nbytes)), "sim5gpu_memcpy_d2h")
+        return out
+
+    def from_numpy(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(_lib.sim5gpu_memcpy_h2d(VP(self.ptr), _p(arr), SZ(arr.nbytes)), "sim5gpu_memcpy_h2d")
+
+    def zero(self):
+        _check(_lib.sim5gpu_memset(VP(self.ptr), I(0), SZ(self.nbytes)), "sim5gpu_memset")
+
+    def free(self):
+        if self.ptr:
+            _lib.sim5gpu_free(VP(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- batch forms of the SIM5 per-ray API -----------------------------------------------------
+def geodesic_init_inf(incl, a, alpha, beta):
+    alpha = _f64(alpha).ravel()
+    n = alpha.size
+    incl, a, beta = _f64(incl, n), _f64(a, n), _f64(beta, n)
+    g = np.zeros(n, dtype=GEODESIC_DTYPE)
+    err = np.zeros(n, dtype=np.int32)
+    ok = np.zeros(n, dtype=np.int32)
+    _check(_lib.sim5gpu_geodesic_init_inf(SZ(n), _p(incl), _p(a), _p(alpha), _p(beta), _p(g), _p(err), _p(ok)),
+           "sim5gpu_geodesic_init_inf")
+    return g, err, ok
+
+
+def geodesic_init_src(a, r, m, k, ppc):
+    k = _f64(k).reshape(-1, 4)
+    n = k.shape[0]
+    a, r, m, ppc = _f64(a, n), _f64(r, n), _f64(m, n), _i32(ppc, n)
+    g = np.zeros(n, dtype=GEODESIC_DTYPE)
+    err = np.zeros(n, dtype=np.int32)
+    ok = np.zeros(n, dtype=np.int32)
+    _check(_lib.sim5gpu_geodesic_init_src(SZ(n), _p(a), _p(r), _p(m), _p(k), _p(ppc), _p(g), _p(err), _p(ok)),
+           "sim5gpu_geodesic_init_src")
+    return g, err, ok
+
+
+def _geod(g):
+    g = np.ascontiguousarray(g, dtype=GEODESIC_DTYPE).ravel()
+    return g, g.size
+
+
+def geodesic_find_midplane_crossing(g, order):
+    g, n = _geod(g)
+    order = _i32(order, n)
+    P = np.empty(n)
+    _check(_lib.sim5gpu_geodesic_find_midplane_crossing(SZ(n), _p(g), _p(order), _p(P)),
+           "sim5gpu_geodesic_find_midplane_crossing")
+    return P
+
+
+def geodesic_P_int(g, r, ppc):
+    g, n = _geod(g)
+    r, ppc = _f64(r, n), _i32(ppc, n)
+    P = np.empty(n)
+    _check(_lib.sim5gpu_geodesic_P_int(SZ(n), _p(g), _p(r), _p(ppc), _p(P)), "sim5gpu_geodesic_P_int")
+    return P
+
+
+def _geod_P(fn, name, g, P):
+    g, n = _geod(g)
+    P = _f64(P, n)
+    out = np.empty(n)
+    _check(fn(SZ(n), _p(g), _p(P), _p(out)), name)
+    return out
+
+
+def geodesic_position_rad(g, P):
+    return _geod_P(_lib.sim5gpu_geodesic_position_rad, "sim5gpu_geodesic_position_rad", g, P)
+
+
+def geodesic_position_pol(g, P):
+    return _geod_P(_lib.sim5gpu_geodesic_position_pol, "sim5gpu_geodesic_position_pol", g, P)
+
+
+def geodesic_dm_sign(g, P):
+    return _geod_P(_lib.sim5gpu_geodesic_dm_sign, "sim5gpu_geodesic_dm_sign", g, P)
+
+
+def geodesic_momentum(g, P, r=0.0, m=0.0):
+    g, n = _geod(g)
+    P, r, m = _f64(P, n), _f64(r, n), _f64(m, n)
+    k = np.zeros((n, 4))
+    _check(_lib.sim5gpu_geodesic_momentum(SZ(n), _p(g), _p(P), _p(r), _p(m), _p(k)), "sim5gpu_geodesic_momentum")
+    return k
+
+
+def geodesic_follow(g, step, P, r, m):
+    g, n = _geod(g)
+    step = _f64(step, n)
+    P, r, m = _f64(P, n).copy(), _f64(r, n).copy(), _f64(m, n).copy()
+    st = np.zeros(n, dtype=np.int32)
+    _check(_lib.sim5gpu_geodesic_follow(SZ(n), _p(g), _p(step), _p(P), _p(r), _p(m), _p(st)),
+           "sim5gpu_geodesic_follow")
+    return P, r, m, st
+
+
+def photon_momentum(a, r, m, l, q, r_sign, m_sign):
+    r = _f64(r).ravel()
+    n = r.size
+    a, m, l, q, rs, ms = (_f64(v, n) for v in (a, m, l, q, r_sign, m_sign))
+    k = np.zeros((n, 4))
+    _check(_lib.sim5gpu_photon_momentum(SZ(n), _p(a), _p(r), _p(m), _p(l), _p(q), _p(rs), _p(ms), _p(k)),
+           "sim5gpu_photon_momentum")
+    return k
+
+
+def photon_motion_constants(a, r, m, k):
+    k = _f64(k).reshape(-1, 4)
+    n = k.shape[0]
+    a, r, m = _f64(a, n), _f64(r, n), _f64(m, n)
+    L, Q = np.empty(n), np.empty(n)
+    _check(_lib.sim5gpu_photon_motion_constants(SZ(n), _p(a), _p(r), _p(m), _p(k), _p(L), _p(Q)),
+           "sim5gpu_photon_motion_constants")
+    return L, Q
+
+
+def photon_carter_const(k, metric):
+    k = _f64(k).reshape(-1, 4)
+    n = k.shape[0]
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    Q = np.empty(n)
+    _check(_lib.sim5gpu_photon_carter_const(SZ(n), _p(k), _p(metric), _p(Q)), "sim5gpu_photon_carter_const")
+    return Q
+
+
+def gfactorK(r, a, l):
+    r = _f64(r).ravel()
+    n = r.size
+    a, l = _f64(a, n), _f64(l, n)
+    g = np.empty(n)
+    _check(_lib.sim5gpu_gfactorK(SZ(n), _p(r), _p(a), _p(l), _p(g)), "sim5gpu_gfactorK")
+    return g
+
+
+def kerr_metric(a, r, m):
+    r = _f64(r).ravel()
+    n = r.size
+    a, m = _f64(a, n), _f64(m, n)
+    out = np.zeros(n, dtype=METRIC_DTYPE)
+    _check(_lib.sim5gpu_kerr_metric(SZ(n), _p(a), _p(r), _p(m), _p(out)), "sim5gpu_kerr_metric")
+    return out
+
+
+def kerr_connection(a, r, m):
+    r = _f64(r).ravel()
+    n = r.size
+    a, m = _f64(a, n), _f64(m, n)
+    G = np.zeros((n, 4, 4, 4))
+    _check(_lib.sim5gpu_kerr_connection(SZ(n), _p(a), _p(r), _p(m), _p(G)), "sim5gpu_kerr_connection")
+    return G
+
+
+def tetrad_zamo(metric):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    n = metric.size
+    t = np.zeros(n, dtype=TETRAD_DTYPE)
+    _check(_lib.sim5gpu_tetrad_zamo(SZ(n), _p(metric), _p(t)), "sim5gpu_tetrad_zamo")
+    return t
+
+
+def tetrad_azimuthal(metric, Omega):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    n = metric.size
+    Omega = _f64(Omega, n)
+    t = np.zeros(n, dtype=TETRAD_DTYPE)
+    _check(_lib.sim5gpu_tetrad_azimuthal(SZ(n), _p(metric), _p(Omega), _p(t)), "sim5gpu_tetrad_azimuthal")
+    return t
+
+
+def tetrad_surface(metric, Omega, V, dhdr):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    n = metric.size
+    Omega, V, dhdr = _f64(Omega, n), _f64(V, n), _f64(dhdr, n)
+    t = np.zeros(n, dtype=TETRAD_DTYPE)
+    _check(_lib.sim5gpu_tetrad_surface(SZ(n), _p(metric), _p(Omega), _p(V), _p(dhdr), _p(t)),
+           "sim5gpu_tetrad_surface")
+    return t
+
+
+def _frame(fn, name, v, t):
+    v = _f64(v).reshape(-1, 4)
+    n = v.shape[0]
+    t = np.ascontiguousarray(t, dtype=TETRAD_DTYPE).ravel()
+    out = np.zeros((n, 4))
+    _check(fn(SZ(n), _p(v), _p(out), _p(t)), name)
+    return out
+
+
+def bl2on(v, t):
+    return _frame(_lib.sim5gpu_bl2on, "sim5gpu_bl2on", v, t)
+
+
+def on2bl(v, t):
+    return _frame(_lib.sim5gpu_on2bl, "sim5gpu_on2bl", v, t)
+
+
+ELLIPTIC = {"rf": 0, "elliptic_k": 1, "jacobi_isn": 2, "jacobi_icn": 3, "jacobi_itn": 4,
+            "jacobi_sn": 5, "jacobi_cn": 6, "jacobi_dn": 7, "rd": 8, "rc": 9, "rj": 10}
+
+
+def elliptic(name, x, y=None, z=None, w=None):
+    x = _f64(x).ravel()
+    n = x.size
+    y = _f64(y, n) if y is not None else None
+    z = _f64(z, n) if z is not None else None
+    w = _f64(w, n) if w is not None else None
+    out = np.empty(n)
+    _check(_lib.sim5gpu_elliptic(I(ELLIPTIC[name]), SZ(n), _p(x),
+                                 _p(y) if y is not None else None,
+                                 _p(z) if z is not None else None,
+                                 _p(w) if w is not None else None, _p(out)), "sim5gpu_elliptic(%s)" % name)
+    return out
+
+
+def disk_nt_setup(M, a, mdot, alpha, options=0):
+    _check(_lib.sim5gpu_disk_nt_setup(D(M), D(a), D(mdot), D(alpha), I(options)), "sim5gpu_disk_nt_setup")
+
+
+def disk_nt_r_min():
+    v = D(0.0)
+    _check(_lib.sim5gpu_disk_nt_r_min(C.byref(v)), "sim5gpu_disk_nt_r_min")
+    return v.value
+
+
+def disk_nt_flux(r):
+    r = _f64(r).ravel()
+    out = np.empty(r.size)
+    _check(_lib.sim5gpu_disk_nt_flux(SZ(r.size), _p(r), _p(out)), "sim5gpu_disk_nt_flux")
+    return out
+
+
+def disk_nt_ell(r):
+    r = _f64(r).ravel()
+    out = np.empty(r.size)
+    _check(_lib.sim5gpu_disk_nt_ell(SZ(r.size), _p(r), _p(out)), "sim5gpu_disk_nt_ell")
+    return out
+
+
+def raytrace_prepare(bh_spin, x, k, precision, options):
+    x = _f64(x).reshape(-1, 4)
+    n = x.shape[0]
+    k = _f64(k, n, 4)
+    a, prec, opt = _f64(bh_spin, n), _f64(precision, n), _i32(options, n)
+    rtd = np.zeros(n, dtype=RAYTRACE_DTYPE)
+    _check(_lib.sim5gpu_raytrace_prepare(SZ(n), _p(a), _p(x), _p(k), _p(prec), _p(opt), _p(rtd)),
+           "sim5gpu_raytrace_prepare")
+    return rtd
+
+
+def raytrace(x, k, step, rtd, nsteps=1):
+    x = _f64(x).reshape(-1, 4).copy()
+    n = x.shape[0]
+    k = _f64(k, n, 4).copy()
+    step = _f64(step, n).copy()
+    rtd = np.ascontiguousarray(rtd, dtype=RAYTRACE_DTYPE).ravel().copy()
+    _check(_lib.sim5gpu_raytrace(SZ(n), _p(x), _p(k), _p(step), _p(rtd), I(nsteps)), "sim5gpu_raytrace")
+    return x, k, step, rtd
+
+
+def raytrace_error(x, k, rtd):
+    x = _f64(x).reshape(-1, 4)
+    n = x.shape[0]
+    k = _f64(k, n, 4)
+    rtd = np.ascontiguousarray(rtd, dtype=RAYTRACE_DTYPE).ravel()
+    out = np.empty(n)
+    _check(_lib.sim5gpu_raytrace_error(SZ(n), _p(x), _p(k), _p(rtd), _p(out)), "sim5gpu_raytrace_error")
+    return out
+
+
+def polarization_constant(k, f, metric):
+    k = _f64(k).reshape(-1, 4)
+    n = k.shape[0]
+    f = _f64(f, n, 4)
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    wp = np.empty((n, 2))
+    _check(_lib.sim5gpu_polarization_constant(SZ(n), _p(k), _p(f), _p(metric), _p(wp)),
+           "sim5gpu_polarization_constant")
+    return wp
+
+
+def polarization_vector(k, wp, metric):
+    k = _f64(k).reshape(-1, 4)
+    n = k.shape[0]
+    wp = _f64(wp, n, 2)
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    f = np.empty((n, 4))
+    _check(_lib.sim5gpu_polarization_vector(SZ(n), _p(k), _p(wp), _p(metric), _p(f)),
+           "sim5gpu_polarization_vector")
+    return f
+
+
+def polarization_constant_infinity(a, alpha, beta, incl):
+    alpha = _f64(alpha).ravel()
+    n = alpha.size
+    a, beta, incl = _f64(a, n), _f64(beta, n), _f64(incl, n)
+    wp = np.empty((n, 2))
+    _check(_lib.sim5gpu_polarization_constant_infinity(SZ(n), _p(a), _p(alpha), _p(beta), _p(incl), _p(wp)),
+           "sim5gpu_polarization_constant_infinity")
+    return wp
+
+
+def polarization_angle_rotation(a, inc, alpha, beta, wp):
+    alpha = _f64(alpha).ravel()
+    n = alpha.size
+    a, inc, beta = _f64(a, n), _f64(inc, n), _f64(beta, n)
+    wp = _f64(wp, n, 2)
+    out = np.empty(n)
+    _check(_lib.sim5gpu_polarization_angle_rotation(SZ(n), _p(a), _p(inc), _p(alpha), _p(beta), _p(wp), _p(out)),
+           "sim5gpu_polarization_angle_rotation")
+    return out
+
+
+def blackbody_Iv(T, hardf, cos_mu, E):
+    E = _f64(E).ravel()
+    n = E.size
+    T, hardf, cos_mu = _f64(T, n), _f64(hardf, n), _f64(cos_mu, n)
+    out = np.empty(n)
+    _check(_lib.sim5gpu_blackbody_Iv(SZ(n), _p(T), _p(hardf), _p(cos_mu), _p(E), _p(out)), "sim5gpu_blackbody_Iv")
+    return out
+
+
+# ---- whole-job kernels --------------------------------------------------------------------------
+def image_desc(nx, ny, a, incl_rad, y0=0, y1=None, rmax=0.0, rms=0.0, bh_mass=10.0, mdot=0.1,
+               alpha_visc=0.1, max_order=2, pol_degree=0.0):
+    """Job description; defaults are those of the reference example (disk-image.c:41-45)."""
+    return ImageDesc(nx=nx, ny=ny, y0=y0, y1=ny if y1 is None else y1, a=a, incl=incl_rad,
+                     rmax=rmax, rms=rms, bh_mass=bh_mass, mdot=mdot, alpha_visc=alpha_visc,
+                     max_order=max_order, flags=0, pol_degree=pol_degree)
+
+
+def disk_image_device(desc, d_image_f, d_image_g, aux=None, stream=None):
+    """Asynchronous launch on device pointers (ints).  aux: dict of device pointers or None."""
+    a = None
+    if aux:
+        a = ImageAux(**{k: aux.get(k) for k in ("cls", "gtype", "r", "g", "flux")})
+    _check(_lib.sim5gpu_disk_image(C.byref(desc), VP(d_image_f), VP(d_image_g),
+                                   C.byref(a) if a is not None else None, VP(stream or 0)),
+           "sim5gpu_disk_image")
+
+
+def disk_image(desc, full=False):
+    """Host-buffer convenience: returns dict(image_f, image_g[, cls, gtype, r, g, flux])."""
+    rows = desc.y1 - desc.y0
+    out = {"image_f": np.zeros((rows, desc.nx), np.float32), "image_g": np.zeros((rows, desc.nx), np.float32)}
+    aux = None
+    if full:
+        out.update(cls=np.zeros((rows, desc.nx), np.uint8), gtype=np.zeros((rows, desc.nx), np.int8),
+                   r=np.zeros((rows, desc.nx)), g=np.zeros((rows, desc.nx)), flux=np.zeros((rows, desc.nx)))
+        aux = ImageAux(cls=out["cls"].ctypes.data, gtype=out["gtype"].ctypes.data, r=out["r"].ctypes.data,
+                       g=out["g"].ctypes.data, flux=out["flux"].ctypes.data)
+    _check(_lib.sim5gpu_disk_image_host(C.byref(desc), _p(out["image_f"]), _p(out["image_g"]),
+                                        C.byref(aux) if aux is not None else None), "sim5gpu_disk_image_host")
+    return out
+
+
+def disk_rays_device(desc, n, d_alpha, d_beta, d_image_f, d_image_g, aux=None, stream=None):
+    a = None
+    if aux:
+        a = ImageAux(**{k: aux.get(k) for k in ("cls", "gtype", "r", "g", "flux")})
+    _check(_lib.sim5gpu_disk_rays(C.byref(desc), SZ(n), VP(d_alpha), VP(d_beta), VP(d_image_f), VP(d_image_g),
+                                  C.byref(a) if a is not None else None, VP(stream or 0)), "sim5gpu_disk_rays")
+
+
+def disk_image_polarized_device(desc, d_stokes, d_chi=None, aux=None, stream=None):
+    a = None
+    if aux:
+        a = ImageAux(**{k: aux.get(k) for k in ("cls", "gtype", "r", "g", "flux")})
+    _check(_lib.sim5gpu_disk_image_polarized(C.byref(desc), VP(d_stokes), VP(d_chi or 0),
+                                             C.byref(a) if a is not None else None, VP(stream or 0)),
+           "sim5gpu_disk_image_polarized")
+
+
+def torus_image_device(desc, d_stokes, aux=None, stream=None):
+    a = None
+    if aux:
+        a = TorusAux(**{k: aux.get(k) for k in ("steps", "max_step_error", "carter_error", "x_end", "k_end")})
+    _check(_lib.sim5gpu_torus_image(C.byref(desc), VP(d_stokes), C.byref(a) if a is not None else None,
+                                    VP(stream or 0)), "sim5gpu_torus_image")

@@ -1,0 +1,572 @@
+// capi_batch.hip -- batch forms of the SIM5 per-ray functions (group (1) of include/sim5gpu.h).
+//
+// Every entry point: validate -> upload the caller's host arrays -> one kernel, one lane per ray,
+// calling the same device routines the image kernels inline -> download.  These exist so that a
+// host program written against the SIM5 scalar API (and the parity tests) can reach each routine
+// through the C-ABI; throughput work goes through the whole-job kernels instead.
+#include "capi_util.hpp"
+#include "s5_raytrace.hpp"
+#include "s5_polar.hpp"
+
+namespace s5 {
+
+template <typename F>
+__global__ __launch_bounds__(256) void map_rays(size_t n, F body)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) body(i);
+}
+
+template <typename F>
+static int run_map(size_t n, F body, const char* what)
+{
+    if (n == 0) return SIM5GPU_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(map_rays<F>, dim3(blocks), dim3(256), 0, 0, n, body);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { set_error(what, e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
+static int arg_error(const char* fn)
+{
+    snprintf(g_err, sizeof g_err, "%s: NULL pointer argument", fn);
+    return SIM5GPU_E_ARG;
+}
+
+#define S5_NEED(fn, cond) do { if (!(cond)) return arg_error(fn); } while (0)
+#define S5_DEVICE_OR_FAIL() do { if (!have_device()) return SIM5GPU_E_NO_DEVICE; } while (0)
+#define S5_BUFS_OK(fn, cond) do { if (!(cond)) { snprintf(g_err, sizeof g_err, "%s: device allocation/copy failed", fn); return SIM5GPU_E_HIP; } } while (0)
+#define S5_RUN(n, what, ...) do { int rc_ = run_map(n, __VA_ARGS__, what); if (rc_) return rc_; } while (0)
+
+} // namespace s5
+
+using namespace s5;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------
+// geodesics
+// ------------------------------------------------------------------------------------------
+int sim5gpu_geodesic_init_inf(size_t n, const double* incl, const double* a, const double* alpha,
+                              const double* beta, sim5gpu_geodesic* g, int* error, int* ok)
+{
+    S5_NEED("geodesic_init_inf", incl && a && alpha && beta && g);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> di(incl, n), da(a, n), dal(alpha, n), dbe(beta, n);
+    DevBuf<Geod> dg((const Geod*)g, n);            // keep caller's bytes in fields we never write
+    DevBuf<int> derr(n), dok(n);
+    S5_BUFS_OK("geodesic_init_inf", di.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok());
+    const double *pi = di.ptr, *pa = da.ptr, *pal = dal.ptr, *pbe = dbe.ptr;
+    Geod* pg = dg.ptr; int *pe = derr.ptr, *po = dok.ptr;
+    S5_RUN(n, "geodesic_init_inf", [=] __device__(size_t i) {
+        Geod gd = pg[i];
+        GeodCache cache;
+        int err = 0;                                // on failure *error receives the GD_* code
+        const double inc = pi[i];
+        const bool ok_ = init_inf(inc, sin(inc), cos(inc), pa[i], pal[i], pbe[i], gd, err, cache);
+        pg[i] = gd;
+        pe[i] = err;
+        po[i] = ok_ ? 1 : 0;
+    });
+    S5_HIP(dg.to_host((Geod*)g));
+    if (error) S5_HIP(derr.to_host(error));
+    if (ok) S5_HIP(dok.to_host(ok));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_geodesic_init_src(size_t n, const double* a, const double* r, const double* m,
+                              const double* k, const int* ppc, sim5gpu_geodesic* g, int* error, int* ok)
+{
+    S5_NEED("geodesic_init_src", a && r && m && k && ppc && g);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), dr(r, n), dm(m, n), dk(k, 4 * n);
+    DevBuf<int> dp(ppc, n), derr(n), dok(n);
+    DevBuf<Geod> dg((const Geod*)g, n);
+    S5_BUFS_OK("geodesic_init_src", da.ok() && dr.ok() && dm.ok() && dk.ok() && dp.ok() && derr.ok() && dok.ok() && dg.ok());
+    const double *pa = da.ptr, *pr = dr.ptr, *pm = dm.ptr, *pk = dk.ptr;
+    const int* pp = dp.ptr; Geod* pg = dg.ptr; int *pe = derr.ptr, *po = dok.ptr;
+    S5_RUN(n, "geodesic_init_src", [=] __device__(size_t i) {
+        Geod gd = pg[i];
+        int err = 0;
+        const double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        const bool ok_ = init_src(pa[i], pr[i], pm[i], kk, pp[i], gd, err);
+        pg[i] = gd; pe[i] = err; po[i] = ok_ ? 1 : 0;
+    });
+    S5_HIP(dg.to_host((Geod*)g));
+    if (error) S5_HIP(derr.to_host(error));
+    if (ok) S5_HIP(dok.to_host(ok));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_geodesic_find_midplane_crossing(size_t n, const sim5gpu_geodesic* g, const int* order, double* P)
+{
+    S5_NEED("geodesic_find_midplane_crossing", g && order && P);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Geod> dg((const Geod*)g, n); DevBuf<int> dord(order, n); DevBuf<double> dP(n);
+    S5_BUFS_OK("geodesic_find_midplane_crossing", dg.ok() && dord.ok() && dP.ok());
+    const Geod* pg = dg.ptr; const int* po = dord.ptr; double* pP = dP.ptr;
+    S5_RUN(n, "geodesic_find_midplane_crossing", [=] __device__(size_t i) {
+        GeodCache none; none.valid = false; none.K = none.icn_i = none.u_i = 0.0;
+        pP[i] = midplane_crossing(pg[i], po[i], none);
+    });
+    S5_HIP(dP.to_host(P));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_geodesic_P_int(size_t n, const sim5gpu_geodesic* g, const double* r, const int* ppc, double* P)
+{
+    S5_NEED("geodesic_P_int", g && r && ppc && P);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Geod> dg((const Geod*)g, n); DevBuf<double> dr(r, n), dP(n); DevBuf<int> dp(ppc, n);
+    S5_BUFS_OK("geodesic_P_int", dg.ok() && dr.ok() && dP.ok() && dp.ok());
+    const Geod* pg = dg.ptr; const double* pr = dr.ptr; const int* pp = dp.ptr; double* pP = dP.ptr;
+    S5_RUN(n, "geodesic_P_int", [=] __device__(size_t i) { pP[i] = P_int(pg[i], pr[i], pp[i]); });
+    S5_HIP(dP.to_host(P));
+    return SIM5GPU_OK;
+}
+
+#define S5_GEOD_P_FN(NAME, DEVFN)                                                              \
+int NAME(size_t n, const sim5gpu_geodesic* g, const double* P, double* out)                    \
+{                                                                                              \
+    S5_NEED(#NAME, g && P && out);                                                             \
+    if (n == 0) return SIM5GPU_OK;                                                             \
+    S5_DEVICE_OR_FAIL();                                                                       \
+    DevBuf<Geod> dg((const Geod*)g, n); DevBuf<double> dP(P, n), dout(n);                      \
+    S5_BUFS_OK(#NAME, dg.ok() && dP.ok() && dout.ok());                                        \
+    const Geod* pg = dg.ptr; const double* pP = dP.ptr; double* po = dout.ptr;                 \
+    S5_RUN(n, #NAME, [=] __device__(size_t i) { po[i] = DEVFN(pg[i], pP[i]); });               \
+    S5_HIP(dout.to_host(out));                                                                 \
+    return SIM5GPU_OK;                                                                         \
+}
+S5_GEOD_P_FN(sim5gpu_geodesic_position_rad, position_rad)
+S5_GEOD_P_FN(sim5gpu_geodesic_position_pol, position_pol)
+S5_GEOD_P_FN(sim5gpu_geodesic_dm_sign, dm_sign)
+#undef S5_GEOD_P_FN
+
+int sim5gpu_geodesic_momentum(size_t n, const sim5gpu_geodesic* g, const double* P, const double* r,
+                              const double* m, double* k)
+{
+    S5_NEED("geodesic_momentum", g && P && r && m && k);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Geod> dg((const Geod*)g, n); DevBuf<double> dP(P, n), dr(r, n), dm(m, n), dk(k, 4 * n);
+    S5_BUFS_OK("geodesic_momentum", dg.ok() && dP.ok() && dr.ok() && dm.ok() && dk.ok());
+    const Geod* pg = dg.ptr; const double *pP = dP.ptr, *pr = dr.ptr, *pm = dm.ptr; double* pk = dk.ptr;
+    S5_RUN(n, "geodesic_momentum", [=] __device__(size_t i) {
+        double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        momentum(pg[i], pP[i], pr[i], pm[i], kk);
+        pk[4 * i] = kk[0]; pk[4 * i + 1] = kk[1]; pk[4 * i + 2] = kk[2]; pk[4 * i + 3] = kk[3];
+    });
+    S5_HIP(dk.to_host(k));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_geodesic_follow(size_t n, const sim5gpu_geodesic* g, const double* step, double* P,
+                            double* r, double* m, int* status)
+{
+    S5_NEED("geodesic_follow", g && step && P && r && m);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Geod> dg((const Geod*)g, n); DevBuf<double> ds(step, n), dP(P, n), dr(r, n), dm(m, n); DevBuf<int> dst(n);
+    S5_BUFS_OK("geodesic_follow", dg.ok() && ds.ok() && dP.ok() && dr.ok() && dm.ok() && dst.ok());
+    const Geod* pg = dg.ptr; const double* ps = ds.ptr; double *pP = dP.ptr, *pr = dr.ptr, *pm = dm.ptr; int* pst = dst.ptr;
+    S5_RUN(n, "geodesic_follow", [=] __device__(size_t i) {
+        double PP = pP[i], rr = pr[i], mm = pm[i]; int st = 0;
+        follow(pg[i], ps[i], PP, rr, mm, st);
+        pP[i] = PP; pr[i] = rr; pm[i] = mm; pst[i] = st;
+    });
+    S5_HIP(dP.to_host(P)); S5_HIP(dr.to_host(r)); S5_HIP(dm.to_host(m));
+    if (status) S5_HIP(dst.to_host(status));
+    return SIM5GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// photon kinematics, metric, tetrads
+// ------------------------------------------------------------------------------------------
+int sim5gpu_photon_momentum(size_t n, const double* a, const double* r, const double* m, const double* l,
+                            const double* q, const double* r_sign, const double* m_sign, double* k)
+{
+    S5_NEED("photon_momentum", a && r && m && l && q && r_sign && m_sign && k);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), dr(r, n), dm(m, n), dl(l, n), dq(q, n), drs(r_sign, n), dms(m_sign, n), dk(k, 4 * n);
+    S5_BUFS_OK("photon_momentum", da.ok() && dr.ok() && dm.ok() && dl.ok() && dq.ok() && drs.ok() && dms.ok() && dk.ok());
+    const double *pa = da.ptr, *pr = dr.ptr, *pm = dm.ptr, *pl = dl.ptr, *pq = dq.ptr, *prs = drs.ptr, *pms = dms.ptr;
+    double* pk = dk.ptr;
+    S5_RUN(n, "photon_momentum", [=] __device__(size_t i) {
+        double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        photon_momentum(pa[i], pr[i], pm[i], pl[i], pq[i], prs[i], pms[i], kk);
+        pk[4 * i] = kk[0]; pk[4 * i + 1] = kk[1]; pk[4 * i + 2] = kk[2]; pk[4 * i + 3] = kk[3];
+    });
+    S5_HIP(dk.to_host(k));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_photon_motion_constants(size_t n, const double* a, const double* r, const double* m,
+                                    const double* k, double* L, double* Q)
+{
+    S5_NEED("photon_motion_constants", a && r && m && k && L && Q);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), dr(r, n), dm(m, n), dk(k, 4 * n), dL(n), dQ(n);
+    S5_BUFS_OK("photon_motion_constants", da.ok() && dr.ok() && dm.ok() && dk.ok() && dL.ok() && dQ.ok());
+    const double *pa = da.ptr, *pr = dr.ptr, *pm = dm.ptr, *pk = dk.ptr; double *pL = dL.ptr, *pQ = dQ.ptr;
+    S5_RUN(n, "photon_motion_constants", [=] __device__(size_t i) {
+        const double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        double L_, Q_;
+        photon_motion_constants(pa[i], pr[i], pm[i], kk, L_, Q_);
+        pL[i] = L_; pQ[i] = Q_;
+    });
+    S5_HIP(dL.to_host(L)); S5_HIP(dQ.to_host(Q));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_photon_carter_const(size_t n, const double* k, const sim5gpu_metric* metric, double* Q)
+{
+    S5_NEED("photon_carter_const", k && metric && Q);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dk(k, 4 * n), dQ(n); DevBuf<Metric> dmt((const Metric*)metric, n);
+    S5_BUFS_OK("photon_carter_const", dk.ok() && dQ.ok() && dmt.ok());
+    const double* pk = dk.ptr; const Metric* pg = dmt.ptr; double* pQ = dQ.ptr;
+    S5_RUN(n, "photon_carter_const", [=] __device__(size_t i) {
+        const double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        pQ[i] = carter_constant(kk, pg[i]);
+    });
+    S5_HIP(dQ.to_host(Q));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_gfactorK(size_t n, const double* r, const double* a, const double* l, double* g)
+{
+    S5_NEED("gfactorK", r && a && l && g);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dr(r, n), da(a, n), dl(l, n), dg(n);
+    S5_BUFS_OK("gfactorK", dr.ok() && da.ok() && dl.ok() && dg.ok());
+    const double *pr = dr.ptr, *pa = da.ptr, *pl = dl.ptr; double* pg = dg.ptr;
+    S5_RUN(n, "gfactorK", [=] __device__(size_t i) { pg[i] = gfactor_kepler(pr[i], pa[i], pl[i]); });
+    S5_HIP(dg.to_host(g));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_kerr_metric(size_t n, const double* a, const double* r, const double* m, sim5gpu_metric* metric)
+{
+    S5_NEED("kerr_metric", a && r && m && metric);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), dr(r, n), dm(m, n); DevBuf<Metric> dmt(n);
+    S5_BUFS_OK("kerr_metric", da.ok() && dr.ok() && dm.ok() && dmt.ok());
+    const double *pa = da.ptr, *pr = dr.ptr, *pm = dm.ptr; Metric* pg = dmt.ptr;
+    S5_RUN(n, "kerr_metric", [=] __device__(size_t i) { Metric g; kerr_metric(pa[i], pr[i], pm[i], g); pg[i] = g; });
+    S5_HIP(dmt.to_host((Metric*)metric));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_kerr_connection(size_t n, const double* a, const double* r, const double* m, double* G)
+{
+    S5_NEED("kerr_connection", a && r && m && G);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), dr(r, n), dm(m, n), dG(64 * n);
+    S5_BUFS_OK("kerr_connection", da.ok() && dr.ok() && dm.ok() && dG.ok());
+    const double *pa = da.ptr, *pr = dr.ptr, *pm = dm.ptr; double* pG = dG.ptr;
+    S5_RUN(n, "kerr_connection", [=] __device__(size_t i) {
+        Conn c; kerr_connection(pa[i], pr[i], pm[i], c);
+        conn_to_dense(c, pG + 64 * i);
+    });
+    S5_HIP(dG.to_host(G));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_tetrad_zamo(size_t n, const sim5gpu_metric* metric, sim5gpu_tetrad* t)
+{
+    S5_NEED("tetrad_zamo", metric && t);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Metric> dmt((const Metric*)metric, n); DevBuf<Tetrad> dt(n);
+    S5_BUFS_OK("tetrad_zamo", dmt.ok() && dt.ok());
+    const Metric* pg = dmt.ptr; Tetrad* pt = dt.ptr;
+    S5_RUN(n, "tetrad_zamo", [=] __device__(size_t i) { Tetrad t_; tetrad_zamo(pg[i], t_); pt[i] = t_; });
+    S5_HIP(dt.to_host((Tetrad*)t));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_tetrad_azimuthal(size_t n, const sim5gpu_metric* metric, const double* Omega, sim5gpu_tetrad* t)
+{
+    S5_NEED("tetrad_azimuthal", metric && Omega && t);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Metric> dmt((const Metric*)metric, n); DevBuf<double> dO(Omega, n); DevBuf<Tetrad> dt(n);
+    S5_BUFS_OK("tetrad_azimuthal", dmt.ok() && dO.ok() && dt.ok());
+    const Metric* pg = dmt.ptr; const double* pO = dO.ptr; Tetrad* pt = dt.ptr;
+    S5_RUN(n, "tetrad_azimuthal", [=] __device__(size_t i) { Tetrad t_; tetrad_azimuthal(pg[i], pO[i], t_); pt[i] = t_; });
+    S5_HIP(dt.to_host((Tetrad*)t));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_tetrad_surface(size_t n, const sim5gpu_metric* metric, const double* Omega, const double* V,
+                           const double* dhdr, sim5gpu_tetrad* t)
+{
+    S5_NEED("tetrad_surface", metric && Omega && V && dhdr && t);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Metric> dmt((const Metric*)metric, n); DevBuf<double> dO(Omega, n), dV(V, n), dh(dhdr, n); DevBuf<Tetrad> dt(n);
+    S5_BUFS_OK("tetrad_surface", dmt.ok() && dO.ok() && dV.ok() && dh.ok() && dt.ok());
+    const Metric* pg = dmt.ptr; const double *pO = dO.ptr, *pV = dV.ptr, *ph = dh.ptr; Tetrad* pt = dt.ptr;
+    S5_RUN(n, "tetrad_surface", [=] __device__(size_t i) { Tetrad t_; tetrad_surface(pg[i], pO[i], pV[i], ph[i], t_); pt[i] = t_; });
+    S5_HIP(dt.to_host((Tetrad*)t));
+    return SIM5GPU_OK;
+}
+
+#define S5_FRAME_FN(NAME, DEVFN)                                                               \
+int NAME(size_t n, const double* vin, double* vout, const sim5gpu_tetrad* t)                   \
+{                                                                                              \
+    S5_NEED(#NAME, vin && vout && t);                                                          \
+    if (n == 0) return SIM5GPU_OK;                                                             \
+    S5_DEVICE_OR_FAIL();                                                                       \
+    DevBuf<double> di(vin, 4 * n), dout(4 * n); DevBuf<Tetrad> dt((const Tetrad*)t, n);        \
+    S5_BUFS_OK(#NAME, di.ok() && dout.ok() && dt.ok());                                        \
+    const double* pi = di.ptr; double* po = dout.ptr; const Tetrad* pt = dt.ptr;               \
+    S5_RUN(n, #NAME, [=] __device__(size_t i) {                                                \
+        const double v[4] = { pi[4 * i], pi[4 * i + 1], pi[4 * i + 2], pi[4 * i + 3] };        \
+        double w[4];                                                                           \
+        DEVFN(v, w, pt[i]);                                                                    \
+        po[4 * i] = w[0]; po[4 * i + 1] = w[1]; po[4 * i + 2] = w[2]; po[4 * i + 3] = w[3];    \
+    });                                                                                        \
+    S5_HIP(dout.to_host(vout));                                                                \
+    return SIM5GPU_OK;                                                                         \
+}
+S5_FRAME_FN(sim5gpu_bl2on, bl2on)
+S5_FRAME_FN(sim5gpu_on2bl, on2bl)
+#undef S5_FRAME_FN
+
+// ------------------------------------------------------------------------------------------
+// elliptic functions
+// ------------------------------------------------------------------------------------------
+int sim5gpu_elliptic(int which, size_t n, const double* x, const double* y, const double* z,
+                     const double* w, double* out)
+{
+    S5_NEED("elliptic", x && out);
+    if (which < 0 || which > 10) { snprintf(g_err, sizeof g_err, "elliptic: unknown selector %d", which); return SIM5GPU_E_ARG; }
+    const bool need_y = (which != 1), need_z = (which == 0 || which == 8 || which == 10), need_w = (which == 10);
+    S5_NEED("elliptic", (!need_y || y) && (!need_z || z) && (!need_w || w));
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dx(x, n), dy(need_y ? y : nullptr, need_y ? n : 0), dz(need_z ? z : nullptr, need_z ? n : 0),
+        dw(need_w ? w : nullptr, need_w ? n : 0), dout(n);
+    S5_BUFS_OK("elliptic", dx.ok() && dy.ok() && dz.ok() && dw.ok() && dout.ok());
+    const double *px = dx.ptr, *py = dy.ptr, *pz = dz.ptr, *pw = dw.ptr; double* po = dout.ptr;
+    S5_RUN(n, "elliptic", [=] __device__(size_t i) {
+        double v = 0.0;
+        switch (which) {                         // wave-uniform selector
+        case 0: v = carlson_rf(px[i], py[i], pz[i]); break;
+        case 1: v = ell_K(px[i]); break;
+        case 2: v = inv_sn(px[i], py[i]); break;
+        case 3: v = inv_cn(px[i], py[i]); break;
+        case 4: v = inv_tn(px[i], py[i]); break;
+        case 5: v = jac_sn(px[i], py[i]); break;
+        case 6: v = jac_cn(px[i], py[i]); break;
+        case 7: v = jac_dn(px[i], py[i]); break;
+        case 8: v = carlson_rd(px[i], py[i], pz[i]); break;
+        case 9: v = carlson_rc(px[i], py[i]); break;
+        case 10: v = carlson_rj(px[i], py[i], pz[i], pw[i]); break;
+        }
+        po[i] = v;
+    });
+    S5_HIP(dout.to_host(out));
+    return SIM5GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// thin disk
+// ------------------------------------------------------------------------------------------
+int sim5gpu_disk_nt_flux(size_t n, const double* r, double* flux)
+{
+    S5_NEED("disk_nt_flux", r && flux);
+    if (!g_disk.ready) { snprintf(g_err, sizeof g_err, "disk_nt_setup has not been called"); return SIM5GPU_E_NOT_SETUP; }
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dr(r, n), df(n);
+    S5_BUFS_OK("disk_nt_flux", dr.ok() && df.ok());
+    const double* pr = dr.ptr; double* pf = df.ptr; const DiskConsts d = g_disk;
+    S5_RUN(n, "disk_nt_flux", [=] __device__(size_t i) { pf[i] = disk_flux(d, pr[i]); });
+    S5_HIP(df.to_host(flux));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_nt_ell(size_t n, const double* r, double* ell)
+{
+    S5_NEED("disk_nt_ell", r && ell);
+    if (!g_disk.ready) { snprintf(g_err, sizeof g_err, "disk_nt_setup has not been called"); return SIM5GPU_E_NOT_SETUP; }
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dr(r, n), dl(n);
+    S5_BUFS_OK("disk_nt_ell", dr.ok() && dl.ok());
+    const double* pr = dr.ptr; double* pl = dl.ptr; const DiskConsts d = g_disk;
+    S5_RUN(n, "disk_nt_ell", [=] __device__(size_t i) { pl[i] = disk_ell(d, pr[i]); });
+    S5_HIP(dl.to_host(ell));
+    return SIM5GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// step-wise integrator
+// ------------------------------------------------------------------------------------------
+int sim5gpu_raytrace_prepare(size_t n, const double* bh_spin, const double* x, const double* k,
+                             const double* precision, const int* options, sim5gpu_raytrace_data* rtd)
+{
+    S5_NEED("raytrace_prepare", bh_spin && x && k && precision && options && rtd);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(bh_spin, n), dx(x, 4 * n), dk(k, 4 * n), dp(precision, n); DevBuf<int> dopt(options, n);
+    DevBuf<RayState> ds((const RayState*)rtd, n);
+    S5_BUFS_OK("raytrace_prepare", da.ok() && dx.ok() && dk.ok() && dp.ok() && dopt.ok() && ds.ok());
+    const double *pa = da.ptr, *px = dx.ptr, *pk = dk.ptr, *pp = dp.ptr; const int* po = dopt.ptr; RayState* ps = ds.ptr;
+    S5_RUN(n, "raytrace_prepare", [=] __device__(size_t i) {
+        RayState s = ps[i];
+        const double xx[4] = { px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3] };
+        const double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        raytrace_prepare(pa[i], xx, kk, pp[i], po[i], s);
+        ps[i] = s;
+    });
+    S5_HIP(ds.to_host((RayState*)rtd));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_raytrace(size_t n, double* x, double* k, double* step, sim5gpu_raytrace_data* rtd, int nsteps)
+{
+    S5_NEED("raytrace", x && k && step && rtd);
+    if (nsteps < 1) { snprintf(g_err, sizeof g_err, "raytrace: nsteps must be >= 1"); return SIM5GPU_E_ARG; }
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dx(x, 4 * n), dk(k, 4 * n), dst(step, n); DevBuf<RayState> ds((const RayState*)rtd, n);
+    S5_BUFS_OK("raytrace", dx.ok() && dk.ok() && dst.ok() && ds.ok());
+    double *px = dx.ptr, *pk = dk.ptr, *pst = dst.ptr; RayState* ps = ds.ptr;
+    S5_RUN(n, "raytrace", [=] __device__(size_t i) {
+        RayState s = ps[i];
+        double xx[4] = { px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3] };
+        double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        const double cap = pst[i];
+        double taken = cap;
+        for (int it = 0; it < nsteps; ++it) { taken = cap; raytrace_step(xx, kk, taken, s); }
+        ps[i] = s; pst[i] = taken;
+        px[4 * i] = xx[0]; px[4 * i + 1] = xx[1]; px[4 * i + 2] = xx[2]; px[4 * i + 3] = xx[3];
+        pk[4 * i] = kk[0]; pk[4 * i + 1] = kk[1]; pk[4 * i + 2] = kk[2]; pk[4 * i + 3] = kk[3];
+    });
+    S5_HIP(dx.to_host(x)); S5_HIP(dk.to_host(k)); S5_HIP(dst.to_host(step)); S5_HIP(ds.to_host((RayState*)rtd));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_raytrace_error(size_t n, const double* x, const double* k, const sim5gpu_raytrace_data* rtd, double* err)
+{
+    S5_NEED("raytrace_error", x && k && rtd && err);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dx(x, 4 * n), dk(k, 4 * n), de(n); DevBuf<RayState> ds((const RayState*)rtd, n);
+    S5_BUFS_OK("raytrace_error", dx.ok() && dk.ok() && de.ok() && ds.ok());
+    const double *px = dx.ptr, *pk = dk.ptr; double* pe = de.ptr; const RayState* ps = ds.ptr;
+    S5_RUN(n, "raytrace_error", [=] __device__(size_t i) {
+        const double xx[4] = { px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3] };
+        const double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        pe[i] = raytrace_error(xx, kk, ps[i]);
+    });
+    S5_HIP(de.to_host(err));
+    return SIM5GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// polarization and radiation
+// ------------------------------------------------------------------------------------------
+int sim5gpu_polarization_constant(size_t n, const double* k, const double* f, const sim5gpu_metric* metric, double* wp)
+{
+    S5_NEED("polarization_constant", k && f && metric && wp);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dk(k, 4 * n), df(f, 4 * n), dw(2 * n); DevBuf<Metric> dmt((const Metric*)metric, n);
+    S5_BUFS_OK("polarization_constant", dk.ok() && df.ok() && dw.ok() && dmt.ok());
+    const double *pk = dk.ptr, *pf = df.ptr; double* pw = dw.ptr; const Metric* pg = dmt.ptr;
+    S5_RUN(n, "polarization_constant", [=] __device__(size_t i) {
+        const double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        const double ff[4] = { pf[4 * i], pf[4 * i + 1], pf[4 * i + 2], pf[4 * i + 3] };
+        double w2[2];
+        polarization_constant(kk, ff, pg[i], w2);
+        pw[2 * i] = w2[0]; pw[2 * i + 1] = w2[1];
+    });
+    S5_HIP(dw.to_host(wp));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_polarization_vector(size_t n, const double* k, const double* wp, const sim5gpu_metric* metric, double* f)
+{
+    S5_NEED("polarization_vector", k && wp && metric && f);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dk(k, 4 * n), dw(wp, 2 * n), df(4 * n); DevBuf<Metric> dmt((const Metric*)metric, n);
+    S5_BUFS_OK("polarization_vector", dk.ok() && dw.ok() && df.ok() && dmt.ok());
+    const double *pk = dk.ptr, *pw = dw.ptr; double* pf = df.ptr; const Metric* pg = dmt.ptr;
+    S5_RUN(n, "polarization_vector", [=] __device__(size_t i) {
+        const double kk[4] = { pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3] };
+        const double w2[2] = { pw[2 * i], pw[2 * i + 1] };
+        double ff[4];
+        polarization_vector(kk, w2, pg[i], ff);
+        pf[4 * i] = ff[0]; pf[4 * i + 1] = ff[1]; pf[4 * i + 2] = ff[2]; pf[4 * i + 3] = ff[3];
+    });
+    S5_HIP(df.to_host(f));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_polarization_constant_infinity(size_t n, const double* a, const double* alpha, const double* beta,
+                                           const double* incl, double* wp)
+{
+    S5_NEED("polarization_constant_infinity", a && alpha && beta && incl && wp);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), dal(alpha, n), dbe(beta, n), di(incl, n), dw(2 * n);
+    S5_BUFS_OK("polarization_constant_infinity", da.ok() && dal.ok() && dbe.ok() && di.ok() && dw.ok());
+    const double *pa = da.ptr, *pal = dal.ptr, *pbe = dbe.ptr, *pi = di.ptr; double* pw = dw.ptr;
+    S5_RUN(n, "polarization_constant_infinity", [=] __device__(size_t i) {
+        double w2[2];
+        polarization_constant_infinity(pa[i], pal[i], pbe[i], sin(pi[i]), w2);
+        pw[2 * i] = w2[0]; pw[2 * i + 1] = w2[1];
+    });
+    S5_HIP(dw.to_host(wp));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_polarization_angle_rotation(size_t n, const double* a, const double* inc, const double* alpha,
+                                        const double* beta, const double* wp, double* angle)
+{
+    S5_NEED("polarization_angle_rotation", a && inc && alpha && beta && wp && angle);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), di(inc, n), dal(alpha, n), dbe(beta, n), dw(wp, 2 * n), dout(n);
+    S5_BUFS_OK("polarization_angle_rotation", da.ok() && di.ok() && dal.ok() && dbe.ok() && dw.ok() && dout.ok());
+    const double *pa = da.ptr, *pi = di.ptr, *pal = dal.ptr, *pbe = dbe.ptr, *pw = dw.ptr; double* po = dout.ptr;
+    S5_RUN(n, "polarization_angle_rotation", [=] __device__(size_t i) {
+        const double w2[2] = { pw[2 * i], pw[2 * i + 1] };
+        po[i] = polarization_angle_rotation(pa[i], sin(pi[i]), pal[i], pbe[i], w2);
+    });
+    S5_HIP(dout.to_host(angle));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_blackbody_Iv(size_t n, const double* T, const double* hardf, const double* cos_mu, const double* E, double* Iv)
+{
+    S5_NEED("blackbody_Iv", T && hardf && cos_mu && E && Iv);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dT(T, n), dh(hardf, n), dc(cos_mu, n), dE(E, n), dI(n);
+    S5_BUFS_OK("blackbody_Iv", dT.ok() && dh.ok() && dc.ok() && dE.ok() && dI.ok());
+    const double *pT = dT.ptr, *ph = dh.ptr, *pc = dc.ptr, *pE = dE.ptr; double* pI = dI.ptr;
+    S5_RUN(n, "blackbody_Iv", [=] __device__(size_t i) { pI[i] = blackbody_Iv(pT[i], ph[i], pc[i], pE[i]); });
+    S5_HIP(dI.to_host(Iv));
+    return SIM5GPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,263 @@
+// capi_core.hip -- C-ABI: runtime helpers, disk model set-up and the whole-job image entry points
+// declared in include/sim5gpu.h.  Host code here only validates arguments, folds per-image
+// constants and launches kernels; there is no CPU implementation of any ray computation.
+#include "capi_util.hpp"
+#include <math.h>
+#include <string.h>
+
+namespace s5 {
+
+thread_local char g_err[512] = "";
+DiskConsts g_disk = {};            // process-global like the reference's statics (src/sim5disk-nt.c:27-32)
+
+void set_error(const char* what, hipError_t e)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+}
+
+int have_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        snprintf(g_err, sizeof g_err, "no HIP device available (%s); libsim5gpu has no CPU fallback",
+                 e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return 0;
+    }
+    return n;
+}
+
+// ISCO radius on the host, the reference's r_ms (src/sim5kerr.c:994-1004)
+static double host_r_ms(double a)
+{
+    double z1 = 1. + cbrt(1. - a * a) * (cbrt(1. + a) + cbrt(1. - a));
+    double z2 = sqrt(3. * a * a + z1 * z1);
+    return 3. + z2 - sqrt((3. - z1) * (3. + z1 + 2. * z2));
+}
+
+// Fold everything that depends only on (M, a, mdot) -- float-rounded as the reference's statics are
+// -- into DiskConsts (ref src/sim5disk-nt.c:37-78 setup, :91-105 r_min, :122-135 flux constants).
+DiskConsts make_disk_consts(double M, double a_in, double mdot)
+{
+    DiskConsts d;
+    const float f_mass = (float)M, f_spin = (float)a_in, f_mdot = (float)mdot;
+    const double a = f_spin;
+    const double sga = (a >= 0.0) ? +1. : -1.;
+    const double z1 = 1. + pow(1. - a * a, 1. / 3.) * (pow(1. + a, 1. / 3.) + pow(1. - a, 1. / 3.));
+    const double z2 = sqrt(3. * a * a + z1 * z1);
+    const double r0 = 3. + z2 - sga * sqrt((3. - z1) * (3. + z1 + 2. * z2));
+    const float f_rms = (float)(r0 + 1e-3);
+    d.a = a;
+    d.rms = f_rms;
+    d.x0 = sqrt((double)f_rms);
+    d.x1 = +2. * cos(1. / 3. * acos(a) - M_PI / 3.);
+    d.x2 = +2. * cos(1. / 3. * acos(a) + M_PI / 3.);
+    d.x3 = -2. * cos(1. / 3. * acos(a));
+    d.p1 = 3. * ((d.x1 - a) * (d.x1 - a)) / (d.x1 * (d.x1 - d.x2) * (d.x1 - d.x3));
+    d.p2 = 3. * ((d.x2 - a) * (d.x2 - a)) / (d.x2 * (d.x2 - d.x1) * (d.x2 - d.x3));
+    d.p3 = 3. * ((d.x3 - a) * (d.x3 - a)) / (d.x3 * (d.x3 - d.x1) * (d.x3 - d.x2));
+    d.d1 = d.x0 - d.x1;
+    d.d2 = d.x0 - d.x2;
+    d.d3 = d.x0 - d.x3;
+    d.mdot = f_mdot;
+    d.mass = f_mass;
+    d.ready = 1;
+    return d;
+}
+
+// validate a job description and turn it into the kernel argument block
+int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p)
+{
+    if (!desc) { snprintf(g_err, sizeof g_err, "image descriptor is NULL"); return SIM5GPU_E_ARG; }
+    if (desc->nx <= 0 || desc->ny <= 0 || desc->y0 < 0 || desc->y1 > desc->ny || desc->y0 >= desc->y1) {
+        snprintf(g_err, sizeof g_err, "bad image geometry nx=%d ny=%d rows=[%d,%d)", desc->nx, desc->ny,
+                 desc->y0, desc->y1);
+        return SIM5GPU_E_ARG;
+    }
+    memset(&p, 0, sizeof p);
+    p.nx = desc->nx; p.ny = desc->ny; p.y0 = desc->y0; p.y1 = desc->y1;
+    p.max_order = desc->max_order > 0 ? desc->max_order : 2;
+    p.a = desc->a;
+    p.incl = desc->incl;
+    p.sin_i = sin(desc->incl);
+    p.cos_i = cos(desc->incl);
+    const double rms = host_r_ms(desc->a);                 // ref disk-image.c:41-42
+    p.rms = desc->rms > 0.0 ? desc->rms : rms;
+    p.rmax = desc->rmax > 0.0 ? desc->rmax : rms + 8.0;
+    p.pol_degree = desc->pol_degree;
+    p.disk = make_disk_consts(desc->bh_mass, desc->a, desc->mdot);   // ref disk-image.c:45
+    return SIM5GPU_OK;
+}
+
+} // namespace s5
+
+using namespace s5;
+
+extern "C" {
+
+int sim5gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sim5gpu_set_device(int device)
+{
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipSetDevice(device));
+    return SIM5GPU_OK;
+}
+
+const char* sim5gpu_last_error(void) { return g_err; }
+const char* sim5gpu_version(void) { return "sim5_amd 0.1 (gfx950)"; }
+
+int sim5gpu_malloc(void** dptr, size_t bytes)
+{
+    if (!dptr) return SIM5GPU_E_ARG;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_free(void* dptr)
+{
+    if (!dptr) return SIM5GPU_OK;
+    S5_HIP(hipFree(dptr));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_memcpy_h2d(void* dst, const void* src, size_t bytes)
+{
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_memcpy_d2h(void* dst, const void* src, size_t bytes)
+{
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_memset(void* dst, int value, size_t bytes)
+{
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipMemset(dst, value, bytes));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_synchronize(void* stream)
+{
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SIM5GPU_OK;
+}
+
+// ---- disk model (process-global, like SIM5) -------------------------------------------------
+int sim5gpu_disk_nt_setup(double M, double a, double mdot, double alpha, int options)
+{
+    (void)alpha;
+    if (options != 0) {
+        snprintf(g_err, sizeof g_err, "disk_nt_setup: only options=0 (mdot-parametrised) is supported");
+        return SIM5GPU_E_ARG;
+    }
+    g_disk = make_disk_consts(M, a, mdot);
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_nt_r_min(double* r_min)
+{
+    if (!r_min) return SIM5GPU_E_ARG;
+    if (!g_disk.ready) { snprintf(g_err, sizeof g_err, "disk_nt_setup has not been called"); return SIM5GPU_E_NOT_SETUP; }
+    // disk_nt_r_min() recomputes r0 + 1e-3 in double from the float spin (ref src/sim5disk-nt.c:91-105)
+    const double a = g_disk.a;
+    const double sga = (a >= 0.0) ? +1. : -1.;
+    const double z1 = 1. + pow(1. - a * a, 1. / 3.) * (pow(1. + a, 1. / 3.) + pow(1. - a, 1. / 3.));
+    const double z2 = sqrt(3. * a * a + z1 * z1);
+    *r_min = 3. + z2 - sga * sqrt((3. - z1) * (3. + z1 + 2. * z2)) + 1e-3;
+    return SIM5GPU_OK;
+}
+
+// ---- whole-job image entry points --------------------------------------------------------------
+static void attach_aux(ImageParams& p, const sim5gpu_image_aux* aux)
+{
+    if (!aux) return;
+    p.cls = aux->cls; p.gtype = aux->gtype; p.r = aux->r; p.g = aux->g; p.flux = aux->flux;
+}
+
+int sim5gpu_disk_image(const sim5gpu_image_desc* desc, float* d_image_f, float* d_image_g,
+                       const sim5gpu_image_aux* d_aux, void* stream)
+{
+    if (!d_image_f || !d_image_g) { snprintf(g_err, sizeof g_err, "output image pointers are NULL"); return SIM5GPU_E_ARG; }
+    ImageParams p;
+    int rc = fill_image_params(desc, p);
+    if (rc) return rc;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    p.img_f = d_image_f; p.img_g = d_image_g;
+    attach_aux(p, d_aux);
+    hipError_t e = (hipError_t)launch_disk_image(p, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("disk_image launch", e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_rays(const sim5gpu_image_desc* desc, size_t n, const double* d_alpha,
+                      const double* d_beta, float* d_image_f, float* d_image_g,
+                      const sim5gpu_image_aux* d_aux, void* stream)
+{
+    if (!d_image_f || !d_image_g || !d_alpha || !d_beta) {
+        snprintf(g_err, sizeof g_err, "disk_rays: NULL pointer argument");
+        return SIM5GPU_E_ARG;
+    }
+    sim5gpu_image_desc dd;
+    if (!desc) return SIM5GPU_E_ARG;
+    dd = *desc;
+    if (dd.nx <= 0) { dd.nx = 1; dd.ny = 1; dd.y0 = 0; dd.y1 = 1; }   // geometry unused in list mode
+    ImageParams p;
+    int rc = fill_image_params(&dd, p);
+    if (rc) return rc;
+    if (n == 0) return SIM5GPU_OK;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    p.img_f = d_image_f; p.img_g = d_image_g;
+    p.alpha = d_alpha; p.beta = d_beta; p.n = n;
+    attach_aux(p, d_aux);
+    hipError_t e = (hipError_t)launch_disk_image(p, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("disk_rays launch", e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_image_host(const sim5gpu_image_desc* desc, float* h_image_f, float* h_image_g,
+                            const sim5gpu_image_aux* h_aux)
+{
+    if (!h_image_f || !h_image_g) return SIM5GPU_E_ARG;
+    ImageParams chk;
+    int rc = fill_image_params(desc, chk);
+    if (rc) return rc;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    const size_t n = (size_t)(desc->y1 - desc->y0) * (size_t)desc->nx;
+    DevBuf<float> f(n), g(n);
+    DevBuf<uint8_t> cls(h_aux && h_aux->cls ? n : 0);
+    DevBuf<int8_t> gt(h_aux && h_aux->gtype ? n : 0);
+    DevBuf<double> r(h_aux && h_aux->r ? n : 0), gg(h_aux && h_aux->g ? n : 0), fl(h_aux && h_aux->flux ? n : 0);
+    if (!f.ok() || !g.ok() || !cls.ok() || !gt.ok() || !r.ok() || !gg.ok() || !fl.ok()) {
+        snprintf(g_err, sizeof g_err, "disk_image_host: device allocation failed");
+        return SIM5GPU_E_HIP;
+    }
+    sim5gpu_image_aux daux = { cls.ptr, gt.ptr, r.ptr, gg.ptr, fl.ptr };
+    rc = sim5gpu_disk_image(desc, f.ptr, g.ptr, &daux, nullptr);
+    if (rc) return rc;
+    S5_HIP(hipDeviceSynchronize());
+    S5_HIP(f.to_host(h_image_f));
+    S5_HIP(g.to_host(h_image_g));
+    if (h_aux) {
+        if (h_aux->cls) S5_HIP(cls.to_host(h_aux->cls));
+        if (h_aux->gtype) S5_HIP(gt.to_host(h_aux->gtype));
+        if (h_aux->r) S5_HIP(r.to_host(h_aux->r));
+        if (h_aux->g) S5_HIP(gg.to_host(h_aux->g));
+        if (h_aux->flux) S5_HIP(fl.to_host(h_aux->flux));
+    }
+    return SIM5GPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,65 @@
+// capi_jobs.hip -- C-ABI of the polarized thin-disk image and of the step-wise torus ray tracer.
+#include "capi_util.hpp"
+#include "k_torus.hpp"
+#include <math.h>
+#include <string.h>
+
+using namespace s5;
+
+extern "C" {
+
+int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stokes, double* d_chi,
+                                 const sim5gpu_image_aux* d_aux, void* stream)
+{
+    if (!d_stokes) { snprintf(g_err, sizeof g_err, "disk_image_polarized: stokes pointer is NULL"); return SIM5GPU_E_ARG; }
+    ImageParams p;
+    int rc = fill_image_params(desc, p);
+    if (rc) return rc;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    p.stokes = d_stokes;
+    p.chi = d_chi;
+    if (d_aux) { p.cls = d_aux->cls; p.gtype = d_aux->gtype; p.r = d_aux->r; p.g = d_aux->g; p.flux = d_aux->flux; }
+    hipError_t e = (hipError_t)launch_disk_image_polarized(p, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("disk_image_polarized launch", e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_torus_image(const sim5gpu_torus_desc* desc, sim5gpu_stokes* d_stokes,
+                        const sim5gpu_torus_aux* d_aux, void* stream)
+{
+    if (!desc || !d_stokes) { snprintf(g_err, sizeof g_err, "torus_image: NULL pointer argument"); return SIM5GPU_E_ARG; }
+    ImageParams ip;
+    int rc = fill_image_params(&desc->img, ip);
+    if (rc) return rc;
+    if (!(desc->r0 > 0.0) || !(desc->precision > 0.0) || desc->max_steps < 1) {
+        snprintf(g_err, sizeof g_err, "torus_image: need r0 > 0, precision > 0, max_steps >= 1");
+        return SIM5GPU_E_ARG;
+    }
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    TorusParams p;
+    memset(&p, 0, sizeof p);
+    p.nx = ip.nx; p.ny = ip.ny; p.y0 = ip.y0; p.y1 = ip.y1;
+    p.nrays = (size_t)(ip.y1 - ip.y0) * (size_t)ip.nx;
+    p.a = ip.a; p.incl = ip.incl; p.sin_i = ip.sin_i; p.cos_i = ip.cos_i; p.rmax = ip.rmax;
+    p.r0 = desc->r0;
+    p.precision = desc->precision;
+    p.dl_max = desc->dl_max > 0.0 ? desc->dl_max : 1e9;
+    p.options = desc->options;
+    p.max_steps = desc->max_steps;
+    p.shape = desc->shape;
+    p.max_error = desc->max_error > 0.0 ? desc->max_error : 1e-2;
+    p.r_stop_in = desc->r_stop_in > 0.0 ? desc->r_stop_in : 1.05;
+    p.r_stop_out = desc->r_stop_out > 0.0 ? desc->r_stop_out : 1.01;
+    p.torus_r = desc->torus_r; p.torus_w = desc->torus_w; p.torus_l = desc->torus_l;
+    p.emis0 = desc->emis0; p.absorb0 = desc->absorb0;
+    TorusAux aux = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (d_aux) {
+        aux.steps = d_aux->steps; aux.max_step_error = d_aux->max_step_error;
+        aux.carter_error = d_aux->carter_error; aux.x_end = d_aux->x_end; aux.k_end = d_aux->k_end;
+    }
+    hipError_t e = (hipError_t)launch_torus(p, d_stokes, aux, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("torus_image launch", e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
+} // extern "C"

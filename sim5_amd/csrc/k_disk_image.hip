@@ -1,0 +1,108 @@
+// k_disk_image.hip -- thin-disk image kernels (elliptic-integral path) for gfx950.
+//
+// One lane traces one image-plane ray through
+//   geodesic_init_inf -> geodesic_find_midplane_crossing -> geodesic_position_rad ->
+//   gfactorK / disk_nt_flux
+// i.e. the body of the caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105,
+// for up to max_order crossings, and writes (float)(F g^4) and (float)g.
+//
+// Launch geometry: a 256-thread workgroup covers a 16 x 16 pixel tile, each wave64 a 16 x 4
+// patch of it.  Rays of a wave are image-plane neighbours, so they share the geodesic class and
+// the Carlson trip counts almost always; each wave row stores 16 consecutive f32 = one full 64-B
+// segment per plane.  No input is read in grid mode (alpha, beta follow from the pixel index,
+// ref disk-image.c:57-58); in list mode alpha[]/beta[] are read coalesced, 8 B per lane.
+#include "s5_disk.hpp"
+#include "kernels.hpp"
+
+namespace s5 {
+
+struct RayResult {
+    int    cls;      // SIM5GPU_PX_*
+    int    gtype;    // geodesic type or -1
+    double r, g, flux;
+    float  image_f, image_g;
+};
+
+S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
+{
+    RayResult out;
+    out.cls = PX_ERROR; out.gtype = -1;
+    out.r = NAN; out.g = 0.0; out.flux = 0.0; out.image_f = 0.0f; out.image_g = 0.0f;
+
+    Geod gd;
+    GeodCache cache;
+    int err = 0;
+    if (!init_inf(p.incl, p.sin_i, p.cos_i, p.a, alpha, beta, gd, err, cache)) return out;
+    out.gtype = gd.type;
+    out.cls = PX_MISS;
+
+    for (int order = 0; order < p.max_order; ++order) {
+        const double P = midplane_crossing(gd, order, cache);
+        if (isnan(P)) { out.cls = (order == 0) ? PX_NAN0 : PX_NAN1; break; }
+        const double r = position_rad(gd, P);
+        if (r >= p.rms) {
+            const double g = gfactor_kepler(r, p.a, gd.l);
+            const double f = disk_flux(p.disk, r);
+            const double g2 = g * g;
+            out.cls = (order == 0) ? PX_HIT0 : PX_HIT1;
+            out.r = r; out.g = g; out.flux = f;
+            out.image_f = (float)(f * (g2 * g2));
+            out.image_g = (float)g;
+            break;
+        }
+    }
+    return out;
+}
+
+S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
+{
+    p.img_f[o] = res.image_f;
+    p.img_g[o] = res.image_g;
+    if (p.cls) p.cls[o] = (uint8_t)res.cls;
+    if (p.gtype) p.gtype[o] = (int8_t)res.gtype;
+    if (p.r) p.r[o] = res.r;
+    if (p.g) p.g[o] = res.g;
+    if (p.flux) p.flux[o] = res.flux;
+}
+
+__global__ __launch_bounds__(256, 2)
+void disk_image_grid_kernel(ImageParams p)
+{
+    // 16 x 16 pixel tile per workgroup; wave w covers rows 4w..4w+3 of the tile
+    const int lane_x = threadIdx.x & 15;
+    const int lane_y = threadIdx.x >> 4;
+    const int ix = blockIdx.x * 16 + lane_x;
+    const int iy = p.y0 + blockIdx.y * 16 + lane_y;
+    if (ix >= p.nx || iy >= p.y1) return;
+
+    // ref disk-image.c:57-58 (operation order kept)
+    const double alpha = (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
+    const double beta = (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax *
+                        ((double)p.ny / (double)p.nx);
+
+    const RayResult res = trace_disk_ray(p, alpha, beta);
+    store_ray(p, (size_t)(iy - p.y0) * (size_t)p.nx + (size_t)ix, res);
+}
+
+__global__ __launch_bounds__(256, 2)
+void disk_image_list_kernel(ImageParams p)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const RayResult res = trace_disk_ray(p, p.alpha[i], p.beta[i]);
+    store_ray(p, i, res);
+}
+
+int launch_disk_image(const ImageParams& p, hipStream_t stream)
+{
+    if (p.alpha) {
+        const unsigned blocks = (unsigned)((p.n + 255) / 256);
+        hipLaunchKernelGGL(disk_image_list_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    } else {
+        const dim3 grid((p.nx + 15) / 16, (p.y1 - p.y0 + 15) / 16);
+        hipLaunchKernelGGL(disk_image_grid_kernel, grid, dim3(256), 0, stream, p);
+    }
+    return (int)hipGetLastError();
+}
+
+} // namespace s5

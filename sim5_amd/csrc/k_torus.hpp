@@ -1,0 +1,28 @@
+// k_torus.hpp -- argument blocks of the step-wise ray tracer kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/sim5gpu.h"
+
+namespace s5 {
+
+struct TorusParams {
+    int nx, ny, y0, y1;
+    size_t nrays;
+    double a, incl, sin_i, cos_i, rmax;
+    double r0, precision, dl_max;
+    int options, max_steps, shape;
+    double max_error, r_stop_in, r_stop_out;
+    double torus_r, torus_w, torus_l, emis0, absorb0;
+};
+
+struct TorusAux {
+    int* steps;
+    float* max_step_error;
+    double* carter_error;
+    double* x_end;
+    double* k_end;
+};
+
+int launch_torus(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream);
+
+} // namespace s5

@@ -1,0 +1,285 @@
+// s5_elliptic.hpp -- Carlson symmetric integrals and the Jacobi functions built on them,
+// as gfx950 device code (FP64 VALU; one lane = one ray).
+//
+// Algorithms restated from the reference (ref: /root/reference/src/sim5elliptic.c):
+//   carlson_rf  <- rf :19-52        carlson_rd <- rd :59-98     carlson_rc <- rc :105-137
+//   carlson_rj  <- rj :145-206      ell_K <- elliptic_k :218    ell_F_sin <- elliptic_f_sin :274
+//   inv_sn/inv_cn/inv_tn <- jacobi_isn/icn/itn :481-528         sncndn <- jacobi_sncndn :536-598
+//
+// Design notes (CDNA4):
+//  * every loop has a trip-count cap so that a wave always drains, whatever the input;
+//  * loops leave as soon as no lane of the wave needs another pass (wave vote), lanes that are
+//    done keep their value under predication -- rays of one wave are neighbours on the image
+//    plane, so their trip counts differ by at most one or two;
+//  * the Landen ladder of sncndn lives in registers (fully unrolled, level index compile-time),
+//    never in scratch or LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#define S5_DEV __device__ __forceinline__
+
+namespace s5 {
+
+S5_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+S5_DEV double sq(double x) { return x * x; }
+S5_DEV double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), fabs(b)), fabs(c)); }
+
+// ---------------------------------------------------------------------------------------
+// R_F(x,y,z) by the duplication theorem, tolerance 3e-4 and 5th-order series as the reference.
+// ---------------------------------------------------------------------------------------
+S5_DEV double carlson_rf(double x, double y, double z)
+{
+    const double tol = 0.0003, third = 1.0 / 3.0;
+    double dx = 0.0, dy = 0.0, dz = 0.0, mu = 1.0;
+    bool live = true;
+    for (int pass = 0; pass < 48; ++pass) {
+        if (live) {
+            double sx = sqrt(x), sy = sqrt(y), sz = sqrt(z);
+            double lam = sx * (sy + sz) + sy * sz;
+            x = 0.25 * (x + lam);
+            y = 0.25 * (y + lam);
+            z = 0.25 * (z + lam);
+            mu = third * (x + y + z);
+            dx = (mu - x) / mu;
+            dy = (mu - y) / mu;
+            dz = (mu - z) / mu;
+            live = max3abs(dx, dy, dz) > tol;      // false for NaN: the lane stops, as in C
+        }
+        if (!wave_any(live)) break;
+    }
+    double e2 = dx * dy - dz * dz;
+    double e3 = dx * dy * dz;
+    return (1.0 + ((1.0 / 24.0) * e2 - 0.1 - (3.0 / 44.0) * e3) * e2 + (1.0 / 14.0) * e3) / sqrt(mu);
+}
+
+// R_C(x,y), Cauchy principal value for y < 0
+S5_DEV double carlson_rc(double x, double y)
+{
+    const double tol = 0.0003, third = 1.0 / 3.0;
+    double xt, yt, w, mu = 1.0, s = 0.0;
+    if (y > 0.0) { xt = x; yt = y; w = 1.0; }
+    else { xt = x - y; yt = -y; w = sqrt(x) / sqrt(xt); }
+    bool live = true;
+    for (int pass = 0; pass < 48; ++pass) {
+        if (live) {
+            double lam = 2.0 * sqrt(xt) * sqrt(yt) + yt;
+            xt = 0.25 * (xt + lam);
+            yt = 0.25 * (yt + lam);
+            mu = third * (xt + yt + yt);
+            s = (yt - mu) / mu;
+            live = fabs(s) > tol;
+        }
+        if (!wave_any(live)) break;
+    }
+    return w * (1.0 + s * s * (0.3 + s * ((1.0 / 7.0) + s * (0.375 + s * (9.0 / 22.0))))) / sqrt(mu);
+}
+
+// R_D(x,y,z)
+S5_DEV double carlson_rd(double x, double y, double z)
+{
+    const double tol = 0.0003;
+    const double c1 = 3.0 / 14.0, c2 = 1.0 / 6.0, c3 = 9.0 / 22.0, c4 = 3.0 / 26.0;
+    const double c5 = 0.25 * c3, c6 = 1.5 * c4;
+    double acc = 0.0, w = 1.0, dx = 0.0, dy = 0.0, dz = 0.0, mu = 1.0;
+    bool live = true;
+    for (int pass = 0; pass < 48; ++pass) {
+        if (live) {
+            double sx = sqrt(x), sy = sqrt(y), sz = sqrt(z);
+            double lam = sx * (sy + sz) + sy * sz;
+            acc += w / (sz * (z + lam));
+            w = 0.25 * w;
+            x = 0.25 * (x + lam);
+            y = 0.25 * (y + lam);
+            z = 0.25 * (z + lam);
+            mu = 0.2 * (x + y + 3.0 * z);
+            dx = (mu - x) / mu;
+            dy = (mu - y) / mu;
+            dz = (mu - z) / mu;
+            live = max3abs(dx, dy, dz) > tol;
+        }
+        if (!wave_any(live)) break;
+    }
+    double ea = dx * dy, eb = dz * dz, ec = ea - eb, ed = ea - 6.0 * eb, ee = ed + ec + ec;
+    return 3.0 * acc + w * (1.0 + ed * (-c1 + c5 * ed - c6 * dz * ee)
+        + dz * (c2 * ee + dz * (-c3 * ec + dz * c4 * ea))) / (mu * sqrt(mu));
+}
+
+// R_J(x,y,z,p); returns 0 for arguments outside the validity box, as the reference does
+S5_DEV double carlson_rj(double x, double y, double z, double p)
+{
+    const double tol = 0.0003;
+    const double tiny = 2.2325156320215171e-103;   // pow(5*DBL_MIN, 1/3)
+    const double big  = 7.8546894664816594e+101;   // 0.3*pow(0.1*DBL_MAX, 1/3)
+    const double c1 = 3.0 / 14.0, c2 = 1.0 / 3.0, c3 = 3.0 / 22.0, c4 = 3.0 / 26.0;
+    const double c5 = 0.75 * c3, c6 = 1.5 * c4, c7 = 0.5 * c2, c8 = c3 + c3;
+    if ((fmin(fmin(x, y), z) < 0.0) || (fmin(fmin(x + y, x + z), fmin(y + z, fabs(p))) < tiny) ||
+        (fmax(fmax(x, y), fmax(z, fabs(p))) > big))
+        return 0.0;
+    double a = 0.0, b = 0.0, rcx = 0.0, acc = 0.0, w = 1.0;
+    double xt, yt, zt, pt, dx = 0.0, dy = 0.0, dz = 0.0, dp = 0.0, mu = 1.0;
+    if (p > 0.0) { xt = x; yt = y; zt = z; pt = p; }
+    else {
+        xt = fmin(fmin(x, y), z);
+        zt = fmax(fmax(x, y), z);
+        yt = x + y + z - xt - zt;
+        a = 1.0 / (yt - p);
+        b = a * (zt - yt) * (yt - xt);
+        pt = yt + b;
+        double rho = xt * zt / yt;
+        double tau = p * pt / yt;
+        rcx = carlson_rc(rho, tau);
+    }
+    bool live = true;
+    for (int pass = 0; pass < 48; ++pass) {
+        if (!live) break;                      // lane-level exit: this routine is off the image path
+        double sx = sqrt(xt), sy = sqrt(yt), sz = sqrt(zt);
+        double lam = sx * (sy + sz) + sy * sz;
+        double al = sq(pt * (sx + sy + sz) + sx * sy * sz);
+        double be = pt * sq(pt + lam);
+        acc += w * carlson_rc(al, be);
+        w = 0.25 * w;
+        xt = 0.25 * (xt + lam);
+        yt = 0.25 * (yt + lam);
+        zt = 0.25 * (zt + lam);
+        pt = 0.25 * (pt + lam);
+        mu = 0.2 * (xt + yt + zt + pt + pt);
+        dx = (mu - xt) / mu;
+        dy = (mu - yt) / mu;
+        dz = (mu - zt) / mu;
+        dp = (mu - pt) / mu;
+        live = fmax(fmax(fabs(dx), fabs(dy)), fmax(fabs(dz), fabs(dp))) > tol;
+    }
+    double ea = dx * (dy + dz) + dy * dz;
+    double eb = dx * dy * dz;
+    double ec = dp * dp;
+    double ed = ea - 3.0 * ec;
+    double ee = eb + 2.0 * dp * (ea - ec);
+    double ans = 3.0 * acc + w * (1.0 + ed * (-c1 + c5 * ed - c6 * ee) + eb * (c7 + dp * (-c8 + dp * c4))
+        + dp * ea * (c2 - dp * c3) - c2 * dp * ec) / (mu * sqrt(mu));
+    if (p <= 0.0) ans = a * (b * ans + 3.0 * (rcx - carlson_rf(xt, yt, zt)));
+    return ans;
+}
+
+// ---------------------------------------------------------------------------------------
+// Legendre / Jacobi
+// ---------------------------------------------------------------------------------------
+S5_DEV double ell_K(double m)
+{
+    if (m == 1.0) m = 1.0 - 1e-8;
+    return carlson_rf(0.0, 1.0 - m, 1.0);
+}
+
+S5_DEV double ell_F_sin(double s, double m)
+{
+    if (m == 1.0) m = 0.99999999;
+    if (s == 0.0) return 0.0;
+    double s2 = s * s;
+    return s * carlson_rf(1. - s2, 1.0 - s2 * m, 1.0);
+}
+
+S5_DEV double inv_sn(double z, double m)
+{
+    if (fabs(m - 0.0) < 1e-8) return asin(z);
+    if (fabs(m - 1.0) < 1e-8) return log(sqrt((1. + z) / (1. - z)));
+    return z * carlson_rf(1.0 - z * z, 1.0 - m * z * z, 1.0);
+}
+
+S5_DEV double inv_cn(double z, double m)
+{
+    if ((z > +1.0) && (z < +1.0 + 1e-8)) z = +1.0;
+    if ((z < -1.0) && (z > -1.0 - 1e-8)) z = -1.0;
+    if ((m > +1.0) && (m < +1.0 + 1e-8)) m = 1.0;
+    if ((m < 0.0) && (m > 0.0 - 1e-8)) m = 0.0;
+
+    if (z == 0.0) return ell_K(m);
+    if (z == 1.0) return 0.0;
+    if (m == 0.0) return acos(z);
+    if (m == 1.0) return log((1. + sqrt(1. - z)) / z);
+
+    double base = sqrt(1. - z * z) * carlson_rf(z * z, 1.0 - m * (1. - z * z), 1.0);
+    if (z > 0.0) return base;
+    return 2. / sqrt(1. - m) * ell_F_sin(-z, m / (m - 1.)) + base;
+}
+
+S5_DEV double inv_tn(double z, double m)
+{
+    if (m == 0.0) return atan(z);
+    if (m == 1.0) return log(z + sqrt(1. + z * z));
+    return inv_sn(sqrt(z * z / (1. + z * z)), m);
+}
+
+// sn, cn, dn by the descending Landen ladder.  13 rungs at most; rung values stay in VGPRs.
+S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
+{
+    if (m == 1.0) m = 0.999999999;
+    const double conv = 1.0e-8;
+    double emc = 1.0 - m;
+    if (emc == 0.0) {                          // unreachable after the clamp above; kept for parity
+        cn = 1.0 / cosh(u);
+        dn = cn;
+        sn = tanh(u);
+        return;
+    }
+    double d = 1.0;
+    const bool flipped = emc < 0.0;
+    if (flipped) {
+        d = 1.0 - emc;
+        emc /= -1.0 / d;
+        d = sqrt(d);
+        u *= d;
+    }
+    double ra[13], rg[13];
+    double a = 1.0, c = 0.0;
+    int top = 12;
+    bool climbing = true;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        if (climbing) {
+            ra[i] = a;
+            emc = sqrt(emc);
+            rg[i] = emc;
+            c = 0.5 * (a + emc);
+            if (fabs(a - emc) <= conv * a) { climbing = false; top = i; }
+            else { emc *= a; a = c; }
+        }
+        if (!wave_any(climbing)) break;        // rungs above are never read (i <= top below)
+    }
+    u *= c;
+    double s0, c0;
+    s0 = sin(u);
+    c0 = cos(u);
+    sn = s0; cn = c0; dn = 1.0;
+    if (s0 != 0.0) {
+        a = c0 / s0;
+        c *= a;
+#pragma unroll
+        for (int i = 12; i >= 0; --i) {
+            if (wave_any(i <= top)) {          // rungs no lane of the wave reached are skipped
+                if (i <= top) {
+                    double b = ra[i];
+                    a *= c;
+                    c *= dn;
+                    dn = (rg[i] + a) / (b + a);
+                    a = c / b;
+                }
+            }
+        }
+        a = 1.0 / sqrt(c * c + 1.0);
+        sn = (s0 >= 0.0 ? a : -a);
+        cn = c * sn;
+    }
+    if (flipped) {
+        a = dn;
+        dn = cn;
+        cn = a;
+        sn /= d;
+    }
+}
+
+S5_DEV double jac_sn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return s; }
+S5_DEV double jac_cn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return c; }
+S5_DEV double jac_dn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return d; }
+
+} // namespace s5

@@ -1,0 +1,384 @@
+// s5_geod.hpp -- null geodesics of the Kerr metric through elliptic integrals, gfx950 device code.
+//
+// Restated from the reference (ref: /root/reference/src/sim5kerr-geod.c, src/sim5polyroots.c:278
+// for the root ordering, src/sim5math.c:50 for the slack clamp).  What is different from the
+// reference's shape, on purpose:
+//  * the four roots of R(r) are produced already ordered from the two square-root discriminants
+//    (no complex type, no generic sort): a pair is real iff its discriminant is >= 0, which is the
+//    C99 csqrt(x + 0i) behaviour the reference's `cimag(z) == 0` test relies on;
+//  * K(mm) and cn^-1(cos_i/sqrt(m2p) | mm) are evaluated once per ray in init and cached next to
+//    the geodesic record: the reference re-evaluates the same expressions in
+//    geodesic_find_midplane_crossing (twice for two crossings).  Same inputs, same routine, same
+//    bits -- 3 Carlson R_F evaluations per ray instead of 6.3;
+//  * the record lives in registers; fields nobody reads are removed by the compiler per kernel.
+//  * the polar roots use double throughout, as the reference's own device branch does
+//    (:1133-1138); its host branch carries one intermediate in x87 long double (:1126-1131).
+#pragma once
+#include "s5_kerr.hpp"
+
+namespace s5 {
+
+enum : int { T_RR = 40, T_RR_DBL = 41, T_RR_BH = 42, T_RC = 2, T_CC = 0 };
+enum : int {
+    GD_OK = 0, GD_E_UNKNOWN = 3, GD_E_RR_DOUBLE = 4, GD_E_Q_RANGE = 7, GD_E_MUPLUS = 8,
+    GD_E_MU0 = 9, GD_E_MM = 10, GD_E_INCL = 11, GD_E_SPIN = 12
+};
+
+// byte-identical to sim5gpu_geodesic / the reference's struct geodesic (240 B)
+struct Geod {
+    double a, alpha, beta, incl, cos_i;
+    double l, q;
+    double r1[2], r2[2], r3[2], r4[2];
+    int nrr, type;
+    double m2p, m2m, mm, mK;
+    double rp, dmdp_inf;
+    double Rpc, Tpp, Tip;
+    double k[4];
+    double p;
+};
+static_assert(sizeof(Geod) == 240, "geodesic record must keep the SIM5 layout");
+
+// values the image kernels reuse between init and the crossing search
+struct GeodCache {
+    double K;        // K(mm)
+    double icn_i;    // cn^-1(cos_i / sqrt(m2p) | mm)
+    double u_i;      // cos_i / sqrt(m2p)
+    bool   valid;
+};
+
+S5_DEV double pol_integral(const Geod& g, double x) { return g.mK * inv_cn(x / sqrt(g.m2p), g.mm); }  // ref :29
+S5_DEV double pol_inverse(const Geod& g, double T) { return sqrt(g.m2p) * jac_cn(T / g.mK, g.mm); }   // ref :30
+
+// ---------------------------------------------------------------------------------------
+// roots of R(r), geodesic class, pericentre and the radial integral to infinity  (ref :986-1104)
+// ---------------------------------------------------------------------------------------
+S5_DEV bool radial_roots(Geod& g, double r0, int& err)
+{
+    const double a = g.a, l = g.l, q = g.q;
+    const double a2 = a * a, l2 = l * l;
+    double A;
+    const double C = sq(a - l) + q;
+    const double D = 2. / 3. * (q + l2 - a2);
+    const double E = 9. / 4. * sq(D) - 12. * a2 * q;
+    const double F = -27. / 4. * (D * D * D) - 108. * a2 * q * D + 108. * sq(C);
+    const double X = sq(F) - 4. * (E * E * E);
+    if (X >= 0) {
+        const double sX = sqrt(X);
+        A = (F > sX ? +1 : -1) * 1. / 3. * pow(fabs(F - sX) / 2., 1. / 3.) +
+            (F > -sX ? +1 : -1) * 1. / 3. * pow(fabs(F + sX) / 2., 1. / 3.);
+    } else {
+        const double sX = sqrt(-X) / 54.;
+        const double Z = sqrt(sq(F / 54.) + sq(sX));
+        const double z = atan2(sX, F / 54.);
+        A = pow(Z, 1. / 3.) * 2. * cos(z / 3.);
+    }
+    const double B = sqrt(A + D);
+    const double w_hi = -A + 2. * D - 4. * C / B;     // discriminant of the pair around +B/2
+    const double w_lo = -A + 2. * D + 4. * C / B;     // discriminant of the pair around -B/2
+    const bool hi_real = (w_hi >= 0.0), lo_real = (w_lo >= 0.0);
+    // csqrt(w + 0i): (sqrt(w), 0) for w >= 0, (0, sqrt(-w)) for w < 0; halves as in `.5*csqrt()`
+    const double h_hi = .5 * sqrt(fabs(w_hi)), h_lo = .5 * sqrt(fabs(w_lo));
+    const double c_hi = +B / 2., c_lo = -B / 2.;
+
+    g.nrr = (hi_real ? 2 : 0) + (lo_real ? 2 : 0);
+    if (hi_real && lo_real) {
+        // four real roots, descending.  Within a pair the "+" root is the larger one.
+        double p0 = c_hi + h_hi, p1 = c_hi - h_hi, p2 = c_lo + h_lo, p3 = c_lo - h_lo;
+        // merge the two ordered pairs (p0>=p1, p2>=p3)
+        double s0 = fmax(p0, p2), t0 = fmin(p0, p2);
+        double s3 = fmin(p1, p3), t3 = fmax(p1, p3);
+        double s1 = fmax(t0, t3), s2 = fmin(t0, t3);
+        g.r1[0] = s0; g.r2[0] = s1; g.r3[0] = s2; g.r4[0] = s3;
+        g.r1[1] = g.r2[1] = g.r3[1] = g.r4[1] = 0.0;
+    } else if (hi_real) {
+        g.r1[0] = c_hi + h_hi; g.r1[1] = 0.0;
+        g.r2[0] = c_hi - h_hi; g.r2[1] = 0.0;
+        g.r3[0] = c_lo; g.r3[1] = +h_lo;
+        g.r4[0] = c_lo; g.r4[1] = -h_lo;
+    } else if (lo_real) {
+        g.r1[0] = c_lo + h_lo; g.r1[1] = 0.0;
+        g.r2[0] = c_lo - h_lo; g.r2[1] = 0.0;
+        g.r3[0] = c_hi; g.r3[1] = +h_hi;
+        g.r4[0] = c_hi; g.r4[1] = -h_hi;
+    } else {
+        g.r1[0] = c_hi; g.r1[1] = +h_hi;
+        g.r2[0] = c_hi; g.r2[1] = -h_hi;
+        g.r3[0] = c_lo; g.r3[1] = +h_lo;
+        g.r4[0] = c_lo; g.r4[1] = -h_lo;
+    }
+
+    if (g.nrr == 4) {
+        g.type = T_RR;
+        if ((r0 < g.r3[0]) || ((r0 > g.r2[0]) && (r0 < g.r1[0]))) { err = GD_E_UNKNOWN; return false; }
+        if (fabs(g.r1[0] - g.r2[0]) < 1e-8) { g.type = T_RR_DBL; err = GD_E_RR_DOUBLE; return false; }
+        if ((r0 >= g.r3[0]) && (r0 <= g.r2[0])) g.type = T_RR_BH;
+    } else if (g.nrr == 2) {
+        g.type = T_RC;
+    } else {
+        g.type = T_CC;
+    }
+
+    if (g.type == T_RR || g.type == T_RR_BH) {
+        const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
+        const double mm = ((r2 - r3) * (r1 - r4)) / ((r2 - r4) * (r1 - r3));
+        const double pre = 2. / sqrt((r1 - r3) * (r2 - r4));
+        if (g.type == T_RR) {
+            g.rp = r1;
+            g.Rpc = pre * inv_sn(sqrt((r2 - r4) / (r1 - r4)), mm);
+        } else {
+            g.rp = r2;
+            g.Rpc = pre * ell_K(mm);
+        }
+    } else if (g.type == T_RC) {
+        const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
+        const double Aq = sqrt(sq(r1 - u) + sq(v));
+        const double Bq = sqrt(sq(r2 - u) + sq(v));
+        const double mm = (sq(Aq + Bq) - sq(r1 - r2)) / (4. * Aq * Bq);
+        g.rp = r1;
+        g.Rpc = 1. / sqrt(Aq * Bq) * inv_cn((Aq - Bq) / (Aq + Bq), mm);
+    } else {
+        const double b1 = g.r1[0], b2 = g.r3[0], a1 = g.r1[1], a2c = g.r3[1];
+        const double Aq = sqrt(sq(b1 - b2) + sq(a1 + a2c));
+        const double Bq = sqrt(sq(b1 - b2) + sq(a1 - a2c));
+        const double g1 = sqrt((4. * sq(a1) - sq(Aq - Bq)) / (sq(Aq + Bq) - 4. * sq(a1)));
+        const double mm = 4. * Aq * Bq / sq(Aq + Bq);
+        g.rp = b1 - a1 * g1;
+        g.Rpc = 2. / (Aq + Bq) * inv_tn(-1. / g1, mm);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// roots of the polar potential  (ref :1110-1184, device branch)
+// ---------------------------------------------------------------------------------------
+S5_DEV bool polar_roots(Geod& g, double m, int& err)
+{
+    const double a = g.a, l = g.l, q = g.q;
+    const double a2 = a * a, l2 = l * l;
+    const double qla = q + l2 - a2;
+    const double X = sqrt(sq(qla) + 4. * q * a2) + qla;
+    g.m2m = X / (a2 + a2);
+    g.m2p = (q + q) / X;
+    if ((g.m2p <= 0.0) || (g.m2p >= 1.0)) { err = GD_E_MUPLUS; return false; }
+    if (q > 0.0) {
+        g.mm = g.m2p / (g.m2p + g.m2m);
+        if ((g.mm < 0.0) || (g.mm >= 1.0)) { err = GD_E_MM; return false; }
+        if (fabs(m) > sqrt(g.m2p)) { err = GD_E_MU0; return false; }
+        g.mK = 1. / sqrt(a2 * (g.m2p + g.m2m));
+    } else if (q < 0.0) {
+        g.mm = (g.m2p + g.m2m) / g.m2p;
+        if ((g.mm < 0.0) || (g.mm >= 1.0)) { err = GD_E_MM; return false; }
+        if ((fabs(m) > sqrt(g.m2p)) || (fabs(m) < sqrt(-g.m2m))) { err = GD_E_MU0; return false; }
+        g.mK = 1. / sqrt(a2 * g.m2p);
+    } else {
+        err = GD_E_Q_RANGE;
+        return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// geodesic from impact parameters at infinity  (ref :42-100).  sin_i / cos_i are sin/cos of the
+// inclination evaluated by the caller (the image kernels take them from the host's libm so that
+// they are the very numbers the reference uses; the batch kernel evaluates them per ray).
+// ---------------------------------------------------------------------------------------
+S5_DEV bool init_inf(double incl, double sin_i, double cos_i, double a, double alpha, double beta,
+                     Geod& g, int& err, GeodCache& cache)
+{
+    cache.valid = false;
+    if ((a < 0.0) || (a > 1. - 1e-6)) { err = GD_E_SPIN; return false; }
+    if ((incl <= 0.0) || (incl >= 1.57079632679)) { err = GD_E_INCL; return false; }
+    if (beta == 0.0) beta = +1e-6;
+
+    g.a = fmax(1e-4, a);
+    g.incl = incl;
+    g.cos_i = cos_i;
+    g.alpha = alpha;
+    g.beta = beta;
+    g.l = -alpha * sin_i;
+    g.q = sq(beta) + sq(cos_i) * (sq(alpha) - sq(a));       // caller's a, not the clamped one
+    if (g.q == 0.0) { err = GD_E_Q_RANGE; return false; }
+
+    if (!radial_roots(g, DBL_MAX, err)) return false;
+    if (!polar_roots(g, g.cos_i, err)) return false;
+
+    // Tpp = 2 mK cn^-1(0|mm) = 2 mK K(mm);  Tip = mK cn^-1(cos_i/sqrt(m2p)|mm)
+    cache.K = ell_K(g.mm);                                   // cn^-1(0|mm) with mm in [0,1)
+    cache.u_i = g.cos_i / sqrt(g.m2p);
+    cache.icn_i = inv_cn(cache.u_i, g.mm);
+    cache.valid = true;
+    g.Tpp = 2. * (g.mK * cache.K);
+    g.Tip = g.mK * cache.icn_i;
+    err = GD_OK;
+    return true;
+}
+
+// position integral from infinity to radius r  (ref :179-263)
+S5_DEV double P_int(const Geod& g, double r, int ppc)
+{
+    if (r == g.rp) return g.Rpc;
+    if (g.type == T_RR || g.type == T_RR_BH) {
+        const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
+        const double mm = ((r2 - r3) * (r1 - r4)) / ((r2 - r4) * (r1 - r3));
+        const double z = (g.type == T_RR) ? sqrt(((r2 - r4) * (r - r1)) / ((r1 - r4) * (r - r2)))
+                                          : sqrt((r1 - r3) / (r2 - r3) * (r2 - r) / (r1 - r));
+        const double R = 2. / sqrt((r1 - r3) * (r2 - r4)) * inv_sn(z, mm);
+        return (ppc) ? g.Rpc + R : g.Rpc - R;
+    }
+    if (g.type == T_RC) {
+        const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
+        const double A = sqrt(sq(r1 - u) + sq(v));
+        const double B = sqrt(sq(r2 - u) + sq(v));
+        const double mm = (sq(A + B) - sq(r1 - r2)) / (4. * A * B);
+        const double R = 1. / sqrt(A * B) *
+                         inv_cn(((A - B) * r + r1 * B - r2 * A) / ((A + B) * r - r1 * B - r2 * A), mm);
+        return g.Rpc - R;
+    }
+    if (g.type == T_CC) {
+        const double b1 = g.r1[0], b2 = g.r3[0], a1 = g.r1[1], a2c = g.r3[1];
+        const double A = sqrt(sq(b1 - b2) + sq(a1 + a2c));
+        const double B = sqrt(sq(b1 - b2) + sq(a1 - a2c));
+        const double g1 = sqrt((4. * sq(a1) - sq(A - B)) / (sq(A + B) - 4. * sq(a1)));
+        const double mm = 4. * A * B / sq(A + B);
+        const double R = 2. / (A + B) * inv_tn((r - b1 + a1 * g1) / (a1 + b1 * g1 - g1 * r), mm);
+        return g.Rpc - R;
+    }
+    return NAN;
+}
+
+// r(P)  (ref :291-357)
+S5_DEV double position_rad(const Geod& g, double P)
+{
+    if ((P <= 0.0) || (P >= 2. * g.Rpc)) return NAN;
+    if (P == g.Rpc) return g.rp;
+    if (g.type == T_RR) {
+        const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
+        const double m4 = ((r2 - r3) * (r1 - r4)) / ((r2 - r4) * (r1 - r3));
+        const double x4 = 0.5 * fabs(P - g.Rpc) * sqrt((r2 - r4) * (r1 - r3));
+        const double sn = jac_sn(x4, m4);
+        const double sn2 = sn * sn;
+        return (r1 * (r2 - r4) - r2 * (r1 - r4) * sn2) / (r2 - r4 - (r1 - r4) * sn2);
+    }
+    if (g.type == T_RC) {
+        if (P > g.Rpc) return NAN;
+        const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
+        const double A = sqrt(sq(r1 - u) + sq(v));
+        const double B = sqrt(sq(r2 - u) + sq(v));
+        const double m2 = (sq(A + B) - sq(r1 - r2)) / (4. * A * B);
+        const double cn = jac_cn(sqrt(A * B) * (g.Rpc - P), m2);
+        return (r2 * A - r1 * B - (r2 * A + r1 * B) * cn) / ((A - B) - (A + B) * cn);
+    }
+    return NAN;
+}
+
+// sign of d(cos theta)/dP at P and the start T of the polar half-period containing P (ref :737-781)
+S5_DEV double polar_phase(const Geod& g, double P, double& T)
+{
+    double sdm = (g.beta >= 0.0) ? +1.0 : -1.0;
+    T = (sdm > 0.0) ? -(g.Tpp - g.Tip) : -(g.Tip);
+    // bounded walk: each turn advances T by Tpp > 0; NaN comparisons stop it at once
+    for (int it = 0; it < 4096 && (P > T + g.Tpp); ++it) { T += g.Tpp; sdm = -sdm; }
+    return sdm;
+}
+
+S5_DEV bool escapes(const Geod& g) { return g.type == T_RR || g.type == T_RC || g.type == T_CC; }
+
+S5_DEV double position_pol(const Geod& g, double P)            // ref :363-407
+{
+    if (!escapes(g)) return NAN;
+    double T;
+    const double sdm = polar_phase(g, P, T);
+    return -sdm * pol_inverse(g, P - T);
+}
+
+S5_DEV double dm_sign(const Geod& g, double P)                 // ref :737-781
+{
+    if (!escapes(g)) return NAN;
+    double T;
+    return polar_phase(g, P, T);
+}
+
+S5_DEV void momentum(const Geod& g, double P, double r, double m, double k[4])   // ref :787-840
+{
+    if ((r == 0.0) && (m == 0.0)) {
+        r = position_rad(g, P);
+        m = position_pol(g, P);
+    }
+    if (escapes(g)) {
+        const double dm = dm_sign(g, P);
+        photon_momentum(g.a, r, m, g.l, g.q, (P < g.Rpc ? -1. : +1.), dm, k);
+    } else if (g.type == T_RR_DBL || g.type == T_RR_BH) {
+        k[0] = k[1] = k[2] = k[3] = NAN;
+    }
+}
+
+// P at the order-th crossing of the equatorial plane  (ref :846-885).  With a valid cache the two
+// elliptic evaluations are reused from init (see header comment).
+S5_DEV double midplane_crossing(const Geod& g, int order, const GeodCache& cache)
+{
+    if (g.q <= 0.0) return NAN;
+    double u = g.cos_i / sqrt(g.m2p);
+    if (u < -1.0 - 1e-4) return NAN;                           // slack clamp, ref src/sim5math.c:50-58
+    if (u > +1.0 + 1e-4) return NAN;
+    if (u < -1.0) u = -1.0;
+    if (u > +1.0) u = +1.0;
+    const double K = cache.valid ? cache.K : ell_K(g.mm);
+    double pos;
+    if (g.beta > 0.0 || g.beta < 0.0) {
+        const double icn = (cache.valid && u == cache.u_i) ? cache.icn_i : inv_cn(u, g.mm);
+        pos = (g.beta > 0.0) ? g.mK * ((2. * (double)order + 1.) * K + icn)
+                             : g.mK * ((2. * (double)order + 1.) * K - icn);
+    } else {
+        pos = g.mK * ((2. * (double)order + 1.) * K);
+    }
+    if (pos > 2. * g.Rpc) pos = NAN;
+    return pos;
+}
+
+// init_src  (ref :106-173)
+S5_DEV bool init_src(double a, double r, double m, const double k[4], int ppc, Geod& g, int& err)
+{
+    double l, q;
+    photon_motion_constants(a, r, m, k, l, q);
+    g.a = fmax(1e-8, a);
+    g.l = l;
+    g.q = q;
+    g.cos_i = g.alpha = g.beta = NAN;
+    if (!radial_roots(g, r, err)) return false;
+    if (!polar_roots(g, m, err)) return false;
+    if (r > g.rp) {
+        const double Tmp = pol_integral(g, m);
+        const double Tpp = 2. * pol_integral(g, 0.0);
+        double T = P_int(g, r, ppc);
+        double sdm = (k[2] < 0.0) ? +1.0 : -1.0;
+        T += (sdm > 0.0) ? Tpp - Tmp : Tmp;
+        for (int it = 0; it < 4096 && (T > Tpp); ++it) { T -= Tpp; sdm = -sdm; }
+        g.cos_i = -sdm * pol_inverse(g, T);
+        g.incl = acos(g.cos_i);
+        g.alpha = -g.l / sqrt(1.0 - sq(g.cos_i));
+        g.beta = -sdm * sqrt(g.q - sq(g.cos_i) * (sq(g.alpha) - sq(g.a)));
+    }
+    g.Tpp = 2. * pol_integral(g, 0.0);
+    g.Tip = pol_integral(g, g.cos_i);
+    err = GD_OK;
+    return true;
+}
+
+// one call of geodesic_follow  (ref :891-925)
+S5_DEV void follow(const Geod& g, double step, double& P, double& r, double& m, int& status)
+{
+    const double cap = 5e-2;
+    for (int it = 0; it < 100000; ++it) {
+        const double truestep = step / fabs(step) * fmin(fabs(step), cap * sqrt(r));
+        P = P + truestep / (sq(r) + sq(g.a * m));
+        r = position_rad(g, P);
+        m = position_pol(g, P);
+        if (r < 1.01 * r_horizon(g.a)) { status = 0; return; }
+        if ((P < 0.0) || (P > 2. * g.Rpc)) { status = 0; return; }
+        step -= truestep;
+        if (!(fabs(step) > 1e-5)) break;
+    }
+    status = 1;
+}
+
+} // namespace s5

@@ -1,0 +1,45 @@
+"""Thin access to the recipe drivers of oracle/cpu_driver.c (TEST INFRASTRUCTURE ONLY)."""
+import ctypes as C
+import math
+
+import numpy as np
+
+import oraclelib as ol
+
+
+def _driver():
+    if not __import__("os").path.exists(ol.DRIVER_SO):
+        ol.build_oracle()
+    drv = C.CDLL(ol.DRIVER_SO)
+    VP, D, I = C.c_void_p, C.c_double, C.c_int
+    drv.cpu_polarized_rays.argtypes = [C.c_char_p, C.c_char_p, D, D, D, I, VP, VP, VP, VP, VP, VP]
+    drv.cpu_polarized_rays.restype = I
+    drv.cpu_verlet_trace.argtypes = [C.c_char_p, C.c_char_p, D, D, D, D, D, D, I, D, D, D, D, I, VP, VP, VP, VP]
+    drv.cpu_verlet_trace.restype = I
+    return drv
+
+
+def verlet_traces(lib, prefix, cases, nmax, dl_max=1e9, max_error=1e-2, r_in_fac=1.05, r_out_fac=1.01):
+    """cases: (a, inc_rad, alpha, beta, r0, precision, options).  Returns [(n, trace, x0, k0, carter)]."""
+    drv = _driver()
+    out = []
+    for (a, inc, al, be, r0, prec, opt) in cases:
+        tr = np.zeros((nmax, 11)); xs = np.zeros(4); ks = np.zeros(4); car = C.c_double(float("nan"))
+        rbh = 1.0 + math.sqrt(1.0 - a * a)
+        n = drv.cpu_verlet_trace(lib.encode(), prefix.encode(), a, inc, al, be, r0, prec, int(opt), dl_max,
+                                 r_in_fac * rbh, r_out_fac * r0, max_error, nmax, tr.ctypes.data,
+                                 xs.ctypes.data, ks.ctypes.data, C.byref(car))
+        out.append((n, tr, xs, ks, car.value))
+    return out
+
+
+def polarized_rays(lib, prefix, a, inc_deg, alpha, beta, rms=-1.0):
+    drv = _driver()
+    al = np.ascontiguousarray(alpha, dtype=np.float64); be = np.ascontiguousarray(beta, dtype=np.float64)
+    m = al.size
+    chi = np.zeros(m); r = np.zeros(m); g = np.zeros(m); wp = np.zeros((m, 2))
+    rc = drv.cpu_polarized_rays(lib.encode(), prefix.encode(), a, inc_deg / 180.0 * math.pi, rms, m,
+                                al.ctypes.data, be.ctypes.data, chi.ctypes.data, r.ctypes.data,
+                                g.ctypes.data, wp.ctypes.data)
+    assert rc == 0
+    return chi, r, g, wp

@@ -1,0 +1,232 @@
+"""The CPU restatement (oracle/) against the golden vectors captured from the unmodified
+reference (oracle/gen_golden.py).  This is what pins the oracle; it runs without a GPU.
+
+Both sides were produced by the same compiler family on the same libm without FMA contraction,
+so agreement is expected to the last bit; the assertions allow 4 ulp so that a different glibc
+on another box does not turn a libm difference into a failure, and report exact-match counts.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oraclelib as ol
+
+ULP4 = 4 * np.finfo(np.float64).eps
+
+
+def close(a, b, rtol=ULP4, what=""):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, what
+    both_nan = np.isnan(a) & np.isnan(b)
+    both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    ok = both_nan | both_inf | (np.abs(a - b) <= rtol * np.maximum(np.abs(a), np.abs(b))) | (a == b)
+    assert ok.all(), "%s: %d/%d differ, worst rel %.3e" % (
+        what, (~ok).sum(), ok.size,
+        np.nanmax(np.abs(a - b)[~ok] / np.maximum(np.abs(b[~ok]), 1e-300)))
+
+
+def test_carlson_and_jacobi(oracle, golden):
+    g = golden("kat_elliptic.npz")
+    close([oracle.rf(*v) for v in zip(g["c_x"], g["c_y"], g["c_z"])], g["rf"], what="rf")
+    close([oracle.rd(*v) for v in zip(g["c_x"], g["c_y"], g["rd_z"])], g["rd"], what="rd")
+    close([oracle.rc(*v) for v in zip(g["rc_x"], g["rc_y"])], g["rc"], what="rc")
+    close([oracle.rj(*v) for v in zip(g["rj_x"], g["rj_y"], g["rj_z"], g["c_p"])], g["rj"], what="rj")
+    close([oracle.elliptic_k(v) for v in g["k_m"]], g["elliptic_k"], what="elliptic_k")
+    close([oracle.jacobi_isn(*v) for v in zip(g["isn_z"], g["k_m"])], g["jacobi_isn"], what="isn")
+    close([oracle.jacobi_icn(*v) for v in zip(g["icn_z"], g["k_m"])], g["jacobi_icn"], what="icn")
+    close([oracle.jacobi_itn(*v) for v in zip(g["itn_z"], g["k_m"])], g["jacobi_itn"], what="itn")
+    s, c, d = C.c_double(), C.c_double(), C.c_double()
+    sn, cn, dn = [], [], []
+    for u, m in zip(g["sn_u"], g["k_m"]):
+        oracle.jacobi_sncndn(u, m, C.byref(s), C.byref(c), C.byref(d))
+        sn.append(s.value); cn.append(c.value); dn.append(d.value)
+    close(sn, g["sn"], what="sn"); close(cn, g["cn"], what="cn"); close(dn, g["dn"], what="dn")
+
+
+GEOD_F64 = ["a", "alpha", "beta", "incl", "cos_i", "l", "q", "m2p", "m2m", "mm", "mK", "rp", "Rpc", "Tpp", "Tip"]
+
+
+def test_geodesic_records(oracle, golden):
+    g = golden("kat_geodesic.npz")
+    n = len(g["inp"])
+    exact = 0
+    for i in range(n):
+        inc, a, al, be = g["inp"][i]
+        gd = ol.Geodesic(); C.memset(C.byref(gd), 0, 240)
+        e = C.c_int(-1)
+        ok = oracle.geodesic_init_inf(inc, a, al, be, C.byref(gd), C.byref(e))
+        assert ok == g["ok"][i] and e.value == g["err"][i], (i, ok, e.value)
+        ref = ol.Geodesic.from_buffer_copy(g["dump"][i].tobytes())
+        if ok:
+            assert (gd.nrr, gd.type) == (ref.nrr, ref.type), i
+            for f in GEOD_F64:
+                close(getattr(gd, f), getattr(ref, f), what="geodesic.%s[%d]" % (f, i))
+            for f in ("r1", "r2", "r3", "r4"):
+                close([getattr(gd, f).re, getattr(gd, f).im], [getattr(ref, f).re, getattr(ref, f).im], what=f)
+            exact += ol.struct_bytes(gd)[:200] == ol.struct_bytes(ref)[:200]
+            close(oracle.geodesic_find_midplane_crossing(C.byref(gd), 0), g["P0"][i], what="P0")
+            close(oracle.geodesic_find_midplane_crossing(C.byref(gd), 1), g["P1"][i], what="P1")
+            if not math.isnan(g["P0"][i]):
+                close(oracle.geodesic_position_rad(C.byref(gd), g["P0"][i]), g["r0"][i], what="r0")
+            if not math.isnan(g["P1"][i]):
+                close(oracle.geodesic_position_rad(C.byref(gd), g["P1"][i]), g["r1"][i], what="r1")
+            if not math.isnan(g["Pq0"][i]):
+                close(oracle.geodesic_P_int(C.byref(gd), g["rq"][i], 0), g["Pq0"][i], what="P_int0")
+            if not math.isnan(g["Pq1"][i]):
+                close(oracle.geodesic_P_int(C.byref(gd), g["rq"][i], 1), g["Pq1"][i], what="P_int1")
+            if not math.isnan(g["Pm"][i]):
+                close(oracle.geodesic_position_pol(C.byref(gd), g["Pm"][i]), g["mpol"][i], what="pol")
+                close(oracle.geodesic_dm_sign(C.byref(gd), g["Pm"][i]), g["dms"][i], what="dm_sign")
+                k = ol.D4()
+                oracle.geodesic_momentum(C.byref(gd), g["Pm"][i], g["rmom"][i], g["mpol"][i], k)
+                close(list(k), g["kmom"][i], what="momentum")
+    nok = int(g["ok"].sum())
+    assert exact == nok, "only %d of %d records are byte-identical with the reference" % (exact, nok)
+
+
+def test_kerr(oracle, golden):
+    g = golden("kat_kerr.npz")
+    n = len(g["a"])
+    for i in range(n):
+        a, r, m = g["a"][i], g["r"][i], g["m"][i]
+        mt = ol.Metric(); mc = ol.Metric(); t = ol.Tetrad(); G = ol.G444()
+        oracle.kerr_metric(a, r, m, C.byref(mt))
+        close(np.frombuffer(ol.struct_bytes(mt), np.float64), g["metric"][i], what="metric")
+        oracle.kerr_metric_contravariant(a, r, m, C.byref(mc))
+        close(np.frombuffer(ol.struct_bytes(mc), np.float64), g["metric_contra"][i], what="metric_contra")
+        oracle.kerr_connection(a, r, m, G)
+        close(np.frombuffer(bytes(memoryview(G)), np.float64), g["connection"][i], what="connection")
+        oracle.tetrad_zamo(C.byref(mt), C.byref(t))
+        close(np.frombuffer(ol.struct_bytes(t), np.float64), g["zamo"][i], what="zamo")
+        oracle.tetrad_azimuthal(C.byref(mt), g["Omega"][i], C.byref(t))
+        close(np.frombuffer(ol.struct_bytes(t), np.float64), g["azim"][i], what="azimuthal")
+        oracle.tetrad_surface(C.byref(mt), g["Omega"][i], g["V"][i], g["dhdr"][i], C.byref(t))
+        close(np.frombuffer(ol.struct_bytes(t), np.float64), g["surf"][i], what="surface")
+        vi = ol.D4(*g["vin"][i]); vo = ol.D4()
+        oracle.bl2on(vi, vo, C.byref(t)); close(list(vo), g["v_on"][i], what="bl2on")
+        oracle.on2bl(vi, vo, C.byref(t)); close(list(vo), g["v_bl"][i], what="on2bl")
+        k = ol.D4()
+        oracle.photon_momentum(a, r, m, g["l"][i], g["q"][i], g["r_sign"][i], g["m_sign"][i], k)
+        close(list(k), g["kph"][i], what="photon_momentum")
+        if not math.isnan(g["kph"][i, 0]):
+            L, Q = C.c_double(), C.c_double()
+            oracle.photon_motion_constants(a, r, m, k, C.byref(L), C.byref(Q))
+            close([L.value, Q.value], [g["L"][i], g["Q"][i]], what="motion constants")
+            close(oracle.photon_carter_const(k, C.byref(mt)), g["Qcarter"][i], what="carter")
+        close(oracle.gfactorK(g["gK_r"][i], a, g["gK_l"][i]), g["gK"][i], what="gfactorK")
+        close(oracle.OmegaK(r, a), g["OmegaK"][i], what="OmegaK")
+        close(oracle.ellK(r, a), g["ellK"][i], what="ellK")
+    close([oracle.r_ms(a) for a in g["r_ms_a"]], g["r_ms"], rtol=0, what="r_ms")
+    close([oracle.r_bh(a) for a in g["r_ms_a"]], g["r_bh"], rtol=0, what="r_bh")
+
+
+def test_disk_nt(oracle, golden):
+    g = golden("kat_disk.npz")
+    for j, a in enumerate(g["spins"]):
+        oracle.disk_nt_setup(10.0, a, 0.1, 0.1)
+        close(oracle.disk_nt_r_min(), g["rmin_%d" % j][0], rtol=0, what="r_min")
+        close([oracle.disk_nt_flux(r) for r in g["r_%d" % j]], g["flux_%d" % j], what="flux a=%g" % a)
+        close([oracle.disk_nt_ell(r) for r in g["r_%d" % j]], g["ell_%d" % j], what="ell")
+        # the band rms <= r <= rms_disk carries zero flux (float-rounded inner edge)
+        assert (g["flux_%d" % j][g["r_%d" % j] <= g["rmin_%d" % j][0] - 2e-3] == 0).all()
+    oracle.disk_nt_setup(3.7e6, 0.7, 0.31, 0.05)
+    close([oracle.disk_nt_flux(r) for r in g["r_x"]], g["flux_x"], what="flux other M, mdot")
+
+
+def test_polarization_and_blackbody(oracle, golden):
+    g = golden("kat_polar.npz")
+    for i in range(len(g["a"])):
+        mt = ol.Metric.from_buffer_copy(g["metric"][i].tobytes())
+        k = ol.D4(*g["k"][i]); f = ol.D4(*g["f"][i])
+        w = oracle.polarization_constant(k, f, C.byref(mt))
+        close([w.re, w.im], g["wp"][i], what="polarization_constant")
+        fo = ol.D4()
+        oracle.polarization_vector(k, ol.Cplx(*g["wp"][i]), C.byref(mt), fo)
+        close(list(fo), g["f_back"][i], what="polarization_vector")
+        w = oracle.polarization_constant_infinity(g["a"][i], g["alpha"][i], g["beta"][i], g["incl"][i])
+        close([w.re, w.im], g["wp_inf"][i], what="constant_infinity")
+        close(oracle.polarization_angle_rotation(g["a"][i], g["incl"][i], g["alpha"][i], g["beta"][i],
+                                                 ol.Cplx(*g["wp"][i])), g["rot"][i], what="angle_rotation")
+        close(oracle.blackbody_Iv(g["T"][i], g["hardf"][i], g["cos_mu"][i], g["E"][i]), g["Iv"][i], what="Iv")
+
+
+def test_raytrace_api(oracle, golden):
+    g = golden("kat_raytrace_api.npz")
+    for i in range(len(g["a"])):
+        x = ol.D4(*g["x"][i]); k = ol.D4(*g["k"][i])
+        rtd = ol.RaytraceData(); C.memset(C.byref(rtd), 0, 144)
+        oracle.raytrace_prepare(g["a"][i], x, k, g["precision"][i], int(g["options"][i]), C.byref(rtd))
+        ref0 = ol.RaytraceData.from_buffer_copy(g["rtd_prepared"][i].tobytes())
+        assert (rtd.opt_gr, rtd.pass_) == (ref0.opt_gr, ref0.pass_)
+        close([rtd.step_epsilon, rtd.E, rtd.Q, rtd.kt] + list(rtd.dk),
+              [ref0.step_epsilon, ref0.E, ref0.Q, ref0.kt] + list(ref0.dk), what="prepare")
+        s = C.c_double(g["stepcap"][i])
+        oracle.raytrace(x, k, C.byref(s), C.byref(rtd))
+        ref1 = ol.RaytraceData.from_buffer_copy(g["rtd_stepped"][i].tobytes())
+        close(list(x), g["x1"][i], what="x after step"); close(list(k), g["k1"][i], what="k after step")
+        close(s.value, g["step"][i], what="step taken")
+        assert rtd.pass_ == ref1.pass_
+        close([rtd.kt, rtd.error] + list(rtd.dk), [ref1.kt, ref1.error] + list(ref1.dk), what="rtd after step")
+        close(oracle.raytrace_error(x, k, C.byref(rtd)), g["carter"][i], rtol=1e-9, what="carter error")
+
+
+def test_raytrace_sequences(oracle, golden):
+    """Whole step sequences: same number of steps, same states at the sampled steps."""
+    import gen_golden_access as gga
+    g = golden("kat_raytrace.npz")
+    cases = g["cases"]
+    res = gga.verlet_traces(ol.ORACLE_SO, "orc_", [tuple(c[:6]) + (int(c[6]),) for c in cases], 6000)
+    for i, (n, tr, xs, ks, car) in enumerate(res):
+        assert n == int(g["n_%d" % i][0]), "ray %d: %d steps, reference %d" % (i, n, g["n_%d" % i][0])
+        close(xs, g["x0_%d" % i], what="x start"); close(ks, g["k0_%d" % i], what="k start")
+        close(tr[g["idx_%d" % i]], g["tr_%d" % i], what="trace %d" % i)
+        close(car, g["carter_%d" % i][0], rtol=1e-9, what="carter")
+
+
+IMAGES = [("img_c2_1024_a0998_i70.npz", 8), ("img_c3_2048_a09_i70.npz", 16)]
+
+
+def test_image_c1_complete(golden):
+    g = golden("img_c1_64_a0_i60.npz")
+    o = ol.cpu_disk_image("port", 64, 64, 0.0, 60.0, nthreads=1, full=True)
+    for k in ("cls", "gtype", "image_f", "image_g"):
+        assert np.array_equal(o[k], g[k]), k
+    for k in ("r", "g", "flux"):
+        close(o[k], g[k], what=k)
+    # the known answers of BASELINE.md for this configuration
+    assert np.bincount(g["cls"].ravel(), minlength=6).tolist() == [0, 0, 3510, 184, 34, 368]
+
+
+@pytest.mark.parametrize("name,threads", IMAGES)
+def test_image_classes_and_samples(golden, name, threads):
+    g = golden(name)
+    n, a, inc, dec = int(g["n"][0]), float(g["a"][0]), float(g["inc_deg"][0]), int(g["dec"][0])
+    o = ol.cpu_disk_image("port", n, n, a, inc, nthreads=threads, full=True)
+    assert np.array_equal(o["cls"], g["cls"]), "class map differs in %d pixels" % (o["cls"] != g["cls"]).sum()
+    sl = (slice(dec // 2, None, dec), slice(dec // 2, None, dec))
+    close(o["r"][sl], g["d_r"], what="r"); close(o["g"][sl], g["d_g"], what="g"); close(o["flux"][sl], g["d_flux"], what="F")
+    assert np.array_equal(o["image_f"][sl], g["d_image_f"]) and np.array_equal(o["image_g"][sl], g["d_image_g"])
+    close(o["g"].sum(dtype=np.float64), g["sum_g"][0], rtol=1e-12, what="sum g")
+    close((o["flux"] * o["g"] ** 4).sum(dtype=np.float64), g["sum_fg4"][0], rtol=1e-12, what="sum F g^4")
+
+
+def test_image_headline_rows(golden):
+    """4096^2 headline image: a band of rows through the shadow (the full map is the GPU test's job)."""
+    g = golden("img_head_4096_a0998_i70.npz")
+    y0, y1 = 2016, 2080
+    o = ol.cpu_disk_image("port", 4096, 4096, 0.998, 70.0, y0=y0, y1=y1, nthreads=8, full=False)
+    assert np.array_equal(o["cls"], g["cls"][y0:y1])
+    assert g["counts"].tolist() == [0, 74725, 15865362, 371216, 0, 465913]
+    assert g["type_counts"].tolist() == [13054020, 3713076, 10120, 0]
+
+
+def test_polarized_recipe(golden):
+    import gen_golden_access as gga
+    g = golden("img_c3_polarized.npz")
+    chi, r, gg, wp = gga.polarized_rays(ol.ORACLE_SO, "orc_", float(g["a"][0]), float(g["inc_deg"][0]),
+                                        g["alpha"], g["beta"])
+    assert np.array_equal(np.isnan(chi), np.isnan(g["chi"]))
+    close(chi, g["chi"], rtol=1e-13, what="chi"); close(r, g["r"], what="r"); close(gg, g["g"], what="g")
+    close(wp, g["wp"], rtol=1e-12, what="kappa")
