@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- null geodesics per second on the headline workload of BASELINE.json:
+a 4096 x 4096 thin-disk image of a Kerr black hole (a = 0.998, i = 70 deg), elliptic-integral
+path, one GPU lane per ray (hand-written HIP, sim5_amd/csrc), through the C-ABI of
+include/sim5gpu.h.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step is one complete image.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
+the SAME image is sharded by 64-row stripes over the ranks (sim5_amd/sharding.py) and the finished
+tiles are gathered to rank 0 by ONE RCCL gather per step, inside the timed region: total work is
+fixed, so "scaling" is "strong" and `value` = 4096*4096*K / max-over-ranks time.
+
+Rank 0 prints one JSON line.  At N = 1 it also carries
+  roofline:     FP64-VALU roofline of the image kernel.  achieved = W_ell (1.3e3 algorithmic FP64
+                operations per ray) x rays per launch / mean kernel time measured
+                with HIP events on the launch stream; peak = 78.6 TFLOP/s FP64 vector (256 CU x 128
+                FLOP/clk x 2.4 GHz).  The path is scalar ODE/special-function work: no MFMA, and HBM
+                traffic is 8 B/ray of output (reported next to it as hbm_*).
+  cpu_baseline: the unmodified reference (oracle/_ref/libsim5ref.so, built from the reference
+                sources in the build container; falls back to our C port when absent) timed on this
+                box's host cores over a bounded row sample of the same image.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NX = NY = 4096
+SPIN, INCL_DEG = 0.998, 70.0
+W_ELL = 1.3e3                     # algorithmic FP64 ops per elliptic thin-disk ray
+PEAK_FP64_VALU_TFLOPS = 78.6      # 256 CU x 128 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBPS = 8000.0
+
+
+def cpu_baseline(budget_s=12.0):
+    """Reference (or port) on the host cores over a bounded sample of the headline image."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as ol
+    kind = "reference" if ol.have_reference() else "port"
+    cores = os.cpu_count() or 1
+    # calibrate on 1/128 of the rows, then size the sample for ~budget_s of wall time
+    cal = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=cores, full=False)
+    rate = cal["rays"] / max(cal["seconds"], 1e-6)
+    rows = int(min(NY, max(32, budget_s * rate / NX)))
+    stride = max(1, NY // rows)
+    run = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=stride // 2, ystride=stride, nthreads=cores, full=False)
+    one = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=1, full=False)
+    return {
+        "value": run["rays"] / run["seconds"], "unit": "null geodesics/s", "cores": cores, "kind": kind,
+        "sample": "every %d-th row of the %dx%d image (%d rays), %d threads, %.1f s wall" % (
+            stride, NX, NY, run["rays"], cores, run["seconds"]),
+        "single_thread_value": one["rays"] / one["seconds"],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    from sim5_amd.build import build
+    if rank == 0:
+        build()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    import sim5_amd.capi as capi            # raises if libsim5gpu.so is missing
+    from sim5_amd import sharding
+    capi.set_device(local_rank)
+
+    dev = torch.device("cuda", local_rank)
+    stripes = sharding.stripes_for_rank(NY, rank, world)
+    rows_max = sharding.max_local_rows(NY, world)
+    # one buffer, two planes (F g^4 | g), tile-local rows: a single contiguous gather payload
+    tile = torch.zeros((2, rows_max, NX), dtype=torch.float32, device=dev)
+    gathered = [torch.zeros_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+    inc = INCL_DEG / 180.0 * math.pi
+    descs = []
+    off = 0
+    for (y0, y1) in stripes:
+        d = capi.image_desc(NX, NY, SPIN, inc, y0=y0, y1=y1)
+        descs.append((d, tile[0, off].data_ptr(), tile[1, off].data_ptr()))
+        off += y1 - y0
+    if world == 1:
+        # one launch covers the whole image
+        descs = [(capi.image_desc(NX, NY, SPIN, inc), tile[0].data_ptr(), tile[1].data_ptr())]
+
+    def step():
+        for (d, pf, pg) in descs:
+            capi.disk_image_device(d, pf, pg, stream=stream)
+        if world > 1:
+            dist.gather(tile, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(capi.Event(), capi.Event()) for _ in range(args.steps)] if world == 1 else None
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if ev:
+            ev[i][0].record(stream)
+        step()
+        if ev:
+            ev[i][1].record(stream)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    rays = NX * NY
+    value = rays * args.steps / dt
+    # sanity: the image that came out is the Kerr disk (known hit count of the reference)
+    img = tile if world == 1 else sharding.assemble(gathered, NY, world)
+    hits = int((img[1, :NY] > 0).sum().item())
+    out = {
+        "metric": "null geodesics/sec, 4096x4096 Kerr disk image (a=0.998, i=70)",
+        "value": value, "unit": "null geodesics/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "4096x4096 thin-disk image, a=0.998, i=70deg, elliptic-integral path, "
+                               "g-factor + Novikov-Thorne flux (BASELINE.json headline / configs[1] at 4096^2)",
+                   "rays_per_step": rays, "parallelism": "row-stripe x%d + 1 RCCL gather" % world if world > 1 else "1 GPU",
+                   "disk_hits": hits, "disk_hits_reference": 15865362},
+    }
+    if world == 1:
+        kms = [a.elapsed_ms(b) for (a, b) in ev]
+        kavg = sum(kms) / len(kms)
+        achieved = rays * W_ELL / (kavg * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+            "kernel": "disk_image_grid_kernel", "kernel_ms_avg": kavg, "algorithmic_flops_per_ray": W_ELL,
+            "hbm_algorithmic_bytes_per_launch": rays * 8,
+            "hbm_achieved_GBps": rays * 8 / (kavg * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+            "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output",
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                       # the baseline is a report, never a blocker
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

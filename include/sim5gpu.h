@@ -112,6 +112,11 @@ int         sim5gpu_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int         sim5gpu_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int         sim5gpu_memset(void *dst, int value, size_t bytes);
 int         sim5gpu_synchronize(void *stream);     /* stream == NULL: default stream  */
+/* HIP events on a caller stream, for timing launches where they are issued (bench.py) */
+int         sim5gpu_event_create(void **event);
+int         sim5gpu_event_record(void *event, void *stream);
+int         sim5gpu_event_elapsed_ms(void *start, void *stop, float *ms);  /* waits for `stop` */
+int         sim5gpu_event_destroy(void *event);
 
 /* ==================================================================================== */
 /* (1) batch forms of the SIM5 per-ray API (HOST arrays, synchronous)                   */

@@ -137,6 +137,30 @@ def synchronize(stream=None):
     _check(_lib.sim5gpu_synchronize(VP(stream or 0)), "sim5gpu_synchronize")
 
 
+class Event:
+    """HIP event recorded on the stream the kernels are launched on."""
+
+    def __init__(self):
+        p = VP()
+        _check(_lib.sim5gpu_event_create(C.byref(p)), "sim5gpu_event_create")
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        _check(_lib.sim5gpu_event_record(VP(self.ptr), VP(stream or 0)), "sim5gpu_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0.0)
+        _check(_lib.sim5gpu_event_elapsed_ms(VP(self.ptr), VP(stop.ptr), C.byref(ms)), "sim5gpu_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.sim5gpu_event_destroy(VP(self.ptr))
+        except Exception:
+            pass
+
+
 # ---- raw device memory (for hosts that do not use torch) -----------------------------------
 class DeviceBuffer:
     def __init__(self, nbytes):

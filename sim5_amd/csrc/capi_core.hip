@@ -155,6 +155,38 @@ int sim5gpu_synchronize(void* stream)
     return SIM5GPU_OK;
 }
 
+int sim5gpu_event_create(void** event)
+{
+    if (!event) return SIM5GPU_E_ARG;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    hipEvent_t e;
+    S5_HIP(hipEventCreate(&e));
+    *event = (void*)e;
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_event_record(void* event, void* stream)
+{
+    if (!event) return SIM5GPU_E_ARG;
+    S5_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    if (!start || !stop || !ms) return SIM5GPU_E_ARG;
+    S5_HIP(hipEventSynchronize((hipEvent_t)stop));
+    S5_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_event_destroy(void* event)
+{
+    if (!event) return SIM5GPU_OK;
+    S5_HIP(hipEventDestroy((hipEvent_t)event));
+    return SIM5GPU_OK;
+}
+
 // ---- disk model (process-global, like SIM5) -------------------------------------------------
 int sim5gpu_disk_nt_setup(double M, double a, double mdot, double alpha, int options)
 {

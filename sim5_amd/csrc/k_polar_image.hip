@@ -11,7 +11,7 @@
 //   I = F g^4,  Q = delta I cos 2chi,  U = delta I sin 2chi
 // The reference has no end-to-end caller for this chain (its unit test only checks that kappa is
 // conserved, src/sim5unittests.c:113-140); the chain is assembled from its public routines and is
-// checked against the same chain evaluated with the reference library (oracle/cpu_driver.c).
+// checked (tests/) against the same chain evaluated with the reference library.
 #include "s5_disk.hpp"
 #include "s5_polar.hpp"
 #include "kernels.hpp"

@@ -1,0 +1,149 @@
+"""Thin-disk image kernels on the GPU, through the C-ABI, against the golden vectors of the
+reference and against the CPU oracle.  Bar (BASELINE.json north_star): hit/miss classes
+bit-exact, g / flux within 1e-6 relative."""
+import math
+
+import numpy as np
+import pytest
+
+import oraclelib as ol
+from gpuutil import REL, assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+HIT = (2, 4)
+
+
+def run(capi, n, a, inc_deg, full=True, y0=0, y1=None, **kw):
+    d = capi.image_desc(n, n, a, inc_deg / 180.0 * math.pi, y0=y0, y1=y1, **kw)
+    return capi.disk_image(d, full=full)
+
+
+def flux_floor(flux):
+    # F is a difference of O(1) terms that cancels towards the inner edge (ref src/sim5disk-nt.c:129-135):
+    # an absolute error of a few ulp of those terms is the floor any libm can reach there.
+    return 1e-9 * float(np.nanmax(flux))
+
+
+def test_c1_complete(capi, golden):
+    g = golden("img_c1_64_a0_i60.npz")
+    o = run(capi, 64, 0.0, 60.0)
+    assert np.array_equal(o["cls"], g["cls"]), "classes differ: %s" % np.argwhere(o["cls"] != g["cls"])[:5]
+    assert np.array_equal(o["gtype"], g["gtype"])
+    hit = np.isin(g["cls"], HIT)
+    assert_close(o["r"], g["r"], what="r")
+    assert_close(o["g"], g["g"], what="g")
+    assert_close(o["flux"], g["flux"], floor=flux_floor(g["flux"]), what="flux")
+    assert_close(o["image_g"], g["image_g"], what="image_g")
+    assert_close(o["image_f"], g["image_f"], floor=1e-9 * float(g["image_f"].max()), what="image_f")
+    assert (o["image_f"][~hit] == 0).all() and (o["image_g"][~hit] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["img_c2_1024_a0998_i70.npz", "img_c3_2048_a09_i70.npz",
+                                  "img_head_4096_a0998_i70.npz"])
+def test_full_size_class_map_and_samples(capi, golden, name):
+    g = golden(name)
+    n, a, inc, dec = int(g["n"][0]), float(g["a"][0]), float(g["inc_deg"][0]), int(g["dec"][0])
+    o = run(capi, n, a, inc)
+    diff = o["cls"] != g["cls"]
+    assert not diff.any(), "%d pixel classes differ, first at %s" % (diff.sum(), np.argwhere(diff)[:8].tolist())
+    assert np.bincount(o["cls"].ravel(), minlength=6).tolist() == g["counts"].tolist()
+    gt = o["gtype"]
+    assert [(gt == 40).sum(), (gt == 2).sum(), (gt == 0).sum(), (gt == -1).sum()] == g["type_counts"].tolist()
+    sl = (slice(dec // 2, None, dec), slice(dec // 2, None, dec))
+    assert_close(o["r"][sl], g["d_r"], what="r")
+    assert_close(o["g"][sl], g["d_g"], what="g")
+    assert_close(o["flux"][sl], g["d_flux"], floor=flux_floor(g["d_flux"]), what="flux")
+    assert_close(o["image_g"][sl], g["d_image_g"], what="image_g")
+    # checksum of the whole image against the reference's sums
+    assert abs(o["g"].sum(dtype=np.float64) / g["sum_g"][0] - 1) < 1e-9
+    assert abs((o["flux"] * o["g"] ** 4).sum(dtype=np.float64) / g["sum_fg4"][0] - 1) < 1e-9
+    assert abs(o["image_g"].astype(np.float64).sum() / g["sum_image_g"][0] - 1) < 1e-7
+
+
+def test_c2_boundary_band(capi, golden):
+    """Every pixel of C2 whose neighbour has a different class (shadow edge, ISCO contour)."""
+    g = golden("img_c2_band.npz")
+    o = run(capi, 1024, 0.998, 70.0)
+    iy, ix = g["iy"], g["ix"]
+    assert np.array_equal(o["cls"][iy, ix], g["cls"])
+    assert_close(o["r"][iy, ix], g["r"], what="band r")
+    assert_close(o["g"][iy, ix], g["g"], what="band g")
+    assert_close(o["flux"][iy, ix], g["flux"], floor=flux_floor(g["flux"]), what="band flux")
+
+
+def test_matches_oracle_other_parameters(capi):
+    """Parameters outside the golden set, GPU vs the CPU oracle on the same inputs."""
+    for (n, a, inc) in [(192, 0.5, 30.0), (160, 0.0, 85.0), (128, 0.999, 5.0), (96, 0.7, 89.0)]:
+        c = ol.cpu_disk_image("port", n, n, a, inc, nthreads=4, full=True)
+        o = run(capi, n, a, inc)
+        assert np.array_equal(o["cls"], c["cls"]), (n, a, inc, int((o["cls"] != c["cls"]).sum()))
+        assert_close(o["r"], c["r"], what="r"); assert_close(o["g"], c["g"], what="g")
+        assert_close(o["flux"], c["flux"], floor=flux_floor(c["flux"]), what="flux")
+
+
+def test_ragged_and_tile_shapes(capi):
+    """Sizes that are not multiples of the 16x16 tile, single rows, non-square images."""
+    base = run(capi, 100, 0.9, 60.0)
+    for (y0, y1) in [(0, 1), (37, 53), (99, 100), (0, 100)]:
+        t = run(capi, 100, 0.9, 60.0, y0=y0, y1=y1)
+        for k in ("cls", "image_f", "image_g", "r"):
+            assert np.array_equal(t[k], base[k][y0:y1], equal_nan=True), (k, y0, y1)
+    d = capi.image_desc(77, 31, 0.9, 1.0)
+    o = capi.disk_image(d, full=True)
+    c_alpha = ((np.arange(77) + .5) / 77 - 0.5) * 2.0
+    assert o["cls"].shape == (31, 77) and c_alpha.size == 77
+
+
+def test_row_tile_sharding_equals_whole_image(capi, golden):
+    """C5 geometry (8192^2, 8 inclinations): 8 row tiles concatenated == one launch; sampled pixels
+    against the reference."""
+    g = golden("img_c5_8192_sampled.npz")
+    n = 8192
+    for inc in (10, 40, 80):
+        tiles = [run(capi, n, 0.998, float(inc), full=True, y0=k * n // 8, y1=(k + 1) * n // 8) for k in range(8)]
+        cls = np.concatenate([t["cls"] for t in tiles]); r = np.concatenate([t["r"] for t in tiles])
+        gg = np.concatenate([t["g"] for t in tiles]); fl = np.concatenate([t["flux"] for t in tiles])
+        sl = (slice(32, None, 64), slice(0, None, 64))
+        assert np.array_equal(cls[sl], g["cls_%d" % inc])
+        assert_close(r[sl], g["r_%d" % inc], what="r"); assert_close(gg[sl], g["g_%d" % inc], what="g")
+        assert_close(fl[sl], g["flux_%d" % inc], floor=flux_floor(g["flux_%d" % inc]), what="flux")
+        if inc == 40:
+            whole = run(capi, n, 0.998, float(inc), full=False)
+            assert np.array_equal(whole["image_g"], np.concatenate([t["image_g"] for t in tiles]))
+            assert np.array_equal(whole["image_f"], np.concatenate([t["image_f"] for t in tiles]))
+
+
+def test_deterministic_and_list_mode(capi):
+    """Same job twice -> identical bits; explicit ray list == implicit pixel grid."""
+    import ctypes as C
+    n, a, inc = 256, 0.998, 70.0
+    o1 = run(capi, n, a, inc); o2 = run(capi, n, a, inc)
+    for k in o1:
+        assert np.array_equal(o1[k], o2[k], equal_nan=True), k
+    rms = ol.Oracle().r_ms(a); rmax = rms + 8.0
+    al = (((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax)[None, :].repeat(n, 0)
+    be = (((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax * (float(n) / float(n)))[:, None].repeat(n, 1)
+    d = capi.image_desc(n, n, a, inc / 180.0 * math.pi)
+    N = n * n
+    bufs = {k: capi.DeviceBuffer(N * s) for k, s in (("al", 8), ("be", 8), ("f", 4), ("g", 4), ("cls", 1), ("r", 8))}
+    bufs["al"].from_numpy(np.ascontiguousarray(al)); bufs["be"].from_numpy(np.ascontiguousarray(be))
+    capi.disk_rays_device(d, N, bufs["al"].ptr, bufs["be"].ptr, bufs["f"].ptr, bufs["g"].ptr,
+                          aux={"cls": bufs["cls"].ptr, "r": bufs["r"].ptr})
+    capi.synchronize()
+    assert np.array_equal(bufs["cls"].to_numpy(np.uint8, (n, n)), o1["cls"])
+    assert np.array_equal(bufs["g"].to_numpy(np.float32, (n, n)), o1["image_g"])
+    assert np.array_equal(bufs["f"].to_numpy(np.float32, (n, n)), o1["image_f"])
+    assert np.array_equal(bufs["r"].to_numpy(np.float64, (n, n)), o1["r"], equal_nan=True)
+
+
+def test_rejects_bad_arguments(capi):
+    d = capi.image_desc(0, 10, 0.5, 1.0)
+    with pytest.raises(capi.Sim5GpuError):
+        capi.disk_image(d)
+    d = capi.image_desc(16, 16, 0.5, 1.0, y0=8, y1=4)
+    with pytest.raises(capi.Sim5GpuError):
+        capi.disk_image(d)
+    # out-of-range physics is a per-ray status, not an API failure: spin > 1-1e-6 rejects every ray
+    o = capi.disk_image(capi.image_desc(16, 16, 0.9999999, 1.0), full=True)
+    assert (o["cls"] == 0).all() and (o["image_f"] == 0).all()

@@ -1,0 +1,112 @@
+"""Batch forms of the SIM5 per-ray functions on the GPU (C-ABI group 1) against the golden
+known-answer vectors captured from the reference."""
+import numpy as np
+import pytest
+
+import oraclelib as ol
+from gpuutil import REL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_elliptic(capi, golden):
+    g = golden("kat_elliptic.npz")
+    assert_close(capi.elliptic("rf", g["c_x"], g["c_y"], g["c_z"]), g["rf"], what="rf")
+    assert_close(capi.elliptic("rd", g["c_x"], g["c_y"], g["rd_z"]), g["rd"], what="rd")
+    assert_close(capi.elliptic("rc", g["rc_x"], g["rc_y"]), g["rc"], what="rc")
+    assert_close(capi.elliptic("rj", g["rj_x"], g["rj_y"], g["rj_z"], g["c_p"]), g["rj"], what="rj")
+    assert_close(capi.elliptic("elliptic_k", g["k_m"]), g["elliptic_k"], what="K")
+    assert_close(capi.elliptic("jacobi_isn", g["isn_z"], g["k_m"]), g["jacobi_isn"], what="isn")
+    assert_close(capi.elliptic("jacobi_icn", g["icn_z"], g["k_m"]), g["jacobi_icn"], floor=1e-9, what="icn")
+    assert_close(capi.elliptic("jacobi_itn", g["itn_z"], g["k_m"]), g["jacobi_itn"], what="itn")
+    assert_close(capi.elliptic("jacobi_sn", g["sn_u"], g["k_m"]), g["sn"], floor=1e-9, what="sn")
+    assert_close(capi.elliptic("jacobi_cn", g["sn_u"], g["k_m"]), g["cn"], floor=1e-9, what="cn")
+    assert_close(capi.elliptic("jacobi_dn", g["sn_u"], g["k_m"]), g["dn"], what="dn")
+
+
+def test_geodesic_init_inf_records(capi, golden):
+    g = golden("kat_geodesic.npz")
+    inp = g["inp"]
+    rec, err, ok = capi.geodesic_init_inf(inp[:, 0], inp[:, 1], inp[:, 2], inp[:, 3])
+    assert np.array_equal(ok, g["ok"]) and np.array_equal(err, g["err"])
+    ref = np.frombuffer(g["dump"].tobytes(), dtype=capi.GEODESIC_DTYPE)
+    good = ok == 1
+    assert np.array_equal(rec["nrr"][good], ref["nrr"][good]) and np.array_equal(rec["type"][good], ref["type"][good])
+    for f in ("a", "alpha", "beta", "incl", "cos_i", "l", "q", "m2p", "m2m", "mm", "mK", "rp", "Rpc", "Tpp", "Tip"):
+        assert_close(rec[f][good], ref[f][good], what="geodesic." + f)
+    for f in ("r1", "r2", "r3", "r4"):
+        assert_close(rec[f][good], ref[f][good], floor=1e-9, what="geodesic." + f)
+    # downstream routines, fed with the REFERENCE's records so that each is tested on its own
+    P0 = capi.geodesic_find_midplane_crossing(ref[good], 0); assert_close(P0, g["P0"][good], what="P0")
+    P1 = capi.geodesic_find_midplane_crossing(ref[good], 1); assert_close(P1, g["P1"][good], what="P1")
+    m = good & ~np.isnan(g["P0"])
+    assert_close(capi.geodesic_position_rad(ref[m], g["P0"][m]), g["r0"][m], what="r0")
+    m = good & ~np.isnan(g["P1"])
+    assert_close(capi.geodesic_position_rad(ref[m], g["P1"][m]), g["r1"][m], what="r1")
+    m = good & ~np.isnan(g["Pq0"])
+    assert_close(capi.geodesic_P_int(ref[m], g["rq"][m], 0), g["Pq0"][m], what="P_int before pericentre")
+    m = good & ~np.isnan(g["Pq1"])
+    assert_close(capi.geodesic_P_int(ref[m], g["rq"][m], 1), g["Pq1"][m], what="P_int after pericentre")
+    m = good & ~np.isnan(g["Pm"])
+    assert_close(capi.geodesic_position_pol(ref[m], g["Pm"][m]), g["mpol"][m], floor=1e-9, what="position_pol")
+    assert np.array_equal(capi.geodesic_dm_sign(ref[m], g["Pm"][m]), g["dms"][m])
+    k = capi.geodesic_momentum(ref[m], g["Pm"][m], g["rmom"][m], g["mpol"][m])
+    assert_close(k, g["kmom"][m], floor=1e-9, what="geodesic_momentum")
+
+
+def test_kerr(capi, golden):
+    g = golden("kat_kerr.npz")
+    a, r, m = g["a"], g["r"], g["m"]
+    met = capi.kerr_metric(a, r, m)
+    assert_close(met.view(np.float64).reshape(-1, 8), g["metric"], floor=1e-12, what="kerr_metric")
+    assert_close(capi.kerr_connection(a, r, m).reshape(-1, 64), g["connection"], floor=1e-12, what="kerr_connection")
+    refmet = np.frombuffer(np.ascontiguousarray(g["metric"]).tobytes(), dtype=capi.METRIC_DTYPE)
+    as24 = lambda t: t.view(np.float64).reshape(-1, 24)
+    assert_close(as24(capi.tetrad_zamo(refmet)), g["zamo"], floor=1e-12, what="tetrad_zamo")
+    assert_close(as24(capi.tetrad_azimuthal(refmet, g["Omega"])), g["azim"], floor=1e-12, what="tetrad_azimuthal")
+    surf = capi.tetrad_surface(refmet, g["Omega"], g["V"], g["dhdr"])
+    assert_close(as24(surf), g["surf"], floor=1e-12, what="tetrad_surface")
+    reft = np.frombuffer(np.ascontiguousarray(g["surf"]).tobytes(), dtype=capi.TETRAD_DTYPE)
+    assert_close(capi.bl2on(g["vin"], reft), g["v_on"], floor=1e-9, what="bl2on")
+    assert_close(capi.on2bl(g["vin"], reft), g["v_bl"], floor=1e-9, what="on2bl")
+    k = capi.photon_momentum(a, r, m, g["l"], g["q"], g["r_sign"], g["m_sign"])
+    assert_close(k, g["kph"], floor=1e-9, what="photon_momentum")
+    v = ~np.isnan(g["kph"][:, 0])
+    L, Q = capi.photon_motion_constants(a[v], r[v], m[v], g["kph"][v])
+    assert_close(L, g["L"][v], floor=1e-6, what="L"); assert_close(Q, g["Q"][v], floor=1e-6, what="Q")
+    assert_close(capi.photon_carter_const(g["kph"][v], refmet[v]), g["Qcarter"][v], floor=1e-6, what="carter")
+    assert_close(capi.gfactorK(g["gK_r"], a, g["gK_l"]), g["gK"], what="gfactorK")
+
+
+def test_disk_nt(capi, golden):
+    g = golden("kat_disk.npz")
+    for j, a in enumerate(g["spins"]):
+        capi.disk_nt_setup(10.0, float(a), 0.1, 0.1)
+        assert capi.disk_nt_r_min() == g["rmin_%d" % j][0]
+        fl = capi.disk_nt_flux(g["r_%d" % j])
+        ref = g["flux_%d" % j]
+        assert np.array_equal(fl == 0, ref == 0), "zero-flux band (r <= float-rounded inner edge) differs"
+        assert_close(fl, ref, floor=1e-9 * ref.max(), what="disk_nt_flux a=%g" % a)
+        assert_close(capi.disk_nt_ell(g["r_%d" % j]), g["ell_%d" % j], what="disk_nt_ell")
+    capi.disk_nt_setup(3.7e6, 0.7, 0.31, 0.05)
+    assert_close(capi.disk_nt_flux(g["r_x"]), g["flux_x"], floor=1e-9 * g["flux_x"].max(), what="flux (other M, mdot)")
+
+
+def test_polarization_and_blackbody(capi, golden):
+    g = golden("kat_polar.npz")
+    met = np.frombuffer(np.ascontiguousarray(g["metric"]).tobytes(), dtype=capi.METRIC_DTYPE)
+    assert_close(capi.polarization_constant(g["k"], g["f"], met), g["wp"], floor=1e-6, what="polarization_constant")
+    assert_close(capi.polarization_vector(g["k"], g["wp"], met), g["f_back"], floor=1e-6, what="polarization_vector")
+    assert_close(capi.polarization_constant_infinity(g["a"], g["alpha"], g["beta"], g["incl"]), g["wp_inf"],
+                 floor=1e-9, what="constant_infinity")
+    rot = capi.polarization_angle_rotation(g["a"], g["incl"], g["alpha"], g["beta"], g["wp"])
+    assert np.max(np.abs(rot - g["rot"])) < 1e-9
+    assert_close(capi.blackbody_Iv(g["T"], g["hardf"], g["cos_mu"], g["E"]), g["Iv"], what="blackbody_Iv")
+
+
+def test_empty_batches_and_null_pointers(capi):
+    import ctypes as C
+    assert capi.gfactorK(np.zeros(0), 0.5, 1.0).size == 0
+    assert capi.elliptic("rf", np.zeros(0), np.zeros(0), np.zeros(0)).size == 0
+    rc = capi._lib.sim5gpu_gfactorK(C.c_size_t(4), None, None, None, None)
+    assert rc == -3

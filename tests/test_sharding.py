@@ -1,0 +1,79 @@
+"""Row-stripe sharding over ranks: index arithmetic, and the gather/assemble path with
+torch.distributed (gloo, world_size 2) on CPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from sim5_amd import sharding
+
+
+@pytest.mark.parametrize("ny,world", [(4096, 1), (4096, 2), (4096, 8), (100, 3), (64, 8), (65, 2), (1, 4)])
+def test_stripes_partition_the_rows(ny, world):
+    seen = np.zeros(ny, int)
+    for r in range(world):
+        rows = 0
+        for (y0, y1) in sharding.stripes_for_rank(ny, r, world):
+            assert 0 <= y0 < y1 <= ny
+            seen[y0:y1] += 1
+            rows += y1 - y0
+        assert rows == sharding.local_rows(ny, r, world) <= sharding.max_local_rows(ny, world)
+    assert (seen == 1).all()
+
+
+def test_assemble_restores_row_order():
+    ny, nx, world = 200, 7, 3
+    full = np.arange(2 * ny * nx, dtype=np.float32).reshape(2, ny, nx)
+    rmax = sharding.max_local_rows(ny, world)
+    tiles = []
+    for r in range(world):
+        t = np.zeros((2, rmax, nx), np.float32)
+        off = 0
+        for (y0, y1) in sharding.stripes_for_rank(ny, r, world):
+            t[:, off:off + y1 - y0] = full[:, y0:y1]
+            off += y1 - y0
+        tiles.append(t)
+    assert np.array_equal(sharding.assemble(tiles, ny, world), full)
+
+
+def _worker(rank, world, port, ny, nx, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # stand-in for the kernel: pixel value = global row * nx + column (plane 0), its negative (plane 1)
+    rmax = sharding.max_local_rows(ny, world)
+    tile = torch.zeros((2, rmax, nx), dtype=torch.float32)
+    off = 0
+    for (y0, y1) in sharding.stripes_for_rank(ny, rank, world):
+        rows = torch.arange(y0, y1, dtype=torch.float32)[:, None] * nx + torch.arange(nx, dtype=torch.float32)[None, :]
+        tile[0, off:off + y1 - y0] = rows
+        tile[1, off:off + y1 - y0] = -rows
+        off += y1 - y0
+    gathered = [torch.zeros_like(tile) for _ in range(world)] if rank == 0 else None
+    dist.barrier()
+    dist.gather(tile, gathered, dst=0)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        img = sharding.assemble(gathered, ny, world)
+        expect = torch.arange(ny * nx, dtype=torch.float32).reshape(ny, nx)
+        q.put((bool(torch.equal(img[0], expect) and torch.equal(img[1], -expect)), float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, 200, 16, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    ok, tmax = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and tmax == 2.0
