@@ -49,12 +49,17 @@ def cpu_baseline(budget_s=12.0):
     rate = cal["rays"] / max(cal["seconds"], 1e-6)
     rows = int(min(NY, max(32, budget_s * rate / NX)))
     stride = max(1, NY // rows)
-    run = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=stride // 2, ystride=stride, nthreads=cores, full=False)
+    rays = 0
+    secs = 0.0
+    reps = 0
+    while secs < 0.6 * budget_s and reps < 64:       # on many-core hosts one pass is short: repeat it
+        run = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=stride // 2, ystride=stride, nthreads=cores, full=False)
+        rays += run["rays"]; secs += run["seconds"]; reps += 1
     one = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=1, full=False)
     return {
-        "value": run["rays"] / run["seconds"], "unit": "null geodesics/s", "cores": cores, "kind": kind,
-        "sample": "every %d-th row of the %dx%d image (%d rays), %d threads, %.1f s wall" % (
-            stride, NX, NY, run["rays"], cores, run["seconds"]),
+        "value": rays / secs, "unit": "null geodesics/s", "cores": cores, "kind": kind,
+        "sample": "every %d-th row of the %dx%d image, %d pass(es), %d rays, %d threads, %.1f s wall" % (
+            stride, NX, NY, reps, rays, cores, secs),
         "single_thread_value": one["rays"] / one["seconds"],
     }
 

@@ -526,12 +526,12 @@ def disk_image_device(desc, d_image_f, d_image_g, aux=None, stream=None):
 
 def disk_image(desc, full=False):
     """Host-buffer convenience: returns dict(image_f, image_g[, cls, gtype, r, g, flux])."""
-    rows = desc.y1 - desc.y0
-    out = {"image_f": np.zeros((rows, desc.nx), np.float32), "image_g": np.zeros((rows, desc.nx), np.float32)}
+    rows, nx = max(desc.y1 - desc.y0, 0), max(desc.nx, 0)       # bad geometry is rejected by the library
+    out = {"image_f": np.zeros((rows, nx), np.float32), "image_g": np.zeros((rows, nx), np.float32)}
     aux = None
     if full:
-        out.update(cls=np.zeros((rows, desc.nx), np.uint8), gtype=np.zeros((rows, desc.nx), np.int8),
-                   r=np.zeros((rows, desc.nx)), g=np.zeros((rows, desc.nx)), flux=np.zeros((rows, desc.nx)))
+        out.update(cls=np.zeros((rows, nx), np.uint8), gtype=np.zeros((rows, nx), np.int8),
+                   r=np.zeros((rows, nx)), g=np.zeros((rows, nx)), flux=np.zeros((rows, nx)))
         aux = ImageAux(cls=out["cls"].ctypes.data, gtype=out["gtype"].ctypes.data, r=out["r"].ctypes.data,
                        g=out["g"].ctypes.data, flux=out["flux"].ctypes.data)
     _check(_lib.sim5gpu_disk_image_host(C.byref(desc), _p(out["image_f"]), _p(out["image_g"]),

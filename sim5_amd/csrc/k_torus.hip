@@ -48,7 +48,27 @@ void torus_start_kernel(TorusParams p, double* __restrict__ cols, int* __restric
     double x[4] = { 0.0, p.r0, 0.0, 0.0 }, k[4] = { 0.0, 0.0, 0.0, 0.0 };
     RayState s;
     s.dk[0] = s.dk[1] = s.dk[2] = s.dk[3] = 0.0; s.kt = 0.0; s.Q = 0.0;
-    if (init_inf(p.incl, p.sin_i, p.cos_i, p.a, alpha, beta, gd, err, cache) && p.r0 > gd.rp) {
+    if (p.options & 1) {
+        // RTOPT_FLAT: there is no geodesic_init_inf for Minkowski space; the ray is the straight line
+        // that reaches the observer's image plane at (alpha, beta), started on the sphere r = r0.
+        // Observer frame: line of sight n = (sin i, 0, cos i), e_alpha = (0,1,0), e_beta = (-cos i, 0, sin i).
+        const double D2 = p.r0 * p.r0 - alpha * alpha - beta * beta;
+        if (D2 > 0.0) {
+            const double D = sqrt(D2);
+            const double X = -beta * p.cos_i + D * p.sin_i, Y = alpha, Z = beta * p.sin_i + D * p.cos_i;
+            const double Vx = -p.sin_i, Vy = 0.0, Vz = -p.cos_i;
+            const double r = sqrt(X * X + Y * Y + Z * Z);
+            const double m = Z / r;
+            const double kr = (X * Vx + Y * Vy + Z * Vz) / r;
+            x[1] = r; x[2] = m; x[3] = atan2(Y, X);
+            k[0] = 1.0;
+            k[1] = kr;
+            k[2] = -(Vz - m * kr) / (r * sqrt(1. - m * m));
+            k[3] = (X * Vy - Y * Vx) / (X * X + Y * Y);
+            raytrace_prepare(p.a, x, k, p.precision, p.options, s);
+            good = 1;
+        }
+    } else if (init_inf(p.incl, p.sin_i, p.cos_i, p.a, alpha, beta, gd, err, cache) && p.r0 > gd.rp) {
         const double P0 = P_int(gd, p.r0, 0);
         x[2] = position_pol(gd, P0);
         momentum(gd, P0, p.r0, x[2], k);
@@ -161,14 +181,17 @@ void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const in
                 Metric g;
                 rt_metric(s, x[1], x[2], g);
                 const double Om = omega_from_ell(p.torus_l, g);
-                const double ut = 1. / sqrt(-(g.g00 + 2. * Om * g.g03 + Om * Om * g.g33));
-                const double k_t = k[0] * g.g00 + k[3] * g.g03;
-                const double k_f = k[3] * g.g33 + k[0] * g.g03;
-                const double gfac = s.E / (ut * (k_t + Om * k_f));      // E_inf / E_local
-                const double ds = dl / gfac;
-                const double g2 = gfac * gfac;
-                I += (g2 * g2) * p.emis0 * rho * exp(-tau) * ds;
-                tau += p.absorb0 * rho * ds;
+                const double nrm = -(g.g00 + 2. * Om * g.g03 + Om * Om * g.g33);
+                if (nrm > 0.0) {                    // a circular orbit with this ell is time-like here
+                    const double ut = 1. / sqrt(nrm);
+                    const double k_t = k[0] * g.g00 + k[3] * g.g03;
+                    const double k_f = k[3] * g.g33 + k[0] * g.g03;
+                    const double gfac = s.E / (ut * (k_t + Om * k_f));      // E_inf / E_local
+                    const double ds = dl / gfac;
+                    const double g2 = gfac * gfac;
+                    I += (g2 * g2) * p.emis0 * rho * exp(-tau) * ds;
+                    tau += p.absorb0 * rho * ds;
+                }
             }
 
             const bool done = !(x[1] > r_in) || !(x[1] < r_out) || ((double)s.error > p.max_error) ||
