@@ -260,7 +260,8 @@ typedef struct sim5gpu_image_desc {
     double pol_degree;      /* polarization degree delta of the disk emission (polarized) */
 } sim5gpu_image_desc;
 
-#define SIM5GPU_IMG_DEFAULT 0
+#define SIM5GPU_IMG_DEFAULT 0   /* tuned FP64 sequences ("fast" variant, sim5_amd/csrc/s5_config.hpp)        */
+#define SIM5GPU_IMG_STRICT  1   /* reference parameters, IEEE sqrt/div, no FMA contraction ("strict")       */
 
 /* optional full-precision outputs (any pointer may be NULL) */
 typedef struct sim5gpu_image_aux {

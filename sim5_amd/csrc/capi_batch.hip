@@ -5,6 +5,7 @@
 // host program written against the SIM5 scalar API (and the parity tests) can reach each routine
 // through the C-ABI; throughput work goes through the whole-job kernels instead.
 #include "capi_util.hpp"
+#include "s5_disk.hpp"
 #include "s5_raytrace.hpp"
 #include "s5_polar.hpp"
 

@@ -229,7 +229,8 @@ int sim5gpu_disk_image(const sim5gpu_image_desc* desc, float* d_image_f, float* 
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
     p.img_f = d_image_f; p.img_g = d_image_g;
     attach_aux(p, d_aux);
-    hipError_t e = (hipError_t)launch_disk_image(p, (hipStream_t)stream);
+    hipError_t e = (hipError_t)((desc->flags & SIM5GPU_IMG_STRICT) ? s5_launch_disk_image_strict(p, (hipStream_t)stream)
+                                                                 : s5_launch_disk_image_fast(p, (hipStream_t)stream));
     if (e != hipSuccess) { set_error("disk_image launch", e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;
 }
@@ -254,7 +255,8 @@ int sim5gpu_disk_rays(const sim5gpu_image_desc* desc, size_t n, const double* d_
     p.img_f = d_image_f; p.img_g = d_image_g;
     p.alpha = d_alpha; p.beta = d_beta; p.n = n;
     attach_aux(p, d_aux);
-    hipError_t e = (hipError_t)launch_disk_image(p, (hipStream_t)stream);
+    hipError_t e = (hipError_t)((desc->flags & SIM5GPU_IMG_STRICT) ? s5_launch_disk_image_strict(p, (hipStream_t)stream)
+                                                                 : s5_launch_disk_image_fast(p, (hipStream_t)stream));
     if (e != hipSuccess) { set_error("disk_rays launch", e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;
 }

@@ -19,7 +19,8 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     p.stokes = d_stokes;
     p.chi = d_chi;
     if (d_aux) { p.cls = d_aux->cls; p.gtype = d_aux->gtype; p.r = d_aux->r; p.g = d_aux->g; p.flux = d_aux->flux; }
-    hipError_t e = (hipError_t)launch_disk_image_polarized(p, (hipStream_t)stream);
+    hipError_t e = (hipError_t)((desc->flags & SIM5GPU_IMG_STRICT) ? s5_launch_disk_image_polarized_strict(p, (hipStream_t)stream)
+                                                                 : s5_launch_disk_image_polarized_fast(p, (hipStream_t)stream));
     if (e != hipSuccess) { set_error("disk_image_polarized launch", e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;
 }

@@ -4,8 +4,11 @@
 #include <stdio.h>
 #include "../../include/sim5gpu.h"
 #include "kernels.hpp"
+#include "s5_config.hpp"
 
 namespace s5 {
+
+using namespace s5abi;
 
 extern thread_local char g_err[512];
 extern DiskConsts g_disk;

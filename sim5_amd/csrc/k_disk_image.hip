@@ -14,7 +14,9 @@
 #include "s5_disk.hpp"
 #include "kernels.hpp"
 
-namespace s5 {
+namespace S5NS {
+
+using namespace s5abi;
 
 struct RayResult {
     int    cls;      // SIM5GPU_PX_*
@@ -39,10 +41,22 @@ S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
     for (int order = 0; order < p.max_order; ++order) {
         const double P = midplane_crossing(gd, order, cache);
         if (isnan(P)) { out.cls = (order == 0) ? PX_NAN0 : PX_NAN1; break; }
+#ifdef S5_KO_RAD                 // diagnostic knock-outs (timing breakdown builds only, never shipped)
+        const double r = 10.0 + P;
+#else
         const double r = position_rad(gd, P);
+#endif
         if (r >= p.rms) {
+#ifdef S5_KO_G
+            const double g = 0.5 + 1e-3 * r;
+#else
             const double g = gfactor_kepler(r, p.a, gd.l);
+#endif
+#ifdef S5_KO_FLUX
+            const double f = 1e20 * r;
+#else
             const double f = disk_flux(p.disk, r);
+#endif
             const double g2 = g * g;
             out.cls = (order == 0) ? PX_HIT0 : PX_HIT1;
             out.r = r; out.g = g; out.flux = f;
@@ -93,8 +107,15 @@ void disk_image_list_kernel(ImageParams p)
     store_ray(p, i, res);
 }
 
-int launch_disk_image(const ImageParams& p, hipStream_t stream)
+} // namespace S5NS
+
+#if S5_FAST
+int s5_launch_disk_image_fast(const s5abi::ImageParams& p, hipStream_t stream)
+#else
+int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
+#endif
 {
+    using namespace S5NS;
     if (p.alpha) {
         const unsigned blocks = (unsigned)((p.n + 255) / 256);
         hipLaunchKernelGGL(disk_image_list_kernel, dim3(blocks), dim3(256), 0, stream, p);
@@ -104,5 +125,3 @@ int launch_disk_image(const ImageParams& p, hipStream_t stream)
     }
     return (int)hipGetLastError();
 }
-
-} // namespace s5

@@ -16,7 +16,9 @@
 #include "s5_polar.hpp"
 #include "kernels.hpp"
 
-namespace s5 {
+namespace S5NS {
+
+using namespace s5abi;
 
 __global__ __launch_bounds__(256, 2)
 void disk_image_polarized_kernel(ImageParams p)
@@ -83,11 +85,16 @@ void disk_image_polarized_kernel(ImageParams p)
     if (p.flux) p.flux[o] = f_hit;
 }
 
-int launch_disk_image_polarized(const ImageParams& p, hipStream_t stream)
+} // namespace S5NS
+
+#if S5_FAST
+int s5_launch_disk_image_polarized_fast(const s5abi::ImageParams& p, hipStream_t stream)
+#else
+int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream_t stream)
+#endif
 {
+    using namespace S5NS;
     const dim3 grid((p.nx + 15) / 16, (p.y1 - p.y0 + 15) / 16);
     hipLaunchKernelGGL(disk_image_polarized_kernel, grid, dim3(256), 0, stream, p);
     return (int)hipGetLastError();
 }
-
-} // namespace s5

@@ -28,6 +28,8 @@
 
 namespace s5 {
 
+using namespace s5abi;
+
 enum : int { COL_X0 = 0, COL_X1, COL_X2, COL_X3, COL_K0, COL_K1, COL_K2, COL_K3,
              COL_DK0, COL_DK1, COL_DK2, COL_DK3, COL_KT, COL_Q, NCOL };
 

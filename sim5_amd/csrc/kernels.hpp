@@ -1,13 +1,26 @@
-// kernels.hpp -- launch-side declarations shared by the kernel translation units and the C-ABI.
+// kernels.hpp -- kernel argument blocks (PODs, namespace s5abi) and the launch entry points of the
+// kernel translation units, shared with the C-ABI.  Each image kernel exists in the two build
+// variants of s5_config.hpp; the launchers carry the variant in their name.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "s5_disk.hpp"
 
-namespace s5 {
+namespace s5abi {
 
 // per-pixel outcome codes (= SIM5GPU_PX_* of include/sim5gpu.h)
 enum : int { PX_ERROR = 0, PX_NAN0 = 1, PX_HIT0 = 2, PX_NAN1 = 3, PX_HIT1 = 4, PX_MISS = 5 };
+
+// Novikov-Thorne disk folded to constants on the host (see s5_disk.hpp); wave-uniform (SGPRs)
+struct DiskConsts {
+    double a;            // (double)(float)spin                                  ref :27-28,51
+    double rms;          // (double)(float)(r_ms_pow(a) + 1e-3): inner edge     ref :58,91-105
+    double x0;           // sqrt(rms)                                            ref :124
+    double x1, x2, x3;   // roots of x^3 - 3x + 2a                               ref :125-127
+    double p1, p2, p3;   // 3 (x_i - a)^2 / (x_i (x_i - x_j)(x_i - x_k))          ref :131-133
+    double d1, d2, d3;   // x0 - x_i                                              ref :131-133
+    double mdot, mass;   // (double)(float) values                               ref :145
+    int    ready;
+};
 
 // kernel argument block of the thin-disk image kernels (wave-uniform: lives in SGPRs)
 struct ImageParams {
@@ -33,7 +46,10 @@ struct ImageParams {
     size_t n;
 };
 
-int launch_disk_image(const ImageParams& p, hipStream_t stream);
-int launch_disk_image_polarized(const ImageParams& p, hipStream_t stream);
+} // namespace s5abi
 
-} // namespace s5
+// fast = tuned FP64 sequences (default); strict = reference parameters, IEEE sqrt/div, no contraction
+int s5_launch_disk_image_fast(const s5abi::ImageParams& p, hipStream_t stream);
+int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream);
+int s5_launch_disk_image_polarized_fast(const s5abi::ImageParams& p, hipStream_t stream);
+int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream_t stream);

@@ -8,31 +8,23 @@
 // radial table to stage in LDS -- the constants are wave-uniform scalars.
 #pragma once
 #include "s5_geod.hpp"
+#include "kernels.hpp"
 
-namespace s5 {
+namespace S5NS {
 
-struct DiskConsts {
-    double a;            // (double)(float)spin                                  ref :27-28,51
-    double rms;          // (double)(float)(r_ms_pow(a) + 1e-3): inner edge     ref :58,91-105
-    double x0;           // sqrt(rms)                                            ref :124
-    double x1, x2, x3;   // roots of x^3 - 3x + 2a                               ref :125-127
-    double p1, p2, p3;   // 3 (x_i - a)^2 / (x_i (x_i - x_j)(x_i - x_k))          ref :131-133
-    double d1, d2, d3;   // x0 - x_i                                              ref :131-133
-    double mdot, mass;   // (double)(float) values                               ref :145
-    int    ready;
-};
+using s5abi::DiskConsts;
 
 S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :110-146
 {
     if (r <= d.rms) return 0.0;
     const double a = d.a;
-    const double x = sqrt(r);
-    const double f0 = x - d.x0 - 1.5 * a * log(x / d.x0);
-    const double f1 = d.p1 * log((x - d.x1) / d.d1);
-    const double f2 = d.p2 * log((x - d.x2) / d.d2);
-    const double f3 = d.p3 * log((x - d.x3) / d.d3);
-    const double F = 1. / (4. * M_PI * r) * 1.5 / (x * x * (x * x * x - 3. * x + 2. * a)) * (f0 - f1 - f2 - f3);
-    return 9.1721376255e+28 * F * d.mdot / d.mass;
+    const double x = msqrt(r);
+    const double f0 = x - d.x0 - 1.5 * a * log(mdiv(x, d.x0));
+    const double f1 = d.p1 * log(mdiv(x - d.x1, d.d1));
+    const double f2 = d.p2 * log(mdiv(x - d.x2, d.d2));
+    const double f3 = d.p3 * log(mdiv(x - d.x3, d.d3));
+    const double F = mdiv(mdiv(1., 4. * M_PI * r) * 1.5, x * x * (x * x * x - 3. * x + 2. * a)) * (f0 - f1 - f2 - f3);
+    return mdiv(9.1721376255e+28 * F * d.mdot, d.mass);
 }
 
 S5_DEV double disk_ell(const DiskConsts& d, double r)                  // ref :260-266
@@ -42,4 +34,4 @@ S5_DEV double disk_ell(const DiskConsts& d, double r)                  // ref :2
     return (r * r - 2. * a * sqrt(r) + a * a) / (sqrt(r) * r - 2. * sqrt(r) + a);
 }
 
-} // namespace s5
+} // namespace S5NS

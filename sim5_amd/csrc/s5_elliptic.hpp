@@ -14,18 +14,53 @@
 //  * the Landen ladder of sncndn lives in registers (fully unrolled, level index compile-time),
 //    never in scratch or LDS.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <float.h>
+#include "s5_math.hpp"
 
-#define S5_DEV __device__ __forceinline__
+namespace S5NS {
 
-namespace s5 {
-
-S5_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-
-S5_DEV double sq(double x) { return x * x; }
-S5_DEV double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), fabs(b)), fabs(c)); }
-
+#if S5_F_RF7
+// ---------------------------------------------------------------------------------------
+// R_F(x,y,z), fast variant.  Same duplication theorem; what changes against the reference's
+// Numerical-Recipes form (ERRTOL 3e-4, 5th-order series, three divisions per pass):
+//  * Carlson's (1995) stopping rule on the initial spread, max|A0 - x_i| 4^-n < tol |A_n|, which needs
+//    no division inside the loop; the scaled deviations X, Y, Z are formed once at the end;
+//  * the series is carried to 7th order (terms E2^3, E3^2, E2^2 E3), error ~ |X|^8, so tol = 0.01
+//    reaches double precision: ~4 passes where the reference needs ~6.5;
+//  * lanes stop individually (their result is a function of their own arguments only, whatever the
+//    neighbours in the wave are); the wave leaves the loop when its last lane has converged.
+// ---------------------------------------------------------------------------------------
+S5_DEV double carlson_rf(double x, double y, double z)
+{
+    const double tol = 0.01, third = 1.0 / 3.0;
+    const bool bad = !(x >= 0.0) || !(y >= 0.0) || !(z >= 0.0);     // sqrt of a negative / NaN -> NaN
+    x = fmax(x, 1e-300); y = fmax(y, 1e-300); z = fmax(z, 1e-300);  // at most one argument may be 0
+    const double A0 = third * (x + y + z);
+    const double dx0 = A0 - x, dy0 = A0 - y;
+    double dev = max3abs(dx0, dy0, A0 - z);
+    double A = A0, scale = 1.0;
+    bool live = dev >= tol * A;
+    for (int pass = 0; pass < 32; ++pass) {
+        if (!wave_any(live)) break;
+        if (live) {                              // a lane's result depends on its own arguments only
+            const double sx = sqrt_pos(x), sy = sqrt_pos(y), sz = sqrt_pos(z);
+            const double lam = sx * (sy + sz) + sy * sz;
+            x = 0.25 * (x + lam);
+            y = 0.25 * (y + lam);
+            z = 0.25 * (z + lam);
+            A = 0.25 * (A + lam);
+            scale *= 0.25;
+            live = dev * scale >= tol * A;
+        }
+    }
+    const double rA = mrcp(A);
+    const double X = dx0 * scale * rA, Y = dy0 * scale * rA, Z = -(X + Y);
+    const double E2 = X * Y - Z * Z, E3 = X * Y * Z;
+    const double ser = 1.0 + E2 * (-0.1 + E2 * (1.0 / 24.0) - E3 * (3.0 / 44.0) - E2 * E2 * (5.0 / 208.0))
+                     + E3 * (1.0 / 14.0 + E3 * (3.0 / 104.0) + E2 * E2 * (1.0 / 16.0));
+    const double res = ser * sqrt_pos(rA);
+    return bad ? NAN : res;
+}
+#else
 // ---------------------------------------------------------------------------------------
 // R_F(x,y,z) by the duplication theorem, tolerance 3e-4 and 5th-order series as the reference.
 // ---------------------------------------------------------------------------------------
@@ -53,6 +88,8 @@ S5_DEV double carlson_rf(double x, double y, double z)
     double e3 = dx * dy * dz;
     return (1.0 + ((1.0 / 24.0) * e2 - 0.1 - (3.0 / 44.0) * e3) * e2 + (1.0 / 14.0) * e3) / sqrt(mu);
 }
+
+#endif
 
 // R_C(x,y), Cauchy principal value for y < 0
 S5_DEV double carlson_rc(double x, double y)
@@ -165,11 +202,33 @@ S5_DEV double carlson_rj(double x, double y, double z, double p)
 // ---------------------------------------------------------------------------------------
 // Legendre / Jacobi
 // ---------------------------------------------------------------------------------------
+#if S5_F_AGMK
+// K(m) by the arithmetic-geometric mean, K = pi / (2 AGM(1, sqrt(1-m))): ~5 square roots where
+// R_F(0, 1-m, 1) takes ~20.  Quadratic convergence: once |a-b| <= 2e-8 a the next mean is exact to
+// double precision, so the loop stops there and uses (a+b)/2.
+S5_DEV double ell_K(double m)
+{
+    if (m == 1.0) m = 1.0 - 1e-8;
+    double a = 1.0, b = msqrt(1.0 - m);
+    bool live = fabs(a - b) > 2e-8 * a;
+    for (int pass = 0; pass < 16; ++pass) {
+        if (!wave_any(live)) break;
+        if (live) {
+            const double an = 0.5 * (a + b);
+            b = sqrt_pos(a * b);
+            a = an;
+            live = fabs(a - b) > 2e-8 * a;
+        }
+    }
+    return mdiv(3.14159265358979323846, a + b);
+}
+#else
 S5_DEV double ell_K(double m)
 {
     if (m == 1.0) m = 1.0 - 1e-8;
     return carlson_rf(0.0, 1.0 - m, 1.0);
 }
+#endif
 
 S5_DEV double ell_F_sin(double s, double m)
 {
@@ -182,7 +241,7 @@ S5_DEV double ell_F_sin(double s, double m)
 S5_DEV double inv_sn(double z, double m)
 {
     if (fabs(m - 0.0) < 1e-8) return asin(z);
-    if (fabs(m - 1.0) < 1e-8) return log(sqrt((1. + z) / (1. - z)));
+    if (fabs(m - 1.0) < 1e-8) return log(msqrt(mdiv(1. + z, 1. - z)));
     return z * carlson_rf(1.0 - z * z, 1.0 - m * z * z, 1.0);
 }
 
@@ -196,18 +255,18 @@ S5_DEV double inv_cn(double z, double m)
     if (z == 0.0) return ell_K(m);
     if (z == 1.0) return 0.0;
     if (m == 0.0) return acos(z);
-    if (m == 1.0) return log((1. + sqrt(1. - z)) / z);
+    if (m == 1.0) return log(mdiv(1. + msqrt(1. - z), z));
 
-    double base = sqrt(1. - z * z) * carlson_rf(z * z, 1.0 - m * (1. - z * z), 1.0);
+    double base = msqrt(1. - z * z) * carlson_rf(z * z, 1.0 - m * (1. - z * z), 1.0);
     if (z > 0.0) return base;
-    return 2. / sqrt(1. - m) * ell_F_sin(-z, m / (m - 1.)) + base;
+    return mdiv(2., msqrt(1. - m)) * ell_F_sin(-z, mdiv(m, m - 1.)) + base;
 }
 
 S5_DEV double inv_tn(double z, double m)
 {
     if (m == 0.0) return atan(z);
-    if (m == 1.0) return log(z + sqrt(1. + z * z));
-    return inv_sn(sqrt(z * z / (1. + z * z)), m);
+    if (m == 1.0) return log(z + msqrt(1. + z * z));
+    return inv_sn(msqrt(mdiv(z * z, 1. + z * z)), m);
 }
 
 // sn, cn, dn by the descending Landen ladder.  13 rungs at most; rung values stay in VGPRs.
@@ -227,7 +286,7 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
     if (flipped) {
         d = 1.0 - emc;
         emc /= -1.0 / d;
-        d = sqrt(d);
+        d = msqrt(d);
         u *= d;
     }
     double ra[13], rg[13];
@@ -238,7 +297,7 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
     for (int i = 0; i < 13; ++i) {
         if (climbing) {
             ra[i] = a;
-            emc = sqrt(emc);
+            emc = msqrt(emc);
             rg[i] = emc;
             c = 0.5 * (a + emc);
             if (fabs(a - emc) <= conv * a) { climbing = false; top = i; }
@@ -248,11 +307,10 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
     }
     u *= c;
     double s0, c0;
-    s0 = sin(u);
-    c0 = cos(u);
+    msincos(u, s0, c0);
     sn = s0; cn = c0; dn = 1.0;
     if (s0 != 0.0) {
-        a = c0 / s0;
+        a = mdiv(c0, s0);
         c *= a;
 #pragma unroll
         for (int i = 12; i >= 0; --i) {
@@ -261,12 +319,12 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
                     double b = ra[i];
                     a *= c;
                     c *= dn;
-                    dn = (rg[i] + a) / (b + a);
-                    a = c / b;
+                    dn = mdiv(rg[i] + a, b + a);
+                    a = mdiv(c, b);
                 }
             }
         }
-        a = 1.0 / sqrt(c * c + 1.0);
+        a = mdiv(1.0, msqrt(c * c + 1.0));
         sn = (s0 >= 0.0 ? a : -a);
         cn = c * sn;
     }
@@ -274,7 +332,7 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
         a = dn;
         dn = cn;
         cn = a;
-        sn /= d;
+        sn = mdiv(sn, d);
     }
 }
 
@@ -282,4 +340,4 @@ S5_DEV double jac_sn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d)
 S5_DEV double jac_cn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return c; }
 S5_DEV double jac_dn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return d; }
 
-} // namespace s5
+} // namespace S5NS

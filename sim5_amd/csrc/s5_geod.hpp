@@ -16,7 +16,7 @@
 #pragma once
 #include "s5_kerr.hpp"
 
-namespace s5 {
+namespace S5NS {
 
 enum : int { T_RR = 40, T_RR_DBL = 41, T_RR_BH = 42, T_RC = 2, T_CC = 0 };
 enum : int {
@@ -63,21 +63,23 @@ S5_DEV bool radial_roots(Geod& g, double r0, int& err)
     const double F = -27. / 4. * (D * D * D) - 108. * a2 * q * D + 108. * sq(C);
     const double X = sq(F) - 4. * (E * E * E);
     if (X >= 0) {
-        const double sX = sqrt(X);
-        A = (F > sX ? +1 : -1) * 1. / 3. * pow(fabs(F - sX) / 2., 1. / 3.) +
-            (F > -sX ? +1 : -1) * 1. / 3. * pow(fabs(F + sX) / 2., 1. / 3.);
+        const double sX = msqrt(X);
+        A = (F > sX ? +1 : -1) * 1. / 3. * mcbrt(fabs(F - sX) / 2.) +
+            (F > -sX ? +1 : -1) * 1. / 3. * mcbrt(fabs(F + sX) / 2.);
     } else {
-        const double sX = sqrt(-X) / 54.;
-        const double Z = sqrt(sq(F / 54.) + sq(sX));
-        const double z = atan2(sX, F / 54.);
-        A = pow(Z, 1. / 3.) * 2. * cos(z / 3.);
+        const double sX = S5_DIVC(msqrt(-X), 54.);
+        const double F54 = S5_DIVC(F, 54.);
+        const double Z = msqrt(sq(F54) + sq(sX));
+        const double z = atan2(sX, F54);
+        A = mcbrt(Z) * 2. * cos(S5_DIVC(z, 3.));
     }
-    const double B = sqrt(A + D);
-    const double w_hi = -A + 2. * D - 4. * C / B;     // discriminant of the pair around +B/2
-    const double w_lo = -A + 2. * D + 4. * C / B;     // discriminant of the pair around -B/2
+    const double B = msqrt(A + D);
+    const double CB = mdiv(4. * C, B);
+    const double w_hi = -A + 2. * D - CB;             // discriminant of the pair around +B/2
+    const double w_lo = -A + 2. * D + CB;             // discriminant of the pair around -B/2
     const bool hi_real = (w_hi >= 0.0), lo_real = (w_lo >= 0.0);
     // csqrt(w + 0i): (sqrt(w), 0) for w >= 0, (0, sqrt(-w)) for w < 0; halves as in `.5*csqrt()`
-    const double h_hi = .5 * sqrt(fabs(w_hi)), h_lo = .5 * sqrt(fabs(w_lo));
+    const double h_hi = .5 * msqrt(fabs(w_hi)), h_lo = .5 * msqrt(fabs(w_lo));
     const double c_hi = +B / 2., c_lo = -B / 2.;
 
     g.nrr = (hi_real ? 2 : 0) + (lo_real ? 2 : 0);
@@ -120,22 +122,22 @@ S5_DEV bool radial_roots(Geod& g, double r0, int& err)
 
     if (g.type == T_RR || g.type == T_RR_BH) {
         const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
-        const double mm = ((r2 - r3) * (r1 - r4)) / ((r2 - r4) * (r1 - r3));
-        const double pre = 2. / sqrt((r1 - r3) * (r2 - r4));
+        const double mm = mdiv((r2 - r3) * (r1 - r4), (r2 - r4) * (r1 - r3));
+        const double pre = mdiv(2., msqrt((r1 - r3) * (r2 - r4)));
         if (g.type == T_RR) {
             g.rp = r1;
-            g.Rpc = pre * inv_sn(sqrt((r2 - r4) / (r1 - r4)), mm);
+            g.Rpc = pre * inv_sn(msqrt(mdiv(r2 - r4, r1 - r4)), mm);
         } else {
             g.rp = r2;
             g.Rpc = pre * ell_K(mm);
         }
     } else if (g.type == T_RC) {
         const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
-        const double Aq = sqrt(sq(r1 - u) + sq(v));
-        const double Bq = sqrt(sq(r2 - u) + sq(v));
-        const double mm = (sq(Aq + Bq) - sq(r1 - r2)) / (4. * Aq * Bq);
+        const double Aq = msqrt(sq(r1 - u) + sq(v));
+        const double Bq = msqrt(sq(r2 - u) + sq(v));
+        const double mm = mdiv(sq(Aq + Bq) - sq(r1 - r2), 4. * Aq * Bq);
         g.rp = r1;
-        g.Rpc = 1. / sqrt(Aq * Bq) * inv_cn((Aq - Bq) / (Aq + Bq), mm);
+        g.Rpc = mdiv(1., msqrt(Aq * Bq)) * inv_cn(mdiv(Aq - Bq, Aq + Bq), mm);
     } else {
         const double b1 = g.r1[0], b2 = g.r3[0], a1 = g.r1[1], a2c = g.r3[1];
         const double Aq = sqrt(sq(b1 - b2) + sq(a1 + a2c));
@@ -156,20 +158,20 @@ S5_DEV bool polar_roots(Geod& g, double m, int& err)
     const double a = g.a, l = g.l, q = g.q;
     const double a2 = a * a, l2 = l * l;
     const double qla = q + l2 - a2;
-    const double X = sqrt(sq(qla) + 4. * q * a2) + qla;
-    g.m2m = X / (a2 + a2);
-    g.m2p = (q + q) / X;
+    const double X = msqrt(sq(qla) + 4. * q * a2) + qla;
+    g.m2m = mdiv(X, a2 + a2);
+    g.m2p = mdiv(q + q, X);
     if ((g.m2p <= 0.0) || (g.m2p >= 1.0)) { err = GD_E_MUPLUS; return false; }
     if (q > 0.0) {
-        g.mm = g.m2p / (g.m2p + g.m2m);
+        g.mm = mdiv(g.m2p, g.m2p + g.m2m);
         if ((g.mm < 0.0) || (g.mm >= 1.0)) { err = GD_E_MM; return false; }
-        if (fabs(m) > sqrt(g.m2p)) { err = GD_E_MU0; return false; }
-        g.mK = 1. / sqrt(a2 * (g.m2p + g.m2m));
+        if (fabs(m) > msqrt(g.m2p)) { err = GD_E_MU0; return false; }
+        g.mK = mdiv(1., msqrt(a2 * (g.m2p + g.m2m)));
     } else if (q < 0.0) {
-        g.mm = (g.m2p + g.m2m) / g.m2p;
+        g.mm = mdiv(g.m2p + g.m2m, g.m2p);
         if ((g.mm < 0.0) || (g.mm >= 1.0)) { err = GD_E_MM; return false; }
-        if ((fabs(m) > sqrt(g.m2p)) || (fabs(m) < sqrt(-g.m2m))) { err = GD_E_MU0; return false; }
-        g.mK = 1. / sqrt(a2 * g.m2p);
+        if ((fabs(m) > msqrt(g.m2p)) || (fabs(m) < msqrt(-g.m2m))) { err = GD_E_MU0; return false; }
+        g.mK = mdiv(1., msqrt(a2 * g.m2p));
     } else {
         err = GD_E_Q_RANGE;
         return false;
@@ -204,7 +206,7 @@ S5_DEV bool init_inf(double incl, double sin_i, double cos_i, double a, double a
 
     // Tpp = 2 mK cn^-1(0|mm) = 2 mK K(mm);  Tip = mK cn^-1(cos_i/sqrt(m2p)|mm)
     cache.K = ell_K(g.mm);                                   // cn^-1(0|mm) with mm in [0,1)
-    cache.u_i = g.cos_i / sqrt(g.m2p);
+    cache.u_i = mdiv(g.cos_i, msqrt(g.m2p));
     cache.icn_i = inv_cn(cache.u_i, g.mm);
     cache.valid = true;
     g.Tpp = 2. * (g.mK * cache.K);
@@ -253,20 +255,20 @@ S5_DEV double position_rad(const Geod& g, double P)
     if (P == g.Rpc) return g.rp;
     if (g.type == T_RR) {
         const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
-        const double m4 = ((r2 - r3) * (r1 - r4)) / ((r2 - r4) * (r1 - r3));
-        const double x4 = 0.5 * fabs(P - g.Rpc) * sqrt((r2 - r4) * (r1 - r3));
+        const double m4 = mdiv((r2 - r3) * (r1 - r4), (r2 - r4) * (r1 - r3));
+        const double x4 = 0.5 * fabs(P - g.Rpc) * msqrt((r2 - r4) * (r1 - r3));
         const double sn = jac_sn(x4, m4);
         const double sn2 = sn * sn;
-        return (r1 * (r2 - r4) - r2 * (r1 - r4) * sn2) / (r2 - r4 - (r1 - r4) * sn2);
+        return mdiv(r1 * (r2 - r4) - r2 * (r1 - r4) * sn2, r2 - r4 - (r1 - r4) * sn2);
     }
     if (g.type == T_RC) {
         if (P > g.Rpc) return NAN;
         const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
-        const double A = sqrt(sq(r1 - u) + sq(v));
-        const double B = sqrt(sq(r2 - u) + sq(v));
-        const double m2 = (sq(A + B) - sq(r1 - r2)) / (4. * A * B);
-        const double cn = jac_cn(sqrt(A * B) * (g.Rpc - P), m2);
-        return (r2 * A - r1 * B - (r2 * A + r1 * B) * cn) / ((A - B) - (A + B) * cn);
+        const double A = msqrt(sq(r1 - u) + sq(v));
+        const double B = msqrt(sq(r2 - u) + sq(v));
+        const double m2 = mdiv(sq(A + B) - sq(r1 - r2), 4. * A * B);
+        const double cn = jac_cn(msqrt(A * B) * (g.Rpc - P), m2);
+        return mdiv(r2 * A - r1 * B - (r2 * A + r1 * B) * cn, (A - B) - (A + B) * cn);
     }
     return NAN;
 }
@@ -317,7 +319,7 @@ S5_DEV void momentum(const Geod& g, double P, double r, double m, double k[4])  
 S5_DEV double midplane_crossing(const Geod& g, int order, const GeodCache& cache)
 {
     if (g.q <= 0.0) return NAN;
-    double u = g.cos_i / sqrt(g.m2p);
+    double u = mdiv(g.cos_i, msqrt(g.m2p));
     if (u < -1.0 - 1e-4) return NAN;                           // slack clamp, ref src/sim5math.c:50-58
     if (u > +1.0 + 1e-4) return NAN;
     if (u < -1.0) u = -1.0;
@@ -381,4 +383,4 @@ S5_DEV void follow(const Geod& g, double step, double& P, double& r, double& m, 
     status = 1;
 }
 
-} // namespace s5
+} // namespace S5NS

@@ -9,7 +9,7 @@
 #pragma once
 #include "s5_elliptic.hpp"
 
-namespace s5 {
+namespace S5NS {
 
 struct Metric { double a, r, m, g00, g11, g22, g33, g03; };   // = sim5gpu_metric (64 B)
 struct Tetrad { double e[4][4]; Metric metric; };               // = sim5gpu_tetrad (192 B)
@@ -277,7 +277,7 @@ S5_DEV void on2bl(const double in[4], double out[4], const Tetrad& t)           
 }
 
 // r^1.5 as r*sqrt(r): two correctly rounded operations, within 1 ulp of pow(r,1.5)
-S5_DEV double omega_kepler(double r, double a) { return 1. / (a + r * sqrt(r)); }       // ref :1037-1047
+S5_DEV double omega_kepler(double r, double a) { return mdiv(1., a + r * msqrt(r)); }       // ref :1037-1047
 
 S5_DEV double ell_kepler(double r, double a)                                              // ref :1050-1072
 {
@@ -291,9 +291,9 @@ S5_DEV double omega_from_ell(double ell, const Metric& g)                       
 
 S5_DEV double gfactor_kepler(double r, double a, double l)                                // ref :1128-1141
 {
-    double Om = 1. / (a + r * sqrt(r));
+    double Om = mdiv(1., a + r * msqrt(r));
     double w = 1. - a * Om;
-    return sqrt(1. - 2. / r * (w * w) - (r * r + a * a) * (Om * Om)) / (1. - Om * l);
+    return mdiv(msqrt(1. - mdiv(2., r) * (w * w) - (r * r + a * a) * (Om * Om)), 1. - Om * l);
 }
 
 S5_DEV void photon_momentum(double a, double r, double m, double l, double q,
@@ -340,4 +340,4 @@ S5_DEV double carter_constant(const double k[4], const Metric& g)               
     return sq(kh) + sq(kf) * m2 / (1. - m2) - sq(g.a) * sq(kt) * m2;
 }
 
-} // namespace s5
+} // namespace S5NS

@@ -1,0 +1,84 @@
+// s5_math.hpp -- FP64 primitives of the device code, in the two build variants of s5_config.hpp.
+//
+// gfx950 has no FP64 divide or square-root instruction: both are software sequences around the
+// quarter-rate v_rcp_f64 / v_rsq_f64 seeds (~26 good bits).  The compiler's IEEE sequences carry
+// operand scaling for the denormal range, a last correctly-rounding step and special-value fix-ups
+// (17 instructions for sqrt, 11 + hazard no-ops for a division).  The values on this path are
+// O(1e-6 .. 1e6), so the fast variant refines the seed directly:
+//   msqrt : rsq, one coupled Newton step (g = sqrt, h = 1/(2 sqrt)), one residual correction
+//           -> 8 instructions + zero/negative guard, error < 1 ulp
+//   mrcp  : rcp, two Newton steps                              -> 5 instructions, error < 1 ulp
+//   mdiv  : mrcp, quotient, one residual correction            -> 8 instructions, error < 1 ulp
+// The strict variant is plain `sqrt` and `/` (correctly rounded).
+#pragma once
+#include "s5_config.hpp"
+
+namespace S5NS {
+
+S5_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+S5_DEV double sq(double x) { return x * x; }
+S5_DEV double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), fabs(b)), fabs(c)); }
+
+#if S5_F_SQRTDIV
+
+// sqrt for x known to be positive, finite and normal
+S5_DEV double sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+// general sqrt: +-0 -> itself, negative / NaN -> NaN (as IEEE), +inf is not expected on this path
+S5_DEV double msqrt(double x)
+{
+    const double g = sqrt_pos(x);
+    return (x == 0.0) ? x : g;          // rsq(0) = inf makes g NaN; rsq(<0) = NaN propagates
+}
+
+S5_DEV double mrcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+S5_DEV double mdiv(double a, double b)
+{
+    const double r = mrcp(b);
+    const double q = a * r;
+    const double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
+}
+
+#else
+
+S5_DEV double sqrt_pos(double x) { return sqrt(x); }
+S5_DEV double msqrt(double x) { return sqrt(x); }
+S5_DEV double mrcp(double b) { return 1.0 / b; }
+S5_DEV double mdiv(double a, double b) { return a / b; }
+
+#endif
+
+#if S5_F_LIBM
+// x^(1/3) for x >= 0 (the reference writes pow(x, 1./3.); 1./3. is not exactly one third, the two
+// differ by ln(x) * 1.85e-17 relative)
+S5_DEV double mcbrt(double x) { return cbrt(x); }
+S5_DEV void msincos(double x, double& s, double& c) { sincos(x, &s, &c); }
+// division by a compile-time constant: multiply by the folded reciprocal
+#define S5_DIVC(a, c) ((a) * (1.0 / (c)))
+#else
+S5_DEV double mcbrt(double x) { return pow(x, 1. / 3.); }
+S5_DEV void msincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
+#define S5_DIVC(a, c) ((a) / (c))
+#endif
+
+} // namespace S5NS

@@ -5,7 +5,7 @@
 #pragma once
 #include "s5_kerr.hpp"
 
-namespace s5 {
+namespace S5NS {
 
 S5_DEV void polarization_constant(const double k[4], const double f[4], const Metric& g, double wp[2])
 {
@@ -73,4 +73,4 @@ S5_DEV double blackbody_Iv(double T, double hardf, double cos_mu, double E)
            expm1((h * freq) / (kB * hardf * T)) * (1. / freq2kev);
 }
 
-} // namespace s5
+} // namespace S5NS

@@ -9,7 +9,7 @@
 #pragma once
 #include "s5_kerr.hpp"
 
-namespace s5 {
+namespace S5NS {
 
 // byte-identical to sim5gpu_raytrace_data / the reference's struct raytrace_data
 struct RayState {
@@ -167,4 +167,4 @@ S5_DEV double raytrace_error(const double x[4], const double k[4], const RayStat
     return rel_diff(s.Q, carter_constant(k, g));
 }
 
-} // namespace s5
+} // namespace S5NS

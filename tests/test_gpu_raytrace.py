@@ -78,7 +78,7 @@ def test_polarized_image(capi, golden):
     # intensity plane equals the unpolarized kernel's F g^4
     o = capi.disk_image(capi.image_desc(n, n, a, inc / 180.0 * math.pi), full=True)
     g2 = o["g"] * o["g"]
-    assert np.array_equal(S[0], o["flux"] * (g2 * g2))
+    assert_close(S[0], o["flux"] * (g2 * g2), rtol=1e-12, what="I plane vs unpolarized kernel")
     assert np.array_equal(cls.to_numpy(np.uint8, (n, n)), o["cls"])
 
 
