@@ -1,0 +1,55 @@
+/* disk_image_batch.c -- the thin-disk image of SIM5's examples/04-disk-image-eqplane, with the pixel
+ * loop moved into ONE call of the MI355X library (sim5gpu_disk_image_host) instead of five SIM5 calls
+ * per pixel.  Same command line, same stdout format ("%d  %d  %e  %e\n" per pixel, blank line per row),
+ * same default image size (1280 x 720).
+ *
+ *   gcc -O2 -Iinclude examples/disk_image_batch.c -o disk-image-batch -Lsim5_amd/lib -lsim5gpu \
+ *       -Wl,-rpath,$PWD/sim5_amd/lib -lm
+ *   ./disk-image-batch <spin> <inclination_deg>  > image.dat
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include "sim5gpu.h"
+
+int main(int argc, char *argv[])
+{
+    const int nx = 1280, ny = 720;
+    if (argc != 3) {
+        fprintf(stderr, "Usage: %s <spin> <inclination>\n", argv[0]);
+        return 0;
+    }
+    const double a = atof(argv[1]);
+    const double inc = atof(argv[2]) / 180.0 * M_PI;
+    float *image_f = calloc((size_t)nx * ny, sizeof(float));
+    float *image_g = calloc((size_t)nx * ny, sizeof(float));
+
+    sim5gpu_image_desc d;
+    d.nx = nx; d.ny = ny; d.y0 = 0; d.y1 = ny;
+    d.a = a; d.incl = inc;
+    d.rmax = 0.0;                 /* r_ms(a) + 8, as the example */
+    d.rms = 0.0;                  /* r_ms(a) */
+    d.bh_mass = 10.0; d.mdot = 0.1; d.alpha_visc = 0.1;
+    d.max_order = 2; d.flags = SIM5GPU_IMG_DEFAULT; d.pol_degree = 0.0;
+
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int rc = sim5gpu_disk_image_host(&d, image_f, image_g, NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (rc != SIM5GPU_OK) {
+        fprintf(stderr, "ERROR: %s\n", sim5gpu_last_error());
+        return 1;
+    }
+    const double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    fprintf(stderr, "Profiling:\n    photons: %d\n    time: %.4f s (allocation, kernel and copies)\n    rate: %.1f photons/s\n",
+            nx * ny, dt, nx * ny / dt);
+    for (int iy = 0; iy < ny; iy++) {
+        for (int ix = 0; ix < nx; ix++)
+            printf("%d  %d  %e  %e\n", iy, ix, image_f[ix + nx * iy], image_g[ix + nx * iy]);
+        printf("\n");
+    }
+    free(image_f);
+    free(image_g);
+    return 0;
+}

@@ -167,6 +167,15 @@ int sim5gpu_photon_motion_constants(size_t n, const double *a, const double *r, 
                                     const double *k, double *L, double *Q);
 int sim5gpu_photon_carter_const(size_t n, const double *k, const sim5gpu_metric *metric, double *Q);
 
+/* r_bh, r_ms, OmegaK, ellK, Omega_from_ell, dotprod (ref src/sim5kerr.c:981, 994, 1037, 1050, 1101, 609);
+ * dotprod: metric == NULL means the Minkowski product -v0w0 + v1w1 + v2w2 + v3w3, as in SIM5 */
+int sim5gpu_r_bh(size_t n, const double *a, double *r);
+int sim5gpu_r_ms(size_t n, const double *a, double *r);
+int sim5gpu_OmegaK(size_t n, const double *r, const double *a, double *Omega);
+int sim5gpu_ellK(size_t n, const double *r, const double *a, double *ell);
+int sim5gpu_Omega_from_ell(size_t n, const double *ell, const sim5gpu_metric *metric, double *Omega);
+int sim5gpu_dotprod(size_t n, const double *v1, const double *v2, const sim5gpu_metric *metric, double *out);
+
 /* gfactorK (ref src/sim5kerr.c:1128-1141) */
 int sim5gpu_gfactorK(size_t n, const double *r, const double *a, const double *l, double *g);
 

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 CSVs that profiles/collect.sh left under gpurun_out/prof_<tag>/ into the
+committed summaries profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and profiles/traffic.json
+(HBM bytes per launch of the image kernel, read by bench.py for roofline.traffic).
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB,
+collected in separate passes; on gfx950 FETCH_SIZE under-reports wide streaming reads by 2x -- this
+kernel reads no input at all (kernel arguments only), so the read side is negligible either way and
+is reported both raw and doubled."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+KERNEL = "disk_image_grid_kernel"
+
+stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+if stats:
+    rows = list(csv.reader(open(stats[0])))
+    with open(os.path.join(root, "profiles", tag + "_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        for r in rows[:12]:
+            w.writerow([c[:160] for c in r])
+
+pmc = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv"))):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(d)):
+        if KERNEL in row["Kernel_Name"]:
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, v in acc.items():
+        pmc[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+trace = glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))
+dur = []
+meta = {}
+if trace:
+    for row in csv.DictReader(open(trace[0])):
+        if KERNEL in row["Kernel_Name"]:
+            dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            meta = {k: row[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size",
+                                        "Workgroup_Size_X", "Grid_Size_X", "Grid_Size_Y") if k in row}
+out = {"kernel": KERNEL, "pmc": pmc, "dispatch": meta,
+       "kernel_ns_avg": sum(dur) / len(dur) if dur else None, "kernel_launches": len(dur)}
+rays = 4096 * 4096
+if "SQ_INSTS_VALU" in pmc:
+    out["valu_wave_instructions_per_ray_lane"] = pmc["SQ_INSTS_VALU"]["mean_per_launch"] / (rays / 64)
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+    write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+    out["hbm"] = {"fetch_bytes_raw": fetch, "fetch_bytes_x2_gfx950": 2 * fetch, "write_bytes": write,
+                  "algorithmic_bytes": rays * 8}
+    json.dump({"hbm_bytes_per_launch": 2 * fetch + write, "source": "profiles/%s_pmc.json" % tag,
+               "note": "2*FETCH_SIZE + WRITE_SIZE, KiB->B, per launch of " + KERNEL},
+              open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+bj = os.path.join(src, "bench_under_rocprof.json")
+if os.path.exists(bj):
+    try:
+        out["bench_under_rocprof"] = json.load(open(bj))
+    except Exception:
+        pass
+json.dump(out, open(os.path.join(root, "profiles", tag + "_pmc.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "bench_under_rocprof"}, indent=1)[:3000])

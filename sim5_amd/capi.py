@@ -309,6 +309,58 @@ def photon_carter_const(k, metric):
     return Q
 
 
+def _unary(fn, name, x):
+    x = _f64(x).ravel()
+    out = np.empty(x.size)
+    _check(fn(SZ(x.size), _p(x), _p(out)), name)
+    return out
+
+
+def r_bh(a):
+    return _unary(_lib.sim5gpu_r_bh, "sim5gpu_r_bh", a)
+
+
+def r_ms(a):
+    return _unary(_lib.sim5gpu_r_ms, "sim5gpu_r_ms", a)
+
+
+def OmegaK(r, a):
+    r = _f64(r).ravel()
+    a = _f64(a, r.size)
+    out = np.empty(r.size)
+    _check(_lib.sim5gpu_OmegaK(SZ(r.size), _p(r), _p(a), _p(out)), "sim5gpu_OmegaK")
+    return out
+
+
+def ellK(r, a):
+    r = _f64(r).ravel()
+    a = _f64(a, r.size)
+    out = np.empty(r.size)
+    _check(_lib.sim5gpu_ellK(SZ(r.size), _p(r), _p(a), _p(out)), "sim5gpu_ellK")
+    return out
+
+
+def Omega_from_ell(ell, metric):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    ell = _f64(ell, metric.size)
+    out = np.empty(metric.size)
+    _check(_lib.sim5gpu_Omega_from_ell(SZ(metric.size), _p(ell), _p(metric), _p(out)), "sim5gpu_Omega_from_ell")
+    return out
+
+
+def dotprod(v1, v2, metric=None):
+    v1 = _f64(v1).reshape(-1, 4)
+    n = v1.shape[0]
+    v2 = _f64(v2, n, 4)
+    mp = None
+    if metric is not None:
+        metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+        mp = _p(metric)
+    out = np.empty(n)
+    _check(_lib.sim5gpu_dotprod(SZ(n), _p(v1), _p(v2), mp, _p(out)), "sim5gpu_dotprod")
+    return out
+
+
 def gfactorK(r, a, l):
     r = _f64(r).ravel()
     n = r.size

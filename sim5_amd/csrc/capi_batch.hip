@@ -244,6 +244,71 @@ int sim5gpu_photon_carter_const(size_t n, const double* k, const sim5gpu_metric*
     return SIM5GPU_OK;
 }
 
+#define S5_UNARY_FN(NAME, EXPR)                                                                \
+int NAME(size_t n, const double* x, double* out)                                               \
+{                                                                                              \
+    S5_NEED(#NAME, x && out);                                                                  \
+    if (n == 0) return SIM5GPU_OK;                                                             \
+    S5_DEVICE_OR_FAIL();                                                                       \
+    DevBuf<double> dx(x, n), dout(n);                                                          \
+    S5_BUFS_OK(#NAME, dx.ok() && dout.ok());                                                   \
+    const double* px = dx.ptr; double* po = dout.ptr;                                          \
+    S5_RUN(n, #NAME, [=] __device__(size_t i) { const double v = px[i]; po[i] = (EXPR); });    \
+    S5_HIP(dout.to_host(out));                                                                 \
+    return SIM5GPU_OK;                                                                         \
+}
+S5_UNARY_FN(sim5gpu_r_bh, r_horizon(v))
+S5_UNARY_FN(sim5gpu_r_ms, r_isco(v))
+#undef S5_UNARY_FN
+
+#define S5_BINARY_FN(NAME, EXPR)                                                               \
+int NAME(size_t n, const double* x, const double* y, double* out)                              \
+{                                                                                              \
+    S5_NEED(#NAME, x && y && out);                                                             \
+    if (n == 0) return SIM5GPU_OK;                                                             \
+    S5_DEVICE_OR_FAIL();                                                                       \
+    DevBuf<double> dx(x, n), dy(y, n), dout(n);                                                \
+    S5_BUFS_OK(#NAME, dx.ok() && dy.ok() && dout.ok());                                        \
+    const double *px = dx.ptr, *py = dy.ptr; double* po = dout.ptr;                            \
+    S5_RUN(n, #NAME, [=] __device__(size_t i) { const double u = px[i], v = py[i]; po[i] = (EXPR); }); \
+    S5_HIP(dout.to_host(out));                                                                 \
+    return SIM5GPU_OK;                                                                         \
+}
+// OmegaK uses pow(r, 1.5) in the reference; r*sqrt(r) is within 1 ulp of it
+S5_BINARY_FN(sim5gpu_OmegaK, omega_kepler(u, v))
+S5_BINARY_FN(sim5gpu_ellK, ell_kepler(u, v))
+#undef S5_BINARY_FN
+
+int sim5gpu_Omega_from_ell(size_t n, const double* ell, const sim5gpu_metric* metric, double* Omega)
+{
+    S5_NEED("Omega_from_ell", ell && metric && Omega);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dl(ell, n), dout(n); DevBuf<Metric> dmt((const Metric*)metric, n);
+    S5_BUFS_OK("Omega_from_ell", dl.ok() && dout.ok() && dmt.ok());
+    const double* pl = dl.ptr; double* po = dout.ptr; const Metric* pg = dmt.ptr;
+    S5_RUN(n, "Omega_from_ell", [=] __device__(size_t i) { po[i] = omega_from_ell(pl[i], pg[i]); });
+    S5_HIP(dout.to_host(Omega));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_dotprod(size_t n, const double* v1, const double* v2, const sim5gpu_metric* metric, double* out)
+{
+    S5_NEED("dotprod", v1 && v2 && out);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> d1(v1, 4 * n), d2(v2, 4 * n), dout(n); DevBuf<Metric> dmt((const Metric*)metric, metric ? n : 0);
+    S5_BUFS_OK("dotprod", d1.ok() && d2.ok() && dout.ok() && dmt.ok());
+    const double *p1 = d1.ptr, *p2 = d2.ptr; double* po = dout.ptr; const Metric* pg = dmt.ptr;
+    S5_RUN(n, "dotprod", [=] __device__(size_t i) {
+        const double u[4] = { p1[4 * i], p1[4 * i + 1], p1[4 * i + 2], p1[4 * i + 3] };
+        const double w[4] = { p2[4 * i], p2[4 * i + 1], p2[4 * i + 2], p2[4 * i + 3] };
+        po[i] = pg ? dot(u, w, pg[i]) : (-u[0] * w[0] + u[1] * w[1] + u[2] * w[2] + u[3] * w[3]);
+    });
+    S5_HIP(dout.to_host(out));
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_gfactorK(size_t n, const double* r, const double* a, const double* l, double* g)
 {
     S5_NEED("gfactorK", r && a && l && g);

@@ -10,6 +10,12 @@ namespace s5 {
 thread_local char g_err[512] = "";
 DiskConsts g_disk = {};            // process-global like the reference's statics (src/sim5disk-nt.c:27-32)
 
+Arena& arena()
+{
+    static thread_local Arena a;
+    return a;
+}
+
 void set_error(const char* what, hipError_t e)
 {
     snprintf(g_err, sizeof g_err, "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));

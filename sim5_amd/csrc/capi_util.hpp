@@ -24,24 +24,58 @@ int  fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p);
         if (e_ != hipSuccess) { s5::set_error(#call, e_); return SIM5GPU_E_HIP; } \
     } while (0)
 
+// Device staging memory of the batch entry points.  A per-thread grow-only arena replaces a
+// hipMalloc/hipFree pair per argument (each tens of microseconds): the SIM5 scalar API of
+// sim5_amd/host/sim5lib.c calls these entry points with n = 1, millions of times.  Buffers are carved
+// in call order and the arena is rewound when the last buffer of a call is destroyed.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    int live = 0;
+    void* take(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (used + bytes > cap) {
+            if (live != 0) return nullptr;                 // cannot move buffers that are in use
+            if (base) (void)hipFree(base);
+            size_t want = cap ? cap * 2 : (size_t)1 << 20;
+            while (want < bytes) want *= 2;
+            if (hipMalloc((void**)&base, want) != hipSuccess) { base = nullptr; cap = 0; return nullptr; }
+            cap = want; used = 0;
+        }
+        void* p = base + used;
+        used += bytes; ++live;
+        return p;
+    }
+    void give() { if (--live == 0) used = 0; }
+};
+Arena& arena();
+
 // RAII device buffer for the host-array (batch) entry points
 template <typename T>
 struct DevBuf {
     T* ptr = nullptr;
     size_t n = 0;
     bool failed = false;
-    explicit DevBuf(size_t count) : n(count)
+    bool from_arena = false;
+    void alloc()
     {
-        if (n && hipMalloc((void**)&ptr, n * sizeof(T)) != hipSuccess) { ptr = nullptr; failed = true; }
+        if (!n) return;
+        ptr = (T*)arena().take(n * sizeof(T));
+        if (ptr) { from_arena = true; return; }
+        if (hipMalloc((void**)&ptr, n * sizeof(T)) != hipSuccess) { ptr = nullptr; failed = true; }
     }
-    DevBuf(const T* host, size_t count) : n(count)
+    explicit DevBuf(size_t count) : n(count) { alloc(); }
+    DevBuf(const T* host, size_t count) : n(host ? count : 0)
     {
-        if (n && host) {
-            if (hipMalloc((void**)&ptr, n * sizeof(T)) != hipSuccess) { ptr = nullptr; failed = true; return; }
-            if (hipMemcpy(ptr, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) failed = true;
-        }
+        alloc();
+        if (ptr && hipMemcpy(ptr, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) failed = true;
     }
-    ~DevBuf() { if (ptr) (void)hipFree(ptr); }
+    ~DevBuf()
+    {
+        if (!ptr) return;
+        if (from_arena) arena().give(); else (void)hipFree(ptr);
+    }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     bool ok() const { return !failed; }

@@ -6,10 +6,10 @@
 // i.e. the body of the caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105,
 // for up to max_order crossings, and writes (float)(F g^4) and (float)g.
 //
-// Launch geometry: a 256-thread workgroup covers a 16 x 16 pixel tile, each wave64 a 16 x 4
+// Launch geometry: a 256-thread workgroup covers a 32 x 8 pixel tile, each wave64 a 32 x 2
 // patch of it.  Rays of a wave are image-plane neighbours, so they share the geodesic class and
-// the Carlson trip counts almost always; each wave row stores 16 consecutive f32 = one full 64-B
-// segment per plane.  No input is read in grid mode (alpha, beta follow from the pixel index,
+// the Carlson trip counts almost always (measured lane utilisation 98 %); each wave row stores 32
+// consecutive f32 = one whole 128-B line per plane.  No input is read in grid mode (alpha, beta follow from the pixel index,
 // ref disk-image.c:57-58); in list mode alpha[]/beta[] are read coalesced, 8 B per lane.
 #include "s5_disk.hpp"
 #include "kernels.hpp"
@@ -79,14 +79,24 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
     if (p.flux) p.flux[o] = res.flux;
 }
 
-__global__ __launch_bounds__(256, 2)
+#ifndef S5_TILE_W
+#define S5_TILE_W 32                     // pixels per wave row: a wave covers 32 x 2 pixels, i.e. each of its
+                                         // f32 stores fills two whole 128-B lines (measured on MI355X, 4096^2:
+                                         // 8x8 1.701 ms, 16x4 1.700, 32x2 1.710, 64x1 1.750)
+#endif
+#ifndef S5_LB_WAVES
+#define S5_LB_WAVES 2
+#endif
+constexpr int TILE_W = S5_TILE_W;        // workgroup tile: TILE_W x (256 / TILE_W) pixels
+constexpr int TILE_H = 256 / TILE_W;
+
+__global__ __launch_bounds__(256, S5_LB_WAVES)
 void disk_image_grid_kernel(ImageParams p)
 {
-    // 16 x 16 pixel tile per workgroup; wave w covers rows 4w..4w+3 of the tile
-    const int lane_x = threadIdx.x & 15;
-    const int lane_y = threadIdx.x >> 4;
-    const int ix = blockIdx.x * 16 + lane_x;
-    const int iy = p.y0 + blockIdx.y * 16 + lane_y;
+    const int lane_x = threadIdx.x % TILE_W;
+    const int lane_y = threadIdx.x / TILE_W;
+    const int ix = blockIdx.x * TILE_W + lane_x;
+    const int iy = p.y0 + blockIdx.y * TILE_H + lane_y;
     if (ix >= p.nx || iy >= p.y1) return;
 
     // ref disk-image.c:57-58 (operation order kept)
@@ -120,7 +130,7 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
         const unsigned blocks = (unsigned)((p.n + 255) / 256);
         hipLaunchKernelGGL(disk_image_list_kernel, dim3(blocks), dim3(256), 0, stream, p);
     } else {
-        const dim3 grid((p.nx + 15) / 16, (p.y1 - p.y0 + 15) / 16);
+        const dim3 grid((p.nx + TILE_W - 1) / TILE_W, (p.y1 - p.y0 + TILE_H - 1) / TILE_H);
         hipLaunchKernelGGL(disk_image_grid_kernel, grid, dim3(256), 0, stream, p);
     }
     return (int)hipGetLastError();

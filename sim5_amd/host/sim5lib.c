@@ -1,0 +1,365 @@
+/*
+ * sim5lib.c -- host side of the SIM5 scalar API over libsim5gpu.so (see sim5lib.h).
+ *
+ * Plain C (builds with the reference's own example Makefile flags: gcc -O3 -w -fgnu89-inline ... -lm).
+ * Each SIM5 function = one batch call with n = 1 through function pointers resolved by dlopen/dlsym
+ * on first use (glibc >= 2.34 has dlopen in libc, so no -ldl is needed).  No ray arithmetic happens in
+ * this file.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include "sim5lib.h"
+
+#ifndef SIM5GPU_LIB_DEFAULT
+#define SIM5GPU_LIB_DEFAULT ""
+#endif
+
+static void *s5_handle;
+
+static void s5_die(const char *what)
+{
+    /* same stderr convention as the reference's error(), but a missing GPU path is fatal */
+    fprintf(stderr, "ERROR: sim5lib (MI355X): %s\n", what);
+    exit(EXIT_FAILURE);
+}
+
+static void *s5_sym(const char *name)
+{
+    if (!s5_handle) {
+        const char *env = getenv("SIM5GPU_LIB");
+        char fromfile[4096];
+        const char *cand[4];
+        int n = 0;
+        if (env && *env) cand[n++] = env;
+        cand[n++] = "libsim5gpu.so";
+        if (SIM5GPU_LIB_DEFAULT[0]) cand[n++] = SIM5GPU_LIB_DEFAULT;
+        /* in-tree build next to this source file, when __FILE__ carries a directory */
+        {
+            const char *f = __FILE__;
+            const char *slash = strrchr(f, '/');
+            if (slash && (size_t)(slash - f) + 32 < sizeof fromfile) {
+                memcpy(fromfile, f, (size_t)(slash - f));
+                strcpy(fromfile + (slash - f), "/../lib/libsim5gpu.so");
+                cand[n++] = fromfile;
+            }
+        }
+        for (int i = 0; i < n && !s5_handle; i++) s5_handle = dlopen(cand[i], RTLD_NOW | RTLD_LOCAL);
+        if (!s5_handle) s5_die("cannot load libsim5gpu.so (set SIM5GPU_LIB); there is no CPU fallback");
+    }
+    void *p = dlsym(s5_handle, name);
+    if (!p) s5_die(name);
+    return p;
+}
+
+static void s5_check(int rc, const char *fn)
+{
+    if (rc != 0) {
+        const char *(*last)(void) = (const char *(*)(void))s5_sym("sim5gpu_last_error");
+        fprintf(stderr, "ERROR: sim5lib (MI355X): %s failed (%d): %s\n", fn, rc, last());
+        exit(EXIT_FAILURE);
+    }
+}
+
+/* resolve once per call site */
+#define S5_FN(type, var, name) static type var; if (!var) var = (type)s5_sym(name)
+
+typedef int (*fn_geod_init_inf)(size_t, const double *, const double *, const double *, const double *, geodesic *, int *, int *);
+typedef int (*fn_geod_init_src)(size_t, const double *, const double *, const double *, const double *, const int *, geodesic *, int *, int *);
+typedef int (*fn_geod_P)(size_t, const geodesic *, const double *, double *);
+typedef int (*fn_geod_order)(size_t, const geodesic *, const int *, double *);
+typedef int (*fn_geod_Pint)(size_t, const geodesic *, const double *, const int *, double *);
+typedef int (*fn_geod_mom)(size_t, const geodesic *, const double *, const double *, const double *, double *);
+typedef int (*fn_geod_follow)(size_t, const geodesic *, const double *, double *, double *, double *, int *);
+typedef int (*fn_d1)(size_t, const double *, double *);
+typedef int (*fn_d2)(size_t, const double *, const double *, double *);
+typedef int (*fn_d3)(size_t, const double *, const double *, const double *, double *);
+
+int geodesic_init_inf(double i, double a, double alpha, double beta, geodesic *g, int *error)
+{
+    S5_FN(fn_geod_init_inf, f, "sim5gpu_geodesic_init_inf");
+    int err = 0, ok = 0;
+    s5_check(f(1, &i, &a, &alpha, &beta, g, &err, &ok), "geodesic_init_inf");
+    if (error) *error = err;
+    return ok ? TRUE : FALSE;
+}
+
+int geodesic_init_src(double a, double r, double m, double k[4], int ppc, geodesic *g, int *error)
+{
+    S5_FN(fn_geod_init_src, f, "sim5gpu_geodesic_init_src");
+    int err = 0, ok = 0;
+    s5_check(f(1, &a, &r, &m, k, &ppc, g, &err, &ok), "geodesic_init_src");
+    if (error) *error = err;
+    return ok ? TRUE : FALSE;
+}
+
+double geodesic_P_int(geodesic *g, double r, int ppc)
+{
+    S5_FN(fn_geod_Pint, f, "sim5gpu_geodesic_P_int");
+    double P = NAN;
+    s5_check(f(1, g, &r, &ppc, &P), "geodesic_P_int");
+    return P;
+}
+
+double geodesic_position_rad(geodesic *g, double P)
+{
+    S5_FN(fn_geod_P, f, "sim5gpu_geodesic_position_rad");
+    double r = NAN;
+    s5_check(f(1, g, &P, &r), "geodesic_position_rad");
+    return r;
+}
+
+double geodesic_position_pol(geodesic *g, double P)
+{
+    S5_FN(fn_geod_P, f, "sim5gpu_geodesic_position_pol");
+    double m = NAN;
+    s5_check(f(1, g, &P, &m), "geodesic_position_pol");
+    return m;
+}
+
+double geodesic_dm_sign(geodesic *g, double P)
+{
+    S5_FN(fn_geod_P, f, "sim5gpu_geodesic_dm_sign");
+    double s = NAN;
+    s5_check(f(1, g, &P, &s), "geodesic_dm_sign");
+    return s;
+}
+
+void geodesic_momentum(geodesic *g, double P, double r, double m, double k[])
+{
+    S5_FN(fn_geod_mom, f, "sim5gpu_geodesic_momentum");
+    s5_check(f(1, g, &P, &r, &m, k), "geodesic_momentum");
+}
+
+double geodesic_find_midplane_crossing(geodesic *g, int order)
+{
+    S5_FN(fn_geod_order, f, "sim5gpu_geodesic_find_midplane_crossing");
+    double P = NAN;
+    s5_check(f(1, g, &order, &P), "geodesic_find_midplane_crossing");
+    return P;
+}
+
+void geodesic_follow(geodesic *g, double step, double *P, double *r, double *m, int *status)
+{
+    S5_FN(fn_geod_follow, f, "sim5gpu_geodesic_follow");
+    int st = 0;
+    s5_check(f(1, g, &step, P, r, m, &st), "geodesic_follow");
+    if (status) *status = st;
+}
+
+void kerr_metric(double a, double r, double m, sim5metric *metric)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, sim5metric *);
+    S5_FN(fn, f, "sim5gpu_kerr_metric");
+    s5_check(f(1, &a, &r, &m, metric), "kerr_metric");
+}
+
+void kerr_connection(double a, double r, double m, double G[4][4][4])
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_kerr_connection");
+    s5_check(f(1, &a, &r, &m, &G[0][0][0]), "kerr_connection");
+}
+
+double dotprod(double V1[4], double V2[4], sim5metric *m)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const sim5metric *, double *);
+    S5_FN(fn, f, "sim5gpu_dotprod");
+    double out = NAN;
+    s5_check(f(1, V1, V2, m, &out), "dotprod");
+    return out;
+}
+
+void tetrad_zamo(sim5metric *m, sim5tetrad *t)
+{
+    typedef int (*fn)(size_t, const sim5metric *, sim5tetrad *);
+    S5_FN(fn, f, "sim5gpu_tetrad_zamo");
+    s5_check(f(1, m, t), "tetrad_zamo");
+}
+
+void tetrad_azimuthal(sim5metric *m, double Omega, sim5tetrad *t)
+{
+    typedef int (*fn)(size_t, const sim5metric *, const double *, sim5tetrad *);
+    S5_FN(fn, f, "sim5gpu_tetrad_azimuthal");
+    s5_check(f(1, m, &Omega, t), "tetrad_azimuthal");
+}
+
+void tetrad_surface(sim5metric *m, double Omega, double V, double dhdr, sim5tetrad *t)
+{
+    typedef int (*fn)(size_t, const sim5metric *, const double *, const double *, const double *, sim5tetrad *);
+    S5_FN(fn, f, "sim5gpu_tetrad_surface");
+    s5_check(f(1, m, &Omega, &V, &dhdr, t), "tetrad_surface");
+}
+
+void bl2on(double Vin[4], double Vout[4], sim5tetrad *t)
+{
+    typedef int (*fn)(size_t, const double *, double *, const sim5tetrad *);
+    S5_FN(fn, f, "sim5gpu_bl2on");
+    s5_check(f(1, Vin, Vout, t), "bl2on");
+}
+
+void on2bl(double Vin[4], double Vout[4], sim5tetrad *t)
+{
+    typedef int (*fn)(size_t, const double *, double *, const sim5tetrad *);
+    S5_FN(fn, f, "sim5gpu_on2bl");
+    s5_check(f(1, Vin, Vout, t), "on2bl");
+}
+
+double r_bh(double a) { S5_FN(fn_d1, f, "sim5gpu_r_bh"); double r = NAN; s5_check(f(1, &a, &r), "r_bh"); return r; }
+double r_ms(double a) { S5_FN(fn_d1, f, "sim5gpu_r_ms"); double r = NAN; s5_check(f(1, &a, &r), "r_ms"); return r; }
+double OmegaK(double r, double a) { S5_FN(fn_d2, f, "sim5gpu_OmegaK"); double o = NAN; s5_check(f(1, &r, &a, &o), "OmegaK"); return o; }
+double ellK(double r, double a) { S5_FN(fn_d2, f, "sim5gpu_ellK"); double o = NAN; s5_check(f(1, &r, &a, &o), "ellK"); return o; }
+
+double Omega_from_ell(double ell, sim5metric *m)
+{
+    typedef int (*fn)(size_t, const double *, const sim5metric *, double *);
+    S5_FN(fn, f, "sim5gpu_Omega_from_ell");
+    double o = NAN;
+    s5_check(f(1, &ell, m, &o), "Omega_from_ell");
+    return o;
+}
+
+double gfactorK(double r, double a, double l)
+{
+    S5_FN(fn_d3, f, "sim5gpu_gfactorK");
+    double g = NAN;
+    s5_check(f(1, &r, &a, &l, &g), "gfactorK");
+    return g;
+}
+
+void photon_momentum(double a, double r, double m, double l, double q, double r_sign, double m_sign, double k[4])
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, const double *,
+                      const double *, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_photon_momentum");
+    s5_check(f(1, &a, &r, &m, &l, &q, &r_sign, &m_sign, k), "photon_momentum");
+}
+
+void photon_motion_constants(double a, double r, double m, double k[4], double *L, double *Q)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, double *, double *);
+    S5_FN(fn, f, "sim5gpu_photon_motion_constants");
+    s5_check(f(1, &a, &r, &m, k, L, Q), "photon_motion_constants");
+}
+
+double photon_carter_const(double k[4], sim5metric *metric)
+{
+    typedef int (*fn)(size_t, const double *, const sim5metric *, double *);
+    S5_FN(fn, f, "sim5gpu_photon_carter_const");
+    double Q = NAN;
+    s5_check(f(1, k, metric, &Q), "photon_carter_const");
+    return Q;
+}
+
+void raytrace_prepare(double bh_spin, double x[4], double k[4], double presision_factor, int options, raytrace_data *rtd)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, const int *, raytrace_data *);
+    S5_FN(fn, f, "sim5gpu_raytrace_prepare");
+    s5_check(f(1, &bh_spin, x, k, &presision_factor, &options, rtd), "raytrace_prepare");
+}
+
+void raytrace(double x[4], double k[4], double *step, raytrace_data *rtd)
+{
+    typedef int (*fn)(size_t, double *, double *, double *, raytrace_data *, int);
+    S5_FN(fn, f, "sim5gpu_raytrace");
+    s5_check(f(1, x, k, step, rtd, 1), "raytrace");
+}
+
+double raytrace_error(double x[4], double k[4], raytrace_data *rtd)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const raytrace_data *, double *);
+    S5_FN(fn, f, "sim5gpu_raytrace_error");
+    double e = NAN;
+    s5_check(f(1, x, k, rtd, &e), "raytrace_error");
+    return e;
+}
+
+int disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int options)
+{
+    typedef int (*fn)(double, double, double, double, int);
+    S5_FN(fn, f, "sim5gpu_disk_nt_setup");
+    s5_check(f(M, a, mdot_or_L, alpha, options), "disk_nt_setup");
+    return 0;
+}
+
+void disk_nt_done(void) {}
+
+double disk_nt_r_min(void)
+{
+    typedef int (*fn)(double *);
+    S5_FN(fn, f, "sim5gpu_disk_nt_r_min");
+    double r = NAN;
+    s5_check(f(&r), "disk_nt_r_min");
+    return r;
+}
+
+double disk_nt_flux(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_flux"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_flux"); return o; }
+double disk_nt_ell(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_ell"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_ell"); return o; }
+
+sim5complex polarization_constant(double k[4], double f[4], sim5metric *metric)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const sim5metric *, double *);
+    S5_FN(fn, fp, "sim5gpu_polarization_constant");
+    double wp[2] = { NAN, NAN };
+    s5_check(fp(1, k, f, metric, wp), "polarization_constant");
+    return wp[0] + _Complex_I * wp[1];
+}
+
+void polarization_vector(double k[4], sim5complex wp, sim5metric *metric, double f[4])
+{
+    typedef int (*fn)(size_t, const double *, const double *, const sim5metric *, double *);
+    S5_FN(fn, fp, "sim5gpu_polarization_vector");
+    double w[2] = { creal(wp), cimag(wp) };
+    s5_check(fp(1, k, w, metric, f), "polarization_vector");
+}
+
+sim5complex polarization_constant_infinity(double a, double alpha, double beta, double incl)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, double *);
+    S5_FN(fn, fp, "sim5gpu_polarization_constant_infinity");
+    double wp[2] = { NAN, NAN };
+    s5_check(fp(1, &a, &alpha, &beta, &incl, wp), "polarization_constant_infinity");
+    return wp[0] + _Complex_I * wp[1];
+}
+
+double polarization_angle_rotation(double a, double inc, double alpha, double beta, sim5complex kappa)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, const double *, double *);
+    S5_FN(fn, fp, "sim5gpu_polarization_angle_rotation");
+    double w[2] = { creal(kappa), cimag(kappa) }, out = NAN;
+    s5_check(fp(1, &a, &inc, &alpha, &beta, w, &out), "polarization_angle_rotation");
+    return out;
+}
+
+double blackbody_Iv(double T, double hardf, double cos_mu, double E)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, double *);
+    S5_FN(fn, fp, "sim5gpu_blackbody_Iv");
+    double out = NAN;
+    s5_check(fp(1, &T, &hardf, &cos_mu, &E, &out), "blackbody_Iv");
+    return out;
+}
+
+/* elliptic functions: selector numbering of sim5gpu_elliptic (include/sim5gpu.h) */
+static double s5_ell(int which, const double *x, const double *y, const double *z, const double *w)
+{
+    typedef int (*fn)(int, size_t, const double *, const double *, const double *, const double *, double *);
+    S5_FN(fn, fp, "sim5gpu_elliptic");
+    double out = NAN;
+    s5_check(fp(which, 1, x, y, z, w, &out), "elliptic");
+    return out;
+}
+double rf(double x, double y, double z) { return s5_ell(0, &x, &y, &z, 0); }
+double elliptic_k(double m) { return s5_ell(1, &m, 0, 0, 0); }
+double jacobi_isn(double z, double m) { return s5_ell(2, &z, &m, 0, 0); }
+double jacobi_icn(double z, double m) { return s5_ell(3, &z, &m, 0, 0); }
+double jacobi_itn(double z, double m) { return s5_ell(4, &z, &m, 0, 0); }
+double jacobi_sn(double u, double m) { return s5_ell(5, &u, &m, 0, 0); }
+double jacobi_cn(double u, double m) { return s5_ell(6, &u, &m, 0, 0); }
+double jacobi_dn(double u, double m) { return s5_ell(7, &u, &m, 0, 0); }
+double rd(double x, double y, double z) { return s5_ell(8, &x, &y, &z, 0); }
+double rc(double x, double y) { return s5_ell(9, &x, &y, 0, 0); }
+double rj(double x, double y, double z, double p) { return s5_ell(10, &x, &y, &z, &p); }
+void jacobi_sncndn(double u, double m, double *sn, double *cn, double *dn)
+{
+    *sn = jacobi_sn(u, m); *cn = jacobi_cn(u, m); *dn = jacobi_dn(u, m);
+}

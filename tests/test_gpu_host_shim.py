@@ -1,0 +1,58 @@
+"""The SIM5 scalar API served by the GPU library (n = 1 batch calls), driven from C."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oraclelib as ol
+from gpuutil import assert_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "sim5_amd", "host")
+
+
+def test_scalar_api_program_matches_oracle(tmp_path, capi):
+    exe = str(tmp_path / "probe")
+    subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", "shim_probe.c"), os.path.join(HOST, "sim5lib.c"),
+                    "-I", HOST, "-o", exe, "-lm", "-O3", "-w", "-fgnu89-inline"], check=True)
+    n, a, inc = 20, 0.9, 65.0
+    env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+    p = subprocess.run([exe, str(a), str(inc), str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    head = lines[0].split()
+    orc = ol.Oracle()
+    orc.disk_nt_setup(10.0, a, 0.1, 0.1)
+    # r_ms goes through the device cbrt (1 ulp from glibc's); r_min is folded on the host like the reference
+    assert abs(float(head[2]) / orc.r_ms(a) - 1) < 1e-15 and float(head[4]) == orc.disk_nt_r_min()
+    assert abs(float(head[6]) / orc.r_bh(a) - 1) < 1e-15
+    rec = np.array([[float(v) for v in ln.split()] for ln in lines[1:1 + n * n]])
+    c = ol.cpu_disk_image("port", n, n, a, inc, nthreads=2, full=True)
+    hit = np.where(c["cls"] == 2, 1, np.where(c["cls"] == 4, 2, 0)).ravel()
+    assert np.array_equal(rec[:, 3].astype(int), hit)
+    m = hit > 0
+    assert_close(rec[m, 4], c["r"].ravel()[m], what="r"); assert_close(rec[m, 5], c["g"].ravel()[m], what="g")
+    assert_close(rec[m, 6], c["flux"].ravel()[m], floor=1e-9 * c["flux"].max(), what="flux")
+    tail = lines[-1].split()
+    assert tail[1] == "verlet" and int(tail[3]) > 100 and float(tail[7]) < 1e-2
+
+
+def test_batch_example_program(tmp_path, capi):
+    """examples/disk_image_batch.c: the reference example's output format from one library call."""
+    exe = str(tmp_path / "batch")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "disk_image_batch.c"),
+                    "-o", exe, "-L", libdir, "-lsim5gpu", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"],
+                   check=True)
+    p = subprocess.run([exe, "0.5", "60"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = [ln.split() for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(rows) == 1280 * 720 and rows[0][:2] == ["0", "0"] and rows[-1][:2] == ["719", "1279"]
+    img_g = np.array([float(r[3]) for r in rows]).reshape(720, 1280)
+    c = ol.cpu_disk_image("port", 1280, 720, 0.5, 60.0, nthreads=8, full=False)
+    # "%e" keeps 7 significant digits
+    assert np.allclose(img_g, c["image_g"], rtol=2e-6, atol=0)
+    assert "photons: 921600" in p.stderr
