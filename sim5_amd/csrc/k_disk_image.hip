@@ -11,7 +11,7 @@
 // the Carlson trip counts almost always (measured lane utilisation 98 %); each wave row stores 32
 // consecutive f32 = one whole 128-B line per plane.  No input is read in grid mode (alpha, beta follow from the pixel index,
 // ref disk-image.c:57-58); in list mode alpha[]/beta[] are read coalesced, 8 B per lane.
-#include "s5_disk.hpp"
+#include "s5_thindisk.hpp"
 #include "kernels.hpp"
 
 namespace S5NS {
@@ -27,44 +27,15 @@ struct RayResult {
 
 S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
 {
+    ThinRay t;
+    trace_thin_disk<false>(p, alpha, beta, t);
     RayResult out;
-    out.cls = PX_ERROR; out.gtype = -1;
-    out.r = NAN; out.g = 0.0; out.flux = 0.0; out.image_f = 0.0f; out.image_g = 0.0f;
-
-    Geod gd;
-    GeodCache cache;
-    int err = 0;
-    if (!init_inf(p.incl, p.sin_i, p.cos_i, p.a, alpha, beta, gd, err, cache)) return out;
-    out.gtype = gd.type;
-    out.cls = PX_MISS;
-
-    for (int order = 0; order < p.max_order; ++order) {
-        const double P = midplane_crossing(gd, order, cache);
-        if (isnan(P)) { out.cls = (order == 0) ? PX_NAN0 : PX_NAN1; break; }
-#ifdef S5_KO_RAD                 // diagnostic knock-outs (timing breakdown builds only, never shipped)
-        const double r = 10.0 + P;
-#else
-        const double r = position_rad(gd, P);
-#endif
-        if (r >= p.rms) {
-#ifdef S5_KO_G
-            const double g = 0.5 + 1e-3 * r;
-#else
-            const double g = gfactor_kepler(r, p.a, gd.l);
-#endif
-#ifdef S5_KO_FLUX
-            const double f = 1e20 * r;
-#else
-            const double f = disk_flux(p.disk, r);
-#endif
-            const double g2 = g * g;
-            out.cls = (order == 0) ? PX_HIT0 : PX_HIT1;
-            out.r = r; out.g = g; out.flux = f;
-            out.image_f = (float)(f * (g2 * g2));
-            out.image_g = (float)g;
-            break;
-        }
-    }
+    out.cls = t.cls; out.gtype = t.gtype;
+    out.r = t.r; out.g = t.g; out.flux = t.flux;
+    const double g2 = t.g * t.g;
+    const bool hit = (t.cls == PX_HIT0) || (t.cls == PX_HIT1);
+    out.image_f = hit ? (float)(t.flux * (g2 * g2)) : 0.0f;
+    out.image_g = hit ? (float)t.g : 0.0f;
     return out;
 }
 
@@ -85,7 +56,7 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
                                          // 8x8 1.701 ms, 16x4 1.700, 32x2 1.710, 64x1 1.750)
 #endif
 #ifndef S5_LB_WAVES
-#define S5_LB_WAVES 2
+#define S5_LB_WAVES 3                    // <= 168 VGPRs; measured 1/2/3/4 waves per SIMD: 1.502/1.500/1.465/1.487 ms
 #endif
 constexpr int TILE_W = S5_TILE_W;        // workgroup tile: TILE_W x (256 / TILE_W) pixels
 constexpr int TILE_H = 256 / TILE_W;

@@ -12,7 +12,7 @@
 // The reference has no end-to-end caller for this chain (its unit test only checks that kappa is
 // conserved, src/sim5unittests.c:113-140); the chain is assembled from its public routines and is
 // checked (tests/) against the same chain evaluated with the reference library.
-#include "s5_disk.hpp"
+#include "s5_thindisk.hpp"
 #include "s5_polar.hpp"
 #include "kernels.hpp"
 
@@ -35,44 +35,32 @@ void disk_image_polarized_kernel(ImageParams p)
     const size_t npix = (size_t)(p.y1 - p.y0) * (size_t)p.nx;
     const size_t o = (size_t)(iy - p.y0) * (size_t)p.nx + (size_t)ix;
 
-    int cls = PX_ERROR, gtype = -1;
-    double r_hit = NAN, g_hit = 0.0, f_hit = 0.0, I = 0.0, Q = 0.0, U = 0.0, chi = NAN;
-
-    Geod gd;
-    GeodCache cache;
-    int err = 0;
-    if (init_inf(p.incl, p.sin_i, p.cos_i, p.a, alpha, beta, gd, err, cache)) {
-        gtype = gd.type;
-        cls = PX_MISS;
-        for (int order = 0; order < p.max_order; ++order) {
-            const double P = midplane_crossing(gd, order, cache);
-            if (isnan(P)) { cls = (order == 0) ? PX_NAN0 : PX_NAN1; break; }
-            const double r = position_rad(gd, P);
-            if (r >= p.rms) {
-                const double g = gfactor_kepler(r, p.a, gd.l);
-                const double f = disk_flux(p.disk, r);
-                const double g2 = g * g;
-                cls = (order == 0) ? PX_HIT0 : PX_HIT1;
-                r_hit = r; g_hit = g; f_hit = f;
-                I = f * (g2 * g2);
-
-                double k[4], n[4], floc[4], fv[4], wp[2];
-                momentum(gd, P, r, 0.0, k);
-                Metric mt;
-                kerr_metric(p.a, r, 0.0, mt);
-                Tetrad t;
-                tetrad_azimuthal(mt, omega_kepler(r, p.a), t);
-                bl2on(k, n, t);
-                floc[0] = 0.0; floc[1] = n[3]; floc[2] = 0.0; floc[3] = -n[1];
-                on2bl(floc, fv, t);
-                normalize_to(fv, 1.0, mt);
-                polarization_constant(k, fv, mt, wp);
-                chi = polarization_angle_rotation(p.a, p.sin_i, alpha, beta, wp);
-                Q = p.pol_degree * I * cos(2.0 * chi);
-                U = p.pol_degree * I * sin(2.0 * chi);
-                break;
-            }
-        }
+    double I = 0.0, Q = 0.0, U = 0.0, chi = NAN;
+    ThinRay t;
+    trace_thin_disk<true>(p, alpha, beta, t);
+    const int cls = t.cls, gtype = t.gtype;
+    const double r_hit = t.r, g_hit = t.g, f_hit = t.flux;
+    if (cls == PX_HIT0 || cls == PX_HIT1) {
+        const double g2 = t.g * t.g;
+        I = t.flux * (g2 * g2);
+        // geodesic_momentum(gd, P, r, m = 0): sign of dm/dP from the polar phase, radial sign from P vs Rpc
+        double sdm = (t.beta >= 0.0) ? +1.0 : -1.0;
+        double T = (sdm > 0.0) ? -(t.Tpp - t.Tip) : -(t.Tip);
+        for (int it = 0; it < 4096 && (t.P > T + t.Tpp); ++it) { T += t.Tpp; sdm = -sdm; }
+        double k[4], n[4], floc[4], fv[4], wp[2];
+        photon_momentum(t.a, t.r, 0.0, t.l, t.q, (t.P < t.Rpc ? -1. : +1.), sdm, k);
+        Metric mt;
+        kerr_metric(p.a, t.r, 0.0, mt);
+        Tetrad tt;
+        tetrad_azimuthal(mt, omega_kepler(t.r, p.a), tt);
+        bl2on(k, n, tt);
+        floc[0] = 0.0; floc[1] = n[3]; floc[2] = 0.0; floc[3] = -n[1];
+        on2bl(floc, fv, tt);
+        normalize_to(fv, 1.0, mt);
+        polarization_constant(k, fv, mt, wp);
+        chi = polarization_angle_rotation(p.a, p.sin_i, alpha, beta, wp);
+        Q = p.pol_degree * I * cos(2.0 * chi);
+        U = p.pol_degree * I * sin(2.0 * chi);
     }
     p.stokes[o] = I;
     p.stokes[npix + o] = Q;

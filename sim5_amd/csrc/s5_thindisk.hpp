@@ -1,0 +1,307 @@
+// s5_thindisk.hpp -- one image-plane ray of the thin-disk problem, fused for the wave64 machine.
+//
+// Same arithmetic as geodesic_init_inf -> geodesic_find_midplane_crossing -> geodesic_position_rad
+// (s5_geod.hpp, i.e. ref: /root/reference/src/sim5kerr-geod.c:42-100, 846-885, 291-357) -- every value is
+// produced by the same expression and the same R_F / sncndn routines -- but arranged so that a wave
+// executes ONE copy of each expensive loop whatever mixture of geodesic classes its lanes hold:
+//
+//  * the three or four Carlson R_F evaluations a ray needs (radial integral to the turning point, K(mm),
+//    cn^-1 of the observer's polar position, and for RC rays with a negative argument the second term of
+//    cn^-1) go through one loop over "slots": per slot each lane selects its own arguments, the single
+//    inlined R_F body runs once for the whole wave, and each lane scales its own result.  RR, RC and CC
+//    lanes share that loop instead of serialising three inlined copies of it;
+//  * r(P) needs sn (RR) or cn (RC) of different arguments: the lanes select (u, m) and ONE Landen ladder
+//    serves both;
+//  * the special cases of the inverse Jacobi functions (m within 1e-8 of 0 or 1, z = 0, z = 1: asin, acos,
+//    log forms, ref src/sim5elliptic.c:483-503) are flagged per lane and, if any lane of the wave has one,
+//    re-evaluated by the generic routine out of line -- they keep their exact semantics without costing
+//    registers or instruction-cache on the common path.
+//
+// The per-ray state that callers need afterwards (polarization, tests) is returned in ThinRay.
+#pragma once
+#include "s5_disk.hpp"
+
+namespace S5NS {
+
+struct ThinRay {
+    int    cls;        // s5abi::PX_*
+    int    gtype;      // geodesic class or -1
+    int    err;        // GD_* of init_inf
+    double r, g, flux; // accepted crossing (r = NaN if none)
+    double P;          // position integral of the accepted crossing
+    // geodesic quantities (valid when err == 0)
+    double a, l, q, beta, Rpc, Tpp, Tip, rp;
+};
+
+// generic routines out of line: taken only by lanes in a special case of the inverse functions
+static __device__ __noinline__ double inv_sn_cold(double z, double m) { return inv_sn(z, m); }
+static __device__ __noinline__ double inv_cn_cold(double z, double m) { return inv_cn(z, m); }
+static __device__ __noinline__ double inv_tn_cold(double z, double m) { return inv_tn(z, m); }
+
+// true if inv_sn(z, m) takes the plain z * R_F(1-z^2, 1-m z^2, 1) form
+S5_DEV bool isn_plain(double m) { return !(fabs(m - 0.0) < 1e-8) && !(fabs(m - 1.0) < 1e-8); }
+// true if inv_cn(z, m) takes the plain sqrt(1-z^2) R_F(z^2, 1-m(1-z^2), 1) [+ second term for z < 0] form
+S5_DEV bool icn_plain(double z, double m)
+{
+    const bool snap = ((z > +1.0) && (z < +1.0 + 1e-8)) || ((z < -1.0) && (z > -1.0 - 1e-8)) ||
+                      ((m > +1.0) && (m < +1.0 + 1e-8)) || ((m < 0.0) && (m > 0.0 - 1e-8));
+    return !snap && !(z == 0.0) && !(z == 1.0) && !(m == 0.0) && !(m == 1.0);
+}
+
+template <bool WANT_STATE>
+S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out)
+{
+    using namespace s5abi;
+    out.cls = PX_ERROR; out.gtype = -1; out.err = GD_OK;
+    out.r = NAN; out.g = 0.0; out.flux = 0.0; out.P = NAN;
+
+    // ---------------- constants of motion and range checks (ref :59-86) ----------------
+    const double a_in = p.a;
+    int err = GD_OK;
+    if ((a_in < 0.0) || (a_in > 1. - 1e-6)) err = GD_E_SPIN;
+    else if ((p.incl <= 0.0) || (p.incl >= 1.57079632679)) err = GD_E_INCL;
+    const double beta = (beta_in == 0.0) ? +1e-6 : beta_in;
+    const double a = fmax(1e-4, a_in);
+    const double l = -alpha * p.sin_i;
+    const double q = sq(beta) + sq(p.cos_i) * (sq(alpha) - sq(a_in));
+    if (err == GD_OK && q == 0.0) err = GD_E_Q_RANGE;
+
+    // ---------------- roots of R(r) (ref :986-1047) ----------------
+    const double a2 = a * a, l2 = l * l;
+    double A;
+    const double C = sq(a - l) + q;
+    const double D = 2. / 3. * (q + l2 - a2);
+    const double E = 9. / 4. * sq(D) - 12. * a2 * q;
+    const double F = -27. / 4. * (D * D * D) - 108. * a2 * q * D + 108. * sq(C);
+    const double X = sq(F) - 4. * (E * E * E);
+    if (X >= 0) {
+        const double sX = msqrt(X);
+        A = (F > sX ? +1 : -1) * 1. / 3. * mcbrt(fabs(F - sX) / 2.) +
+            (F > -sX ? +1 : -1) * 1. / 3. * mcbrt(fabs(F + sX) / 2.);
+    } else {
+        const double sX = S5_DIVC(msqrt(-X), 54.);
+        const double F54 = S5_DIVC(F, 54.);
+        const double Z = msqrt(sq(F54) + sq(sX));
+        const double z = atan2(sX, F54);
+        A = mcbrt(Z) * 2. * cos(S5_DIVC(z, 3.));
+    }
+    const double B = msqrt(A + D);
+    const double CB = mdiv(4. * C, B);
+    const double w_hi = -A + 2. * D - CB;
+    const double w_lo = -A + 2. * D + CB;
+    const bool hi_real = (w_hi >= 0.0), lo_real = (w_lo >= 0.0);
+    const double h_hi = .5 * msqrt(fabs(w_hi)), h_lo = .5 * msqrt(fabs(w_lo));
+    const double c_hi = +B / 2., c_lo = -B / 2.;
+
+    // four scalars describe the roots; their meaning depends on the class:
+    //   RR: r1 >= r2 >= r3 >= r4      RC: r1 >= r2 real, (u, v) = Re, Im of the complex pair
+    //   CC: (b1, a1), (b2, a2) = Re, Im of the two pairs
+    double ra, rb, rc_, rd_;
+    int type;
+    if (hi_real && lo_real) {
+        const double p0 = c_hi + h_hi, p1 = c_hi - h_hi, p2 = c_lo + h_lo, p3 = c_lo - h_lo;
+        const double t0 = fmin(p0, p2), t3 = fmax(p1, p3);
+        ra = fmax(p0, p2); rb = fmax(t0, t3); rc_ = fmin(t0, t3); rd_ = fmin(p1, p3);
+        type = T_RR;
+        // r0 = DBL_MAX is above r1, so only the double-root test can fire (ref :1023-1036)
+        if (err == GD_OK && (DBL_MAX < rc_ || (DBL_MAX > rb && DBL_MAX < ra))) err = GD_E_UNKNOWN;
+        if (err == GD_OK && fabs(ra - rb) < 1e-8) { type = T_RR_DBL; err = GD_E_RR_DOUBLE; }
+    } else if (hi_real) {
+        ra = c_hi + h_hi; rb = c_hi - h_hi; rc_ = c_lo; rd_ = h_lo; type = T_RC;
+    } else if (lo_real) {
+        ra = c_lo + h_lo; rb = c_lo - h_lo; rc_ = c_hi; rd_ = h_hi; type = T_RC;
+    } else {
+        ra = c_hi; rb = h_hi; rc_ = c_lo; rd_ = h_lo; type = T_CC;      // (b1, a1, b2, a2)
+    }
+
+    // ---------------- per-class set-up of the radial integral (ref :1051-1100) ----------------
+    // Rpc = pre * inverse-Jacobi(zR | mR); sqAB is reused by r(P)
+    double mR, zR, pre, sqAB, rp;
+    if (type == T_RR || type == T_RR_DBL) {
+        mR = mdiv((rb - rc_) * (ra - rd_), (rb - rd_) * (ra - rc_));
+        sqAB = msqrt((ra - rc_) * (rb - rd_));
+        pre = mdiv(2., sqAB);
+        zR = msqrt(mdiv(rb - rd_, ra - rd_));
+        rp = ra;
+    } else if (type == T_RC) {
+        const double Aq = msqrt(sq(ra - rc_) + sq(rd_));
+        const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
+        mR = mdiv(sq(Aq + Bq) - sq(ra - rb), 4. * Aq * Bq);
+        sqAB = msqrt(Aq * Bq);
+        pre = mdiv(1., sqAB);
+        zR = mdiv(Aq - Bq, Aq + Bq);
+        rp = ra;
+        // keep A, B for r(P): the RC formula needs them again
+        A = Aq;                       // kept for r(P); B is recomputed there from the same expression
+    } else {
+        const double b1 = ra, a1 = rb, b2 = rc_, a2c = rd_;
+        const double Aq = msqrt(sq(b1 - b2) + sq(a1 + a2c));
+        const double Bq = msqrt(sq(b1 - b2) + sq(a1 - a2c));
+        const double g1 = msqrt(mdiv(4. * sq(a1) - sq(Aq - Bq), sq(Aq + Bq) - 4. * sq(a1)));
+        mR = mdiv(4. * Aq * Bq, sq(Aq + Bq));
+        sqAB = 0.0;
+        pre = mdiv(2., Aq + Bq);
+        zR = mdiv(-1., g1);
+        rp = b1 - a1 * g1;
+    }
+
+    // ---------------- roots of the polar potential (ref :1110-1184, device branch) ----------------
+    const double qla = q + l2 - a2;
+    const double XT = msqrt(sq(qla) + 4. * q * a2) + qla;
+    const double m2m = mdiv(XT, a2 + a2);
+    const double m2p = mdiv(q + q, XT);
+    double mmT = 0.0, mK = 0.0;
+    if (err == GD_OK) {
+        if ((m2p <= 0.0) || (m2p >= 1.0)) err = GD_E_MUPLUS;
+        else if (q > 0.0) {
+            mmT = mdiv(m2p, m2p + m2m);
+            if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
+            else if (fabs(p.cos_i) > msqrt(m2p)) err = GD_E_MU0;
+            else mK = mdiv(1., msqrt(a2 * (m2p + m2m)));
+        } else if (q < 0.0) {
+            mmT = mdiv(m2p + m2m, m2p);
+            if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
+            else if ((fabs(p.cos_i) > msqrt(m2p)) || (fabs(p.cos_i) < msqrt(-m2m))) err = GD_E_MU0;
+            else mK = mdiv(1., msqrt(a2 * m2p));
+        } else {
+            err = GD_E_Q_RANGE;
+        }
+    }
+    out.err = err;
+    const bool ok = (err == GD_OK);
+    const double u_i = mdiv(p.cos_i, msqrt(m2p));
+
+    // ---------------- the R_F evaluations of this ray, one shared loop (see header) ----------------
+    // slot 0: radial integral   slot 1: K(mmT)   slot 2: cn^-1(u_i | mmT)   slot 3: RC, zR < 0: second term
+    const double zT = (type == T_CC) ? msqrt(mdiv(zR * zR, 1. + zR * zR)) : zR;       // tn^-1 -> sn^-1 (ref :527)
+    const bool plain0 = (type == T_RC) ? icn_plain(zR, mR)
+                      : (type == T_CC) ? (!(mR == 0.0) && !(mR == 1.0) && isn_plain(mR))
+                                       : isn_plain(mR);
+    const bool plain2 = icn_plain(u_i, mmT);
+    const bool need3 = ok && (type == T_RC) && plain0 && !(zR > 0.0);
+    double m3 = mdiv(mR, mR - 1.);                      // modulus of the second term (ref :513, :280)
+    if (m3 == 1.0) m3 = 0.99999999;
+    double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
+#pragma unroll 1
+    for (int slot = 0; slot < 4; ++slot) {
+        if (slot == 3 && !wave_any(need3)) break;
+        double x, y, mult;
+        if (slot == 0) {
+            const double z2 = zT * zT;
+            if (type == T_RC) { x = z2; y = 1.0 - mR * (1. - z2); mult = msqrt(1. - z2); }
+            else { x = 1.0 - z2; y = 1.0 - mR * zT * zT; mult = zT; }      // (m z) z, as ref :485
+        } else if (slot == 1) {
+            x = 0.0; y = 1.0 - mmT; mult = 1.0;
+        } else if (slot == 2) {
+            const double z2 = u_i * u_i;
+            x = z2; y = 1.0 - mmT * (1. - z2); mult = msqrt(1. - z2);
+        } else {
+            const double s = -zR, s2 = s * s;
+            x = 1. - s2; y = 1.0 - s2 * m3; mult = s;
+        }
+#ifdef S5_KO_RF                  // diagnostic knock-outs: timing-breakdown builds only, never shipped
+        const double v = mult * (1.5 + 0.1 * x + 0.01 * y);
+#else
+        const double v = mult * carlson_rf(x, y, 1.0);
+#endif
+        if (slot == 0) res0 = v; else if (slot == 1) res1 = v; else if (slot == 2) res2 = v; else res3 = v;
+    }
+    // assemble as the generic routines do
+    double Rint = res0;
+    if (type == T_RC && need3) Rint = mdiv(2., msqrt(1. - mR)) * res3 + res0;
+    double K = res1;
+    double icn_i = res2;
+    // special cases, out of line
+    if (wave_any(ok && !plain0)) {
+        if (ok && !plain0)
+            Rint = (type == T_RC) ? inv_cn_cold(zR, mR) : (type == T_CC) ? inv_tn_cold(zR, mR) : inv_sn_cold(zR, mR);
+    }
+    if (wave_any(ok && !plain2)) {
+        if (ok && !plain2) icn_i = inv_cn_cold(u_i, mmT);
+    }
+    const double Rpc = pre * Rint;
+
+    if (WANT_STATE) {
+        out.a = a; out.l = l; out.q = q; out.beta = beta; out.Rpc = Rpc; out.rp = rp;
+        out.Tpp = 2. * (mK * K); out.Tip = mK * icn_i;
+    }
+    if (!ok) return;
+    out.gtype = type;
+    out.cls = PX_MISS;
+
+    // ---------------- equatorial crossings and r(P) (ref :846-885, :291-357) ----------------
+    const bool q_pos = (q > 0.0);
+    double uu = u_i;
+    bool u_bad = (uu < -1.0 - 1e-4) || (uu > +1.0 + 1e-4);
+    if (uu < -1.0) uu = -1.0;
+    if (uu > +1.0) uu = +1.0;
+    double icn_u = icn_i;
+    if (wave_any(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
+        if (uu != u_i && !u_bad && q_pos) icn_u = inv_cn_cold(uu, mmT);
+    }
+    bool done = false;
+#pragma unroll 1
+    for (int order = 0; order < p.max_order; ++order) {
+        if (!wave_any(!done)) break;
+        if (!done) {
+            double P;
+            if (!q_pos || u_bad) P = NAN;
+            else {
+                if (beta > 0.0) P = mK * ((2. * (double)order + 1.) * K + icn_u);
+                else if (beta < 0.0) P = mK * ((2. * (double)order + 1.) * K - icn_u);
+                else P = mK * ((2. * (double)order + 1.) * K);
+                if (P > 2. * Rpc) P = NAN;
+            }
+            if (isnan(P)) { out.cls = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; }
+            else {
+                // r(P): RR through sn, RC through cn, one ladder for both
+                double r;
+                const bool in_range = !((P <= 0.0) || (P >= 2. * Rpc));
+                const bool at_peri = (P == Rpc);
+                const bool rr = (type == T_RR), rcx = (type == T_RC) && !(P > Rpc);
+                const bool use_ladder = in_range && !at_peri && (rr || rcx);
+                double su = 0.0, sm = 0.5;
+                if (rr) su = 0.5 * fabs(P - Rpc) * sqAB;
+                else if (rcx) su = sqAB * (Rpc - P);
+                if (use_ladder) sm = mR;
+                double sn = 0.0, cn = 1.0, dn = 1.0;
+                if (wave_any(use_ladder)) {
+#ifdef S5_KO_RAD
+                    if (use_ladder) { sn = 0.3 + 1e-3 * su; cn = 0.9 - 1e-3 * sm; }
+#else
+                    if (use_ladder) sncndn(su, sm, sn, cn, dn);
+#endif
+                }
+                if (!in_range) r = NAN;
+                else if (at_peri) r = rp;
+                else if (rr) {
+                    const double sn2 = sn * sn;
+                    r = mdiv(ra * (rb - rd_) - rb * (ra - rd_) * sn2, rb - rd_ - (ra - rd_) * sn2);
+                } else if (rcx) {
+                    const double Aq = A;
+                    const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
+                    r = mdiv(rb * Aq - ra * Bq - (rb * Aq + ra * Bq) * cn, (Aq - Bq) - (Aq + Bq) * cn);
+                } else r = NAN;
+                if (r >= p.rms) {
+                    out.cls = (order == 0) ? PX_HIT0 : PX_HIT1;
+                    out.r = r; out.P = P;
+                    done = true;
+                }
+            }
+        }
+    }
+    if (out.cls == PX_HIT0 || out.cls == PX_HIT1) {
+#ifdef S5_KO_G
+        out.g = 0.5 + 1e-3 * out.r;
+#else
+        out.g = gfactor_kepler(out.r, a_in, l);
+#endif
+#ifdef S5_KO_FLUX
+        out.flux = 1e20 * out.r;
+#else
+        out.flux = disk_flux(p.disk, out.r);
+#endif
+    }
+}
+
+} // namespace S5NS
