@@ -1,0 +1,31 @@
+import sys, math, numpy as np
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sim5_amd.capi as capi
+def timeit(fn, reps=5, warm=1):
+    for _ in range(warm): fn()
+    capi.synchronize(); e0=capi.Event(); e1=capi.Event(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); return e0.elapsed_ms(e1)/reps
+# C3 polarized 2048^2 a=0.9
+n=2048; d=capi.image_desc(n,n,0.9,70/180*math.pi,pol_degree=0.1)
+st=capi.DeviceBuffer(3*n*n*8); ch=capi.DeviceBuffer(n*n*8)
+ms=timeit(lambda: capi.disk_image_polarized_device(d, st.ptr, ch.ptr))
+print("C3 polarized 2048^2 fast: %.3f ms  %.3e rays/s"%(ms, n*n/ms*1e3))
+d.flags=1
+ms=timeit(lambda: capi.disk_image_polarized_device(d, st.ptr, ch.ptr))
+print("C3 polarized 2048^2 strict: %.3f ms  %.3e rays/s"%(ms, n*n/ms*1e3))
+# C2 1024^2
+n=1024; d=capi.image_desc(n,n,0.998,70/180*math.pi); f=capi.DeviceBuffer(n*n*4); g=capi.DeviceBuffer(n*n*4)
+ms=timeit(lambda: capi.disk_image_device(d,f.ptr,g.ptr), reps=20)
+print("C2 1024^2 fast: %.3f ms  %.3e rays/s"%(ms, n*n/ms*1e3))
+# C4 torus 1024^2 Verlet
+import test_gpu_raytrace as T
+n=1024
+for prec in (1.0, 0.01):
+    dd=T.torus_desc(capi,n,0.9,70.0,r0=100.0,precision=prec,max_steps=100000)
+    N=n*n; sb=capi.DeviceBuffer(N*40); steps=capi.DeviceBuffer(N*4)
+    ms=timeit(lambda: capi.torus_image_device(dd, sb.ptr, aux={"steps":steps.ptr}), reps=2, warm=1)
+    s=steps.to_numpy(np.int32,(N,))
+    tot=int(s.sum())
+    print("C4 torus 1024^2 precision %g: %.1f ms  %.3e rays/s  mean steps %.1f  %.3e steps/s  W_step frac=%.4f"%(prec, ms, N/ms*1e3, s.mean(), tot/ms*1e3, tot*750/ms*1e3/78.6e12))
+    print("   hist", np.histogram(s, bins=[0,1,2,10,50,100,300,600,2000,100000])[0].tolist())

@@ -212,16 +212,40 @@ void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const in
     }
 }
 
+// Workspace of the torus job (ray-state columns, start-up flags, cursor): one grow-only device
+// allocation per process, made before the launches (no allocation call sits between kernels).  A job on
+// another stream than the previous one first waits for that stream, so two jobs never share it.
+struct TorusWorkspace {
+    char* base = nullptr;
+    size_t cap = 0;
+    hipStream_t last = nullptr;
+    bool used = false;
+};
+static TorusWorkspace g_ws;
+
 int launch_torus(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream)
 {
     const size_t n = p.nrays;
-    double* cols = nullptr;
-    int* ok = nullptr;
-    unsigned long long* cursor = nullptr;
+    const size_t cols_bytes = (sizeof(double) * NCOL * n + 255) & ~size_t(255);
+    const size_t ok_bytes = (sizeof(int) * n + 255) & ~size_t(255);
+    const size_t need = cols_bytes + ok_bytes + 256;
     hipError_t e;
-    if ((e = hipMallocAsync((void**)&cols, sizeof(double) * NCOL * n, stream)) != hipSuccess) return (int)e;
-    if ((e = hipMallocAsync((void**)&ok, sizeof(int) * n, stream)) != hipSuccess) return (int)e;
-    if ((e = hipMallocAsync((void**)&cursor, sizeof(unsigned long long), stream)) != hipSuccess) return (int)e;
+    if (g_ws.used && g_ws.last != stream) {
+        if ((e = hipStreamSynchronize(g_ws.last)) != hipSuccess) return (int)e;
+    }
+    if (need > g_ws.cap) {
+        if (g_ws.base) {
+            if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
+            (void)hipFree(g_ws.base);
+            g_ws.base = nullptr; g_ws.cap = 0;
+        }
+        if ((e = hipMalloc((void**)&g_ws.base, need)) != hipSuccess) return (int)e;
+        g_ws.cap = need;
+    }
+    g_ws.last = stream; g_ws.used = true;
+    double* cols = (double*)g_ws.base;
+    int* ok = (int*)(g_ws.base + cols_bytes);
+    unsigned long long* cursor = (unsigned long long*)(g_ws.base + cols_bytes + ok_bytes);
     if ((e = hipMemsetAsync(cursor, 0, sizeof(unsigned long long), stream)) != hipSuccess) return (int)e;
 
     const unsigned blocks_a = (unsigned)((n + 255) / 256);
@@ -237,10 +261,6 @@ int launch_torus(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux,
     if (blocks_b > needed) blocks_b = needed;
     hipLaunchKernelGGL(torus_march_kernel, dim3((unsigned)blocks_b), dim3(256), 0, stream, p, cols, ok, cursor, out, aux);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-
-    (void)hipFreeAsync(cols, stream);
-    (void)hipFreeAsync(ok, stream);
-    (void)hipFreeAsync(cursor, stream);
     return 0;
 }
 
