@@ -14,7 +14,8 @@ LIB = os.path.join(LIBDIR, "libsim5gpu.so")
 
 # (source, object, variant): the image kernels are built in both arithmetic variants
 SOURCES = [("capi_core.hip", "capi_core.o", "strict"), ("capi_batch.hip", "capi_batch.o", "strict"),
-           ("capi_jobs.hip", "capi_jobs.o", "strict"), ("k_torus.hip", "k_torus.o", "strict"),
+           ("capi_jobs.hip", "capi_jobs.o", "strict"),
+           ("k_torus.hip", "k_torus_strict.o", "strict"), ("k_torus.hip", "k_torus_fast.o", "fast"),
            ("k_disk_image.hip", "k_disk_image_strict.o", "strict"), ("k_disk_image.hip", "k_disk_image_fast.o", "fast"),
            ("k_polar_image.hip", "k_polar_image_strict.o", "strict"), ("k_polar_image.hip", "k_polar_image_fast.o", "fast")]
 
@@ -48,6 +49,8 @@ def build(force=False, verbose=False):
         objs.append(o)
         if force or not _newer(o, [s] + headers):
             extra = os.environ.get("S5_FAST_EXTRA", "").split() if variant == "fast" else []
+            if src == "k_torus.hip":
+                extra = extra + os.environ.get("S5_TORUS_EXTRA", "").split()
             cmd = [hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))

@@ -58,7 +58,8 @@ int sim5gpu_torus_image(const sim5gpu_torus_desc* desc, sim5gpu_stokes* d_stokes
         aux.steps = d_aux->steps; aux.max_step_error = d_aux->max_step_error;
         aux.carter_error = d_aux->carter_error; aux.x_end = d_aux->x_end; aux.k_end = d_aux->k_end;
     }
-    hipError_t e = (hipError_t)launch_torus(p, d_stokes, aux, (hipStream_t)stream);
+    hipError_t e = (hipError_t)((desc->img.flags & SIM5GPU_IMG_STRICT) ? s5::launch_torus_strict(p, d_stokes, aux, (hipStream_t)stream)
+                                                                     : s5f::launch_torus_fast(p, d_stokes, aux, (hipStream_t)stream));
     if (e != hipSuccess) { set_error("torus_image launch", e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;
 }

@@ -59,8 +59,10 @@ void disk_image_polarized_kernel(ImageParams p)
         normalize_to(fv, 1.0, mt);
         polarization_constant(k, fv, mt, wp);
         chi = polarization_angle_rotation(p.a, p.sin_i, alpha, beta, wp);
-        Q = p.pol_degree * I * cos(2.0 * chi);
-        U = p.pol_degree * I * sin(2.0 * chi);
+        double s2c, c2c;
+        msincos(2.0 * chi, s2c, c2c);
+        Q = p.pol_degree * I * c2c;
+        U = p.pol_degree * I * s2c;
     }
     p.stokes[o] = I;
     p.stokes[npix + o] = Q;

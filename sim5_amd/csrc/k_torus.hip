@@ -26,7 +26,7 @@
 #include "s5_raytrace.hpp"
 #include "k_torus.hpp"
 
-namespace s5 {
+namespace S5NS {
 
 using namespace s5abi;
 
@@ -97,7 +97,10 @@ S5_DEV double torus_density(const TorusParams& p, double r, double m)
     return (d2 < 36. * w2) ? exp(-d2 / w2) : 0.0;       // cut at 6 sqrt(2) w: exp(-36) ~ 2e-16
 }
 
-__global__ __launch_bounds__(256, 2)
+#ifndef S5_MARCH_WAVES
+#define S5_MARCH_WAVES 2
+#endif
+__global__ __launch_bounds__(256, S5_MARCH_WAVES)
 void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const int* __restrict__ ok,
                         unsigned long long* __restrict__ cursor, sim5gpu_stokes* __restrict__ out,
                         TorusAux aux)
@@ -116,7 +119,7 @@ void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const in
 
     s.opt_gr = !((p.options & 1) == 1);
     s.opt_pol = 0;
-    s.step_epsilon = sqrt(p.precision) / 10.;
+    s.step_epsilon = S5_DIVC(msqrt(p.precision), 10.);
     s.bh_spin = p.a;
 
     // the loop is bounded: every pass either advances a held ray by one step (at most max_steps
@@ -171,12 +174,21 @@ void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const in
             continue;                             // some lane just dropped a rejected ray: refill again
         }
 
-        // ---- one raytrace() call for every lane that holds a ray ----
+        // ---- one raytrace() call for every lane that holds a ray --------------------------------------
+        // raytrace() = Verlet attempt and, if its precision check fails, an RK4 step of the same size
+        // (ref src/sim5raytrace.c:220-227; at precision 1 a third of all calls fall back).  Parking the
+        // failed lanes until many of them can run the RK4 body together was measured and is not faster
+        // (73.7 vs 71.5 ms on the C4 job): the kernel is limited by register pressure, not divergence.
+        bool stepped = false;
+        double dl_taken = 0.0;
         if (holding) {
-            double dl = p.dl_max;
-            raytrace_step(x, k, dl, s);
-            worst = fmaxf(worst, s.error);
+            double dl;
+            if (!verlet_attempt(x, k, p.dl_max, dl, s)) rk4_step(x, k, dl, s);
+            stepped = true; dl_taken = dl;
+        }
 
+        if (stepped) {
+            worst = fmaxf(worst, s.error);
             // transfer over the step just taken, evaluated at its end point
             const double rho = torus_density(p, x[1], x[2]);
             if (rho > 0.0) {
@@ -185,11 +197,11 @@ void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const in
                 const double Om = omega_from_ell(p.torus_l, g);
                 const double nrm = -(g.g00 + 2. * Om * g.g03 + Om * Om * g.g33);
                 if (nrm > 0.0) {                    // a circular orbit with this ell is time-like here
-                    const double ut = 1. / sqrt(nrm);
+                    const double ut = mdiv(1., msqrt(nrm));
                     const double k_t = k[0] * g.g00 + k[3] * g.g03;
                     const double k_f = k[3] * g.g33 + k[0] * g.g03;
-                    const double gfac = s.E / (ut * (k_t + Om * k_f));      // E_inf / E_local
-                    const double ds = dl / gfac;
+                    const double gfac = mdiv(s.E, ut * (k_t + Om * k_f));   // E_inf / E_local
+                    const double ds = mdiv(dl_taken, gfac);
                     const double g2 = gfac * gfac;
                     I += (g2 * g2) * p.emis0 * rho * exp(-tau) * ds;
                     tau += p.absorb0 * rho * ds;
@@ -223,7 +235,11 @@ struct TorusWorkspace {
 };
 static TorusWorkspace g_ws;
 
-int launch_torus(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream)
+#if S5_FAST
+int launch_torus_fast(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream)
+#else
+int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream)
+#endif
 {
     const size_t n = p.nrays;
     const size_t cols_bytes = (sizeof(double) * NCOL * n + 255) & ~size_t(255);
@@ -256,7 +272,7 @@ int launch_torus(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux,
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    size_t blocks_b = (size_t)cus * 2;
+    size_t blocks_b = (size_t)cus * S5_MARCH_WAVES;
     const size_t needed = (n + 255) / 256;
     if (blocks_b > needed) blocks_b = needed;
     hipLaunchKernelGGL(torus_march_kernel, dim3((unsigned)blocks_b), dim3(256), 0, stream, p, cols, ok, cursor, out, aux);
@@ -264,4 +280,4 @@ int launch_torus(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux,
     return 0;
 }
 
-} // namespace s5
+} // namespace S5NS

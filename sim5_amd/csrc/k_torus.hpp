@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/sim5gpu.h"
 
-namespace s5 {
+namespace s5abi {
 
 struct TorusParams {
     int nx, ny, y0, y1;
@@ -23,6 +23,8 @@ struct TorusAux {
     double* k_end;
 };
 
-int launch_torus(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream);
 
-} // namespace s5
+} // namespace s5abi
+
+namespace s5 { int launch_torus_strict(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream); }
+namespace s5f { int launch_torus_fast(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream); }

@@ -14,7 +14,7 @@
 //  * the Landen ladder of sncndn lives in registers (fully unrolled, level index compile-time),
 //    never in scratch or LDS.
 #pragma once
-#include "s5_math.hpp"
+#include "s5_trig.hpp"
 
 namespace S5NS {
 

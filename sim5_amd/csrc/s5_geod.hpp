@@ -71,7 +71,7 @@ S5_DEV bool radial_roots(Geod& g, double r0, int& err)
         const double F54 = S5_DIVC(F, 54.);
         const double Z = msqrt(sq(F54) + sq(sX));
         const double z = atan2(sX, F54);
-        A = mcbrt(Z) * 2. * cos(S5_DIVC(z, 3.));
+        A = mcbrt(Z) * 2. * mcos(S5_DIVC(z, 3.));
     }
     const double B = msqrt(A + D);
     const double CB = mdiv(4. * C, B);

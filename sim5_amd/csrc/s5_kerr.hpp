@@ -42,10 +42,10 @@ S5_DEV void kerr_metric(double a, double r, double m, Metric& g)               /
 {
     double r2 = r * r, a2 = a * a, m2 = m * m;
     double S = r2 + a2 * m2;
-    double s2_S = (1.0 - m2) / S;
+    double s2_S = mdiv(1.0 - m2, S);
     g.a = a; g.r = r; g.m = m;
-    g.g00 = -1. + 2.0 * r / S;
-    g.g11 = S / (r2 - 2. * r + a2);
+    g.g00 = -1. + mdiv(2.0 * r, S);
+    g.g11 = mdiv(S, r2 - 2. * r + a2);
     g.g22 = S;
     g.g33 = ((a2 + r2) * S + 2. * r * a2 * s2_S * S) * s2_S;
     g.g03 = -2. * a * r * s2_S;
@@ -82,7 +82,7 @@ S5_DEV void flat_connection(double r, double m, Conn& G)                       /
 S5_DEV void kerr_connection(double a, double r, double m, Conn& G)             // ref :233-316
 {
     double rS = 2.0 * r;
-    double s = sqrt(1. - m * m);
+    double s = msqrt(1. - m * m);
     double cs = s * m;
     double c2 = m * m;
     double s2 = s * s;
@@ -103,11 +103,11 @@ S5_DEV void kerr_connection(double a, double r, double m, Conn& G)             /
     double R = Rq * Rq;
     double D = r2 - 2. * r + a2;
     double S = r2 + a2c2;
-    double S_1 = 1. / S;
-    double S_3 = 1. / (S * S * S);
-    double D_1 = 1. / D;
-    double R_1 = 1. / R;
-    double m_s = m / s;
+    double S_1 = mdiv(1., S);
+    double S_3 = mdiv(1., S * S * S);
+    double D_1 = mdiv(1., D);
+    double R_1 = mdiv(1., R);
+    double m_s = mdiv(m, s);
     double DR_1 = D_1 * R_1;
     double DS_1 = D_1 * S_1;
     double dbl_r2 = 2. * r2;
@@ -125,7 +125,7 @@ S5_DEV void kerr_connection(double a, double r, double m, Conn& G)             /
     G.r33 = -D * s2 * (2. * a2c2 * r3 + r2 * r3 + a2 * a2c2 * s2 + a2c2 * a2c2 * r - a2r2 * s2) * S_3;
 
     G.h00 = -2.0 * r * a2cs * S_3;
-    G.h03 = 2.0 * -G.h00 * a2_r2 / a;
+    G.h03 = mdiv(2.0 * -G.h00 * a2_r2, a);
     G.h11 = +a2cs * DS_1;
     G.h12 = 2.0 * r * S_1;
     G.h22 = -a2cs * S_1;

@@ -72,12 +72,10 @@ S5_DEV double mdiv(double a, double b) { return a / b; }
 // x^(1/3) for x >= 0 (the reference writes pow(x, 1./3.); 1./3. is not exactly one third, the two
 // differ by ln(x) * 1.85e-17 relative)
 S5_DEV double mcbrt(double x) { return cbrt(x); }
-S5_DEV void msincos(double x, double& s, double& c) { sincos(x, &s, &c); }
 // division by a compile-time constant: multiply by the folded reciprocal
 #define S5_DIVC(a, c) ((a) * (1.0 / (c)))
 #else
 S5_DEV double mcbrt(double x) { return pow(x, 1. / 3.); }
-S5_DEV void msincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
 #define S5_DIVC(a, c) ((a) / (c))
 #endif
 

@@ -24,7 +24,15 @@ struct RayState {
 };
 static_assert(sizeof(RayState) == 144, "raytrace_data must keep the SIM5 layout");
 
-S5_DEV double rel_diff(double a, double b) { return fabs(b - a) / (fabs(b) + 1e-40); }   // ref :31
+// Scheduling fence between the phases of a step: without it the compiler overlaps metric, connection
+// and corrector arithmetic for ILP and runs out of registers (spills to scratch).
+#ifdef S5_NO_FENCE
+#define S5_FENCE() do {} while (0)
+#else
+#define S5_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+S5_DEV double rel_diff(double a, double b) { return mdiv(fabs(b - a), fabs(b) + 1e-40); }   // ref :31
 
 S5_DEV void rt_metric(const RayState& s, double r, double m, Metric& g)
 {
@@ -39,7 +47,7 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
                              int options, RayState& s)                        // ref :44-94
 {
     s.opt_gr = !((options & 1) == 1);
-    s.step_epsilon = sqrt(precision) / 10.;
+    s.step_epsilon = S5_DIVC(msqrt(precision), 10.);
     s.bh_spin = bh_spin;
     Metric g;
     Conn G;
@@ -54,36 +62,55 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
     transport_rhs(G, k, k, s.dk);
 }
 
-// classical RK4 on (x,k), theta as the angle (ref :251-323)
+// classical RK4 on (x,k), theta as the angle (ref :251-323).  The stage sums are accumulated as the
+// stages are produced, in the reference's order ((k1 + 2 k2) + 2 k3) + k4, so only the latest stage is
+// live (8 doubles instead of 32) and every rounding is the reference's.
+#ifdef S5_RK4_NOINLINE
+static __device__ __noinline__ void rk4_step(double x[4], double k[4], double dl, RayState& s)
+#else
 S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s)
+#endif
 {
     Conn G;
-    double xp[4], k1[4], d1[4], k2[4], d2[4], k3[4], d3[4], k4[4], d4[4];
+    double xp[4], ki[4], di[4], sx[4], sk[4];
     const double h = 0.5 * dl;
     const double kt0 = s.kt;
-    x[2] = acos(x[2]);
+    x[2] = macos(x[2]);
+    // stage 1
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i]; k1[i] = k[i]; }
-    rt_connection(s, xp[1], cos(xp[2]), G);
-    transport_rhs(G, k1, k1, d1);
+    for (int i = 0; i < 4; ++i) { xp[i] = x[i]; ki[i] = k[i]; }
+    rt_connection(s, xp[1], mcos(xp[2]), G);
+    transport_rhs(G, ki, ki, di);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + k1[i] * h; k2[i] = k[i] + d1[i] * h; }
-    rt_connection(s, xp[1], cos(xp[2]), G);
-    transport_rhs(G, k2, k2, d2);
+    for (int i = 0; i < 4; ++i) { sx[i] = ki[i]; sk[i] = di[i]; }
+    S5_FENCE();
+    // stage 2
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + k2[i] * h; k3[i] = k[i] + d2[i] * h; }
-    rt_connection(s, xp[1], cos(xp[2]), G);
-    transport_rhs(G, k3, k3, d3);
+    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * h; ki[i] = k[i] + di[i] * h; }
+    rt_connection(s, xp[1], mcos(xp[2]), G);
+    transport_rhs(G, ki, ki, di);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + k3[i] * dl; k4[i] = k[i] + d3[i] * dl; }
-    rt_connection(s, xp[1], cos(xp[2]), G);
-    transport_rhs(G, k4, k4, d4);
+    for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + 2. * ki[i]; sk[i] = sk[i] + 2. * di[i]; }
+    S5_FENCE();
+    // stage 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * h; ki[i] = k[i] + di[i] * h; }
+    rt_connection(s, xp[1], mcos(xp[2]), G);
+    transport_rhs(G, ki, ki, di);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + 2. * ki[i]; sk[i] = sk[i] + 2. * di[i]; }
+    S5_FENCE();
+    // stage 4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * dl; ki[i] = k[i] + di[i] * dl; }
+    rt_connection(s, xp[1], mcos(xp[2]), G);
+    transport_rhs(G, ki, ki, di);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        x[i] += dl / 6. * (k1[i] + 2. * k2[i] + 2. * k3[i] + k4[i]);
-        k[i] += dl / 6. * (d1[i] + 2. * d2[i] + 2. * d3[i] + d4[i]);
+        x[i] += S5_DIVC(dl, 6.) * (sx[i] + ki[i]);
+        k[i] += S5_DIVC(dl, 6.) * (sk[i] + di[i]);
     }
-    x[2] = cos(x[2]);
+    x[2] = mcos(x[2]);
     rt_connection(s, x[1], x[2], G);
     transport_rhs(G, k, k, s.dk);
     Metric g;
@@ -92,19 +119,20 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s)
     s.error = (float)rel_diff(kt1, kt0);
 }
 
-// one adaptive step (ref :109-245); `step` in: cap on the step, out: step taken
-S5_DEV void raytrace_step(double x[4], double k[4], double& step, RayState& s)
+// Verlet part of one adaptive step (ref :109-245 up to the precision check :217-220).  Returns true if
+// the step was accepted (x, k, s advanced); false if the reference would now fall back to RK4: x and k
+// are then unchanged (restored) and `dl` holds the step size the fallback must use.  s.pass is counted
+// either way, as in the reference.
+S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl, RayState& s)
 {
     const double tiny = 1e-40;
-    double x0[4], k0[4], xp[4], kp[4], kq[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { x0[i] = x[i]; k0[i] = k[i]; }
+    double xp[4], kh[4], kp[4], kq[4];
     const double* dk = s.dk;
 
-    const double stepsize = s.step_epsilon /
-        (fabs(dk[0]) / (fabs(k[0]) + tiny) + fabs(dk[1]) / (fabs(k[1]) + tiny) +
-         fabs(dk[2]) / (fabs(k[2]) + tiny) + fabs(dk[3]) / (fabs(k[3]) + tiny) + tiny);
-    double dl = fmin(step, stepsize);
+    const double stepsize = mdiv(s.step_epsilon,
+        mdiv(fabs(dk[0]), fabs(k[0]) + tiny) + mdiv(fabs(dk[1]), fabs(k[1]) + tiny) +
+        mdiv(fabs(dk[2]), fabs(k[2]) + tiny) + mdiv(fabs(dk[3]), fabs(k[3]) + tiny) + tiny);
+    dl = fmin(step_cap, stepsize);
     if (dl < 1e-3) dl = 1e-3;
     s.pass++;
 
@@ -112,17 +140,20 @@ S5_DEV void raytrace_step(double x[4], double k[4], double& step, RayState& s)
     const double half_dl2 = 0.5 * dl * dl;
     xp[0] = x[0] + k[0] * dl + dk[0] * half_dl2;
     xp[1] = x[1] + k[1] * dl + dk[1] * half_dl2;
-    xp[2] = cos(acos(x[2]) + (k[2] * dl + dk[2] * half_dl2));
+    xp[2] = mcos(macos(x[2]) + (k[2] * dl + dk[2] * half_dl2));
     xp[3] = x[3] + k[3] * dl + dk[3] * half_dl2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k[i] += dk[i] * half_dl;
+    for (int i = 0; i < 4; ++i) kh[i] = k[i] + dk[i] * half_dl;          // the reference updates k in place
 
+    S5_FENCE();
     Metric g;
     Conn G;
     rt_metric(s, xp[1], xp[2], g);
+    S5_FENCE();
     rt_connection(s, xp[1], xp[2], G);
+    S5_FENCE();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kp[i] = k[i] + dk[i] * half_dl;
+    for (int i = 0; i < 4; ++i) kp[i] = kh[i] + dk[i] * half_dl;
 
     float kerr = 0.0f;
     bool again = true;
@@ -136,27 +167,30 @@ S5_DEV void raytrace_step(double x[4], double k[4], double& step, RayState& s)
             geodesic_accel(G, kq, acc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                kp[i] = k[i] + acc[i] * half_dl;
+                kp[i] = kh[i] + acc[i] * half_dl;
                 kerr = (float)((double)kerr + rel_diff(kp[i], kq[i]));
             }
             again = (double)kerr > 1e-2 * 1e-3;
         }
+        S5_FENCE();
     }
 
     const double kt = kp[0] * g.g00 + kp[3] * g.g03;
     const double kk = fabs(dot(kp, kp, g));
     s.error = (float)fmax(rel_diff(kt, s.kt), kk);
-    if (((double)kerr > 1e-2 * 1e-2) || ((double)s.error > 1e-2 * 1e-2)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = x0[i]; k[i] = k0[i]; }
-        rk4_step(x, k, dl, s);
-        step = dl;
-        return;
-    }
+    if (((double)kerr > 1e-2 * 1e-2) || ((double)s.error > 1e-2 * 1e-2)) return false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x[i] = xp[i]; k[i] = kp[i]; }
     geodesic_accel(G, kp, s.dk);
     s.kt = kt;
+    return true;
+}
+
+// one adaptive step (ref :109-245); `step` in: cap on the step, out: step taken
+S5_DEV void raytrace_step(double x[4], double k[4], double& step, RayState& s)
+{
+    double dl;
+    if (!verlet_attempt(x, k, step, dl, s)) rk4_step(x, k, dl, s);
     step = dl;
 }
 

@@ -1,0 +1,115 @@
+// s5_trig.hpp -- sin, cos, acos for the bounded arguments of this path, fast variant.
+//
+// The device libm's f64 sin/cos carry a Payne-Hanek reduction for huge arguments: never taken here, but
+// it costs registers (the RK4 fallback of the step-wise integrator needed 210 VGPRs mostly because of
+// four inlined cos) and instructions.  Every angle on this path is a polar angle, an AGM amplitude or a
+// third of an atan2: |x| < ~1e3.  For those a two-constant Cody-Waite reduction by pi/2 with FMAs is exact
+// to < 1 ulp of the reduced argument, followed by the classical minimax kernels on [-pi/4, pi/4]
+// (coefficients: fdlibm k_sin.c / k_cos.c / e_acos.c, Sun Microsystems, freely distributable).
+// ~35 instructions for sin and cos together, ~45 for acos; errors < 1 ulp on the stated ranges.
+// The strict variant keeps the device libm.
+#pragma once
+#include "s5_math.hpp"
+
+namespace S5NS {
+
+#if S5_F_LIBM
+
+// sin(y), cos(y) for |y| <= pi/4 (+ a little), y = yh + yl
+S5_DEV double kernel_sin(double y, double yl)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = y * y;
+    const double v = z * y;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return y - ((z * (0.5 * yl - v * r) - yl) - v * S1);
+}
+
+S5_DEV double kernel_cos(double y, double yl)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = y * y;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - y * yl));
+}
+
+// |x| up to ~1e5: n = nearest integer to x / (pi/2), reduced argument as a head/tail pair
+S5_DEV int reduce_pio2(double x, double& yh, double& yl)
+{
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632679489655800e+00;     // 0x1.921fb54442d18p+0
+    const double pio2_lo = 6.12323399573676603587e-17;     // 0x1.1a62633145c07p-54
+    const double fn = __builtin_rint(x * two_over_pi);
+    const double r = __builtin_fma(-fn, pio2_hi, x);       // exact when it cancels
+    const double w = fn * pio2_lo;
+    yh = r - w;
+    yl = (r - yh) - w;
+    return (int)fn;
+}
+
+S5_DEV void msincos(double x, double& s, double& c)
+{
+    double yh, yl;
+    const int n = reduce_pio2(x, yh, yl);
+    const double ks = kernel_sin(yh, yl), kc = kernel_cos(yh, yl);
+    const bool swap = (n & 1) != 0;
+    const double ss = swap ? kc : ks;
+    const double cc = swap ? ks : kc;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
+
+S5_DEV double mcos(double x) { double s, c; msincos(x, s, c); return c; }
+S5_DEV double msin(double x) { double s, c; msincos(x, s, c); return s; }
+
+// acos(x), |x| <= 1 (NaN outside), after fdlibm e_acos.c
+S5_DEV double macos(double x)
+{
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    const double pi = 3.14159265358979311600e+00;
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05;
+    const double qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    const double ax = fabs(x);
+    if (!(ax <= 1.0)) return NAN;
+    if (ax < 0.5) {
+        const double z = x * x;
+        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double r = mdiv(p, q);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    const double z = (1.0 - ax) * 0.5;
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double sq_ = msqrt(z);
+    const double r = mdiv(p, q);
+    if (x < 0.0) {
+        const double w = r * sq_ - pio2_lo;
+        return pi - 2.0 * (sq_ + w);
+    }
+    // head of sqrt(z) with the low 32 bits cleared, for an exact correction term
+    const double df = __longlong_as_double(__double_as_longlong(sq_) & 0xffffffff00000000ll);
+    const double cc = mdiv(z - df * df, sq_ + df);
+    const double w = r * sq_ + cc;
+    return 2.0 * (df + w);
+}
+
+#else
+
+S5_DEV void msincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
+S5_DEV double mcos(double x) { return cos(x); }
+S5_DEV double msin(double x) { return sin(x); }
+S5_DEV double macos(double x) { return acos(x); }
+
+#endif
+
+} // namespace S5NS
