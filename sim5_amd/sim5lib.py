@@ -1,0 +1,360 @@
+"""sim5lib -- the names of SIM5's SWIG module (ref: src/sim5lib.swig:11-47), served by libsim5gpu.so.
+
+Python callers written against `from sim5lib import *` (ref: python/sim5diskraytrace.py:13,
+python/sim5diskmodel.py:15) keep working when this module is the `sim5lib` they import, e.g.
+
+    import sys, sim5_amd.sim5lib as sim5lib;  sys.modules["sim5lib"] = sim5lib
+
+Each call is one batch call with n = 1 through the C-ABI (sim5_amd/capi.py); no ray arithmetic happens
+here and there is no CPU fallback.  Throughput work should use sim5_amd.diskraytrace (batched) or the
+whole-job kernels instead; this module is the compatibility layer.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi as _c
+
+# ---- constants (ref: src/sim5const.h:24-95) --------------------------------------------------------
+TINY = 1e-40
+grav_radius = 1.476716e+05
+speed_of_light = 2.997925e+10
+speed_of_light2 = 8.987554e+20
+boltzmann_k = 1.380650e-16
+sb_sigma = 5.670400e-05
+sigma_thomson = 6.652458e-25
+parsec = 3.085680e+18
+mass_proton = 1.672622e-24
+mass_electron = 9.109382e-28
+solar_mass = 1.988920e+33
+grav_const = 6.673000e-08
+planck_h = 6.626069e-27
+Mdot_Edd = 2.225475942e+18
+L_Edd = 1.257142540e+38
+kev2freq = 2.417990e+17
+freq2kev = 4.135667e-18
+kev2erg = 1.602177e-09
+erg2kev = 6.241507e+08
+
+GEOD_TYPE_RR, GEOD_TYPE_RR_DBL, GEOD_TYPE_RR_BH, GEOD_TYPE_RC, GEOD_TYPE_CC = 40, 41, 42, 2, 0
+GD_OK = 0
+RTOPT_NONE, RTOPT_FLAT, RTOPT_POLARIZATION = 0, 1, 2
+
+
+# ---- the SWIG helper types (cpointer.i / carrays.i: ref src/sim5lib.swig:20-27) -------------------------
+class intp:
+    def __init__(self):
+        self._v = 0
+
+    def assign(self, v):
+        self._v = int(v)
+
+    def value(self):
+        return self._v
+
+
+class doublep:
+    def __init__(self):
+        self._v = 0.0
+
+    def assign(self, v):
+        self._v = float(v)
+
+    def value(self):
+        return self._v
+
+
+class doubleArray:
+    def __init__(self, n):
+        self._a = np.zeros(int(n))
+
+    def __getitem__(self, i):
+        return float(self._a[i])
+
+    def __setitem__(self, i, v):
+        self._a[i] = v
+
+    def __len__(self):
+        return self._a.size
+
+
+class intArray(doubleArray):
+    def __init__(self, n):
+        self._a = np.zeros(int(n), dtype=np.int32)
+
+
+def double_array_getitem(a, i):
+    return float(_arr(a)[i])
+
+
+def double_array_setitem(a, i, v):
+    _arr(a)[i] = v
+
+
+def sim5vector(components):
+    v = doubleArray(4)
+    for i in range(4):
+        v[i] = components[i]
+    return v
+
+
+def _arr(v):
+    return v._a if isinstance(v, doubleArray) else np.asarray(v, dtype=np.float64)
+
+
+class _Record:
+    """attribute access to a one-element numpy record with a SIM5 struct layout"""
+    _dtype = None
+
+    def __init__(self):
+        object.__setattr__(self, "_rec", np.zeros(1, dtype=self._dtype))
+
+    def __getattr__(self, name):
+        rec = object.__getattribute__(self, "_rec")
+        if name in rec.dtype.names:
+            v = rec[name][0]
+            return v.item() if np.ndim(v) == 0 else v
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self._rec[name][0] = value
+
+
+class geodesic(_Record):
+    _dtype = _c.GEODESIC_DTYPE
+
+
+class raytrace_data(_Record):
+    _dtype = _c.RAYTRACE_DTYPE
+
+
+class sim5metric(_Record):
+    _dtype = _c.METRIC_DTYPE
+
+
+class _MetricView:
+    def __init__(self, rec):
+        self._m = rec
+
+    def __getattr__(self, name):
+        return float(self._m[name])
+
+
+class sim5tetrad(_Record):
+    _dtype = _c.TETRAD_DTYPE
+
+    @property
+    def metric(self):
+        return _MetricView(self._rec["metric"][0])
+
+    @property
+    def e(self):
+        return self._rec["e"][0]
+
+
+def _met(m):
+    return m._rec if isinstance(m, sim5metric) else (m._m.reshape(1) if isinstance(m, _MetricView) else m)
+
+
+# ---- functions ----------------------------------------------------------------------------------------
+def r_bh(a):
+    return float(_c.r_bh([a])[0])
+
+
+def r_ms(a):
+    return float(_c.r_ms([a])[0])
+
+
+def OmegaK(r, a):
+    return float(_c.OmegaK([r], a)[0])
+
+
+def ellK(r, a):
+    return float(_c.ellK([r], a)[0])
+
+
+def gfactorK(r, a, l):
+    return float(_c.gfactorK([r], a, l)[0])
+
+
+def kerr_metric(a, r, m, metric):
+    metric._rec[:] = _c.kerr_metric(a, [r], m)
+
+
+def kerr_connection(a, r, m, G=None):
+    return _c.kerr_connection(a, [r], m)[0]
+
+
+def Omega_from_ell(ell, metric):
+    return float(_c.Omega_from_ell(ell, _met(metric))[0])
+
+
+def dotprod(v1, v2, metric):
+    return float(_c.dotprod(_arr(v1), _arr(v2), None if metric is None else _met(metric))[0])
+
+
+def tetrad_zamo(metric, tetrad):
+    tetrad._rec[:] = _c.tetrad_zamo(_met(metric))
+
+
+def tetrad_azimuthal(metric, Omega, tetrad):
+    tetrad._rec[:] = _c.tetrad_azimuthal(_met(metric), Omega)
+
+
+def tetrad_surface(metric, Omega, V, dhdr, tetrad):
+    tetrad._rec[:] = _c.tetrad_surface(_met(metric), Omega, V, dhdr)
+
+
+def bl2on(vin, vout, tetrad):
+    _arr(vout)[:] = _c.bl2on(_arr(vin), tetrad._rec)[0]
+
+
+def on2bl(vin, vout, tetrad):
+    _arr(vout)[:] = _c.on2bl(_arr(vin), tetrad._rec)[0]
+
+
+def photon_momentum(a, r, m, l, q, r_sign, m_sign, k):
+    _arr(k)[:] = _c.photon_momentum(a, [r], m, l, q, r_sign, m_sign)[0]
+
+
+def photon_carter_const(k, metric):
+    return float(_c.photon_carter_const(_arr(k), _met(metric))[0])
+
+
+def geodesic_init_inf(i, a, alpha, beta, g, status=None):
+    rec, err, ok = _c.geodesic_init_inf(i, a, [alpha], beta)
+    g._rec[:] = rec
+    if status is not None:
+        status.assign(int(err[0]))
+    return int(ok[0])
+
+
+def geodesic_init_src(a, r, m, k, ppc, g, status=None):
+    rec, err, ok = _c.geodesic_init_src(a, r, m, _arr(k), ppc)
+    g._rec[:] = rec
+    if status is not None:
+        status.assign(int(err[0]))
+    return int(ok[0])
+
+
+def geodesic_find_midplane_crossing(g, order):
+    return float(_c.geodesic_find_midplane_crossing(g._rec, order)[0])
+
+
+def geodesic_P_int(g, r, ppc):
+    return float(_c.geodesic_P_int(g._rec, r, ppc)[0])
+
+
+def geodesic_position_rad(g, P):
+    return float(_c.geodesic_position_rad(g._rec, P)[0])
+
+
+def geodesic_position_pol(g, P):
+    return float(_c.geodesic_position_pol(g._rec, P)[0])
+
+
+def geodesic_dm_sign(g, P):
+    return float(_c.geodesic_dm_sign(g._rec, P)[0])
+
+
+def geodesic_momentum(g, P, r, m, k):
+    _arr(k)[:] = _c.geodesic_momentum(g._rec, P, r, m)[0]
+
+
+def geodesic_follow(g, step, P, r, m, status=None):
+    P2, r2, m2, st = _c.geodesic_follow(g._rec, step, P.value(), r.value(), m.value())
+    P.assign(P2[0]); r.assign(r2[0]); m.assign(m2[0])
+    if status is not None:
+        status.assign(int(st[0]))
+
+
+def disk_nt_setup(M, a, mdot_or_L, alpha, options=0):
+    _c.disk_nt_setup(M, a, mdot_or_L, alpha, options)
+    return 0
+
+
+def disk_nt_done():
+    pass
+
+
+def disk_nt_r_min():
+    return _c.disk_nt_r_min()
+
+
+def disk_nt_flux(r):
+    return float(_c.disk_nt_flux([r])[0])
+
+
+def disk_nt_ell(r):
+    return float(_c.disk_nt_ell([r])[0])
+
+
+def disk_nt_vr(r):
+    return 0.0
+
+
+def disk_nt_h(r):
+    return 0.0
+
+
+def disk_nt_dhdr(r):
+    return 0.0
+
+
+def raytrace_prepare(bh_spin, x, k, precision, options, rtd):
+    rtd._rec[:] = _c.raytrace_prepare(bh_spin, _arr(x), _arr(k), precision, options)
+
+
+def raytrace(x, k, step, rtd):
+    x2, k2, st, r2 = _c.raytrace(_arr(x), _arr(k), step.value(), rtd._rec, 1)
+    _arr(x)[:] = x2[0]; _arr(k)[:] = k2[0]; step.assign(st[0]); rtd._rec[:] = r2
+
+
+def raytrace_error(x, k, rtd):
+    return float(_c.raytrace_error(_arr(x), _arr(k), rtd._rec)[0])
+
+
+def polarization_constant(k, f, metric):
+    w = _c.polarization_constant(_arr(k), _arr(f), _met(metric))[0]
+    return complex(w[0], w[1])
+
+
+def polarization_vector(k, wp, metric, f):
+    _arr(f)[:] = _c.polarization_vector(_arr(k), [[wp.real, wp.imag]], _met(metric))[0]
+
+
+def polarization_constant_infinity(a, alpha, beta, incl):
+    w = _c.polarization_constant_infinity(a, [alpha], beta, incl)[0]
+    return complex(w[0], w[1])
+
+
+def polarization_angle_rotation(a, inc, alpha, beta, kappa):
+    return float(_c.polarization_angle_rotation(a, inc, [alpha], beta, [[kappa.real, kappa.imag]])[0])
+
+
+def blackbody_Iv(T, hardf, cos_mu, E):
+    return float(_c.blackbody_Iv(T, hardf, cos_mu, [E])[0])
+
+
+def rf(x, y, z):
+    return float(_c.elliptic("rf", [x], y, z)[0])
+
+
+def elliptic_k(m):
+    return float(_c.elliptic("elliptic_k", [m])[0])
+
+
+def jacobi_isn(z, m):
+    return float(_c.elliptic("jacobi_isn", [z], m)[0])
+
+
+def jacobi_icn(z, m):
+    return float(_c.elliptic("jacobi_icn", [z], m)[0])
+
+
+def jacobi_sn(u, m):
+    return float(_c.elliptic("jacobi_sn", [u], m)[0])
+
+
+def jacobi_cn(u, m):
+    return float(_c.elliptic("jacobi_cn", [u], m)[0])
