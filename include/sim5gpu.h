@@ -267,6 +267,11 @@ typedef struct sim5gpu_image_desc {
     int    max_order;       /* number of equatorial crossings tried (reference: 2)       */
     int    flags;           /* SIM5GPU_IMG_*                                             */
     double pol_degree;      /* polarization degree delta of the disk emission (polarized) */
+    /* Optional striping for multi-GPU sharding: with stripe_rows > 0 the call traces the rows
+     * [y0 + j*stripe_step, y0 + j*stripe_step + stripe_rows) for j = 0, 1, ... below y1, in ONE launch;
+     * the outputs hold those rows packed in that order.  stripe_rows == 0: the contiguous range.     */
+    int    stripe_rows;
+    int    stripe_step;
 } sim5gpu_image_desc;
 
 #define SIM5GPU_IMG_DEFAULT 0   /* tuned FP64 sequences ("fast" variant, sim5_amd/csrc/s5_config.hpp)        */
@@ -280,6 +285,9 @@ typedef struct sim5gpu_image_aux {
     double  *g;             /* g-factor (0 if no hit)               */
     double  *flux;          /* local disk flux F(r) (0 if no hit)   */
 } sim5gpu_image_aux;
+
+/* rows of output a job description produces (y1 - y0, or the total height of its stripes) */
+int sim5gpu_image_rows(const sim5gpu_image_desc *desc);
 
 /* The caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105 as one kernel:
  * image_f = (float)(F g^4), image_g = (float)g, zero where the ray does not hit the disk. */

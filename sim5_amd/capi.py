@@ -64,7 +64,7 @@ class ImageDesc(C.Structure):
     _fields_ = [("nx", I), ("ny", I), ("y0", I), ("y1", I),
                 ("a", D), ("incl", D), ("rmax", D), ("rms", D),
                 ("bh_mass", D), ("mdot", D), ("alpha_visc", D),
-                ("max_order", I), ("flags", I), ("pol_degree", D)]
+                ("max_order", I), ("flags", I), ("pol_degree", D), ("stripe_rows", I), ("stripe_step", I)]
 
 
 class ImageAux(C.Structure):
@@ -562,12 +562,18 @@ IMG_DEFAULT, IMG_STRICT = 0, 1
 
 
 def image_desc(nx, ny, a, incl_rad, y0=0, y1=None, rmax=0.0, rms=0.0, bh_mass=10.0, mdot=0.1,
-               alpha_visc=0.1, max_order=2, pol_degree=0.0, strict=False):
+               alpha_visc=0.1, max_order=2, pol_degree=0.0, strict=False, stripe_rows=0, stripe_step=0):
     """Job description; defaults are those of the reference example (disk-image.c:41-45).
     strict=True selects the reference-parameter arithmetic variant (SIM5GPU_IMG_STRICT)."""
     return ImageDesc(nx=nx, ny=ny, y0=y0, y1=ny if y1 is None else y1, a=a, incl=incl_rad,
                      rmax=rmax, rms=rms, bh_mass=bh_mass, mdot=mdot, alpha_visc=alpha_visc,
-                     max_order=max_order, flags=IMG_STRICT if strict else IMG_DEFAULT, pol_degree=pol_degree)
+                     max_order=max_order, flags=IMG_STRICT if strict else IMG_DEFAULT, pol_degree=pol_degree,
+                     stripe_rows=stripe_rows, stripe_step=stripe_step)
+
+
+def image_rows(desc):
+    _lib.sim5gpu_image_rows.restype = I
+    return _lib.sim5gpu_image_rows(C.byref(desc))
 
 
 def disk_image_device(desc, d_image_f, d_image_g, aux=None, stream=None):
@@ -582,7 +588,7 @@ def disk_image_device(desc, d_image_f, d_image_g, aux=None, stream=None):
 
 def disk_image(desc, full=False):
     """Host-buffer convenience: returns dict(image_f, image_g[, cls, gtype, r, g, flux])."""
-    rows, nx = max(desc.y1 - desc.y0, 0), max(desc.nx, 0)       # bad geometry is rejected by the library
+    rows, nx = max(image_rows(desc), 0), max(desc.nx, 0)       # bad geometry is rejected by the library
     out = {"image_f": np.zeros((rows, nx), np.float32), "image_g": np.zeros((rows, nx), np.float32)}
     aux = None
     if full:

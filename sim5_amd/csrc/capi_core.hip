@@ -80,8 +80,14 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p)
                  desc->y0, desc->y1);
         return SIM5GPU_E_ARG;
     }
+    if (desc->stripe_rows < 0 || (desc->stripe_rows > 0 && desc->stripe_step < desc->stripe_rows)) {
+        snprintf(g_err, sizeof g_err, "bad striping stripe_rows=%d stripe_step=%d", desc->stripe_rows, desc->stripe_step);
+        return SIM5GPU_E_ARG;
+    }
     memset(&p, 0, sizeof p);
     p.nx = desc->nx; p.ny = desc->ny; p.y0 = desc->y0; p.y1 = desc->y1;
+    p.stripe_rows = desc->stripe_rows; p.stripe_step = desc->stripe_step;
+    p.nrows = sim5gpu_image_rows(desc);
     p.max_order = desc->max_order > 0 ? desc->max_order : 2;
     p.a = desc->a;
     p.incl = desc->incl;
@@ -218,6 +224,17 @@ int sim5gpu_disk_nt_r_min(double* r_min)
     return SIM5GPU_OK;
 }
 
+// number of (packed) output rows of a job description: y1 - y0, or the total height of its stripes
+int sim5gpu_image_rows(const sim5gpu_image_desc* desc)
+{
+    if (!desc || desc->y1 <= desc->y0) return 0;
+    if (desc->stripe_rows <= 0) return desc->y1 - desc->y0;
+    int rows = 0;
+    for (int y = desc->y0; y < desc->y1; y += desc->stripe_step)
+        rows += (y + desc->stripe_rows <= desc->y1) ? desc->stripe_rows : desc->y1 - y;
+    return rows;
+}
+
 // ---- whole-job image entry points --------------------------------------------------------------
 static void attach_aux(ImageParams& p, const sim5gpu_image_aux* aux)
 {
@@ -275,7 +292,7 @@ int sim5gpu_disk_image_host(const sim5gpu_image_desc* desc, float* h_image_f, fl
     int rc = fill_image_params(desc, chk);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
-    const size_t n = (size_t)(desc->y1 - desc->y0) * (size_t)desc->nx;
+    const size_t n = (size_t)sim5gpu_image_rows(desc) * (size_t)desc->nx;
     DevBuf<float> f(n), g(n);
     DevBuf<uint8_t> cls(h_aux && h_aux->cls ? n : 0);
     DevBuf<int8_t> gt(h_aux && h_aux->gtype ? n : 0);

@@ -68,8 +68,10 @@ void disk_image_grid_kernel(ImageParams p)
     const int lane_x = threadIdx.x % TILE_W;
     const int lane_y = threadIdx.x / TILE_W;
     const int ix = blockIdx.x * TILE_W + lane_x;
-    const int iy = p.y0 + blockIdx.y * TILE_H + lane_y;
-    if (ix >= p.nx || iy >= p.y1) return;
+    const int lr = blockIdx.y * TILE_H + lane_y;                 // packed (local) row
+    if (ix >= p.nx || lr >= p.nrows) return;
+    const int iy = p.stripe_rows > 0 ? p.y0 + (lr / p.stripe_rows) * p.stripe_step + lr % p.stripe_rows
+                                     : p.y0 + lr;
 
     // ref disk-image.c:57-58 (operation order kept)
     const double alpha = (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
@@ -77,7 +79,7 @@ void disk_image_grid_kernel(ImageParams p)
                         ((double)p.ny / (double)p.nx);
 
     const RayResult res = trace_disk_ray(p, alpha, beta);
-    store_ray(p, (size_t)(iy - p.y0) * (size_t)p.nx + (size_t)ix, res);
+    store_ray(p, (size_t)lr * (size_t)p.nx + (size_t)ix, res);
 }
 
 __global__ __launch_bounds__(256, 2)
@@ -102,7 +104,7 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
         const unsigned blocks = (unsigned)((p.n + 255) / 256);
         hipLaunchKernelGGL(disk_image_list_kernel, dim3(blocks), dim3(256), 0, stream, p);
     } else {
-        const dim3 grid((p.nx + TILE_W - 1) / TILE_W, (p.y1 - p.y0 + TILE_H - 1) / TILE_H);
+        const dim3 grid((p.nx + TILE_W - 1) / TILE_W, (p.nrows + TILE_H - 1) / TILE_H);
         hipLaunchKernelGGL(disk_image_grid_kernel, grid, dim3(256), 0, stream, p);
     }
     return (int)hipGetLastError();

@@ -26,14 +26,16 @@ void disk_image_polarized_kernel(ImageParams p)
     const int lane_x = threadIdx.x & 15;
     const int lane_y = threadIdx.x >> 4;
     const int ix = blockIdx.x * 16 + lane_x;
-    const int iy = p.y0 + blockIdx.y * 16 + lane_y;
-    if (ix >= p.nx || iy >= p.y1) return;
+    const int lr = blockIdx.y * 16 + lane_y;                     // packed (local) row
+    if (ix >= p.nx || lr >= p.nrows) return;
+    const int iy = p.stripe_rows > 0 ? p.y0 + (lr / p.stripe_rows) * p.stripe_step + lr % p.stripe_rows
+                                     : p.y0 + lr;
 
     const double alpha = (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
     const double beta = (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax *
                         ((double)p.ny / (double)p.nx);
-    const size_t npix = (size_t)(p.y1 - p.y0) * (size_t)p.nx;
-    const size_t o = (size_t)(iy - p.y0) * (size_t)p.nx + (size_t)ix;
+    const size_t npix = (size_t)p.nrows * (size_t)p.nx;
+    const size_t o = (size_t)lr * (size_t)p.nx + (size_t)ix;
 
     double I = 0.0, Q = 0.0, U = 0.0, chi = NAN;
     ThinRay t;
@@ -84,7 +86,7 @@ int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream
 #endif
 {
     using namespace S5NS;
-    const dim3 grid((p.nx + 15) / 16, (p.y1 - p.y0 + 15) / 16);
+    const dim3 grid((p.nx + 15) / 16, (p.nrows + 15) / 16);
     hipLaunchKernelGGL(disk_image_polarized_kernel, grid, dim3(256), 0, stream, p);
     return (int)hipGetLastError();
 }

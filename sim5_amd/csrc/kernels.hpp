@@ -25,6 +25,8 @@ struct DiskConsts {
 // kernel argument block of the thin-disk image kernels (wave-uniform: lives in SGPRs)
 struct ImageParams {
     int nx, ny, y0, y1;
+    int nrows;                         // rows traced by this launch (packed output rows)
+    int stripe_rows, stripe_step;      // 0: rows y0..y1-1; else stripes of stripe_rows rows every stripe_step
     int max_order;
     double a, incl, sin_i, cos_i;      // sin/cos from the host libm
     double rmax, rms;

@@ -43,3 +43,44 @@ def assemble(tiles, ny, world, stripe=STRIPE):
             out[..., y0:y1, :] = tiles[r][..., off:off + (y1 - y0), :]
             off += y1 - y0
     return out
+
+
+class TilePipeline:
+    """Double-buffered "trace my stripes, gather them to rank 0" loop shared by bench.py and the CPU
+    (gloo) test.  `trace(buffer)` must enqueue the work that fills `buffer` ([2, rows_max, nx] tensor);
+    the gather of image i is issued asynchronously and overlaps the tracing of image i+1; `drain()`
+    waits for every outstanding gather.  With world == 1 there is no gather and a single buffer."""
+
+    def __init__(self, torch, dist, rank, world, ny, nx, device, dtype=None):
+        self.dist, self.rank, self.world, self.ny = dist, rank, world, ny
+        dtype = dtype or torch.float32
+        rows_max = max_local_rows(ny, world)
+        self.nbuf = 2 if world > 1 else 1
+        self.tiles = [torch.zeros((2, rows_max, nx), dtype=dtype, device=device) for _ in range(self.nbuf)]
+        self.gathered = [[torch.zeros_like(self.tiles[0]) for _ in range(world)] for _ in range(self.nbuf)] \
+            if (world > 1 and rank == 0) else [None] * self.nbuf
+        self.pending = [None] * self.nbuf
+        self.count = 0
+
+    def step(self, trace):
+        b = self.count % self.nbuf
+        if self.pending[b] is not None:
+            self.pending[b].wait()              # the gather that last read this buffer has finished
+            self.pending[b] = None
+        trace(self.tiles[b])
+        if self.world > 1:
+            self.pending[b] = self.dist.gather(self.tiles[b], self.gathered[b], dst=0, async_op=True)
+        self.count += 1
+
+    def drain(self):
+        for b in range(self.nbuf):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def last_image(self):
+        """Rank 0: the most recent complete image, [2, ny, nx] (call after drain())."""
+        b = (self.count - 1) % self.nbuf
+        if self.world == 1:
+            return self.tiles[b][:, :self.ny]
+        return assemble(self.gathered[b], self.ny, self.world)

@@ -131,6 +131,27 @@ def test_row_tile_sharding_equals_whole_image(capi, golden):
             assert np.array_equal(whole["image_f"], np.concatenate([t["image_f"] for t in tiles]))
 
 
+def test_striped_launch_equals_separate_stripes(capi):
+    """One launch over a rank's stripes (what bench.py --gpus N does) == the stripes traced one by one."""
+    from sim5_amd import sharding
+    n, a, inc, world = 1000, 0.998, 70.0, 3             # 1000 rows: the last stripe is ragged
+    whole = run(capi, n, a, inc, full=True)
+    tiles = []
+    for rank in range(world):
+        d = capi.image_desc(n, n, a, inc / 180.0 * math.pi, y0=rank * sharding.STRIPE, y1=n,
+                            stripe_rows=sharding.STRIPE, stripe_step=world * sharding.STRIPE)
+        assert capi.image_rows(d) == sharding.local_rows(n, rank, world)
+        t = capi.disk_image(d, full=True)
+        ref = np.concatenate([whole["image_g"][y0:y1] for (y0, y1) in sharding.stripes_for_rank(n, rank, world)])
+        assert np.array_equal(t["image_g"], ref)
+        rmax = sharding.max_local_rows(n, world)
+        pad = np.zeros((2, rmax, n), np.float32)
+        pad[0, :t["image_f"].shape[0]] = t["image_f"]; pad[1, :t["image_g"].shape[0]] = t["image_g"]
+        tiles.append(pad)
+    img = sharding.assemble(tiles, n, world)
+    assert np.array_equal(img[0], whole["image_f"]) and np.array_equal(img[1], whole["image_g"])
+
+
 def test_deterministic_and_list_mode(capi):
     """Same job twice -> identical bits; explicit ray list == implicit pixel grid."""
     import ctypes as C

@@ -64,6 +64,52 @@ def _worker(rank, world, port, ny, nx, q):
     dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, ny, nx, nimages, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe = sharding.TilePipeline(torch, dist, rank, world, ny, nx, torch.device("cpu"))
+    state = {"img": 0}
+
+    def trace(buf):                               # stand-in kernel: value = image number * 1e6 + row * nx + col
+        off = 0
+        for (y0, y1) in sharding.stripes_for_rank(ny, rank, world):
+            rows = torch.arange(y0, y1, dtype=torch.float32)[:, None] * nx + torch.arange(nx, dtype=torch.float32)[None, :]
+            buf[0, off:off + y1 - y0] = rows + 1e6 * state["img"]
+            buf[1, off:off + y1 - y0] = -rows
+            off += y1 - y0
+        state["img"] += 1
+
+    for _ in range(nimages):
+        pipe.step(trace)
+    pipe.drain()
+    dist.barrier()
+    if rank == 0:
+        img = pipe.last_image()
+        expect = torch.arange(ny * nx, dtype=torch.float32).reshape(ny, nx)
+        q.put(bool(torch.equal(img[0], expect + 1e6 * (nimages - 1)) and torch.equal(img[1], -expect)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nimages", [1, 4, 5])
+def test_overlapped_gather_pipeline_gloo(nimages):
+    """The bench's double-buffered trace/gather loop with world size 2 on CPU."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 200, 16, nimages, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
 def test_gather_world_size_2_gloo():
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
