@@ -289,12 +289,15 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
         d = msqrt(d);
         u *= d;
     }
-    double ra[13], rg[13];
+    // 13 rungs as in the reference; the AGM of a double-precision modulus (1 - m >= 1.1e-16) converges to
+    // 1e-8 within 9 rungs, so the fast variant keeps 10 (20 registers less)
+    constexpr int NR = S5_FAST ? 10 : 13;
+    double ra[NR], rg[NR];
     double a = 1.0, c = 0.0;
-    int top = 12;
+    int top = NR - 1;
     bool climbing = true;
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
+    for (int i = 0; i < NR; ++i) {
         if (climbing) {
             ra[i] = a;
             emc = msqrt(emc);
@@ -313,7 +316,7 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
         a = mdiv(c0, s0);
         c *= a;
 #pragma unroll
-        for (int i = 12; i >= 0; --i) {
+        for (int i = NR - 1; i >= 0; --i) {
             if (wave_any(i <= top)) {          // rungs no lane of the wave reached are skipped
                 if (i <= top) {
                     double b = ra[i];

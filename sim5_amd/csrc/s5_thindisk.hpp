@@ -184,6 +184,9 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
     double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
 #pragma unroll 1
     for (int slot = 0; slot < 4; ++slot) {
+#if S5_F_AGMK
+        if (slot == 1) continue;                         // K(mmT) comes from the AGM below
+#endif
         if (slot == 3 && !wave_any(need3)) break;
         double x, y, mult;
         if (slot == 0) {
@@ -209,6 +212,9 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
     // assemble as the generic routines do
     double Rint = res0;
     if (type == T_RC && need3) Rint = mdiv(2., msqrt(1. - mR)) * res3 + res0;
+#if S5_F_AGMK
+    res1 = ell_K(mmT);
+#endif
     double K = res1;
     double icn_i = res2;
     // special cases, out of line

@@ -103,8 +103,36 @@ S5_DEV double macos(double x)
     return 2.0 * (df + w);
 }
 
+// log(x) for positive, finite, normal x (after fdlibm e_log.c): x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2),
+// s = f/(2+f), log(1+f) = f - f^2/2 + s (f^2/2 + R(s^2)); < 1 ulp.  The exponent/mantissa split uses
+// the v_frexp instructions instead of integer surgery.
+S5_DEV double mlog(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    double m = __builtin_amdgcn_frexp_mant(x);                 // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = mdiv(f, 2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double res = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    return (x > 0.0) ? res : ((x == 0.0) ? -INFINITY : NAN);
+}
+
 #else
 
+S5_DEV double mlog(double x) { return log(x); }
 S5_DEV void msincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
 S5_DEV double mcos(double x) { return cos(x); }
 S5_DEV double msin(double x) { return sin(x); }
