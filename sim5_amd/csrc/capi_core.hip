@@ -88,6 +88,8 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p)
     p.nx = desc->nx; p.ny = desc->ny; p.y0 = desc->y0; p.y1 = desc->y1;
     p.stripe_rows = desc->stripe_rows; p.stripe_step = desc->stripe_step;
     p.nrows = sim5gpu_image_rows(desc);
+    p.inv_nx = 1.0 / (double)desc->nx; p.inv_ny = 1.0 / (double)desc->ny;
+    p.ny_over_nx = (double)desc->ny / (double)desc->nx;
     p.max_order = desc->max_order > 0 ? desc->max_order : 2;
     p.a = desc->a;
     p.incl = desc->incl;

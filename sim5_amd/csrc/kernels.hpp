@@ -30,6 +30,7 @@ struct ImageParams {
     int max_order;
     double a, incl, sin_i, cos_i;      // sin/cos from the host libm
     double rmax, rms;
+    double inv_nx, inv_ny, ny_over_nx; // 1/nx, 1/ny, ny/nx (host doubles; used by the fast variant)
     double pol_degree;
     DiskConsts disk;
     // outputs (tile-local, row-major)
