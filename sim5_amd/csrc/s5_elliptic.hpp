@@ -36,28 +36,31 @@ S5_DEV double carlson_rf(double x, double y, double z)
     x = fmax(x, 1e-300); y = fmax(y, 1e-300); z = fmax(z, 1e-300);  // at most one argument may be 0
     const double A0 = third * (x + y + z);
     const double dx0 = A0 - x, dy0 = A0 - y;
-    double dev = max3abs(dx0, dy0, A0 - z);
-    double A = A0, scale = 1.0;
+    const double dev = max3abs(dx0, dy0, A0 - z);
+    // The loop carries X_n = 4^n x_n (same for y, z, A): then x_{n+1} = (x_n + lambda_n)/4 becomes
+    // X_{n+1} = X_n + Lambda_n with Lambda_n = sqrt(X_n Y_n) + sqrt(X_n Z_n) + sqrt(Y_n Z_n) -- no scaling
+    // by 1/4 inside the loop, and since powers of two are exact the values are those of the textbook form.
+    double A = A0, pw = 1.0;                        // pw = 2^n
     bool live = dev >= tol * A;
     for (int pass = 0; pass < 32; ++pass) {
         if (!wave_any(live)) break;
         if (live) {                              // a lane's result depends on its own arguments only
             const double sx = sqrt_pos(x), sy = sqrt_pos(y), sz = sqrt_pos(z);
             const double lam = sx * (sy + sz) + sy * sz;
-            x = 0.25 * (x + lam);
-            y = 0.25 * (y + lam);
-            z = 0.25 * (z + lam);
-            A = 0.25 * (A + lam);
-            scale *= 0.25;
-            live = dev * scale >= tol * A;
+            x += lam;
+            y += lam;
+            z += lam;
+            A += lam;
+            pw += pw;
+            live = dev >= tol * A;
         }
     }
-    const double rA = mrcp(A);
-    const double X = dx0 * scale * rA, Y = dy0 * scale * rA, Z = -(X + Y);
+    const double rA = mrcp(A);                      // 1 / (4^n A_n)
+    const double X = dx0 * rA, Y = dy0 * rA, Z = -(X + Y);
     const double E2 = X * Y - Z * Z, E3 = X * Y * Z;
     const double ser = 1.0 + E2 * (-0.1 + E2 * (1.0 / 24.0) - E3 * (3.0 / 44.0) - E2 * E2 * (5.0 / 208.0))
                      + E3 * (1.0 / 14.0 + E3 * (3.0 / 104.0) + E2 * E2 * (1.0 / 16.0));
-    const double res = ser * sqrt_pos(rA);
+    const double res = ser * pw * sqrt_pos(rA);     // A_n^-1/2 = 2^n (4^n A_n)^-1/2
     return bad ? NAN : res;
 }
 #else
