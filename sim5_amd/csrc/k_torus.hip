@@ -100,6 +100,27 @@ S5_DEV double torus_density(const TorusParams& p, double r, double m)
 #ifndef S5_MARCH_WAVES
 #define S5_MARCH_WAVES 2
 #endif
+// Emission and absorption picked up over one accepted step (see the header comment for the model).
+S5_DEV void accumulate_transfer(const TorusParams& p, const RayState& s, const double x[4], const double k[4],
+                         double dl_taken, double& I, double& tau)
+{
+    const double rho = torus_density(p, x[1], x[2]);
+    if (!(rho > 0.0)) return;
+    Metric g;
+    rt_metric(s, x[1], x[2], g);
+    const double Om = omega_from_ell(p.torus_l, g);
+    const double nrm = -(g.g00 + 2. * Om * g.g03 + Om * Om * g.g33);
+    if (!(nrm > 0.0)) return;                           // no time-like circular orbit with this ell here
+    const double ut = mdiv(1., msqrt(nrm));
+    const double k_t = k[0] * g.g00 + k[3] * g.g03;
+    const double k_f = k[3] * g.g33 + k[0] * g.g03;
+    const double gfac = mdiv(s.E, ut * (k_t + Om * k_f));   // E_inf / E_local
+    const double ds = mdiv(dl_taken, gfac);
+    const double g2 = gfac * gfac;
+    I += (g2 * g2) * p.emis0 * rho * exp(-tau) * ds;
+    tau += p.absorb0 * rho * ds;
+}
+
 __global__ __launch_bounds__(256, S5_MARCH_WAVES)
 void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const int* __restrict__ ok,
                         unsigned long long* __restrict__ cursor, sim5gpu_stokes* __restrict__ out,
@@ -190,23 +211,7 @@ void torus_march_kernel(TorusParams p, const double* __restrict__ cols, const in
         if (stepped) {
             worst = fmaxf(worst, s.error);
             // transfer over the step just taken, evaluated at its end point
-            const double rho = torus_density(p, x[1], x[2]);
-            if (rho > 0.0) {
-                Metric g;
-                rt_metric(s, x[1], x[2], g);
-                const double Om = omega_from_ell(p.torus_l, g);
-                const double nrm = -(g.g00 + 2. * Om * g.g03 + Om * Om * g.g33);
-                if (nrm > 0.0) {                    // a circular orbit with this ell is time-like here
-                    const double ut = mdiv(1., msqrt(nrm));
-                    const double k_t = k[0] * g.g00 + k[3] * g.g03;
-                    const double k_f = k[3] * g.g33 + k[0] * g.g03;
-                    const double gfac = mdiv(s.E, ut * (k_t + Om * k_f));   // E_inf / E_local
-                    const double ds = mdiv(dl_taken, gfac);
-                    const double g2 = gfac * gfac;
-                    I += (g2 * g2) * p.emis0 * rho * exp(-tau) * ds;
-                    tau += p.absorb0 * rho * ds;
-                }
-            }
+            accumulate_transfer(p, s, x, k, dl_taken, I, tau);
 
             const bool done = !(x[1] > r_in) || !(x[1] < r_out) || ((double)s.error > p.max_error) ||
                               (s.pass >= p.max_steps);

@@ -170,6 +170,22 @@ S5_DEV void geodesic_accel(const Conn& G, const double k[4], double out[4])
     out[3] = s;
 }
 
+// transport_rhs(G, k, k) without the symmetrisation: 0.5 G (k_j k_k + k_k k_j) = G (k_j k_k) exactly
+// (doubling and halving are exact), so this is the same number as the reference's Gamma(G, k, k) for half
+// the multiplications.  NOT the same rounding as geodesic_accel, which forms (G k_a) k_b.
+#define S5_GK(Gjk, j, k) s -= (Gjk) * (K[j] * K[k])
+S5_DEV void transport_self(const Conn& G, const double K[4], double out[4])
+{
+    double s;
+    s = 0.0; S5_GK(G.t01, 0, 1); S5_GK(G.t02, 0, 2); S5_GK(G.t13, 1, 3); S5_GK(G.t23, 2, 3); out[0] = s;
+    s = 0.0; S5_GK(G.r00, 0, 0); S5_GK(G.r03, 0, 3); S5_GK(G.r11, 1, 1); S5_GK(G.r12, 1, 2);
+    S5_GK(G.r22, 2, 2); S5_GK(G.r33, 3, 3); out[1] = s;
+    s = 0.0; S5_GK(G.h00, 0, 0); S5_GK(G.h03, 0, 3); S5_GK(G.h11, 1, 1); S5_GK(G.h12, 1, 2);
+    S5_GK(G.h22, 2, 2); S5_GK(G.h33, 3, 3); out[2] = s;
+    s = 0.0; S5_GK(G.p01, 0, 1); S5_GK(G.p02, 0, 2); S5_GK(G.p13, 1, 3); S5_GK(G.p23, 2, 3); out[3] = s;
+}
+#undef S5_GK
+
 // -G^i_jk U^j V^k with the half weight for the doubled storage (ref :422-439)
 #define S5_GT(Gjk, j, k) s -= 0.5 * (Gjk) * (U[j] * V[k] + U[k] * V[j])
 S5_DEV void transport_rhs(const Conn& G, const double U[4], const double V[4], double out[4])

@@ -59,12 +59,14 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
     s.refines = 0;
     s.kt = s.E;
     s.error = 0.0f;
-    transport_rhs(G, k, k, s.dk);
+    transport_self(G, k, s.dk);
 }
 
-// classical RK4 on (x,k), theta as the angle (ref :251-323).  The stage sums are accumulated as the
-// stages are produced, in the reference's order ((k1 + 2 k2) + 2 k3) + k4, so only the latest stage is
-// live (8 doubles instead of 32) and every rounding is the reference's.
+// classical RK4 on (x,k), theta as the angle (ref :251-323).  The four stages run as one rolled loop
+// (stage offsets 0, h, h, dl and weights 1, 2, 2, 1 selected by the wave-uniform stage index): one copy of
+// the connection code, and only the latest stage plus the running sums are live -- 8+8 doubles instead of
+// 32.  The sums are accumulated in the reference's order ((k1 + 2 k2) + 2 k3) + k4 and the stage-0
+// operations with a zero offset / unit weight are exact, so every rounding is the reference's.
 #ifdef S5_RK4_NOINLINE
 static __device__ __noinline__ void rk4_step(double x[4], double k[4], double dl, RayState& s)
 #else
@@ -76,43 +78,27 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s)
     const double h = 0.5 * dl;
     const double kt0 = s.kt;
     x[2] = macos(x[2]);
-    // stage 1
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i]; ki[i] = k[i]; }
-    rt_connection(s, xp[1], mcos(xp[2]), G);
-    transport_rhs(G, ki, ki, di);
+    for (int i = 0; i < 4; ++i) { ki[i] = 0.0; di[i] = 0.0; sx[i] = 0.0; sk[i] = 0.0; }
+#pragma unroll 1
+    for (int stage = 0; stage < 4; ++stage) {
+        const double off = (stage == 0) ? 0.0 : (stage == 3) ? dl : h;
+        const double wgt = (stage == 1 || stage == 2) ? 2.0 : 1.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sx[i] = ki[i]; sk[i] = di[i]; }
-    S5_FENCE();
-    // stage 2
+        for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * off; ki[i] = k[i] + di[i] * off; }
+        rt_connection(s, xp[1], mcos(xp[2]), G);
+        transport_self(G, ki, di);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * h; ki[i] = k[i] + di[i] * h; }
-    rt_connection(s, xp[1], mcos(xp[2]), G);
-    transport_rhs(G, ki, ki, di);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + 2. * ki[i]; sk[i] = sk[i] + 2. * di[i]; }
-    S5_FENCE();
-    // stage 3
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * h; ki[i] = k[i] + di[i] * h; }
-    rt_connection(s, xp[1], mcos(xp[2]), G);
-    transport_rhs(G, ki, ki, di);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + 2. * ki[i]; sk[i] = sk[i] + 2. * di[i]; }
-    S5_FENCE();
-    // stage 4
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * dl; ki[i] = k[i] + di[i] * dl; }
-    rt_connection(s, xp[1], mcos(xp[2]), G);
-    transport_rhs(G, ki, ki, di);
+        for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + wgt * ki[i]; sk[i] = sk[i] + wgt * di[i]; }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        x[i] += S5_DIVC(dl, 6.) * (sx[i] + ki[i]);
-        k[i] += S5_DIVC(dl, 6.) * (sk[i] + di[i]);
+        x[i] += S5_DIVC(dl, 6.) * sx[i];
+        k[i] += S5_DIVC(dl, 6.) * sk[i];
     }
     x[2] = mcos(x[2]);
     rt_connection(s, x[1], x[2], G);
-    transport_rhs(G, k, k, s.dk);
+    transport_self(G, k, s.dk);
     Metric g;
     kerr_metric(s.bh_spin, x[1], x[2], g);          // Kerr metric also in flat mode, ref :302
     const double kt1 = k[0] * g.g00 + k[3] * g.g03;
