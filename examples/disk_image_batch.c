@@ -32,7 +32,7 @@ int main(int argc, char *argv[])
     d.rms = 0.0;                  /* r_ms(a) */
     d.bh_mass = 10.0; d.mdot = 0.1; d.alpha_visc = 0.1;
     d.max_order = 2; d.flags = SIM5GPU_IMG_DEFAULT; d.pol_degree = 0.0;
-    d.stripe_rows = 0; d.stripe_step = 0;
+    d.stripe_rows = 0; d.stripe_step = 0; d.disk_spin = -1.0;
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

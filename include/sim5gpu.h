@@ -272,6 +272,8 @@ typedef struct sim5gpu_image_desc {
      * the outputs hold those rows packed in that order.  stripe_rows == 0: the contiguous range.     */
     int    stripe_rows;
     int    stripe_step;
+    double disk_spin;       /* spin the disk model was set up with, if it differs from `a` (callers that
+                               clamp the ray-tracing spin, ref python/sim5diskraytrace.py:32); < 0: use a */
 } sim5gpu_image_desc;
 
 #define SIM5GPU_IMG_DEFAULT 0   /* tuned FP64 sequences ("fast" variant, sim5_amd/csrc/s5_config.hpp)        */
@@ -311,6 +313,17 @@ int sim5gpu_disk_rays(const sim5gpu_image_desc *desc, size_t n, const double *d_
  * d_stokes: 3 planes [I | Q | U], each (y1-y0) x nx doubles; d_chi optional. */
 int sim5gpu_disk_image_polarized(const sim5gpu_image_desc *desc, double *d_stokes,
                                  double *d_chi, const sim5gpu_image_aux *d_aux, void *stream);
+
+/* Observed spectrum of the thin disk over the pixel grid of `desc` (first-order crossings, as the
+ * reference's Python ray tracer: python/sim5diskraytrace.py:96-123, black body of
+ * python/sim5diskspectrum.py:54-88): spectrum[j] = sum over pixels of I_nu(E_j / g) g^3, with T_eff from the
+ * Novikov-Thorne flux, g and the emission angle from the local frame of the disk surface.  The caller
+ * multiplies by the solid angle of a pixel.  d_energies [keV] and d_spectrum hold n_energies doubles in
+ * DEVICE memory; d_workspace needs sim5gpu_disk_spectrum_workspace(desc, n_energies) bytes. */
+size_t sim5gpu_disk_spectrum_workspace(const sim5gpu_image_desc *desc, int n_energies);
+int sim5gpu_disk_spectrum(const sim5gpu_image_desc *desc, int n_energies, const double *d_energies,
+                          double hardening, int limb_darkening, double *d_spectrum,
+                          void *d_workspace, void *stream);
 
 /* Step-wise (Verlet) ray tracer with radiative transfer through an optically thin torus.
  * Rays start on the incoming branch at radius r0 (geodesic_init_inf -> geodesic_P_int ->

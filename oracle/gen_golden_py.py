@@ -78,6 +78,7 @@ def main():
     sys.path.insert(0, REFPY)
     import sim5diskmodel
     import sim5diskraytrace
+    import sim5diskspectrum
     devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(2); os.dup2(devnull, 2)
     out = {}
     try:
@@ -101,6 +102,22 @@ def main():
                         rr[y, x] = r; kk[y, x] = [k[0], k[1], k[2], k[3]]
             out["geo%d_r" % ci] = rr; out["geo%d_k" % ci] = kk
             out["rmax%d" % ci] = np.array([rmax])
+            # spectrum of the pixel grid with the reference's black-body class (python/sim5diskspectrum.py:54-88),
+            # accumulated as DiskRaytrace.spectrum does (python/sim5diskraytrace.py:122-123): sum Iv(E/g) g^3 per pixel
+            bb = sim5diskspectrum.DiskSpectrum_BlackBody()
+            E = 10.0 ** np.linspace(-1.5, 1.5, 48)
+            for (tag, limb, hard) in (("a", 1, 1.7), ("b", 0, 1.0)):
+                spec = np.zeros(len(E))
+                g_ = np.array(img["gfactor"], dtype=np.float64); T_ = np.array(img["T"], dtype=np.float64)
+                mu_ = np.cos(np.radians(np.array(img["mue"], dtype=np.float64)))
+                for y in range(N):
+                    for x in range(N):
+                        if not np.isfinite(g_[y, x]):
+                            continue
+                        e = mu_[y, x] if limb > 0 else -1.0
+                        spec += bb.spectrum(T_[y, x], e, hard, E / g_[y, x]) * g_[y, x] ** 3
+                out["spec%d%s" % (ci, tag)] = spec
+            out["spec_E"] = E
     finally:
         os.dup2(saved, 2)
     path = os.path.join(ROOT, "tests", "golden", "py_diskraytrace.npz")

@@ -64,7 +64,8 @@ class ImageDesc(C.Structure):
     _fields_ = [("nx", I), ("ny", I), ("y0", I), ("y1", I),
                 ("a", D), ("incl", D), ("rmax", D), ("rms", D),
                 ("bh_mass", D), ("mdot", D), ("alpha_visc", D),
-                ("max_order", I), ("flags", I), ("pol_degree", D), ("stripe_rows", I), ("stripe_step", I)]
+                ("max_order", I), ("flags", I), ("pol_degree", D), ("stripe_rows", I), ("stripe_step", I),
+                ("disk_spin", D)]
 
 
 class ImageAux(C.Structure):
@@ -562,13 +563,14 @@ IMG_DEFAULT, IMG_STRICT = 0, 1
 
 
 def image_desc(nx, ny, a, incl_rad, y0=0, y1=None, rmax=0.0, rms=0.0, bh_mass=10.0, mdot=0.1,
-               alpha_visc=0.1, max_order=2, pol_degree=0.0, strict=False, stripe_rows=0, stripe_step=0):
+               alpha_visc=0.1, max_order=2, pol_degree=0.0, strict=False, stripe_rows=0, stripe_step=0,
+               disk_spin=-1.0):
     """Job description; defaults are those of the reference example (disk-image.c:41-45).
     strict=True selects the reference-parameter arithmetic variant (SIM5GPU_IMG_STRICT)."""
     return ImageDesc(nx=nx, ny=ny, y0=y0, y1=ny if y1 is None else y1, a=a, incl=incl_rad,
                      rmax=rmax, rms=rms, bh_mass=bh_mass, mdot=mdot, alpha_visc=alpha_visc,
                      max_order=max_order, flags=IMG_STRICT if strict else IMG_DEFAULT, pol_degree=pol_degree,
-                     stripe_rows=stripe_rows, stripe_step=stripe_step)
+                     stripe_rows=stripe_rows, stripe_step=stripe_step, disk_spin=disk_spin)
 
 
 def image_rows(desc):
@@ -616,6 +618,19 @@ def disk_image_polarized_device(desc, d_stokes, d_chi=None, aux=None, stream=Non
     _check(_lib.sim5gpu_disk_image_polarized(C.byref(desc), VP(d_stokes), VP(d_chi or 0),
                                              C.byref(a) if a is not None else None, VP(stream or 0)),
            "sim5gpu_disk_image_polarized")
+
+
+def disk_spectrum(desc, energies, hardening=1.7, limb_darkening=1):
+    """Sum over the pixels of `desc` of I_nu(E/g) g^3 for each energy [keV]; host arrays in and out."""
+    E = np.ascontiguousarray(energies, dtype=np.float64).ravel()
+    _lib.sim5gpu_disk_spectrum_workspace.restype = SZ
+    ws_bytes = _lib.sim5gpu_disk_spectrum_workspace(C.byref(desc), I(E.size))
+    dE = DeviceBuffer(E.nbytes); dS = DeviceBuffer(E.nbytes); ws = DeviceBuffer(max(ws_bytes, 8))
+    dE.from_numpy(E)
+    _check(_lib.sim5gpu_disk_spectrum(C.byref(desc), I(E.size), VP(dE.ptr), D(hardening), I(limb_darkening),
+                                      VP(dS.ptr), VP(ws.ptr), VP(0)), "sim5gpu_disk_spectrum")
+    synchronize()
+    return dS.to_numpy(np.float64, (E.size,))
 
 
 def torus_image_device(desc, d_stokes, aux=None, stream=None):

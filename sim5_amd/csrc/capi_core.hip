@@ -99,7 +99,7 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p)
     p.rms = desc->rms > 0.0 ? desc->rms : rms;
     p.rmax = desc->rmax > 0.0 ? desc->rmax : rms + 8.0;
     p.pol_degree = desc->pol_degree;
-    p.disk = make_disk_consts(desc->bh_mass, desc->a, desc->mdot);   // ref disk-image.c:45
+    p.disk = make_disk_consts(desc->bh_mass, desc->disk_spin >= 0.0 ? desc->disk_spin : desc->a, desc->mdot);   // ref disk-image.c:45
     return SIM5GPU_OK;
 }
 

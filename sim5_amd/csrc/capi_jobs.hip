@@ -25,6 +25,48 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     return SIM5GPU_OK;
 }
 
+static void spectrum_grid(const sim5gpu_image_desc* desc, size_t& nblocks)
+{
+    const int rows = sim5gpu_image_rows(desc);
+    nblocks = (size_t)((desc->nx + 31) / 32) * (size_t)((rows + 7) / 8);
+}
+
+size_t sim5gpu_disk_spectrum_workspace(const sim5gpu_image_desc* desc, int n_energies)
+{
+    if (!desc || n_energies <= 0 || desc->nx <= 0) return 0;
+    size_t nblocks;
+    spectrum_grid(desc, nblocks);
+    return nblocks * (size_t)n_energies * sizeof(double);
+}
+
+int sim5gpu_disk_spectrum(const sim5gpu_image_desc* desc, int n_energies, const double* d_energies,
+                          double hardening, int limb_darkening, double* d_spectrum, void* d_workspace, void* stream)
+{
+    if (!d_energies || !d_spectrum || !d_workspace || n_energies <= 0 || !(hardening > 0.0)) {
+        snprintf(g_err, sizeof g_err, "disk_spectrum: need energies, spectrum, workspace, n_energies > 0, hardening > 0");
+        return SIM5GPU_E_ARG;
+    }
+    if (desc && desc->stripe_rows != 0) { snprintf(g_err, sizeof g_err, "disk_spectrum: striping is not supported"); return SIM5GPU_E_ARG; }
+    ImageParams p;
+    int rc = fill_image_params(desc, p);
+    if (rc) return rc;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    p.max_order = 1;                  // the Python ray tracer uses the first crossing only
+    p.rms = 0.0;                      // and lets the disk model decide (zero flux inside its inner edge)
+    SpectrumParams sp;
+    sp.n_energies = n_energies;
+    int eb = 1;
+    while (eb < n_energies && eb < 256) eb *= 2;
+    sp.bins_per_pass = eb;
+    sp.limb_darkening = limb_darkening;
+    sp.hardening = hardening;
+    hipError_t e = (hipError_t)((desc->flags & SIM5GPU_IMG_STRICT)
+        ? s5_launch_disk_spectrum_strict(p, sp, d_energies, (double*)d_workspace, d_spectrum, (hipStream_t)stream)
+        : s5_launch_disk_spectrum_fast(p, sp, d_energies, (double*)d_workspace, d_spectrum, (hipStream_t)stream));
+    if (e != hipSuccess) { set_error("disk_spectrum launch", e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_torus_image(const sim5gpu_torus_desc* desc, sim5gpu_stokes* d_stokes,
                         const sim5gpu_torus_aux* d_aux, void* stream)
 {

@@ -49,6 +49,14 @@ struct ImageParams {
     size_t n;
 };
 
+// spectrum job (k_spectrum.hip)
+struct SpectrumParams {
+    int n_energies;
+    int bins_per_pass;     // power of two <= 256: energy bins handled concurrently by a workgroup
+    int limb_darkening;
+    double hardening;
+};
+
 } // namespace s5abi
 
 // fast = tuned FP64 sequences (default); strict = reference parameters, IEEE sqrt/div, no contraction
@@ -56,3 +64,7 @@ int s5_launch_disk_image_fast(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_image_polarized_fast(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream_t stream);
+int s5_launch_disk_spectrum_fast(const s5abi::ImageParams& p, const s5abi::SpectrumParams& sp,
+                                 const double* energies, double* partial, double* spectrum, hipStream_t stream);
+int s5_launch_disk_spectrum_strict(const s5abi::ImageParams& p, const s5abi::SpectrumParams& sp,
+                                   const double* energies, double* partial, double* spectrum, hipStream_t stream);

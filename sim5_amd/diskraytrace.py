@@ -22,6 +22,7 @@ class DiskModel_ThinDisk:
         _c.disk_nt_setup(bh_mass, bh_spin, mdot, alpha, options or 0)
         self.name = "Novikov-Thorne"
         self.mdot = mdot
+        self.bh_spin = bh_spin
         self.r_min = _c.disk_nt_r_min()
 
     def flux(self, R):
@@ -88,6 +89,15 @@ class DiskRaytrace:
         N = _c.on2bl(np.tile([0.0, 0.0, 1.0, 0.0], (n, 1)), tetrad)
         mue = _c.dotprod(k, N, metric) / _c.dotprod(k, U, metric)
         return np.where((mue < 0.0) & (mue > -1e-2), 1e-3, mue)
+
+    def spectrum_image(self, incl, rmax, N, energies, limbdk=1, hardening=1.7):
+        """Observed spectrum [erg/s/cm2/keV] of the N x N pixel grid: the accumulation of the reference's
+        spectrum() (ref :96-123: black body at E/g, times g^3 dOmega) fused with the ray tracing in one kernel."""
+        incl = math.radians(max(1.0, incl))
+        d = _c.image_desc(N, N, self.bh_spin, incl, rmax=rmax, bh_mass=self.bh_mass, mdot=self.disk.mdot,
+                          disk_spin=getattr(self.disk, "bh_spin", -1.0))
+        dOmega = (2.0 * rmax / N) ** 2 * ((self.bh_mass * grav_radius) / (self.bh_dist * parsec * 1e3)) ** 2
+        return _c.disk_spectrum(d, energies, hardening=hardening, limb_darkening=limbdk) * dOmega
 
     def image(self, incl, rmax, N, limbdk=1):
         """Disk image (ref :138-210).  incl in degrees; returns the reference's dict of N x N arrays
