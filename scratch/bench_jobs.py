@@ -29,3 +29,13 @@ for prec in (1.0, 0.01):
     tot=int(s.sum())
     print("C4 torus 1024^2 precision %g: %.1f ms  %.3e rays/s  mean steps %.1f  %.3e steps/s  W_step frac=%.4f"%(prec, ms, N/ms*1e3, s.mean(), tot/ms*1e3, tot*750/ms*1e3/78.6e12))
     print("   hist", np.histogram(s, bins=[0,1,2,10,50,100,300,600,2000,100000])[0].tolist())
+# spectrum: 1024^2 pixels x 128 energies
+n=1024; d=capi.image_desc(n,n,0.998,70/180*math.pi)
+E=10.0**np.linspace(-1,1.5,128)
+import ctypes as C
+capi._lib.sim5gpu_disk_spectrum_workspace.restype = capi.SZ
+ws_bytes = capi._lib.sim5gpu_disk_spectrum_workspace(C.byref(d), capi.I(E.size))
+dE=capi.DeviceBuffer(E.nbytes); dS=capi.DeviceBuffer(E.nbytes); ws=capi.DeviceBuffer(ws_bytes); dE.from_numpy(E)
+fn=lambda: capi._check(capi._lib.sim5gpu_disk_spectrum(C.byref(d), capi.I(E.size), capi.VP(dE.ptr), capi.D(1.7), capi.I(1), capi.VP(dS.ptr), capi.VP(ws.ptr), capi.VP(0)),"spec")
+ms=timeit(fn, reps=5)
+print("spectrum 1024^2 x 128 energies: %.3f ms  %.3e rays/s  %.3e (ray,energy) pairs/s"%(ms, n*n/ms*1e3, n*n*128/ms*1e3))
