@@ -314,6 +314,18 @@ int sim5gpu_disk_rays(const sim5gpu_image_desc *desc, size_t n, const double *d_
 int sim5gpu_disk_image_polarized(const sim5gpu_image_desc *desc, double *d_stokes,
                                  double *d_chi, const sim5gpu_image_aux *d_aux, void *stream);
 
+/* Intersection of rays from infinity with the photosphere of a geometrically thick disk: the surface
+ * search of the reference's Python ray tracer (python/sim5diskraytrace.py:214-335, geodesic(flat=False) and
+ * __find_surface), one lane per ray.  The surface is H(R) given as a table (R ascending, n_table <= 4096
+ * points, DEVICE memory), interpolated linearly, H = H[0] below the first point and a constant opening angle
+ * beyond the last.  Outputs (DEVICE, n each; k is n x 4 and may be NULL): position integral P, radius r,
+ * cos(theta) m, photon momentum k (pointing away from the disk, as :250) and status 1 = found / 0 = none.
+ * strict != 0 selects the reference-parameter arithmetic. */
+int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double *d_R, const double *d_H,
+                              size_t n, const double *d_alpha, const double *d_beta,
+                              double *d_P, double *d_r, double *d_m, double *d_k, int *d_status,
+                              int strict, void *stream);
+
 /* Observed spectrum of the thin disk over the pixel grid of `desc` (first-order crossings, as the
  * reference's Python ray tracer: python/sim5diskraytrace.py:96-123, black body of
  * python/sim5diskspectrum.py:54-88): spectrum[j] = sum over pixels of I_nu(E_j / g) g^3, with T_eff from the

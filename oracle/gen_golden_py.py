@@ -36,7 +36,12 @@ def make_shim(ref):
         def assign(self, v): self.c.value = float(v)
 
     m.intp, m.doublep = intp, doublep
-    m.geodesic = ol.Geodesic
+    class geodesic(ol.Geodesic):
+        # the reference's python code reads gd.i (python/sim5diskraytrace.py:265); the C struct member is incl
+        @property
+        def i(self):
+            return self.incl
+    m.geodesic = geodesic
     m.sim5metric = ol.Metric
     m.sim5tetrad = ol.Tetrad
     m.doubleArray = lambda n: (C.c_double * n)()
@@ -59,6 +64,7 @@ def make_shim(ref):
     m.geodesic_position_rad = lambda gd, P: ref.geodesic_position_rad(C.byref(gd), P)
     m.geodesic_position_pol = lambda gd, P: ref.geodesic_position_pol(C.byref(gd), P)
     m.geodesic_P_int = lambda gd, r, ppc: ref.geodesic_P_int(C.byref(gd), r, ppc)
+    m.geodesic_follow = lambda gd, step, P, r, mm, st: ref.geodesic_follow(C.byref(gd), step, C.byref(P.c), C.byref(r.c), C.byref(mm.c), C.byref(st.c))
     m.photon_momentum = lambda a, r, mm, l, q, rs, ms, k: ref.photon_momentum(a, r, mm, l, q, rs, ms, k)
     m.kerr_metric = lambda a, r, mm, met: ref.kerr_metric(a, r, mm, C.byref(met))
     m.tetrad_surface = lambda met, Om, V, dh, t: ref.tetrad_surface(C.byref(met), Om, V, dh, C.byref(t))
@@ -120,9 +126,46 @@ def main():
             out["spec_E"] = E
     finally:
         os.dup2(saved, 2)
+    # ---- thick disk: the surface search (python/sim5diskraytrace.py:257-335) with a tabulated H(R) ------
+    os.dup2(devnull, 2)
+    try:
+        tR = 10.0 ** np.linspace(0.0, 3.0, 256)
+        tH = np.where(tR > 2.0, 0.25 * (tR - 2.0), 0.0)
+
+        class ThickDisk(sim5diskmodel.DiskModel):
+            """H(R): linear interpolation of the table, H[0] below it, constant opening angle beyond it
+            (the definition sim5gpu_disk_surface_rays uses)."""
+            def h(self, R):
+                if not (R > tR[0]): return float(tH[0])
+                if R >= tR[-1]: return float(tH[-1] * (R / tR[-1]))
+                hi = int(np.searchsorted(tR, R, side="left")); lo = hi - 1
+                w = (R - tR[lo]) / (tR[hi] - tR[lo])
+                return float(tH[lo] + w * (tH[hi] - tH[lo]))
+
+        out["surf_R"] = tR; out["surf_H"] = tH
+        scases = [(a, inc) for a in (0.5, 0.9) for inc in (30.0, 60.0, 80.0)]
+        out["surf_cases"] = np.array(scases)
+        Ns, rmax_s = 12, 30.0
+        c = ((np.arange(Ns) + .5) / Ns - 0.5) * 2.0 * rmax_s
+        out["surf_alpha"] = np.tile(c, Ns); out["surf_beta"] = np.repeat(c, Ns)
+        for ci, (a, inc) in enumerate(scases):
+            rt = sim5diskraytrace.DiskRaytrace(10.0, a, 10.0, ThickDisk(), None)
+            rr = np.zeros(Ns * Ns); mm = np.zeros(Ns * Ns); ok = np.zeros(Ns * Ns, np.int32); kk = np.full((Ns * Ns, 4), np.nan)
+            PP = np.full(Ns * Ns, np.nan)
+            for j in range(Ns * Ns):
+                r, m, gd, k = rt.geodesic(math.radians(inc), float(out["surf_alpha"][j]), float(out["surf_beta"][j]), flat=False)
+                if gd is not None:
+                    rr[j], mm[j], ok[j] = r, m, 1
+                    kk[j] = [k[0], k[1], k[2], k[3]]
+            out["surf%d_r" % ci] = rr; out["surf%d_m" % ci] = mm; out["surf%d_ok" % ci] = ok; out["surf%d_k" % ci] = kk
+    finally:
+        os.dup2(saved, 2)
     path = os.path.join(ROOT, "tests", "golden", "py_diskraytrace.npz")
     np.savez_compressed(path, **out)
     print(path, "%.1f KiB" % (os.path.getsize(path) / 1024.0))
+    for ci in range(len(scases)):
+        print("thick disk", scases[ci], "rays on the surface:", int(out["surf%d_ok" % ci].sum()), "of", Ns * Ns,
+              "above the plane:", int((out["surf%d_m" % ci] > 1e-6).sum()))
     for ci in range(len(cases)):
         print(cases[ci], "pixels with flux:", int(np.isfinite(out["img%d_flux" % ci]).sum()),
               "geodesics:", int(np.isfinite(out["geo%d_r" % ci]).sum()))

@@ -633,6 +633,27 @@ def disk_spectrum(desc, energies, hardening=1.7, limb_darkening=1):
     return dS.to_numpy(np.float64, (E.size,))
 
 
+def disk_surface_rays(a, incl_rad, table_R, table_H, alpha, beta, strict=False):
+    """Surface search for a thick disk H(R) (host arrays in and out): dict(P, r, m, k[n,4], status)."""
+    tR = np.ascontiguousarray(table_R, dtype=np.float64).ravel()
+    tH = np.ascontiguousarray(table_H, dtype=np.float64).ravel()
+    al = np.ascontiguousarray(alpha, dtype=np.float64).ravel()
+    be = np.ascontiguousarray(beta, dtype=np.float64).ravel()
+    n = al.size
+    bufs = {}
+    for name, arr in (("tR", tR), ("tH", tH), ("al", al), ("be", be)):
+        bufs[name] = DeviceBuffer(max(arr.nbytes, 8)); bufs[name].from_numpy(arr)
+    out = {k: DeviceBuffer(max(n * s, 8)) for k, s in (("P", 8), ("r", 8), ("m", 8), ("k", 32), ("st", 4))}
+    _check(_lib.sim5gpu_disk_surface_rays(D(a), D(incl_rad), I(tR.size), VP(bufs["tR"].ptr), VP(bufs["tH"].ptr),
+                                          SZ(n), VP(bufs["al"].ptr), VP(bufs["be"].ptr), VP(out["P"].ptr),
+                                          VP(out["r"].ptr), VP(out["m"].ptr), VP(out["k"].ptr), VP(out["st"].ptr),
+                                          I(1 if strict else 0), VP(0)), "sim5gpu_disk_surface_rays")
+    synchronize()
+    return {"P": out["P"].to_numpy(np.float64, (n,)), "r": out["r"].to_numpy(np.float64, (n,)),
+            "m": out["m"].to_numpy(np.float64, (n,)), "k": out["k"].to_numpy(np.float64, (n, 4)),
+            "status": out["st"].to_numpy(np.int32, (n,))}
+
+
 def torus_image_device(desc, d_stokes, aux=None, stream=None):
     a = None
     if aux:

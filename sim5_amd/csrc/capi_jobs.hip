@@ -25,6 +25,30 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     return SIM5GPU_OK;
 }
 
+int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double* d_R, const double* d_H,
+                              size_t n, const double* d_alpha, const double* d_beta,
+                              double* d_P, double* d_r, double* d_m, double* d_k, int* d_status,
+                              int strict, void* stream)
+{
+    if (!d_R || !d_H || !d_alpha || !d_beta || !d_P || !d_r || !d_m || !d_status) {
+        snprintf(g_err, sizeof g_err, "disk_surface_rays: NULL pointer argument");
+        return SIM5GPU_E_ARG;
+    }
+    if (n_table < 2 || n_table > 4096) {
+        snprintf(g_err, sizeof g_err, "disk_surface_rays: n_table must be in [2, 4096]");
+        return SIM5GPU_E_ARG;
+    }
+    if (n == 0) return SIM5GPU_OK;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    SurfaceParams p;
+    p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
+    hipError_t e = (hipError_t)(strict
+        ? s5_launch_disk_surface_strict(p, d_R, d_H, d_alpha, d_beta, d_P, d_r, d_m, d_k, d_status, (hipStream_t)stream)
+        : s5_launch_disk_surface_fast(p, d_R, d_H, d_alpha, d_beta, d_P, d_r, d_m, d_k, d_status, (hipStream_t)stream));
+    if (e != hipSuccess) { set_error("disk_surface_rays launch", e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
 static void spectrum_grid(const sim5gpu_image_desc* desc, size_t& nblocks)
 {
     const int rows = sim5gpu_image_rows(desc);

@@ -57,6 +57,13 @@ struct SpectrumParams {
     double hardening;
 };
 
+// surface search job (k_surface.hip)
+struct SurfaceParams {
+    size_t n;
+    int n_table;
+    double a, incl, sin_i, cos_i;
+};
+
 } // namespace s5abi
 
 // fast = tuned FP64 sequences (default); strict = reference parameters, IEEE sqrt/div, no contraction
@@ -68,3 +75,9 @@ int s5_launch_disk_spectrum_fast(const s5abi::ImageParams& p, const s5abi::Spect
                                  const double* energies, double* partial, double* spectrum, hipStream_t stream);
 int s5_launch_disk_spectrum_strict(const s5abi::ImageParams& p, const s5abi::SpectrumParams& sp,
                                    const double* energies, double* partial, double* spectrum, hipStream_t stream);
+int s5_launch_disk_surface_strict(const s5abi::SurfaceParams& p, const double* tabR, const double* tabH,
+                                  const double* alpha, const double* beta, double* P, double* r, double* m,
+                                  double* k, int* status, hipStream_t stream);
+int s5_launch_disk_surface_fast(const s5abi::SurfaceParams& p, const double* tabR, const double* tabH,
+                                const double* alpha, const double* beta, double* P, double* r, double* m,
+                                double* k, int* status, hipStream_t stream);

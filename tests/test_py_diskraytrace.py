@@ -120,3 +120,25 @@ def test_fused_spectrum_kernel(golden, capi):
     # consistency with the image: total of the spectrum bins equals the per-pixel sum done on the host
     img = capi.disk_image(capi.image_desc(100, 60, 0.9, 1.2, max_order=1, rms=1e-9), full=True)
     assert (img["flux"] > 0).sum() > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fast"])
+def test_thick_disk_surface_search(golden, capi, strict):
+    """sim5gpu_disk_surface_rays against the reference's Python __find_surface run on the same table."""
+    g = golden("py_diskraytrace.npz")
+    for ci, (a, inc) in enumerate(g["surf_cases"]):
+        s = capi.disk_surface_rays(float(a), math.radians(float(inc)), g["surf_R"], g["surf_H"],
+                                   g["surf_alpha"], g["surf_beta"], strict=strict)
+        ok = g["surf%d_ok" % ci] == 1
+        assert np.array_equal(s["status"] == 1, ok), (ci, int(((s["status"] == 1) != ok).sum()))
+        r_ref, m_ref, k_ref = g["surf%d_r" % ci][ok], g["surf%d_m" % ci][ok], g["surf%d_k" % ci][ok]
+        # the search stops within `accuracy` = 1e-2 of the surface at a point fixed by its step sequence;
+        # identical sequences give identical points
+        assert np.max(np.abs(s["r"][ok] / r_ref - 1)) < 1e-6, (ci, np.max(np.abs(s["r"][ok] / r_ref - 1)))
+        assert np.max(np.abs(s["m"][ok] - m_ref)) < 1e-6
+        assert np.max(np.abs(s["k"][ok] - k_ref) / np.maximum(np.abs(k_ref), 1e-6)) < 1e-5
+        # and the points do lie on the tabulated surface to the search accuracy
+        R = s["r"][ok] * np.sqrt(1 - s["m"][ok] ** 2); H = s["r"][ok] * s["m"][ok]
+        Hd = np.interp(R, g["surf_R"], g["surf_H"])
+        assert np.max(np.abs(H - Hd)) < 2e-2
