@@ -129,14 +129,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    ev = [(capi.Event(), capi.Event()) for _ in range(args.steps)] if world == 1 else None
+    # HIP events around every kernel launch on rank 0 (on the stream the kernel is launched on)
+    ev = [(capi.Event(), capi.Event()) for _ in range(args.steps)] if rank == 0 else None
+    if ev:
+        def trace(buf, _i=[0]):                  # noqa: B006 -- the timed flavour of trace()
+            a, b = ev[_i[0] % len(ev)]
+            a.record(stream)
+            capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
+            b.record(stream)
+            _i[0] += 1
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if ev:
-            ev[i][0].record(stream)
         step(i)
-        if ev:
-            ev[i][1].record(stream)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -163,10 +167,11 @@ def main():
                    "rays_per_step": rays, "parallelism": "row-stripe x%d + 1 RCCL gather" % world if world > 1 else "1 GPU",
                    "disk_hits": hits, "disk_hits_reference": 15865362},
     }
-    if world == 1:
+    if ev:
+        rays_launch = capi.image_rows(desc) * NX             # rays of one launch of rank 0 (its stripes)
         kms = [a.elapsed_ms(b) for (a, b) in ev]
         kavg = sum(kms) / len(kms)
-        achieved = rays * W_ELL / (kavg * 1e-3) / 1e12
+        achieved = rays_launch * W_ELL / (kavg * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -178,11 +183,14 @@ def main():
             "bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
             "kernel": "disk_image_grid_kernel", "kernel_ms_avg": kavg, "algorithmic_flops_per_ray": W_ELL,
-            "hbm_algorithmic_bytes_per_launch": rays * 8,
-            "hbm_achieved_GBps": rays * 8 / (kavg * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+            "rays_per_launch": rays_launch, "per": "GPU (rank 0)",
+            "hbm_algorithmic_bytes_per_launch": rays_launch * 8,
+            "hbm_achieved_GBps": rays_launch * 8 / (kavg * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
             "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output",
         }
-        if not args.no_cpu_baseline:
+        if world > 1:
+            out["roofline"]["traffic"] = None          # the PMC traffic figure was collected for the 1-GPU launch
+        if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:                       # the baseline is a report, never a blocker
