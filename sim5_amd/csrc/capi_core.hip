@@ -67,6 +67,8 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot)
     d.d3 = d.x0 - d.x3;
     d.mdot = f_mdot;
     d.mass = f_mass;
+    d.inv_x0 = 1.0 / d.x0; d.inv_d1 = 1.0 / d.d1; d.inv_d2 = 1.0 / d.d2; d.inv_d3 = 1.0 / d.d3;
+    d.scale = 9.1721376255e+28 * d.mdot / d.mass;
     d.ready = 1;
     return d;
 }
@@ -90,6 +92,7 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p)
     p.nrows = sim5gpu_image_rows(desc);
     p.inv_nx = 1.0 / (double)desc->nx; p.inv_ny = 1.0 / (double)desc->ny;
     p.ny_over_nx = (double)desc->ny / (double)desc->nx;
+    { const double ac = fmax(1e-4, desc->a); p.inv_2a2 = 1.0 / (2.0 * ac * ac); }
     p.max_order = desc->max_order > 0 ? desc->max_order : 2;
     p.a = desc->a;
     p.incl = desc->incl;

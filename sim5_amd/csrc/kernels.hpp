@@ -19,6 +19,8 @@ struct DiskConsts {
     double p1, p2, p3;   // 3 (x_i - a)^2 / (x_i (x_i - x_j)(x_i - x_k))          ref :131-133
     double d1, d2, d3;   // x0 - x_i                                              ref :131-133
     double mdot, mass;   // (double)(float) values                               ref :145
+    // reciprocals and the overall scale, folded on the host for the fast variant
+    double inv_x0, inv_d1, inv_d2, inv_d3, scale;
     int    ready;
 };
 
@@ -31,6 +33,7 @@ struct ImageParams {
     double a, incl, sin_i, cos_i;      // sin/cos from the host libm
     double rmax, rms;
     double inv_nx, inv_ny, ny_over_nx; // 1/nx, 1/ny, ny/nx (host doubles; used by the fast variant)
+    double inv_2a2;                    // 1 / (2 max(a, 1e-4)^2)              (fast variant)
     double pol_degree;
     DiskConsts disk;
     // outputs (tile-local, row-major)

@@ -325,12 +325,22 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
                     double b = ra[i];
                     a *= c;
                     c *= dn;
+#if S5_FAST
+                    const double t = mrcp((b + a) * b);      // one reciprocal for both quotients
+                    dn = (rg[i] + a) * b * t;
+                    a = c * (b + a) * t;
+#else
                     dn = mdiv(rg[i] + a, b + a);
                     a = mdiv(c, b);
+#endif
                 }
             }
         }
+#if S5_FAST
+        a = rsqrt_pos(c * c + 1.0);
+#else
         a = mdiv(1.0, msqrt(c * c + 1.0));
+#endif
         sn = (s0 >= 0.0 ? a : -a);
         cn = c * sn;
     }

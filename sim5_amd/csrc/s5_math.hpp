@@ -35,6 +35,25 @@ S5_DEV double sqrt_pos(double x)
     return __builtin_fma(d, h, g);
 }
 
+// sqrt(x) and 1/sqrt(x) together for positive normal x: 11 instructions (a sqrt plus a division would be 16)
+S5_DEV void sqrt_rsqrt_pos(double x, double& s, double& rs)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    r = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, r, h);
+    s = g;
+    rs = h + h;
+}
+
+S5_DEV double rsqrt_pos(double x) { double s, rs; sqrt_rsqrt_pos(x, s, rs); return rs; }
+
 // general sqrt: +-0 -> itself, negative / NaN -> NaN (as IEEE), +inf is not expected on this path
 S5_DEV double msqrt(double x)
 {
@@ -62,6 +81,8 @@ S5_DEV double mdiv(double a, double b)
 #else
 
 S5_DEV double sqrt_pos(double x) { return sqrt(x); }
+S5_DEV void sqrt_rsqrt_pos(double x, double& s, double& rs) { s = sqrt(x); rs = 1.0 / s; }
+S5_DEV double rsqrt_pos(double x) { return 1.0 / sqrt(x); }
 S5_DEV double msqrt(double x) { return sqrt(x); }
 S5_DEV double mrcp(double b) { return 1.0 / b; }
 S5_DEV double mdiv(double a, double b) { return a / b; }

@@ -79,14 +79,27 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
         A = (F > sX ? +1 : -1) * 1. / 3. * mcbrt(fabs(F - sX) / 2.) +
             (F > -sX ? +1 : -1) * 1. / 3. * mcbrt(fabs(F + sX) / 2.);
     } else {
+#if S5_FAST
+        // Z^2 = (F^2 - X)/54^2 = 4 E^3/54^2, so Z^(1/3) = sqrt(E)/3: one square root instead of a square
+        // root and a cube root; atan2 is scale-free, so the divisions by 54 drop out as well
+        const double z = atan2(msqrt(-X), F);
+        A = msqrt(E) * (2. / 3.) * mcos(S5_DIVC(z, 3.));
+#else
         const double sX = S5_DIVC(msqrt(-X), 54.);
         const double F54 = S5_DIVC(F, 54.);
         const double Z = msqrt(sq(F54) + sq(sX));
         const double z = atan2(sX, F54);
         A = mcbrt(Z) * 2. * mcos(S5_DIVC(z, 3.));
+#endif
     }
+#if S5_FAST
+    double B, rB;
+    sqrt_rsqrt_pos(A + D, B, rB);
+    const double CB = 4. * C * rB;
+#else
     const double B = msqrt(A + D);
     const double CB = mdiv(4. * C, B);
+#endif
     const double w_hi = -A + 2. * D - CB;
     const double w_lo = -A + 2. * D + CB;
     const bool hi_real = (w_hi >= 0.0), lo_real = (w_lo >= 0.0);
@@ -119,16 +132,25 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
     double mR, zR, pre, sqAB, rp;
     if (type == T_RR || type == T_RR_DBL) {
         mR = mdiv((rb - rc_) * (ra - rd_), (rb - rd_) * (ra - rc_));
+#if S5_FAST
+        sqrt_rsqrt_pos((ra - rc_) * (rb - rd_), sqAB, pre);
+        pre = pre + pre;
+#else
         sqAB = msqrt((ra - rc_) * (rb - rd_));
         pre = mdiv(2., sqAB);
+#endif
         zR = msqrt(mdiv(rb - rd_, ra - rd_));
         rp = ra;
     } else if (type == T_RC) {
         const double Aq = msqrt(sq(ra - rc_) + sq(rd_));
         const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
         mR = mdiv(sq(Aq + Bq) - sq(ra - rb), 4. * Aq * Bq);
+#if S5_FAST
+        sqrt_rsqrt_pos(Aq * Bq, sqAB, pre);
+#else
         sqAB = msqrt(Aq * Bq);
         pre = mdiv(1., sqAB);
+#endif
         zR = mdiv(Aq - Bq, Aq + Bq);
         rp = ra;
         // keep A, B for r(P): the RC formula needs them again
@@ -148,20 +170,34 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
     // ---------------- roots of the polar potential (ref :1110-1184, device branch) ----------------
     const double qla = q + l2 - a2;
     const double XT = msqrt(sq(qla) + 4. * q * a2) + qla;
+#if S5_FAST
+    const double m2m = XT * p.inv_2a2;
+#else
     const double m2m = mdiv(XT, a2 + a2);
+#endif
     const double m2p = mdiv(q + q, XT);
+#if S5_FAST
+    double s_m2p, rs_m2p;                                   // sqrt(m2p) and its reciprocal, used three times
+    sqrt_rsqrt_pos(m2p, s_m2p, rs_m2p);
+#else
+    const double s_m2p = msqrt(m2p);
+#endif
     double mmT = 0.0, mK = 0.0;
     if (err == GD_OK) {
         if ((m2p <= 0.0) || (m2p >= 1.0)) err = GD_E_MUPLUS;
         else if (q > 0.0) {
             mmT = mdiv(m2p, m2p + m2m);
             if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
-            else if (fabs(p.cos_i) > msqrt(m2p)) err = GD_E_MU0;
+            else if (fabs(p.cos_i) > s_m2p) err = GD_E_MU0;
+#if S5_FAST
+            else mK = rsqrt_pos(a2 * (m2p + m2m));
+#else
             else mK = mdiv(1., msqrt(a2 * (m2p + m2m)));
+#endif
         } else if (q < 0.0) {
             mmT = mdiv(m2p + m2m, m2p);
             if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
-            else if ((fabs(p.cos_i) > msqrt(m2p)) || (fabs(p.cos_i) < msqrt(-m2m))) err = GD_E_MU0;
+            else if ((fabs(p.cos_i) > s_m2p) || (fabs(p.cos_i) < msqrt(-m2m))) err = GD_E_MU0;
             else mK = mdiv(1., msqrt(a2 * m2p));
         } else {
             err = GD_E_Q_RANGE;
@@ -169,18 +205,23 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
     }
     out.err = err;
     const bool ok = (err == GD_OK);
-    const double u_i = mdiv(p.cos_i, msqrt(m2p));
+#if S5_FAST
+    const double u_i = p.cos_i * rs_m2p;
+#else
+    const double u_i = mdiv(p.cos_i, s_m2p);
+#endif
 
     // ---------------- the R_F evaluations of this ray, one shared loop (see header) ----------------
     // slot 0: radial integral   slot 1: K(mmT)   slot 2: cn^-1(u_i | mmT)   slot 3: RC, zR < 0: second term
-    const double zT = (type == T_CC) ? msqrt(mdiv(zR * zR, 1. + zR * zR)) : zR;       // tn^-1 -> sn^-1 (ref :527)
+    double zT = zR;
+    if (wave_any(type == T_CC)) {                                                     // tn^-1 -> sn^-1 (ref :527)
+        if (type == T_CC) zT = msqrt(mdiv(zR * zR, 1. + zR * zR));
+    }
     const bool plain0 = (type == T_RC) ? icn_plain(zR, mR)
                       : (type == T_CC) ? (!(mR == 0.0) && !(mR == 1.0) && isn_plain(mR))
                                        : isn_plain(mR);
     const bool plain2 = icn_plain(u_i, mmT);
     const bool need3 = ok && (type == T_RC) && plain0 && !(zR > 0.0);
-    double m3 = mdiv(mR, mR - 1.);                      // modulus of the second term (ref :513, :280)
-    if (m3 == 1.0) m3 = 0.99999999;
     double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
 #pragma unroll 1
     for (int slot = 0; slot < 4; ++slot) {
@@ -199,6 +240,8 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
             const double z2 = u_i * u_i;
             x = z2; y = 1.0 - mmT * (1. - z2); mult = msqrt(1. - z2);
         } else {
+            double m3 = mdiv(mR, mR - 1.);              // modulus of the second term (ref :513, :280)
+            if (m3 == 1.0) m3 = 0.99999999;
             const double s = -zR, s2 = s * s;
             x = 1. - s2; y = 1.0 - s2 * m3; mult = s;
         }
