@@ -272,8 +272,33 @@ S5_DEV double inv_tn(double z, double m)
     return inv_sn(msqrt(mdiv(z * z, 1. + z * z)), m);
 }
 
-// sn, cn, dn by the descending Landen ladder.  13 rungs at most; rung values stay in VGPRs.
-S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
+// sn, cn, dn by the descending Landen ladder (ref: src/sim5elliptic.c:580-642).  The rungs (a_i, g_i) that
+// the climb produces and the descent consumes are kept by a storage policy:
+//   LadderRegs  in VGPRs (generic per-ray routines; any launch shape)
+//   LadderLds   in LDS, element k of a lane at base[k * 256] (256-thread workgroups only).  The whole-image
+//               kernels use this one: the register arrays cost 40 VGPRs and, worse, whole-array v_mov chains
+//               at every control-flow join around the inlined call; in LDS a rung is two ds_write_b64 and two
+//               ds_read_b64 with immediate offsets, lanes 8 B apart (conflict-free), 40 KB per workgroup.
+// 13 rungs as in the reference; the AGM of a double-precision modulus (1 - m >= 1.1e-16) converges to 1e-8
+// within 9 rungs, so the fast variant keeps 10.
+constexpr int LADDER_RUNGS = S5_FAST ? 10 : 13;
+
+struct LadderRegs {
+    double a[LADDER_RUNGS], g[LADDER_RUNGS];
+    S5_DEV void put(int i, double av, double gv) { a[i] = av; g[i] = gv; }
+    S5_DEV double get_a(int i) const { return a[i]; }
+    S5_DEV double get_g(int i) const { return g[i]; }
+};
+
+struct LadderLds {
+    double* base;                               // this lane's column of the workgroup's ladder block
+    S5_DEV void put(int i, double av, double gv) { base[(2 * i) * 256] = av; base[(2 * i + 1) * 256] = gv; }
+    S5_DEV double get_a(int i) const { return base[(2 * i) * 256]; }
+    S5_DEV double get_g(int i) const { return base[(2 * i + 1) * 256]; }
+};
+
+template <class Ladder>
+S5_DEV void sncndn_with(Ladder& lad, double u, double m, double& sn, double& cn, double& dn)
 {
     if (m == 1.0) m = 0.999999999;
     const double conv = 1.0e-8;
@@ -292,19 +317,15 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
         d = msqrt(d);
         u *= d;
     }
-    // 13 rungs as in the reference; the AGM of a double-precision modulus (1 - m >= 1.1e-16) converges to
-    // 1e-8 within 9 rungs, so the fast variant keeps 10 (20 registers less)
-    constexpr int NR = S5_FAST ? 10 : 13;
-    double ra[NR], rg[NR];
+    constexpr int NR = LADDER_RUNGS;
     double a = 1.0, c = 0.0;
     int top = NR - 1;
     bool climbing = true;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         if (climbing) {
-            ra[i] = a;
             emc = msqrt(emc);
-            rg[i] = emc;
+            lad.put(i, a, emc);
             c = 0.5 * (a + emc);
             if (fabs(a - emc) <= conv * a) { climbing = false; top = i; }
             else { emc *= a; a = c; }
@@ -322,15 +343,15 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
         for (int i = NR - 1; i >= 0; --i) {
             if (wave_any(i <= top)) {          // rungs no lane of the wave reached are skipped
                 if (i <= top) {
-                    double b = ra[i];
+                    const double b = lad.get_a(i);
                     a *= c;
                     c *= dn;
 #if S5_FAST
                     const double t = mrcp((b + a) * b);      // one reciprocal for both quotients
-                    dn = (rg[i] + a) * b * t;
+                    dn = (lad.get_g(i) + a) * b * t;
                     a = c * (b + a) * t;
 #else
-                    dn = mdiv(rg[i] + a, b + a);
+                    dn = mdiv(lad.get_g(i) + a, b + a);
                     a = mdiv(c, b);
 #endif
                 }
@@ -350,6 +371,20 @@ S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
         cn = a;
         sn = mdiv(sn, d);
     }
+}
+
+S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
+{
+    LadderRegs lad;
+    sncndn_with(lad, u, m, sn, cn, dn);
+}
+
+// LDS-backed form for kernels launched with 256-thread one-dimensional workgroups
+S5_DEV void sncndn_lds(double u, double m, double& sn, double& cn, double& dn)
+{
+    __shared__ double s_ladder[2 * LADDER_RUNGS * 256];
+    LadderLds lad{&s_ladder[threadIdx.x]};
+    sncndn_with(lad, u, m, sn, cn, dn);
 }
 
 S5_DEV double jac_sn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return s; }

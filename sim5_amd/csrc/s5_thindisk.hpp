@@ -318,7 +318,7 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
 #ifdef S5_KO_RAD
                     if (use_ladder) { sn = 0.3 + 1e-3 * su; cn = 0.9 - 1e-3 * sm; }
 #else
-                    if (use_ladder) sncndn(su, sm, sn, cn, dn);
+                    if (use_ladder) sncndn_lds(su, sm, sn, cn, dn);        // 256-thread workgroups (all callers)
 #endif
                 }
                 if (!in_range) r = NAN;
