@@ -58,8 +58,9 @@ S5_DEV double carlson_rf(double x, double y, double z)
     const double rA = mrcp(A);                      // 1 / (4^n A_n)
     const double X = dx0 * rA, Y = dy0 * rA, Z = -(X + Y);
     const double E2 = X * Y - Z * Z, E3 = X * Y * Z;
-    const double ser = 1.0 + E2 * (-0.1 + E2 * (1.0 / 24.0) - E3 * (3.0 / 44.0) - E2 * E2 * (5.0 / 208.0))
-                     + E3 * (1.0 / 14.0 + E3 * (3.0 / 104.0) + E2 * E2 * (1.0 / 16.0));
+    const double E22 = E2 * E2;
+    const double ser = hfma(E2, hfma(E2, 1.0 / 24.0, hfma(E3, -3.0 / 44.0, hfma(E22, -5.0 / 208.0, -0.1))),
+                            hfma(E3, hfma(E3, 3.0 / 104.0, hfma(E22, 1.0 / 16.0, 1.0 / 14.0)), 1.0));
     const double res = ser * pw * sqrt_pos(rA);     // A_n^-1/2 = 2^n (4^n A_n)^-1/2
     return bad ? NAN : res;
 }

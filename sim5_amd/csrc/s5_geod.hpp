@@ -70,7 +70,7 @@ S5_DEV bool radial_roots(Geod& g, double r0, int& err)
         const double sX = S5_DIVC(msqrt(-X), 54.);
         const double F54 = S5_DIVC(F, 54.);
         const double Z = msqrt(sq(F54) + sq(sX));
-        const double z = atan2(sX, F54);
+        const double z = matan2(sX, F54);
         A = mcbrt(Z) * 2. * mcos(S5_DIVC(z, 3.));
     }
     const double B = msqrt(A + D);

@@ -20,6 +20,10 @@ S5_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 S5_DEV double sq(double x) { return x * x; }
 S5_DEV double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), fabs(b)), fabs(c)); }
 
+// Horner step a*b + c as one instruction (the build runs with -ffp-contract=off; the approximation kernels
+// of the fast variant ask for the fused form explicitly)
+S5_DEV double hfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 #if S5_F_SQRTDIV
 
 // sqrt for x known to be positive, finite and normal

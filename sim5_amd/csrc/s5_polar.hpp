@@ -59,7 +59,7 @@ S5_DEV double polarization_angle_rotation(double a, double sin_i, double alpha, 
     const double T = +beta;
     const double X = (-S * wp[1] - T * wp[0]) / (S * S + T * T);
     const double Y = (-S * wp[0] + T * wp[1]) / (S * S + T * T);
-    return atan2(Y, X);
+    return matan2(Y, X);
 }
 
 S5_DEV double blackbody_Iv(double T, double hardf, double cos_mu, double E)
