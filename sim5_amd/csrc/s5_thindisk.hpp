@@ -83,7 +83,7 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
         // Z^2 = (F^2 - X)/54^2 = 4 E^3/54^2, so Z^(1/3) = sqrt(E)/3: one square root instead of a square
         // root and a cube root; atan2 is scale-free, so the divisions by 54 drop out as well
         const double z = matan2(msqrt(-X), F);
-        A = msqrt(E) * (2. / 3.) * mcos(S5_DIVC(z, 3.));
+        A = msqrt(E) * (2. / 3.) * mcos_third(z);
 #else
         const double sX = S5_DIVC(msqrt(-X), 54.);
         const double F54 = S5_DIVC(F, 54.);
