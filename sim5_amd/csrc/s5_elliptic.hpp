@@ -60,10 +60,10 @@ S5_DEV double carlson_rf(double x, double y, double z)
     const double E2 = X * Y - Z * Z, E3 = X * Y * Z;
     // coefficient of E2^j E3^k: (-1)^j (1/2)_(j+k) / (j! k! (2(2j+3k)+1))  (DLMF 19.19.7 with E1 = 0), all terms
     // of total degree <= 9 in the deviations
-    const double s2 = hfma(E2, hfma(E2, hfma(E2, 35.0 / 2176.0, -5.0 / 208.0), 1.0 / 24.0), -0.1);          // pure E2
-    const double s3 = hfma(E3, hfma(E3, 5.0 / 304.0, 3.0 / 104.0), 1.0 / 14.0);                            // pure E3
+    const double s2 = hfmac(E2, hfmac(E2, hfma(E2, 35.0 / 2176.0, -5.0 / 208.0), 1.0 / 24.0), -0.1);          // pure E2
+    const double s3 = hfmac(E3, hfma(E3, 5.0 / 304.0, 3.0 / 104.0), 1.0 / 14.0);                            // pure E3
     const double sx = hfma(E2, hfma(E2, -35.0 / 608.0, 1.0 / 16.0), hfma(E3, -15.0 / 272.0, -3.0 / 44.0)); // x E2 E3
-    const double ser = hfma(E2, hfma(E3, sx, s2), hfma(E3, s3, 1.0));
+    const double ser = hfma(E2, hfma(E3, sx, s2), hfmac(E3, s3, 1.0));
     const double res = ser * pw * sqrt_pos(rA);     // A_n^-1/2 = 2^n (4^n A_n)^-1/2
     return bad ? NAN : res;
 }
@@ -285,7 +285,11 @@ S5_DEV double inv_tn(double z, double m)
 //               ds_read_b64 with immediate offsets, lanes 8 B apart (conflict-free), 40 KB per workgroup.
 // 13 rungs as in the reference; the AGM of a double-precision modulus (1 - m >= 1.1e-16) converges to 1e-8
 // within 9 rungs, so the fast variant keeps 10.
+#ifdef S5_LADDER_RUNGS_OVERRIDE          // timing experiments only
+constexpr int LADDER_RUNGS = S5_LADDER_RUNGS_OVERRIDE;
+#else
 constexpr int LADDER_RUNGS = S5_FAST ? 10 : 13;
+#endif
 
 struct LadderRegs {
     double a[LADDER_RUNGS], g[LADDER_RUNGS];

@@ -24,6 +24,17 @@ S5_DEV double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), 
 // of the fast variant ask for the fused form explicitly)
 S5_DEV double hfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// a*b + C for a literal constant C.  The compiler's own choice for this shape is v_fmac_f64 with C copied into
+// the destination VGPR pair first -- two v_mov_b32 per coefficient, i.e. a Horner step costs three VALU slots.
+// Written out as the three-address form with C in an SGPR pair (two s_mov_b32 on the scalar unit) it is one.
+// Measured on the 4096^2 image: 1 694 -> see DESIGN.md VALU instructions per ray.
+S5_DEV double hfmac(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
 #if S5_F_SQRTDIV
 
 // sqrt for x known to be positive, finite and normal

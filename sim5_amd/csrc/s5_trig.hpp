@@ -23,7 +23,7 @@ S5_DEV double kernel_sin(double y, double yl)
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double z = y * y;
     const double v = z * y;
-    const double r = hfma(z, hfma(z, hfma(z, hfma(z, S6, S5), S4), S3), S2);
+    const double r = hfmac(z, hfmac(z, hfmac(z, hfma(z, S6, S5), S4), S3), S2);
     return y - ((z * (0.5 * yl - v * r) - yl) - v * S1);
 }
 
@@ -33,7 +33,7 @@ S5_DEV double kernel_cos(double y, double yl)
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double z = y * y;
-    const double r = z * hfma(z, hfma(z, hfma(z, hfma(z, hfma(z, C6, C5), C4), C3), C2), C1);
+    const double r = z * hfmac(z, hfmac(z, hfmac(z, hfmac(z, hfma(z, C6, C5), C4), C3), C2), C1);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     return w + (((1.0 - w) - hz) + (z * r - y * yl));
@@ -82,14 +82,14 @@ S5_DEV double macos(double x)
     if (!(ax <= 1.0)) return NAN;
     if (ax < 0.5) {
         const double z = x * x;
-        const double p = z * hfma(z, hfma(z, hfma(z, hfma(z, hfma(z, pS5, pS4), pS3), pS2), pS1), pS0);
-        const double q = hfma(z, hfma(z, hfma(z, hfma(z, qS4, qS3), qS2), qS1), 1.0);
+        const double p = z * hfmac(z, hfmac(z, hfmac(z, hfmac(z, hfma(z, pS5, pS4), pS3), pS2), pS1), pS0);
+        const double q = hfmac(z, hfmac(z, hfmac(z, hfma(z, qS4, qS3), qS2), qS1), 1.0);
         const double r = mdiv(p, q);
         return pio2_hi - (x - (pio2_lo - x * r));
     }
     const double z = (1.0 - ax) * 0.5;
-    const double p = z * hfma(z, hfma(z, hfma(z, hfma(z, hfma(z, pS5, pS4), pS3), pS2), pS1), pS0);
-    const double q = hfma(z, hfma(z, hfma(z, hfma(z, qS4, qS3), qS2), qS1), 1.0);
+    const double p = z * hfmac(z, hfmac(z, hfmac(z, hfmac(z, hfma(z, pS5, pS4), pS3), pS2), pS1), pS0);
+    const double q = hfmac(z, hfmac(z, hfmac(z, hfma(z, qS4, qS3), qS2), qS1), 1.0);
     const double sq_ = msqrt(z);
     const double r = mdiv(p, q);
     if (x < 0.0) {
@@ -124,7 +124,7 @@ S5_DEV double matan2(double y, double x)
     const double den = fold ? mn + mx : mx;
     const double r = mdiv(num, den);
     const double s2 = r * r;
-    const double P = hfma(s2, hfma(s2, hfma(s2, hfma(s2, hfma(s2, hfma(s2, hfma(s2, hfma(s2, hfma(s2,
+    const double P = hfmac(s2, hfmac(s2, hfmac(s2, hfmac(s2, hfmac(s2, hfmac(s2, hfmac(s2, hfmac(s2, hfmac(s2,
                      hfma(s2, A10, A9), A8), A7), A6), A5), A4), A3), A2), A1), A0);
     double t = hfma(r * s2, P, fold ? pio4_lo : 0.0) + r;       // atan(mn/mx) - (fold ? pi/4 head : 0)
     t = fold ? pio4_hi + t : t;
@@ -142,7 +142,7 @@ S5_DEV double mcos_third(double z)
                  c4 = 3.7801535284439776e-09, c5 = -4.6668561610329095e-12, c6 = 3.9283232935466075e-15,
                  c7 = -2.3976517600295036e-18, c8 = 1.084136668630678e-21;
     const double u = z * z;
-    return hfma(u, hfma(u, hfma(u, hfma(u, hfma(u, hfma(u, hfma(u, hfma(u, c8, c7), c6), c5), c4), c3), c2), c1), 1.0);
+    return hfmac(u, hfmac(u, hfmac(u, hfmac(u, hfmac(u, hfmac(u, hfmac(u, hfma(u, c8, c7), c6), c5), c4), c3), c2), c1), 1.0);
 }
 
 // log(x) for positive, finite, normal x (after fdlibm e_log.c): x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2),
@@ -164,8 +164,8 @@ S5_DEV double mlog(double x)
     const double dk = (double)k;
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * hfma(w, hfma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * hfma(w, hfma(w, hfma(w, Lg7, Lg5), Lg3), Lg1);
+    const double t1 = w * hfmac(w, hfma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * hfmac(w, hfmac(w, hfma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double res = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
