@@ -13,7 +13,7 @@ import csv, glob, collections
 for d in sorted(glob.glob("gpurun_out/prof_torus/pmc*/*/*counter_collection.csv")):
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(d)):
-        if "torus_round" in row["Kernel_Name"]:
+        if "torus_pool" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k,v in acc.items():
         print(k, "n=%d"%len(v), "mean=%.6g"%(sum(v)/len(v)))

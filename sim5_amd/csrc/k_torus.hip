@@ -7,19 +7,10 @@
 //      -> geodesic_momentum -> raytrace_prepare (ref src/sim5kerr-geod.c:42,179,363,787;
 //      src/sim5raytrace.c:44).  The state goes to HBM as a structure of arrays (one 8-B column
 //      per quantity, so every load/store below is a coalesced 512-B wave access).
-//  (B) torus_round_kernel: the rays march in global lock-step, K raytrace() calls (ref
-//      src/sim5raytrace.c:109-245) per launch ("round"), accumulating the transfer integral after each
-//      accepted step.  A round reads the state of the rays that are still alive from one SoA buffer and
-//      writes the survivors, compacted, to the other (wave ballot, ONE atomic per wave reserves the
-//      slots, lanes take their prefix rank; runs of image neighbours stay together).  Why lock-step:
-//      raytrace() is a Verlet attempt plus, when its precision check fails, an RK4 step of the same
-//      size, and a ray fails for long stretches (near the hole P(RK4 | previous RK4) = 0.9-1.0, elsewhere
-//      P(RK4 | previous Verlet) = 0.02; a third of all calls at precision 1).  Image neighbours at the
-//      SAME step index are in the same regime, so a wave either skips the RK4 body or runs it with most
-//      lanes.  The earlier persistent kernel refilled idle lanes one by one from a cursor; that keeps
-//      lanes busy but mixes rays at unrelated step indices in a wave, which then pays Verlet + RK4 on
-//      nearly every call with a third of the lanes active in RK4 (measured VALU lane utilisation 54 %).
-//      Every launch is bounded (K steps), there is no persistent loop and no inter-wave waiting.
+//  (B) torus_pool_kernel: persistent waves advance rays with raytrace() (ref src/sim5raytrace.c:109-245),
+//      accumulating the transfer integral after each accepted step; each wave keeps a pool of 128 rays in
+//      LDS and runs the Verlet half and the RK4 half of raytrace() as separate full-width batches (see
+//      the comment at the kernel).
 //
 // Transfer model (the reference has no transfer integrator nor torus; this is
 // this project's definition, stated in DESIGN.md): fluid on circular orbits with constant specific
@@ -37,13 +28,10 @@ namespace S5NS {
 using namespace s5abi;
 
 enum : int { COL_X0 = 0, COL_X1, COL_X2, COL_X3, COL_K0, COL_K1, COL_K2, COL_K3,
-             COL_DK0, COL_DK1, COL_DK2, COL_DK3, COL_KT, COL_Q, COL_E, COL_I, COL_TAU, NCOL };
-// integer / float columns of the state (4 B each), after the NCOL double columns of a buffer
-enum : int { ICOL_RAY = 0, ICOL_PASS, ICOL_WORST, NICOL };
+             COL_DK0, COL_DK1, COL_DK2, COL_DK3, COL_KT, COL_Q, NCOL };
 
-struct RayCols {                 // one SoA state buffer: column c of ray slot i is d[c * cap + i]
+struct RayCols {                 // start state, structure of arrays: column c of ray i is d[c * cap + i]
     double* d;
-    int* i32;
     size_t cap;
 };
 
@@ -100,9 +88,6 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok)
     cols[COL_DK0 * n + i] = s.dk[0]; cols[COL_DK1 * n + i] = s.dk[1];
     cols[COL_DK2 * n + i] = s.dk[2]; cols[COL_DK3 * n + i] = s.dk[3];
     cols[COL_KT * n + i] = s.kt; cols[COL_Q * n + i] = s.Q;
-    cols[COL_E * n + i] = s.kt; cols[COL_I * n + i] = 0.0; cols[COL_TAU * n + i] = 0.0;
-    st.i32[ICOL_RAY * n + i] = (int)i; st.i32[ICOL_PASS * n + i] = 0;
-    ((float*)st.i32)[ICOL_WORST * n + i] = 0.0f;
     ok[i] = good;
 }
 
@@ -135,7 +120,8 @@ S5_DEV void accumulate_transfer(const TorusParams& p, const RayState& s, const d
     const double gfac = mdiv(s.E, ut * (k_t + Om * k_f));   // E_inf / E_local
     const double ds = mdiv(dl_taken, gfac);
     const double g2 = gfac * gfac;
-    I += (g2 * g2) * p.emis0 * rho * exp(-tau) * ds;
+    const double att = (p.absorb0 == 0.0) ? 1.0 : exp(-tau);     // tau stays 0 without absorption (wave-uniform test)
+    I += (g2 * g2) * p.emis0 * rho * att * ds;
     tau += p.absorb0 * rho * ds;
 }
 
@@ -153,137 +139,239 @@ S5_DEV void write_ray_end(const TorusParams& p, const TorusAux& aux, sim5gpu_sto
 #endif
 }
 
-// One round: lanes [0, *n_in) of `src` advance by at most `k_steps` raytrace() calls; survivors go, compacted,
-// to `dst` and are counted in *n_out (zeroed by the host before the launch).  `first` marks round 0, which
-// also writes the empty records of the rays the start kernel rejected.
-__global__ __launch_bounds__(256, S5_MARCH_WAVES)
-void torus_round_kernel(TorusParams p, RayCols src, RayCols dst, const unsigned* __restrict__ n_in,
-                        unsigned* __restrict__ n_out, const int* __restrict__ ok, int first, int k_steps,
-                        sim5gpu_stokes* __restrict__ out, TorusAux aux)
+// ---------------------------------------------------------------------------------------------------------
+// torus_pool_kernel: persistent waves, each with a private pool of 128 rays in LDS.
+//
+// What occupancy counters showed when 64 image neighbours march in lock-step (C4, 1024^2): at precision 1,
+// 76 % of the wave-steps contain a lane whose Verlet attempt fails, 27 of 64 lanes on average; at precision 0.01, 29 % of
+// the wave-steps, 2.9 lanes on average.  The RK4 body (5 connection evaluations) costs ~3 Verlet attempts, so
+// a wave spends most of its time in RK4 with a fraction of its lanes -- whatever the order of the rays.
+// Here the two halves of raytrace() are separate batches over the wave's pool:
+//   V batch: up to 64 pool rays whose next action is a Verlet attempt.  Accepted -> the step is finished
+//            (transfer, end test) and the ray stays V.  Rejected -> nothing was modified (the attempt
+//            restores x, k; ref :221-222), the ray is tagged R.
+//   R batch: up to 64 rays tagged R: recompute the step size (same expression, same operands as the failed
+//            attempt), RK4 step, finish the step, back to V.
+// With 128 rays in the pool one of the two batches always has >= 64 rays while the pool is full, so both bodies
+// run with (nearly) all lanes.  A ray's arithmetic is unchanged: same calls, same operands, same order.
+// Finished rays are replaced from the global cursor (one atomic per wave and refill pass).  No inter-wave
+// communication: the pool, its tags and the batch list are private to the wave (LDS, 18 KB per wave).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int POOL_SLOTS = 128;
+#ifndef POOL_KEEP_NUM
+#define POOL_KEEP_NUM 7                   // ... while at least NUM/DEN of its lanes are still stepping
+#define POOL_KEEP_DEN 8
+#endif
+#ifndef POOL_RUN
+#define POOL_RUN 4                       // Verlet attempts a batch may take before it returns to the pool
+#endif
+enum : int { PC_X0 = 0, PC_X1, PC_X2, PC_X3, PC_K0, PC_K1, PC_K2, PC_K3, PC_DK0, PC_DK1, PC_DK2, PC_DK3,
+             PC_KT, PC_E, PC_I, PC_TAU, NPC };
+enum : int { TAG_EMPTY = 0, TAG_V = 1, TAG_R = 2 };
+constexpr int POOL_WAVE_BYTES = NPC * POOL_SLOTS * 8 + 3 * POOL_SLOTS * 4 + POOL_SLOTS + 128;
+
+S5_DEV void wave_lds_fence()
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t count = (size_t)*n_in;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256, S5_MARCH_WAVES)
+void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
+                       unsigned long long* __restrict__ cursor, sim5gpu_stokes* __restrict__ out, TorusAux aux)
+{
+    extern __shared__ char pool_raw[];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    char* wb = pool_raw + (size_t)wave * POOL_WAVE_BYTES;
+    double* pd = (double*)wb;                                        // [NPC][POOL_SLOTS]
+    int* pray = (int*)(wb + NPC * POOL_SLOTS * 8);                   // [POOL_SLOTS]
+    int* ppass = pray + POOL_SLOTS;
+    float* pworst = (float*)(ppass + POOL_SLOTS);
+    unsigned char* ptag = (unsigned char*)(pworst + POOL_SLOTS);     // [POOL_SLOTS]
+    unsigned char* plist = ptag + POOL_SLOTS;                        // [64] slots of the current batch
+
+    const size_t n = p.nrays;
     const double r_in = p.r_stop_in * r_horizon(p.a);
     const double r_out = p.r_stop_out * p.r0;
-    bool alive = i < count;
+    const double* __restrict__ sc = start.d;
+    const size_t scap = start.cap;
 
-    size_t ray = 0;
-    double x[4] = { 0.0, 0.0, 0.0, 0.0 }, k[4] = { 0.0, 0.0, 0.0, 0.0 };
+    ptag[lane] = TAG_EMPTY; ptag[lane + 64] = TAG_EMPTY;
+    bool drained = false;                                            // wave-uniform: the cursor ran past the last ray
+
     RayState s;
-    double I = 0.0, tau = 0.0;
-    float worst = 0.0f;
     s.opt_gr = !((p.options & 1) == 1);
     s.opt_pol = 0;
     s.step_epsilon = S5_DIVC(msqrt(p.precision), 10.);
     s.bh_spin = p.a;
-    s.refines = 0; s.error = 0.0f; s.pass = 0;
-    s.dk[0] = s.dk[1] = s.dk[2] = s.dk[3] = 0.0; s.kt = 0.0; s.E = 0.0; s.Q = 0.0;
-    if (alive) {
-        const size_t n = src.cap;
-        const double* __restrict__ c = src.d;
-        ray = (size_t)src.i32[ICOL_RAY * n + i];
-        s.pass = src.i32[ICOL_PASS * n + i];
-        worst = ((const float*)src.i32)[ICOL_WORST * n + i];
-        x[0] = c[COL_X0 * n + i]; x[1] = c[COL_X1 * n + i]; x[2] = c[COL_X2 * n + i]; x[3] = c[COL_X3 * n + i];
-        k[0] = c[COL_K0 * n + i]; k[1] = c[COL_K1 * n + i]; k[2] = c[COL_K2 * n + i]; k[3] = c[COL_K3 * n + i];
-        s.dk[0] = c[COL_DK0 * n + i]; s.dk[1] = c[COL_DK1 * n + i];
-        s.dk[2] = c[COL_DK2 * n + i]; s.dk[3] = c[COL_DK3 * n + i];
-        s.kt = c[COL_KT * n + i]; s.Q = c[COL_Q * n + i]; s.E = c[COL_E * n + i];
-        I = c[COL_I * n + i]; tau = c[COL_TAU * n + i];
-        if (first && !ok[ray]) {
-            // ray rejected at start-up: an empty record, no steps
-            sim5gpu_stokes z = { 0.0, 0.0, 0.0, 0.0, 0.0 };
-            out[ray] = z;
-            if (aux.steps) aux.steps[ray] = 0;
-            if (aux.max_step_error) aux.max_step_error[ray] = 0.0f;
-            if (aux.carter_error) aux.carter_error[ray] = NAN;
-            if (aux.x_end) { for (int cc = 0; cc < 4; ++cc) aux.x_end[4 * ray + cc] = x[cc]; }
-#ifndef S5_TORUS_DEBUG
-            if (aux.k_end) { for (int cc = 0; cc < 4; ++cc) aux.k_end[4 * ray + cc] = k[cc]; }
-#endif
-            alive = false;
-        }
-    }
+    s.refines = 0; s.Q = 0.0;
 
+    // every pass either consumes cursor positions or advances at least one pooled ray by half a raytrace() call
+    const unsigned long long guard = 2ull * (unsigned long long)(p.max_steps + 2) * ((n + 63) / 64 + 2);
+    for (unsigned long long it = 0; it < guard; ++it) {
+        wave_lds_fence();
+        // ---- 1. refill empty slots from the cursor: lane l owns slots l and l + 64 ----
 #pragma unroll 1
-    for (int step = 0; step < k_steps; ++step) {
-        if (!wave_any(alive)) break;
-        if (alive) {
-            // raytrace() = Verlet attempt and, if its precision check fails, an RK4 step of the same size
-            // (ref src/sim5raytrace.c:220-227)
-            double dl;
-#ifdef S5_TORUS_DEBUG            // lane-occupancy counters (scratch builds only): aux.k_end is the counter block
-            const bool v_ok = verlet_attempt(x, k, p.dl_max, dl, s);
-            {
-                unsigned long long* dbg = (unsigned long long*)aux.k_end;
-                const unsigned long long mA = __builtin_amdgcn_ballot_w64(true), mR = __builtin_amdgcn_ballot_w64(!v_ok);
-                const double rho_dbg = torus_density(p, x[1], x[2]);
-                const unsigned long long mT = __builtin_amdgcn_ballot_w64(rho_dbg > 0.0);
-                if (__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u)) == 0u) {
-                    atomicAdd(&dbg[0], 1ull); atomicAdd(&dbg[1], (unsigned long long)__builtin_popcountll(mA));
-                    if (mR) { atomicAdd(&dbg[2], 1ull); atomicAdd(&dbg[3], (unsigned long long)__builtin_popcountll(mR)); }
-                    if (mT) { atomicAdd(&dbg[4], 1ull); atomicAdd(&dbg[5], (unsigned long long)__builtin_popcountll(mT)); }
+        for (int half = 0; half < 2; ++half) {
+            const int slot = lane + 64 * half;
+            const bool want = !drained && (ptag[slot] == TAG_EMPTY);
+            const unsigned long long idle = __builtin_amdgcn_ballot_w64(want);
+            if (idle) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                const int leader = __builtin_ctzll(idle);
+                const unsigned cnt = (unsigned)__builtin_popcountll(idle);
+                unsigned long long base = 0;
+                if (want && rank == 0u) base = atomicAdd(cursor, (unsigned long long)cnt);
+                base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader, 64) << 32) |
+                       (unsigned long long)(unsigned)__shfl((int)(unsigned)base, leader, 64);
+                if (base + cnt >= n) drained = true;
+                const unsigned long long mine = base + rank;
+                if (want && mine < n) {
+                    const size_t ray = (size_t)mine;
+                    if (!ok[ray]) {
+                        // rejected at start-up: an empty record, the slot stays empty
+                        sim5gpu_stokes z = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+                        out[ray] = z;
+                        if (aux.steps) aux.steps[ray] = 0;
+                        if (aux.max_step_error) aux.max_step_error[ray] = 0.0f;
+                        if (aux.carter_error) aux.carter_error[ray] = NAN;
+                        if (aux.x_end) { for (int c = 0; c < 4; ++c) aux.x_end[4 * ray + c] = sc[(COL_X0 + c) * scap + ray]; }
+#ifndef S5_TORUS_DEBUG
+                        if (aux.k_end) { for (int c = 0; c < 4; ++c) aux.k_end[4 * ray + c] = sc[(COL_K0 + c) * scap + ray]; }
+#endif
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 13; ++c) pd[c * POOL_SLOTS + slot] = sc[c * scap + ray];   // x, k, dk, kt
+                        pd[PC_E * POOL_SLOTS + slot] = sc[COL_KT * scap + ray];
+                        pd[PC_I * POOL_SLOTS + slot] = 0.0;
+                        pd[PC_TAU * POOL_SLOTS + slot] = 0.0;
+                        pray[slot] = (int)ray; ppass[slot] = 0; pworst[slot] = 0.0f;
+                        ptag[slot] = TAG_V;
+                    }
                 }
             }
-            if (!v_ok) rk4_step(x, k, dl, s);
-#else
-            if (!verlet_attempt(x, k, p.dl_max, dl, s)) rk4_step(x, k, dl, s);
-#endif
-            worst = fmaxf(worst, s.error);
-            // transfer over the step just taken, evaluated at its end point
-            accumulate_transfer(p, s, x, k, dl, I, tau);
-            const bool done = !(x[1] > r_in) || !(x[1] < r_out) || ((double)s.error > p.max_error) ||
-                              (s.pass >= p.max_steps);
-            if (done) {
-                write_ray_end(p, aux, out, ray, x, k, s, I, tau, worst);
-                alive = false;
-            }
         }
-    }
+        wave_lds_fence();
 
-    // ---- survivors to the other buffer, compacted (wave-aggregated reservation) ----
-    const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
-    if (live) {
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32),
-                                  __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
-        const int leader = __builtin_ctzll(live);
-        unsigned base = 0;
-        if (alive && rank == 0u) base = atomicAdd(n_out, (unsigned)__builtin_popcountll(live));
-        base = (unsigned)__shfl((int)base, leader, 64);
-        if (alive) {
-            const size_t n = dst.cap, j = (size_t)base + rank;
-            double* __restrict__ c = dst.d;
-            dst.i32[ICOL_RAY * n + j] = (int)ray;
-            dst.i32[ICOL_PASS * n + j] = s.pass;
-            ((float*)dst.i32)[ICOL_WORST * n + j] = worst;
-            c[COL_X0 * n + j] = x[0]; c[COL_X1 * n + j] = x[1]; c[COL_X2 * n + j] = x[2]; c[COL_X3 * n + j] = x[3];
-            c[COL_K0 * n + j] = k[0]; c[COL_K1 * n + j] = k[1]; c[COL_K2 * n + j] = k[2]; c[COL_K3 * n + j] = k[3];
-            c[COL_DK0 * n + j] = s.dk[0]; c[COL_DK1 * n + j] = s.dk[1];
-            c[COL_DK2 * n + j] = s.dk[2]; c[COL_DK3 * n + j] = s.dk[3];
-            c[COL_KT * n + j] = s.kt; c[COL_Q * n + j] = s.Q; c[COL_E * n + j] = s.E;
-            c[COL_I * n + j] = I; c[COL_TAU * n + j] = tau;
+        // ---- 2. what is in the pool ----
+        const int t0 = ptag[lane], t1 = ptag[lane + 64];
+        const unsigned long long v0 = __builtin_amdgcn_ballot_w64(t0 == TAG_V), v1 = __builtin_amdgcn_ballot_w64(t1 == TAG_V);
+        const unsigned long long q0 = __builtin_amdgcn_ballot_w64(t0 == TAG_R), q1 = __builtin_amdgcn_ballot_w64(t1 == TAG_R);
+        const int nV = __builtin_popcountll(v0) + __builtin_popcountll(v1);
+        const int nR = __builtin_popcountll(q0) + __builtin_popcountll(q1);
+        if (nV + nR == 0) {
+            if (drained) break;                      // nothing pooled, nothing left: the wave retires
+            continue;                                // only rejected rays came in: refill again
+        }
+        const bool do_rk4 = (nR >= 64) || (nV == 0) || (nV < 64 && nR > nV);
+        const unsigned long long m0 = do_rk4 ? q0 : v0, m1 = do_rk4 ? q1 : v1;
+        const int c0 = __builtin_popcountll(m0);
+        const int total = c0 + __builtin_popcountll(m1);
+        const int take = total < 64 ? total : 64;
+
+        // ---- 3. batch list: the first `take` slots of the chosen kind ----
+        if ((m0 >> lane) & 1ull) {
+            const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+            if (r < 64) plist[r] = (unsigned char)lane;
+        }
+        if ((m1 >> lane) & 1ull) {
+            const int r = c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+            if (r < 64) plist[r] = (unsigned char)(64 + lane);
+        }
+        wave_lds_fence();
+        const bool active = lane < take;
+        const int slot = active ? (int)plist[lane] : 0;
+
+        // ---- 4. the batch: [RK4 half of the pending call for an R batch], then up to POOL_RUN Verlet attempts;
+        //         a lane whose attempt is rejected stops (tag R), the wave goes back to the pool when a quarter
+        //         of the batch has stopped.  Consecutive accepted steps stay in registers.
+        if (active) {
+            double x[4], k[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                x[c] = pd[(PC_X0 + c) * POOL_SLOTS + slot];
+                k[c] = pd[(PC_K0 + c) * POOL_SLOTS + slot];
+                s.dk[c] = pd[(PC_DK0 + c) * POOL_SLOTS + slot];
+            }
+            s.kt = pd[PC_KT * POOL_SLOTS + slot];
+            s.E = pd[PC_E * POOL_SLOTS + slot];
+            s.pass = ppass[slot];
+            s.error = 0.0f;
+            const size_t ray = (size_t)pray[slot];
+            double I = pd[PC_I * POOL_SLOTS + slot], tau = pd[PC_TAU * POOL_SLOTS + slot];
+            float worst = pworst[slot];
+            int tag = do_rk4 ? TAG_R : TAG_V;
+            bool on = true;
+#pragma unroll 1
+            for (int run = 0; run <= POOL_RUN; ++run) {
+                if (on) {
+                    double dl;
+                    bool advanced;
+                    if (run == 0 && do_rk4) {
+                        dl = next_step_size(k, p.dl_max, s);      // the value the rejected attempt used
+                        rk4_step(x, k, dl, s);
+                        advanced = true;
+                    } else {
+                        advanced = verlet_attempt(x, k, p.dl_max, dl, s);
+                    }
+#ifdef S5_TORUS_DEBUG
+                    {
+                        unsigned long long* dbg = (unsigned long long*)aux.k_end;
+                        const unsigned long long mA = __builtin_amdgcn_ballot_w64(true);
+                        const int w = (run == 0 && do_rk4) ? 2 : 0;
+                        if (__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u)) == 0u) {
+                            atomicAdd(&dbg[w], 1ull); atomicAdd(&dbg[w + 1], (unsigned long long)__builtin_popcountll(mA));
+                        }
+                    }
+#endif
+                    if (!advanced) {
+                        tag = TAG_R; on = false;                  // x, k, dk untouched; the attempt counts as a pass (ref :168)
+                    } else {
+                        tag = TAG_V;
+                        worst = fmaxf(worst, s.error);
+                        accumulate_transfer(p, s, x, k, dl, I, tau);
+                        const bool done = !(x[1] > r_in) || !(x[1] < r_out) || ((double)s.error > p.max_error) ||
+                                          (s.pass >= p.max_steps);
+                        if (done) {
+                            s.Q = sc[COL_Q * scap + ray];
+                            write_ray_end(p, aux, out, ray, x, k, s, I, tau, worst);
+                            tag = TAG_EMPTY; on = false;
+                        }
+                    }
+                }
+                if (POOL_KEEP_DEN * __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)) < POOL_KEEP_NUM * take) break;
+            }
+            if (tag != TAG_EMPTY) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pd[(PC_X0 + c) * POOL_SLOTS + slot] = x[c];
+                    pd[(PC_K0 + c) * POOL_SLOTS + slot] = k[c];
+                    pd[(PC_DK0 + c) * POOL_SLOTS + slot] = s.dk[c];
+                }
+                pd[PC_KT * POOL_SLOTS + slot] = s.kt;
+                pd[PC_I * POOL_SLOTS + slot] = I;
+                pd[PC_TAU * POOL_SLOTS + slot] = tau;
+                ppass[slot] = s.pass;
+                pworst[slot] = worst;
+            }
+            ptag[slot] = (unsigned char)tag;
         }
     }
 }
 
-// Workspace of the torus job (two ray-state buffers, start-up flags, two counters): one grow-only device
-// allocation per process plus one pinned host word for the per-round count.  A job on another stream than
-// the previous one first waits for that stream, so two jobs never share it.
+// Workspace of the torus job (start state of every ray, start-up flags, cursor): one grow-only device
+// allocation per process, made before the launches (no allocation call sits between kernels).  A job on
+// another stream than the previous one first waits for that stream, so two jobs never share it.
 struct TorusWorkspace {
     char* base = nullptr;
     size_t cap = 0;
-    unsigned* host_count = nullptr;
     hipStream_t last = nullptr;
     bool used = false;
 };
 static TorusWorkspace g_ws;
 
-#ifndef S5_ROUND_STEPS
-#define S5_ROUND_STEPS 32
-#endif
-
-// The job synchronises `stream` once per round (it needs the survivor count to size the next launch): on
-// return all results are complete.
 #if S5_FAST
 int launch_torus_fast(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream)
 #else
@@ -291,17 +379,13 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
 #endif
 {
     const size_t n = p.nrays;
-    if (n > 0xfffffff0ull) return (int)hipErrorInvalidValue;            // ray slots are 32-bit
+    if (n > 0x7ffffff0ull) return (int)hipErrorInvalidValue;            // ray numbers are kept as int in the pool
     const size_t dcol_bytes = (sizeof(double) * NCOL * n + 255) & ~size_t(255);
-    const size_t icol_bytes = (sizeof(int) * NICOL * n + 255) & ~size_t(255);
     const size_t ok_bytes = (sizeof(int) * n + 255) & ~size_t(255);
-    const size_t need = 2 * (dcol_bytes + icol_bytes) + ok_bytes + 256;
+    const size_t need = dcol_bytes + ok_bytes + 256;
     hipError_t e;
     if (g_ws.used && g_ws.last != stream) {
         if ((e = hipStreamSynchronize(g_ws.last)) != hipSuccess) return (int)e;
-    }
-    if (!g_ws.host_count) {
-        if ((e = hipHostMalloc((void**)&g_ws.host_count, 64, hipHostMallocDefault)) != hipSuccess) return (int)e;
     }
     if (need > g_ws.cap) {
         if (g_ws.base) {
@@ -313,39 +397,33 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
         g_ws.cap = need;
     }
     g_ws.last = stream; g_ws.used = true;
-    RayCols buf[2];
-    char* q = g_ws.base;
-    for (int b = 0; b < 2; ++b) {
-        buf[b].d = (double*)q; q += dcol_bytes;
-        buf[b].i32 = (int*)q; q += icol_bytes;
-        buf[b].cap = n;
-    }
-    int* ok = (int*)q; q += ok_bytes;
-    unsigned* counts = (unsigned*)q;                                     // counts[0], counts[1]
+    RayCols start;
+    start.d = (double*)g_ws.base;
+    start.cap = n;
+    int* ok = (int*)(g_ws.base + dcol_bytes);
+    unsigned long long* cursor = (unsigned long long*)(g_ws.base + dcol_bytes + ok_bytes);
+    if ((e = hipMemsetAsync(cursor, 0, sizeof(unsigned long long), stream)) != hipSuccess) return (int)e;
 
     const unsigned blocks_a = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(torus_start_kernel, dim3(blocks_a), dim3(256), 0, stream, p, buf[0], ok);
+    hipLaunchKernelGGL(torus_start_kernel, dim3(blocks_a), dim3(256), 0, stream, p, start, ok);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
 
-    unsigned alive = (unsigned)n;
-    if ((e = hipMemcpyAsync(&counts[0], &alive, sizeof(unsigned), hipMemcpyHostToDevice, stream)) != hipSuccess) return (int)e;
-    int cur = 0;
-    // every ray takes at least one step per round it is alive in and at most max_steps in all
-    const long long max_rounds = (long long)p.max_steps + 2;
-    for (long long round = 0; round < max_rounds && alive > 0; ++round) {
-        // short rounds while most rays are alive (less idling behind rays that end inside a round), longer
-        // ones for the thin tail of long rays (fewer launches)
-        const int k_steps = (alive > n / 16) ? S5_ROUND_STEPS : 8 * S5_ROUND_STEPS;
-        if ((e = hipMemsetAsync(&counts[cur ^ 1], 0, sizeof(unsigned), stream)) != hipSuccess) return (int)e;
-        const unsigned blocks = (unsigned)(((size_t)alive + 255) / 256);
-        hipLaunchKernelGGL(torus_round_kernel, dim3(blocks), dim3(256), 0, stream, p, buf[cur], buf[cur ^ 1],
-                           &counts[cur], &counts[cur ^ 1], ok, (int)(round == 0), k_steps, out, aux);
-        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-        if ((e = hipMemcpyAsync(g_ws.host_count, &counts[cur ^ 1], sizeof(unsigned), hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
-        alive = *g_ws.host_count;
-        cur ^= 1;
+    // persistent grid: 2 workgroups of 4 waves per CU (VGPR-bound occupancy 2 waves/SIMD; 2 x 71 KB of LDS),
+    // never more waves than 128-ray pools to fill
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    size_t blocks_b = (size_t)cus * S5_MARCH_WAVES;
+    const size_t needed = (n + 4 * POOL_SLOTS - 1) / (4 * POOL_SLOTS);
+    if (blocks_b > needed) blocks_b = needed;
+    const size_t lds = 4 * (size_t)POOL_WAVE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if ((e = hipFuncSetAttribute((const void*)torus_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+        attr_set = true;
     }
+    hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(256), lds, stream, p, start, ok, cursor, out, aux);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     return 0;
 }
 

@@ -86,8 +86,21 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s)
         const double wgt = (stage == 1 || stage == 2) ? 2.0 : 1.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * off; ki[i] = k[i] + di[i] * off; }
+#if S5_FAST
+        // stage 0 is the acceleration at the current point with the current momentum: the value every step
+        // leaves in s.dk (Verlet :232, RK4 :299, prepare :90).  The reference recomputes it through
+        // cos(acos(m)) and the other summation order; the fast variant reuses it (one connection less).
+        if (stage == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) di[i] = s.dk[i];
+        } else {
+            rt_connection(s, xp[1], mcos(xp[2]), G);
+            transport_self(G, ki, di);
+        }
+#else
         rt_connection(s, xp[1], mcos(xp[2]), G);
         transport_self(G, ki, di);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + wgt * ki[i]; sk[i] = sk[i] + wgt * di[i]; }
     }
@@ -109,17 +122,26 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s)
 // the step was accepted (x, k, s advanced); false if the reference would now fall back to RK4: x and k
 // are then unchanged (restored) and `dl` holds the step size the fallback must use.  s.pass is counted
 // either way, as in the reference.
-S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl, RayState& s)
+// size of the next step (ref :164-166): a function of k and dk only, so a caller that defers the RK4
+// fallback can recompute exactly the value the failed Verlet attempt used
+S5_DEV double next_step_size(const double k[4], double step_cap, const RayState& s)
 {
     const double tiny = 1e-40;
-    double xp[4], kh[4], kp[4], kq[4];
     const double* dk = s.dk;
-
     const double stepsize = mdiv(s.step_epsilon,
         mdiv(fabs(dk[0]), fabs(k[0]) + tiny) + mdiv(fabs(dk[1]), fabs(k[1]) + tiny) +
         mdiv(fabs(dk[2]), fabs(k[2]) + tiny) + mdiv(fabs(dk[3]), fabs(k[3]) + tiny) + tiny);
-    dl = fmin(step_cap, stepsize);
+    double dl = fmin(step_cap, stepsize);
     if (dl < 1e-3) dl = 1e-3;
+    return dl;
+}
+
+S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl, RayState& s)
+{
+    double xp[4], kh[4], kp[4], kq[4];
+    const double* dk = s.dk;
+
+    dl = next_step_size(k, step_cap, s);
     s.pass++;
 
     const double half_dl = 0.5 * dl;
