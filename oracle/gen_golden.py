@@ -344,6 +344,87 @@ def kat_raytrace(ref, rng):
 
 
 # ------------------------------------------------------------------------------------------
+AZM_FUNCS = ["elliptic_f_cos", "elliptic_e_cos", "elliptic_pi_complete", "elliptic_pi_cos", "integral_C2",
+             "integral_C2_cos", "integral_Z1", "integral_Z2", "integral_Rm1", "integral_Rm2", "integral_R1",
+             "integral_R2", "integral_R_r0_re", "integral_R_r0_re_inf", "integral_R_r1_re", "integral_R_r2_re",
+             "integral_R_rp_re", "integral_R_rp_re_inf", "integral_R_r0_cc", "integral_R_r0_cc_inf",
+             "integral_R_r1_cc", "integral_R_r2_cc", "integral_R_rp_cc2", "integral_R_rp_cc2_inf",
+             "integral_T_m0", "integral_T_m2", "integral_T_mp"]
+
+
+def azm_arguments(name, rng):
+    """One argument tuple in the domain the geodesic routines use the function on."""
+    if name.startswith("integral_R_r") and "_re" in name:
+        d_, c_, b_, a_ = np.sort(rng.uniform(-5, 6, 4))
+        X = a_ + 10 ** rng.uniform(-2, 2); p = rng.uniform(0.1, 1.9)
+        return {"integral_R_r0_re": [a_, b_, c_, d_, X], "integral_R_r0_re_inf": [a_, b_, c_, d_],
+                "integral_R_r1_re": [a_, b_, c_, d_, X], "integral_R_r2_re": [a_, b_, c_, d_, X],
+                "integral_R_rp_re": [a_, b_, c_, d_, p, X], "integral_R_rp_re_inf": [a_, b_, c_, d_, p]}[name]
+    if "_cc" in name:
+        b_, a_ = np.sort(rng.uniform(0.5, 6, 2)); u = rng.uniform(-3, 3); v = rng.uniform(0.01, 3)
+        X1 = a_ + 10 ** rng.uniform(-2, 1.5); X2 = X1 + 10 ** rng.uniform(-2, 2); p = rng.uniform(0.1, min(1.9, b_))
+        return {"integral_R_r0_cc": [a_, b_, u, v, X1], "integral_R_r0_cc_inf": [a_, b_, u, v],
+                "integral_R_r1_cc": [a_, b_, u, v, X1, X2], "integral_R_r2_cc": [a_, b_, u, v, X1, X2],
+                "integral_R_rp_cc2": [a_, b_, u, v, p, X1, X2], "integral_R_rp_cc2_inf": [a_, b_, u, v, p, X1]}[name]
+    if name.startswith("integral_T"):
+        a2 = rng.uniform(0.01, 50); b2 = rng.uniform(0.01, 0.99); X = rng.uniform(-1, 1) * math.sqrt(b2)
+        if name != "integral_T_mp":
+            X = abs(X)
+        return [a2, b2, X] if name != "integral_T_mp" else [a2, b2, 1.0, X]
+    if name in ("elliptic_f_cos", "elliptic_e_cos", "integral_C2_cos"):
+        return [rng.uniform(-1, 1), rng.uniform(0.001, 0.999)]
+    if name == "elliptic_pi_complete":
+        return [rng.uniform(-5, 0.99), rng.uniform(0.001, 0.999)]
+    if name == "elliptic_pi_cos":
+        return [rng.uniform(-1, 1), rng.uniform(-5, 0.99), rng.uniform(0.001, 0.999)]
+    if name == "integral_C2":
+        return [rng.uniform(0, 3), rng.uniform(0.001, 0.999)]
+    if name in ("integral_Z1", "integral_Z2"):
+        return [rng.uniform(-3, 0.9), rng.uniform(-3, 3), rng.uniform(0, 1.5), rng.uniform(0.001, 0.999)]
+    return [rng.uniform(-4, 4), rng.uniform(0, 3), rng.uniform(0.001, 0.999)]       # Rm1, Rm2, R1, R2: (a, u, m)
+
+
+def kat_azimuth(ref):
+    """geodesic_position_azm / geodesic_timedelay and every integral below them."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    for name in AZM_FUNCS:
+        fn = getattr(ref, name)
+        args = np.array([azm_arguments(name, rng) for _ in range(300)])
+        out["in_" + name] = args
+        out["out_" + name] = np.array([fn(*row) for row in args])
+    rows = []
+    for a in [0.0, 0.3, 0.9, 0.998]:
+        for inc in [deg(15.0), deg(45.0), deg(70.0), deg(85.0)]:
+            for _ in range(160):
+                rad = 16.0 * rng.random() ** 1.5
+                ang = rng.uniform(0, 2 * math.pi)
+                rows.append((inc, a, rad * math.cos(ang), rad * math.sin(ang)))
+    inp = np.array(rows); n = len(inp)
+    P1 = np.full(n, np.nan); P2 = np.full(n, np.nan); r1 = np.full(n, np.nan); m1 = np.full(n, np.nan)
+    r2 = np.full(n, np.nan); m2 = np.full(n, np.nan); phi = np.full(n, np.nan)
+    dt_auto = np.full(n, np.nan); dt_expl = np.full(n, np.nan); gtype = np.full(n, -1, np.int32)
+    for i, (inc, a, al, be) in enumerate(inp):
+        g = ol.Geodesic(); e = C.c_int(-1)
+        if not ref.geodesic_init_inf(inc, a, al, be, C.byref(g), C.byref(e)):
+            continue
+        gtype[i] = g.type
+        if g.type not in (40, 2):
+            continue
+        hi = 2.0 * g.Rpc if g.type == 40 else g.Rpc
+        P1[i] = hi * (0.01 + 0.97 * rng.random()); P2[i] = hi * (0.01 + 0.97 * rng.random())
+        r1[i] = ref.geodesic_position_rad(C.byref(g), P1[i]); m1[i] = ref.geodesic_position_pol(C.byref(g), P1[i])
+        r2[i] = ref.geodesic_position_rad(C.byref(g), P2[i]); m2[i] = ref.geodesic_position_pol(C.byref(g), P2[i])
+        if r1[i] == r1[i] and m1[i] == m1[i]:
+            phi[i] = ref.geodesic_position_azm(C.byref(g), r1[i], m1[i], P1[i])
+        dt_auto[i] = ref.geodesic_timedelay(C.byref(g), P1[i], 0.0, 0.0, P2[i], 0.0, 0.0)
+        if r1[i] == r1[i] and r2[i] == r2[i]:
+            dt_expl[i] = ref.geodesic_timedelay(C.byref(g), P1[i], r1[i], m1[i], P2[i], r2[i], m2[i])
+    save("kat_azimuth.npz", inp=inp, gtype=gtype, P1=P1, P2=P2, r1=r1, m1=m1, r2=r2, m2=m2, phi=phi,
+         dt_auto=dt_auto, dt_expl=dt_expl, **out)
+
+
+# ------------------------------------------------------------------------------------------
 def image_fixture(name, n, a, inc_deg, dec):
     """Full class map + every dec-th pixel at full precision + counts and sums."""
     o = ol.cpu_disk_image("reference", n, n, a, inc_deg, nthreads=NTHREADS, full=True)
@@ -423,6 +504,9 @@ def main():
     saved = os.dup(2)
     os.dup2(devnull, 2)          # the reference prints diagnostics for out-of-range KAT inputs
     try:
+        if len(sys.argv) > 1 and sys.argv[1] == "azimuth":      # only the newest fixture
+            kat_azimuth(ref)
+            return
         kat_elliptic(ref, rng)
         kat_geodesic(ref, rng)
         kat_kerr(ref, rng)
@@ -431,6 +515,7 @@ def main():
         kat_raytrace(ref, rng)
         polarized()
         images()
+        kat_azimuth(ref)
     finally:
         os.dup2(saved, 2)
 

@@ -14,6 +14,7 @@
  */
 #include "sim5_oracle.h"
 
+#include <complex.h>
 #include <float.h>
 #include <math.h>
 #include <string.h>
@@ -199,6 +200,65 @@ double orc_jacobi_itn(double z, double m)
     return orc_jacobi_isn(sqrt(z * z / (1. + z * z)), m);
 }
 
+/* F(acos(c), m); ref: src/sim5elliptic.c:255-271 */
+double orc_elliptic_f_cos(double c, double m)
+{
+    if (m == 1.0) m = 0.99999999;
+    if (c == 1.0) return 0.0;
+    double whole = 0.0;
+    if (c < 0.0) {
+        c = -c;
+        whole = 2.0 * orc_rf(0.0, 1.0 - m, 1.0);
+    }
+    double s2 = 1.0 - SQ(c);
+    return whole + ((whole == 0.0) ? (+1) : (-1)) * sqrt(s2) * orc_rf(1.0 - s2, 1.0 - s2 * m, 1.0);
+}
+
+/* E(acos(c), m) through R_F and R_D; ref: src/sim5elliptic.c:319-337 */
+double orc_elliptic_e_cos(double c, double m)
+{
+    if (m == 1.0) m = 0.99999999;
+    if (c == 1.0) return 0.0;
+    double whole = 0.0;
+    if (c < 0.0) {
+        c = -c;
+        whole = 2.0 * (orc_rf(0.0, 1.0 - m, 1.0) - m * orc_rd(0.0, 1.0 - m, 1.0) / 3.0);
+    }
+    double c2 = SQ(c);
+    double s = sqrt(1.0 - c2);
+    double q = 1.0 - m + c2 * m;
+    return whole + ((whole == 0.0) ? (+1) : (-1)) * s * (orc_rf(c2, q, 1.0) - SQ(s * sqrt(m)) * orc_rd(c2, q, 1.0) / 3.0);
+}
+
+/* complete Pi(n, m), Mathematica's sign of n; ref: src/sim5elliptic.c:366-378 */
+double orc_elliptic_pi_complete(double n, double m)
+{
+    if (isinf(n)) return 0.0;
+    if (m == 1.0) m = 0.99999999;
+    if (n == 1.0) n = 0.99999999;
+    double q = 1.0 - m;
+    return orc_rf(0.0, q, 1.0) + n * orc_rj(0.0, q, 1.0, 1.0 - n) / 3.0;
+}
+
+/* Pi(acos(c), n, m); ref: src/sim5elliptic.c:426-450 */
+double orc_elliptic_pi_cos(double c, double n, double m)
+{
+    if (isinf(n)) return 0.0;
+    if (c == 1.0) return 0.0;
+    if (c == 0.0) return orc_elliptic_pi_complete(n, m);
+    if (m == 1.0) m = 0.99999999;
+    double whole = 0.0;
+    if (c < 0.0) {
+        c = -c;
+        whole = 2.0 * ((orc_rf(0.0, 1.0 - m, 1.0) + n * orc_rj(0.0, 1.0 - m, 1.0, 1.0 - n) / 3.0));
+    }
+    double c2 = SQ(c);
+    double s = sqrt(1.0 - c2);
+    double ns2 = -n * (1.0 - c2);
+    double q = 1.0 - (1.0 - c2) * m;
+    return whole + ((whole == 0.0) ? (+1) : (-1)) * s * (orc_rf(c2, q, 1.0) - ns2 * orc_rj(c2, q, 1.0, 1.0 + ns2) / 3.0);
+}
+
 /* sn, cn, dn by descending Landen (AGM) transformation; ref: src/sim5elliptic.c:536-598 */
 void orc_jacobi_sncndn(double u, double m, double *sn, double *cn, double *dn)
 {
@@ -260,6 +320,277 @@ void orc_jacobi_sncndn(double u, double m, double *sn, double *cn, double *dn)
 double orc_jacobi_sn(double u, double m) { double s, c, d; orc_jacobi_sncndn(u, m, &s, &c, &d); return s; }
 double orc_jacobi_cn(double u, double m) { double s, c, d; orc_jacobi_sncndn(u, m, &s, &c, &d); return c; }
 double orc_jacobi_dn(double u, double m) { double s, c, d; orc_jacobi_sncndn(u, m, &s, &c, &d); return d; }
+
+/* ================================================================================== */
+/*  Byrd & Friedman integrals of Jacobi functions and the radial / polar integrals    */
+/*  built on them (used by geodesic_position_azm and geodesic_timedelay)              */
+/* ================================================================================== */
+
+/* int cn^2 du from the cn of the upper limit; ref: src/sim5elliptic.c:668-673 */
+double orc_integral_C2_cos(double cn_u, double m)
+{
+    return 1. / m * (orc_elliptic_e_cos(cn_u, m) - (1. - m) * orc_elliptic_f_cos(cn_u, m));
+}
+
+/* int_0^u cn^2 du; ref: src/sim5elliptic.c:657-664 */
+double orc_integral_C2(double u, double m)
+{
+    double sn, cn, dn;
+    orc_jacobi_sncndn(u, m, &sn, &cn, &dn);
+    return 1. / m * (orc_elliptic_e_cos(cn, m) - (1. - m) * u);
+}
+
+/* int (1 - b sn^2)/(1 - a sn^2) du, B&F 340.01; ref: src/sim5elliptic.c:677-690 */
+double orc_integral_Z1(double a, double b, double u, double m)
+{
+    double sn, cn, dn;
+    orc_jacobi_sncndn(u, m, &sn, &cn, &dn);
+    return 1. / a * ((a - b) * orc_elliptic_pi_cos(cn, a, m) + b * u);
+}
+
+/* int (1 - b sn^2)^2/(1 - a sn^2)^2 du, B&F 340.02; ref: src/sim5elliptic.c:694-715 */
+double orc_integral_Z2(double a, double b, double u, double m)
+{
+    double sn, cn, dn;
+    orc_jacobi_sncndn(u, m, &sn, &cn, &dn);
+    double V1 = orc_elliptic_pi_cos(cn, a, m);
+    double V2 = 0.5 / ((a - 1.) * (m - a)) * (
+                    a * orc_elliptic_e_cos(cn, m) + (m - a) * u +
+                    (2. * a * m + 2. * a - a * a - 3. * m) * V1 -
+                    (a * a * sn * cn * dn) / (1. - a * sn * sn));
+    double ab = a - b;
+    return 1. / SQ(a) * (SQ(b) * u + 2. * b * ab * V1 + ab * ab * V2);
+}
+
+/* int (1 + a cn) du, B&F 341.00; ref: src/sim5elliptic.c:719-729 */
+double orc_integral_Rm1(double a, double u, double m)
+{
+    return u + a / sqrt(m) * acos(orc_jacobi_dn(u, m));
+}
+
+/* int (1 + a cn)^2 du, B&F 341.01; ref: src/sim5elliptic.c:733-745 */
+double orc_integral_Rm2(double a, double u, double m)
+{
+    double a2 = SQ(a);
+    double sn, cn, dn;
+    orc_jacobi_sncndn(u, m, &sn, &cn, &dn);
+    return 1 / m * ((m - a2 * (1. - m)) * u + a2 * orc_elliptic_e_cos(cn, m) + 2 * a * sqrt(m) * acos(dn));
+}
+
+/* int du/(1 + a cn), B&F 341.03 / 361.54, complex intermediate as on the reference's host path;
+   ref: src/sim5elliptic.c:756-792 */
+double orc_integral_R1(double a, double u, double m)
+{
+    double a2 = SQ(a);
+    double n = a2 / (a2 - 1.);
+    double sn, cn, dn;
+    orc_jacobi_sncndn(u, m, &sn, &cn, &dn);
+    double mma = (m + (1. - m) * a2) / (1. - a2);
+    orc_cplx f1 = (fabs(mma) > 1e-5)
+                      ? csqrt((1. / mma) + _Complex_I * 0.0) * catan(csqrt((mma) + _Complex_I * 0.0) * sn / dn)
+                      : ((sn / dn) + _Complex_I * 0.0);
+    orc_cplx ellpi = orc_elliptic_pi_cos(cn, n, m);
+    orc_cplx res = 1. / (1. - a2) * (ellpi + a * f1);
+    return creal(res);
+}
+
+/* int du/(1 + a cn)^2, B&F 341.04; ref: src/sim5elliptic.c:796-816 */
+double orc_integral_R2(double a, double u, double m)
+{
+    double a2 = SQ(a);
+    double mma = (m + (1. - m) * a2);
+    double sn, cn, dn;
+    orc_jacobi_sncndn(u, m, &sn, &cn, &dn);
+    return 1 / (a2 - 1.) / mma * (
+               (a2 * (2. * m - 1.) - 2. * m) * orc_integral_R1(a, u, m) +
+               2. * m * orc_integral_Rm1(a, u, m) -
+               m * orc_integral_Rm2(a, u, m) +
+               a * a2 * sn * dn / (1. + a * cn));
+}
+
+/* int_a^X dx/sqrt((x-a)(x-b)(x-c)(x-d)), four real roots, B&F 258.00; ref: src/sim5elliptic.c:826-838 */
+double orc_integral_R_r0_re(double a, double b, double c, double d, double X)
+{
+    double m4 = ((b - c) * (a - d)) / ((a - c) * (b - d));
+    double sn = sqrt(((b - d) * (X - a)) / ((a - d) * (X - b)));
+    return 2.0 / sqrt((a - c) * (b - d)) * orc_jacobi_isn(sn, m4);
+}
+
+/* the same up to infinity; ref: src/sim5elliptic.c:842-854 */
+double orc_integral_R_r0_re_inf(double a, double b, double c, double d)
+{
+    double m4 = ((b - c) * (a - d)) / ((a - c) * (b - d));
+    double sn = sqrt((b - d) / (a - d));
+    return 2.0 / sqrt((a - c) * (b - d)) * orc_jacobi_isn(sn, m4);
+}
+
+/* two real roots and a complex pair c, c*, B&F 260.00; ref: src/sim5elliptic.c:858-872 */
+double orc_integral_R_r0_cc(double a, double b, orc_cplx c, double X)
+{
+    double u = creal(c);
+    double v2 = SQ(cimag(c));
+    double A = sqrt(SQ(a - u) + v2);
+    double B = sqrt(SQ(b - u) + v2);
+    double m2 = (SQ(A + B) - SQ(a - b)) / (4. * A * B);
+    double cn = (X * (A - B) + a * B - b * A) / (X * (A + B) - a * B - b * A);
+    return 1. / sqrt(A * B) * orc_jacobi_icn(cn, m2);
+}
+
+/* ref: src/sim5elliptic.c:876-889 */
+double orc_integral_R_r0_cc_inf(double a, double b, orc_cplx c)
+{
+    double u = creal(c);
+    double v2 = SQ(cimag(c));
+    double A = sqrt(SQ(a - u) + v2);
+    double B = sqrt(SQ(b - u) + v2);
+    double m2 = (SQ(A + B) - SQ(a - b)) / (4. * A * B);
+    double cn = (A - B) / (A + B);
+    return 1. / sqrt(A * B) * orc_jacobi_icn(cn, m2);
+}
+
+/* int_a^X x dx/sqrt(...), four real roots, B&F 258.11; ref: src/sim5elliptic.c:893-905 */
+double orc_integral_R_r1_re(double a, double b, double c, double d, double X)
+{
+    double m2 = ((b - c) * (a - d)) / ((a - c) * (b - d));
+    double sn = sqrt(((b - d) * (X - a)) / ((a - d) * (X - b)));
+    double u = orc_jacobi_isn(sn, m2);
+    double a2 = (a - d) / (b - d);
+    double b2 = ((a - d) * b) / (a * (b - d));
+    double Z = orc_integral_Z1(a2, b2, u, m2) - orc_integral_Z1(a2, b2, 0, m2);
+    return a * 2.0 / sqrt((a - c) * (b - d)) * Z;
+}
+
+/* helper of the complex-pair forms: the amplitude u(X) = F(acos(cn(X)), m); ref: src/sim5elliptic.c:924-925 */
+static double cc_amplitude(double a, double b, double A, double B, double X, double m)
+{
+    return orc_elliptic_f_cos((X * (A - B) + a * B - b * A) / (X * (A + B) - a * B - b * A), m);
+}
+
+/* int_X1^X2 x dx/sqrt(...), complex pair, B&F 260.03; ref: src/sim5elliptic.c:910-930 */
+double orc_integral_R_r1_cc(double a, double b, orc_cplx c, double X1, double X2)
+{
+    double u = creal(c);
+    double v2 = SQ(cimag(c));
+    double A = sqrt(SQ(a - u) + v2);
+    double B = sqrt(SQ(b - u) + v2);
+    double m = (SQ(A + B) - SQ(a - b)) / (4. * A * B);
+    double g = 1. / sqrt(A * B);
+    double alpha1 = (B * a + b * A) / (B * a - b * A);
+    double alpha2 = (B + A) / (B - A);
+    double u1 = cc_amplitude(a, b, A, B, X1, m);
+    double u2 = cc_amplitude(a, b, A, B, X2, m);
+    double t0 = alpha1 * (u2 - u1);
+    double t1 = (alpha2 - alpha1) * (orc_integral_R1(alpha2, u2, m) - orc_integral_R1(alpha2, u1, m));
+    return (B * a - b * A) / (B + A) * g * (t0 + t1);
+}
+
+/* int_a^X x^2 dx/sqrt(...), four real roots; ref: src/sim5elliptic.c:955-967 */
+double orc_integral_R_r2_re(double a, double b, double c, double d, double X)
+{
+    double m2 = ((b - c) * (a - d)) / ((a - c) * (b - d));
+    double sn = sqrt(((b - d) * (X - a)) / ((a - d) * (X - b)));
+    double u = orc_jacobi_isn(sn, m2);
+    double a2 = (a - d) / (b - d);
+    double b2 = ((a - d) * b) / (a * (b - d));
+    double Z = orc_integral_Z2(a2, b2, u, m2) - orc_integral_Z2(a2, b2, 0, m2);
+    return SQ(a) * 2.0 / sqrt((a - c) * (b - d)) * Z;
+}
+
+/* int_X1^X2 x^2 dx/sqrt(...), complex pair; ref: src/sim5elliptic.c:972-993 */
+double orc_integral_R_r2_cc(double a, double b, orc_cplx c, double X1, double X2)
+{
+    double u = creal(c);
+    double v2 = SQ(cimag(c));
+    double A = sqrt(SQ(a - u) + v2);
+    double B = sqrt(SQ(b - u) + v2);
+    double m = (SQ(A + B) - SQ(a - b)) / (4. * A * B);
+    double g = 1. / sqrt(A * B);
+    double alpha1 = (B * a + b * A) / (B * a - b * A);
+    double alpha2 = (B + A) / (B - A);
+    double u1 = cc_amplitude(a, b, A, B, X1, m);
+    double u2 = cc_amplitude(a, b, A, B, X2, m);
+    double t0 = pow(alpha1, 2.) * (u2 - u1);
+    double t1 = 2. * alpha1 * (alpha2 - alpha1) * (orc_integral_R1(alpha2, u2, m) - orc_integral_R1(alpha2, u1, m));
+    double t2 = pow(alpha2 - alpha1, 2.) * (orc_integral_R2(alpha2, u2, m) - orc_integral_R2(alpha2, u1, m));
+    return pow((B * a - b * A) / (B + A), 2.) * g * (t0 + t1 + t2);
+}
+
+/* int_a^X dx/[(x-p) sqrt(...)], four real roots, B&F 258.39; ref: src/sim5elliptic.c:1017-1028 */
+double orc_integral_R_rp_re(double a, double b, double c, double d, double p, double X)
+{
+    double m2 = ((b - c) * (a - d)) / ((a - c) * (b - d));
+    double sn = sqrt(((b - d) * (X - a)) / ((a - d) * (X - b)));
+    double u1 = orc_jacobi_isn(sn, m2);
+    double a2 = (a - d) / (b - d);
+    double c2 = ((p - b) * (a - d)) / ((p - a) * (b - d));
+    return -2.0 / sqrt((a - c) * (b - d)) / (p - a) * (orc_integral_Z1(c2, a2, u1, m2) - orc_integral_Z1(c2, a2, 0, m2));
+}
+
+/* ref: src/sim5elliptic.c:1032-1043 */
+double orc_integral_R_rp_re_inf(double a, double b, double c, double d, double p)
+{
+    double m2 = ((b - c) * (a - d)) / ((a - c) * (b - d));
+    double sn = sqrt((b - d) / (a - d));
+    double u1 = orc_jacobi_isn(sn, m2);
+    double a2 = (a - d) / (b - d);
+    double c2 = ((p - b) * (a - d)) / ((p - a) * (b - d));
+    return -2.0 / sqrt((a - c) * (b - d)) / (p - a) * (orc_integral_Z1(c2, a2, u1, m2) - orc_integral_Z1(c2, a2, 0, m2));
+}
+
+/* int_X1^X2 dx/[(x-p) sqrt(...)], complex pair, B&F 260.04; ref: src/sim5elliptic.c:1048-1078.
+   X2 < 0 stands for the upper limit at infinity (ref :1083-1113, cn = (A-B)/(A+B)) */
+static double rp_cc2_core(double a, double b, orc_cplx c, double p, double X1, double X2, int to_infinity)
+{
+    double u = creal(c);
+    double v2 = SQ(cimag(c));
+    double A = sqrt(SQ(a - u) + v2);
+    double B = sqrt(SQ(b - u) + v2);
+    double m = (SQ(A + B) - SQ(a - b)) / (4. * A * B);
+    double g = 1. / sqrt(A * B);
+    double alpha1 = (B * a + b * A - p * A - p * B) / (B * a - b * A + p * A - p * B);
+    double alpha2 = (B + A) / (B - A);
+    double u1 = cc_amplitude(a, b, A, B, X1, m);
+    double u2 = to_infinity ? orc_elliptic_f_cos((A - B) / (A + B), m) : cc_amplitude(a, b, A, B, X2, m);
+    double t0 = alpha2 * (u2 - u1);
+    double t1 = (alpha1 - alpha2) * (orc_integral_R1(alpha1, u2, m) - orc_integral_R1(alpha1, u1, m));
+    return (B - A) * g / (B * a + b * A - p * A - p * B) * (t0 + t1);
+}
+
+double orc_integral_R_rp_cc2(double a, double b, orc_cplx c, double p, double X1, double X2)
+{
+    return rp_cc2_core(a, b, c, p, X1, X2, 0);
+}
+
+double orc_integral_R_rp_cc2_inf(double a, double b, orc_cplx c, double p, double X1)
+{
+    return rp_cc2_core(a, b, c, p, X1, 0.0, 1);
+}
+
+/* int_X^b dx/sqrt((a^2+x^2)(b^2-x^2)), B&F 213.00; ref: src/sim5elliptic.c:1122-1129 */
+double orc_integral_T_m0(double a2, double b2, double X)
+{
+    double m = b2 / (a2 + b2);
+    return 1. / sqrt(a2 + b2) * orc_jacobi_icn(X / sqrt(b2), m);
+}
+
+/* int_X^b x^2 dx/sqrt(...), B&F 213.06; ref: src/sim5elliptic.c:1133-1141 */
+double orc_integral_T_m2(double a2, double b2, double X)
+{
+    double m = b2 / (a2 + b2);
+    double cn = X / sqrt(b2);
+    return b2 / sqrt(a2 + b2) * (orc_integral_C2_cos(cn, m) - orc_integral_C2(0, m));
+}
+
+/* int_X^b dx/[(p - x^2) sqrt(...)], B&F 213.02; ref: src/sim5elliptic.c:1145-1161 */
+double orc_integral_T_mp(double a2, double b2, double p, double X)
+{
+    double m = b2 / (a2 + b2);
+    double n = b2 / (b2 - p);
+    if (X >= 0.0)
+        return 1. / sqrt(a2 + b2) / (p - b2) * orc_elliptic_pi_cos(X / sqrt(b2), n, m);
+    else
+        return 1. / sqrt(a2 + b2) / (p - b2) * (2. * orc_elliptic_pi_complete(n, m) - orc_elliptic_pi_cos(-X / sqrt(b2), n, m));
+}
 
 /* ================================================================================== */
 /*  Kerr spacetime                                                                    */
@@ -959,6 +1290,99 @@ void orc_geodesic_follow(const orc_geodesic *g, double step, double *P, double *
         step -= truestep;
     } while (fabs(step) > 1e-5);
     if (status) *status = 1;
+}
+
+/* change of azimuth between infinity and the point (r, m) at position integral P;
+   ref: src/sim5kerr-geod.c:463-556 */
+double orc_geodesic_position_azm(const orc_geodesic *g, double r, double m, double P)
+{
+    double phi = 0.0;
+    int ppc = (g->nrr > 0) && (P > g->Rpc);
+    double a2 = SQ(g->a);
+    double rp = 1. + sqrt(1. - a2);
+    double rm = 1. - sqrt(1. - a2);
+    double r1, r2, r3, r4, A, B;
+
+    if (g->type == ORC_RR) {
+        r1 = creal(g->r1); r2 = creal(g->r2); r3 = creal(g->r3); r4 = creal(g->r4);
+        A = orc_integral_R_rp_re_inf(r1, r2, r3, r4, rp) + (ppc ? +1 : -1) * orc_integral_R_rp_re(r1, r2, r3, r4, rp, r);
+        B = orc_integral_R_rp_re_inf(r1, r2, r3, r4, rm) + (ppc ? +1 : -1) * orc_integral_R_rp_re(r1, r2, r3, r4, rm, r);
+        phi += 1. / sqrt(1. - a2) * (A * (g->a * rp - g->l * a2 / 2.) - B * (g->a * rm - g->l * a2 / 2.));
+    } else if (g->type == ORC_RC) {
+        r1 = creal(g->r1); r2 = creal(g->r2);
+        A = orc_integral_R_rp_cc2_inf(r1, r2, g->r3, rp, r);
+        B = orc_integral_R_rp_cc2_inf(r1, r2, g->r3, rm, r);
+        phi += 1. / sqrt(1. - a2) * (A * (g->a * rp - g->l * a2 / 2.) - B * (g->a * rm - g->l * a2 / 2.));
+    } else if (g->type == ORC_RR_DBL || g->type == ORC_RR_BH || g->type == ORC_CC) {
+        return NAN;
+    }
+
+    /* polar part */
+    double phi_pp = 2.0 * g->l / g->a * orc_integral_T_mp(g->m2m, g->m2p, 1.0, 0.0);
+    double phi_ip = g->l / g->a * orc_integral_T_mp(g->m2m, g->m2p, 1.0, g->cos_i);
+    double phi_mp = g->l / g->a * orc_integral_T_mp(g->m2m, g->m2p, 1.0, m);
+
+    double T;
+    double sign_dm = (g->beta >= 0.0) ? +1.0 : -1.0;
+    if (sign_dm > 0.0) {
+        T = -(g->Tpp - g->Tip);
+        phi -= phi_pp - phi_ip;
+    } else {
+        T = -g->Tip;
+        phi -= phi_ip;
+    }
+    if (P >= T + g->Tpp) {                      /* the reference's while-loop leaves after one pass (:545-550) */
+        T += g->Tpp;
+        phi += phi_pp;
+        sign_dm = -sign_dm;
+    }
+    phi += (sign_dm < 0) ? phi_mp : phi_pp - phi_mp;
+    return phi;
+}
+
+/* light-travel time between two points of a geodesic (radial part, as the reference: the polar
+   part is commented out there); ref: src/sim5kerr-geod.c:560-664 */
+double orc_geodesic_timedelay(const orc_geodesic *g, double P1, double r1, double m1, double P2, double r2, double m2)
+{
+    double time = 0.0;
+    if (P1 > P2) {
+        double tmp;
+        tmp = P2; P2 = P1; P1 = tmp;
+        tmp = r2; r2 = r1; r1 = tmp;
+        tmp = m2; m2 = m1; m1 = tmp;
+    }
+    if (r1 == 0) { r1 = orc_geodesic_position_rad(g, P1); m1 = orc_geodesic_position_pol(g, P1); }
+    if (r2 == 0) { r2 = orc_geodesic_position_rad(g, P2); m2 = orc_geodesic_position_pol(g, P2); }
+    (void)m1; (void)m2;
+
+    double a2 = SQ(g->a);
+    double rp = 1. + sqrt(1. - a2);
+    double rm = 1. - sqrt(1. - a2);
+    double ra = creal(g->r1), rb = creal(g->r2), rc = creal(g->r3), rd = creal(g->r4);
+    double R0, R1, R2, RA, RB, A, B, s;
+
+    if (g->type == ORC_RR) {
+        s = (((P1 > g->Rpc) && (P2 < g->Rpc)) || ((P1 < g->Rpc) && (P2 > g->Rpc))) ? +1 : -1;
+        R0 = orc_integral_R_r0_re(ra, rb, rc, rd, r1) + s * orc_integral_R_r0_re(ra, rb, rc, rd, r2);
+        R1 = orc_integral_R_r1_re(ra, rb, rc, rd, r1) + s * orc_integral_R_r1_re(ra, rb, rc, rd, r2);
+        R2 = orc_integral_R_r2_re(ra, rb, rc, rd, r1) + s * orc_integral_R_r2_re(ra, rb, rc, rd, r2);
+        RA = orc_integral_R_rp_re(ra, rb, rc, rd, rp, r1) + s * orc_integral_R_rp_re(ra, rb, rc, rd, rp, r2);
+        RB = orc_integral_R_rp_re(ra, rb, rc, rd, rm, r1) + s * orc_integral_R_rp_re(ra, rb, rc, rd, rm, r2);
+    } else if (g->type == ORC_RC) {
+        R0 = orc_integral_R_r0_cc(ra, rb, g->r3, r1) - orc_integral_R_r0_cc(ra, rb, g->r3, r2);
+        R1 = (r1 < r2) ? orc_integral_R_r1_cc(ra, rb, g->r3, r1, r2) : orc_integral_R_r1_cc(ra, rb, g->r3, r2, r1);
+        R2 = (r1 < r2) ? orc_integral_R_r2_cc(ra, rb, g->r3, r1, r2) : orc_integral_R_r2_cc(ra, rb, g->r3, r2, r1);
+        RA = (r1 < r2) ? orc_integral_R_rp_cc2(ra, rb, g->r3, rp, r1, r2) : orc_integral_R_rp_cc2(ra, rb, g->r3, rp, r2, r1);
+        RB = (r1 < r2) ? orc_integral_R_rp_cc2(ra, rb, g->r3, rm, r1, r2) : orc_integral_R_rp_cc2(ra, rb, g->r3, rm, r2, r1);
+    } else if (g->type == ORC_RR_DBL || g->type == ORC_RR_BH || g->type == ORC_CC) {
+        return NAN;
+    } else {
+        return time;
+    }
+    A = (-g->a * g->l + 4.) * rp - 2. * a2;
+    B = (+g->a * g->l - 4.) * rm + 2. * a2;
+    time += 4. * fabs(R0) + 2. * fabs(R1) + fabs(R2) + (A * fabs(RA) + B * fabs(RB)) / sqrt(1. - a2);
+    return time;
 }
 
 /* ================================================================================== */

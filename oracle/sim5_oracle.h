@@ -79,6 +79,35 @@ double orc_jacobi_sn(double u, double m);
 double orc_jacobi_cn(double u, double m);
 double orc_jacobi_dn(double u, double m);
 
+/* Legendre integrals through Carlson's and the Byrd & Friedman integrals on top (ref: src/sim5elliptic.c:255-1161) */
+double orc_elliptic_f_cos(double c, double m);
+double orc_elliptic_e_cos(double c, double m);
+double orc_elliptic_pi_complete(double n, double m);
+double orc_elliptic_pi_cos(double c, double n, double m);
+double orc_integral_C2(double u, double m);
+double orc_integral_C2_cos(double cn_u, double m);
+double orc_integral_Z1(double a, double b, double u, double m);
+double orc_integral_Z2(double a, double b, double u, double m);
+double orc_integral_Rm1(double a, double u, double m);
+double orc_integral_Rm2(double a, double u, double m);
+double orc_integral_R1(double a, double u, double m);
+double orc_integral_R2(double a, double u, double m);
+double orc_integral_R_r0_re(double a, double b, double c, double d, double X);
+double orc_integral_R_r0_re_inf(double a, double b, double c, double d);
+double orc_integral_R_r0_cc(double a, double b, orc_cplx c, double X);
+double orc_integral_R_r0_cc_inf(double a, double b, orc_cplx c);
+double orc_integral_R_r1_re(double a, double b, double c, double d, double X);
+double orc_integral_R_r1_cc(double a, double b, orc_cplx c, double X1, double X2);
+double orc_integral_R_r2_re(double a, double b, double c, double d, double X);
+double orc_integral_R_r2_cc(double a, double b, orc_cplx c, double X1, double X2);
+double orc_integral_R_rp_re(double a, double b, double c, double d, double p, double X);
+double orc_integral_R_rp_re_inf(double a, double b, double c, double d, double p);
+double orc_integral_R_rp_cc2(double a, double b, orc_cplx c, double p, double X1, double X2);
+double orc_integral_R_rp_cc2_inf(double a, double b, orc_cplx c, double p, double X1);
+double orc_integral_T_m0(double a2, double b2, double X);
+double orc_integral_T_m2(double a2, double b2, double X);
+double orc_integral_T_mp(double a2, double b2, double p, double X);
+
 /* --- Kerr spacetime (reference src/sim5kerr.c) ------------------------------------ */
 double orc_r_bh(double a);
 double orc_r_ms(double a);
@@ -116,6 +145,9 @@ double orc_geodesic_position_pol(const orc_geodesic *g, double P);
 double orc_geodesic_dm_sign(const orc_geodesic *g, double P);
 void   orc_geodesic_momentum(const orc_geodesic *g, double P, double r, double m, double k[4]);
 double orc_geodesic_find_midplane_crossing(const orc_geodesic *g, int order);
+/* azimuth and light-travel time (ref: src/sim5kerr-geod.c:463-664) */
+double orc_geodesic_position_azm(const orc_geodesic *g, double r, double m, double P);
+double orc_geodesic_timedelay(const orc_geodesic *g, double P1, double r1, double m1, double P2, double r2, double m2);
 void   orc_geodesic_follow(const orc_geodesic *g, double step, double *P, double *r,
                            double *m, int *status);
 

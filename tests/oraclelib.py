@@ -118,6 +118,24 @@ _COMMON = {
     "polarization_constant_infinity": (Cplx, [D, D, D, D]),
     "polarization_angle_rotation": (D, [D, D, D, D, Cplx]),
     "blackbody_Iv": (D, [D, D, D, D]),
+    # azimuth / light-travel time and the integrals below them (ref src/sim5elliptic.c:255-1161).
+    # A `sim5complex` (double _Complex) argument passed by value travels as two consecutive doubles
+    # (re, im) in the SysV x86-64 calling convention, which is how it is declared here.
+    "elliptic_f_cos": (D, [D, D]), "elliptic_e_cos": (D, [D, D]),
+    "elliptic_pi_complete": (D, [D, D]), "elliptic_pi_cos": (D, [D, D, D]),
+    "integral_C2": (D, [D, D]), "integral_C2_cos": (D, [D, D]),
+    "integral_Z1": (D, [D, D, D, D]), "integral_Z2": (D, [D, D, D, D]),
+    "integral_Rm1": (D, [D, D, D]), "integral_Rm2": (D, [D, D, D]),
+    "integral_R1": (D, [D, D, D]), "integral_R2": (D, [D, D, D]),
+    "integral_R_r0_re": (D, [D] * 5), "integral_R_r0_re_inf": (D, [D] * 4),
+    "integral_R_r1_re": (D, [D] * 5), "integral_R_r2_re": (D, [D] * 5),
+    "integral_R_rp_re": (D, [D] * 6), "integral_R_rp_re_inf": (D, [D] * 5),
+    "integral_R_r0_cc": (D, [D] * 5), "integral_R_r0_cc_inf": (D, [D] * 4),
+    "integral_R_r1_cc": (D, [D] * 6), "integral_R_r2_cc": (D, [D] * 6),
+    "integral_R_rp_cc2": (D, [D] * 7), "integral_R_rp_cc2_inf": (D, [D] * 6),
+    "integral_T_m0": (D, [D] * 3), "integral_T_m2": (D, [D] * 3), "integral_T_mp": (D, [D] * 4),
+    "geodesic_position_azm": (D, [PG, D, D, D]),
+    "geodesic_timedelay": (D, [PG, D, D, D, D, D, D]),
 }
 
 

@@ -86,6 +86,40 @@ def test_geodesic_records(oracle, golden):
     assert exact == nok, "only %d of %d records are byte-identical with the reference" % (exact, nok)
 
 
+AZM_FUNCS = ["elliptic_f_cos", "elliptic_e_cos", "elliptic_pi_complete", "elliptic_pi_cos", "integral_C2",
+             "integral_C2_cos", "integral_Z1", "integral_Z2", "integral_Rm1", "integral_Rm2", "integral_R1",
+             "integral_R2", "integral_R_r0_re", "integral_R_r0_re_inf", "integral_R_r1_re", "integral_R_r2_re",
+             "integral_R_rp_re", "integral_R_rp_re_inf", "integral_R_r0_cc", "integral_R_r0_cc_inf",
+             "integral_R_r1_cc", "integral_R_r2_cc", "integral_R_rp_cc2", "integral_R_rp_cc2_inf",
+             "integral_T_m0", "integral_T_m2", "integral_T_mp"]
+
+
+def test_azimuth_and_timedelay(oracle, golden):
+    """geodesic_position_azm, geodesic_timedelay and the 27 integrals under them."""
+    g = golden("kat_azimuth.npz")
+    for name in AZM_FUNCS:
+        fn = getattr(oracle, name)
+        close([fn(*row) for row in g["in_" + name]], g["out_" + name], what=name)
+    n = len(g["inp"])
+    phi = np.full(n, np.nan); dt_a = np.full(n, np.nan); dt_e = np.full(n, np.nan)
+    for i in range(n):
+        if g["gtype"][i] not in (40, 2):
+            continue
+        inc, a, al, be = g["inp"][i]
+        gd = ol.Geodesic(); e = C.c_int(-1)
+        assert oracle.geodesic_init_inf(inc, a, al, be, C.byref(gd), C.byref(e))
+        if not (math.isnan(g["r1"][i]) or math.isnan(g["m1"][i])):
+            phi[i] = oracle.geodesic_position_azm(C.byref(gd), g["r1"][i], g["m1"][i], g["P1"][i])
+        dt_a[i] = oracle.geodesic_timedelay(C.byref(gd), g["P1"][i], 0.0, 0.0, g["P2"][i], 0.0, 0.0)
+        if not (math.isnan(g["r1"][i]) or math.isnan(g["r2"][i])):
+            dt_e[i] = oracle.geodesic_timedelay(C.byref(gd), g["P1"][i], g["r1"][i], g["m1"][i],
+                                                g["P2"][i], g["r2"][i], g["m2"][i])
+    close(phi, g["phi"], what="position_azm")
+    close(dt_a, g["dt_auto"], what="timedelay (r, m from P)")
+    close(dt_e, g["dt_expl"], what="timedelay (explicit r, m)")
+    assert np.isfinite(g["phi"]).sum() > 2000 and np.isfinite(g["dt_auto"]).sum() > 2000
+
+
 def test_kerr(oracle, golden):
     g = golden("kat_kerr.npz")
     n = len(g["a"])
