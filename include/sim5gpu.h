@@ -202,6 +202,28 @@ int sim5gpu_on2bl(size_t n, const double *vin, double *vout, const sim5gpu_tetra
 int sim5gpu_elliptic(int which, size_t n, const double *x, const double *y, const double *z,
                      const double *w, double *out);
 
+/* geodesic_position_azm: change of azimuth between infinity and the point (r, m) at position integral P
+ * (ref src/sim5kerr-geod.c:463-556); NaN for RR_DBL / RR_BH / CC geodesics as in the reference.
+ * geodesic_timedelay: light-travel time between two points of a geodesic (ref :560-664; the reference
+ * evaluates the radial part, its polar part is commented out); r = 0 asks for r, m to be derived from P. */
+int sim5gpu_geodesic_position_azm(size_t n, const sim5gpu_geodesic *g, const double *r, const double *m,
+                                  const double *P, double *phi);
+int sim5gpu_geodesic_timedelay(size_t n, const sim5gpu_geodesic *g, const double *P1, const double *r1,
+                               const double *m1, const double *P2, const double *r2, const double *m2,
+                               double *dt);
+
+/* The integrals under them (ref src/sim5elliptic.c:255-1161).  args holds nargs rows of n values, one row
+ * per argument in the reference's order; a `sim5complex c` argument is two rows (re, im).  which:
+ *  0 elliptic_f_cos(c,m)        1 elliptic_e_cos(c,m)       2 elliptic_pi_complete(n,m)  3 elliptic_pi_cos(c,n,m)
+ *  4 integral_C2(u,m)           5 integral_C2_cos(cn,m)     6 integral_Z1(a,b,u,m)       7 integral_Z2(a,b,u,m)
+ *  8 integral_Rm1(a,u,m)        9 integral_Rm2(a,u,m)      10 integral_R1(a,u,m)        11 integral_R2(a,u,m)
+ * 12 integral_R_r0_re(a,b,c,d,X)         13 integral_R_r0_re_inf(a,b,c,d)      14 integral_R_r1_re(a,b,c,d,X)
+ * 15 integral_R_r2_re(a,b,c,d,X)         16 integral_R_rp_re(a,b,c,d,p,X)      17 integral_R_rp_re_inf(a,b,c,d,p)
+ * 18 integral_R_r0_cc(a,b,c,X)           19 integral_R_r0_cc_inf(a,b,c)        20 integral_R_r1_cc(a,b,c,X1,X2)
+ * 21 integral_R_r2_cc(a,b,c,X1,X2)       22 integral_R_rp_cc2(a,b,c,p,X1,X2)   23 integral_R_rp_cc2_inf(a,b,c,p,X1)
+ * 24 integral_T_m0(a2,b2,X)              25 integral_T_m2(a2,b2,X)             26 integral_T_mp(a2,b2,p,X) */
+int sim5gpu_integral(int which, size_t n, int nargs, const double *args, double *out);
+
 /* Novikov-Thorne disk (ref src/sim5disk-nt.c:37-146, 260-266).  As in SIM5 the disk model
  * is process-global state set once by disk_nt_setup; options must be 0 (mdot-parametrised). */
 int sim5gpu_disk_nt_setup(double M, double a, double mdot, double alpha, int options);

@@ -271,6 +271,44 @@ def geodesic_momentum(g, P, r=0.0, m=0.0):
     return k
 
 
+def geodesic_position_azm(g, r, m, P):
+    g, n = _geod(g)
+    r, m, P = _f64(r, n), _f64(m, n), _f64(P, n)
+    out = np.empty(n)
+    _check(_lib.sim5gpu_geodesic_position_azm(SZ(n), _p(g), _p(r), _p(m), _p(P), _p(out)),
+           "sim5gpu_geodesic_position_azm")
+    return out
+
+
+def geodesic_timedelay(g, P1, r1, m1, P2, r2, m2):
+    g, n = _geod(g)
+    P1, r1, m1, P2, r2, m2 = (_f64(v, n) for v in (P1, r1, m1, P2, r2, m2))
+    out = np.empty(n)
+    _check(_lib.sim5gpu_geodesic_timedelay(SZ(n), _p(g), _p(P1), _p(r1), _p(m1), _p(P2), _p(r2), _p(m2), _p(out)),
+           "sim5gpu_geodesic_timedelay")
+    return out
+
+
+INTEGRALS = ["elliptic_f_cos", "elliptic_e_cos", "elliptic_pi_complete", "elliptic_pi_cos", "integral_C2",
+             "integral_C2_cos", "integral_Z1", "integral_Z2", "integral_Rm1", "integral_Rm2", "integral_R1",
+             "integral_R2", "integral_R_r0_re", "integral_R_r0_re_inf", "integral_R_r1_re", "integral_R_r2_re",
+             "integral_R_rp_re", "integral_R_rp_re_inf", "integral_R_r0_cc", "integral_R_r0_cc_inf",
+             "integral_R_r1_cc", "integral_R_r2_cc", "integral_R_rp_cc2", "integral_R_rp_cc2_inf",
+             "integral_T_m0", "integral_T_m2", "integral_T_mp"]
+
+
+def integral(name, *args):
+    """One of the 27 Legendre / Byrd & Friedman integrals (reference argument order; a complex root is two
+    arguments re, im).  Arguments broadcast to a common length."""
+    cols = np.broadcast_arrays(*[np.asarray(a, dtype=np.float64).ravel() for a in args])
+    n = cols[0].size
+    packed = np.ascontiguousarray(np.stack(cols, axis=0))
+    out = np.empty(n)
+    _check(_lib.sim5gpu_integral(I(INTEGRALS.index(name)), SZ(n), I(len(cols)), _p(packed), _p(out)),
+           "sim5gpu_integral(%s)" % name)
+    return out
+
+
 def geodesic_follow(g, step, P, r, m):
     g, n = _geod(g)
     step = _f64(step, n)

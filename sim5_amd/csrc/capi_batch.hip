@@ -8,6 +8,7 @@
 #include "s5_disk.hpp"
 #include "s5_raytrace.hpp"
 #include "s5_polar.hpp"
+#include "s5_azimuth.hpp"
 
 namespace s5 {
 
@@ -447,6 +448,87 @@ int sim5gpu_elliptic(int which, size_t n, const double* x, const double* y, cons
         po[i] = v;
     });
     S5_HIP(dout.to_host(out));
+    return SIM5GPU_OK;
+}
+
+// Legendre / Byrd & Friedman integrals behind position_azm and timedelay: selector in the order of the
+// reference's definitions (see include/sim5gpu.h); args is nargs x n, one row per argument
+int sim5gpu_integral(int which, size_t n, int nargs, const double* args, double* out)
+{
+    static const int need[27] = { 2, 2, 2, 3, 2, 2, 4, 4, 3, 3, 3, 3, 5, 4, 5, 5, 6, 5, 5, 4, 6, 6, 7, 6, 3, 3, 4 };
+    S5_NEED("integral", args && out);
+    if (which < 0 || which > 26) { snprintf(g_err, sizeof g_err, "integral: unknown selector %d", which); return SIM5GPU_E_ARG; }
+    if (nargs != need[which]) { snprintf(g_err, sizeof g_err, "integral: selector %d takes %d arguments, got %d", which, need[which], nargs); return SIM5GPU_E_ARG; }
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(args, (size_t)nargs * n), dout(n);
+    S5_BUFS_OK("integral", da.ok() && dout.ok());
+    const double* pa = da.ptr; double* po = dout.ptr;
+    S5_RUN(n, "integral", [=] __device__(size_t i) {
+        double v[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        for (int k = 0; k < nargs; ++k) v[k] = pa[(size_t)k * n + i];
+        double r = 0.0;
+        switch (which) {                         // wave-uniform selector
+        case 0: r = ell_F_cos(v[0], v[1]); break;
+        case 1: r = ell_E_cos(v[0], v[1]); break;
+        case 2: r = ell_Pi_complete(v[0], v[1]); break;
+        case 3: r = ell_Pi_cos(v[0], v[1], v[2]); break;
+        case 4: r = int_C2(v[0], v[1]); break;
+        case 5: r = int_C2_cos(v[0], v[1]); break;
+        case 6: r = int_Z1(v[0], v[1], v[2], v[3]); break;
+        case 7: r = int_Z2(v[0], v[1], v[2], v[3]); break;
+        case 8: r = int_Rm1(v[0], v[1], v[2]); break;
+        case 9: r = int_Rm2(v[0], v[1], v[2]); break;
+        case 10: r = int_R1(v[0], v[1], v[2]); break;
+        case 11: r = int_R2(v[0], v[1], v[2]); break;
+        case 12: r = R_r0_re(v[0], v[1], v[2], v[3], v[4]); break;
+        case 13: r = R_r0_re_inf(v[0], v[1], v[2], v[3]); break;
+        case 14: r = R_r1_re(v[0], v[1], v[2], v[3], v[4]); break;
+        case 15: r = R_r2_re(v[0], v[1], v[2], v[3], v[4]); break;
+        case 16: r = R_rp_re(v[0], v[1], v[2], v[3], v[4], v[5], false); break;
+        case 17: r = R_rp_re(v[0], v[1], v[2], v[3], v[4], 0.0, true); break;
+        case 18: r = R_r0_cc(v[0], v[1], v[2], v[3], v[4]); break;
+        case 19: r = R_r0_cc_inf(v[0], v[1], v[2], v[3]); break;
+        case 20: r = R_r1_cc(v[0], v[1], v[2], v[3], v[4], v[5]); break;
+        case 21: r = R_r2_cc(v[0], v[1], v[2], v[3], v[4], v[5]); break;
+        case 22: r = R_rp_cc2(v[0], v[1], v[2], v[3], v[4], v[5], v[6], false); break;
+        case 23: r = R_rp_cc2(v[0], v[1], v[2], v[3], v[4], v[5], 0.0, true); break;
+        case 24: r = T_m0(v[0], v[1], v[2]); break;
+        case 25: r = T_m2(v[0], v[1], v[2]); break;
+        case 26: r = T_mp(v[0], v[1], v[2], v[3]); break;
+        }
+        po[i] = r;
+    });
+    S5_HIP(dout.to_host(out));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_geodesic_position_azm(size_t n, const sim5gpu_geodesic* g, const double* r, const double* m,
+                                  const double* P, double* phi)
+{
+    S5_NEED("geodesic_position_azm", g && r && m && P && phi);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Geod> dg((const Geod*)g, n); DevBuf<double> dr(r, n), dm(m, n), dP(P, n), dout(n);
+    S5_BUFS_OK("geodesic_position_azm", dg.ok() && dr.ok() && dm.ok() && dP.ok() && dout.ok());
+    const Geod* pg = dg.ptr; const double *pr = dr.ptr, *pm = dm.ptr, *pP = dP.ptr; double* po = dout.ptr;
+    S5_RUN(n, "geodesic_position_azm", [=] __device__(size_t i) { po[i] = position_azm(pg[i], pr[i], pm[i], pP[i]); });
+    S5_HIP(dout.to_host(phi));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_geodesic_timedelay(size_t n, const sim5gpu_geodesic* g, const double* P1, const double* r1,
+                               const double* m1, const double* P2, const double* r2, const double* m2, double* dt)
+{
+    S5_NEED("geodesic_timedelay", g && P1 && r1 && m1 && P2 && r2 && m2 && dt);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<Geod> dg((const Geod*)g, n); DevBuf<double> a1(P1, n), b1(r1, n), c1(m1, n), a2(P2, n), b2(r2, n), c2(m2, n), dout(n);
+    S5_BUFS_OK("geodesic_timedelay", dg.ok() && a1.ok() && b1.ok() && c1.ok() && a2.ok() && b2.ok() && c2.ok() && dout.ok());
+    const Geod* pg = dg.ptr; const double *q1 = a1.ptr, *s1 = b1.ptr, *t1 = c1.ptr, *q2 = a2.ptr, *s2 = b2.ptr, *t2 = c2.ptr;
+    double* po = dout.ptr;
+    S5_RUN(n, "geodesic_timedelay", [=] __device__(size_t i) { po[i] = timedelay(pg[i], q1[i], s1[i], t1[i], q2[i], s2[i], t2[i]); });
+    S5_HIP(dout.to_host(dt));
     return SIM5GPU_OK;
 }
 

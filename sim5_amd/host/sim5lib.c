@@ -69,6 +69,8 @@ typedef int (*fn_geod_P)(size_t, const geodesic *, const double *, double *);
 typedef int (*fn_geod_order)(size_t, const geodesic *, const int *, double *);
 typedef int (*fn_geod_Pint)(size_t, const geodesic *, const double *, const int *, double *);
 typedef int (*fn_geod_mom)(size_t, const geodesic *, const double *, const double *, const double *, double *);
+typedef int (*fn_geod_azm)(size_t, const geodesic *, const double *, const double *, const double *, double *);
+typedef int (*fn_geod_delay)(size_t, const geodesic *, const double *, const double *, const double *, const double *, const double *, const double *, double *);
 typedef int (*fn_geod_follow)(size_t, const geodesic *, const double *, double *, double *, double *, int *);
 typedef int (*fn_d1)(size_t, const double *, double *);
 typedef int (*fn_d2)(size_t, const double *, const double *, double *);
@@ -128,6 +130,24 @@ void geodesic_momentum(geodesic *g, double P, double r, double m, double k[])
 {
     S5_FN(fn_geod_mom, f, "sim5gpu_geodesic_momentum");
     s5_check(f(1, g, &P, &r, &m, k), "geodesic_momentum");
+}
+
+/* ref: src/sim5kerr-geod.c:463-556 */
+double geodesic_position_azm(geodesic *g, double r, double m, double P)
+{
+    S5_FN(fn_geod_azm, f, "sim5gpu_geodesic_position_azm");
+    double phi = NAN;
+    s5_check(f(1, g, &r, &m, &P, &phi), "geodesic_position_azm");
+    return phi;
+}
+
+/* ref: src/sim5kerr-geod.c:560-664 */
+double geodesic_timedelay(geodesic *g, double P1, double r1, double m1, double P2, double r2, double m2)
+{
+    S5_FN(fn_geod_delay, f, "sim5gpu_geodesic_timedelay");
+    double dt = NAN;
+    s5_check(f(1, g, &P1, &r1, &m1, &P2, &r2, &m2, &dt), "geodesic_timedelay");
+    return dt;
 }
 
 double geodesic_find_midplane_crossing(geodesic *g, int order)

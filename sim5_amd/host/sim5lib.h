@@ -112,6 +112,8 @@ double geodesic_position_rad(geodesic *g, double P);
 double geodesic_position_pol(geodesic *g, double P);
 double geodesic_dm_sign(geodesic *g, double P);
 void   geodesic_momentum(geodesic *g, double P, double r, double m, double k[]);
+double geodesic_position_azm(geodesic *g, double r, double m, double P);
+double geodesic_timedelay(geodesic *g, double P1, double r1, double m1, double P2, double r2, double m2);
 double geodesic_find_midplane_crossing(geodesic *g, int order);
 void   geodesic_follow(geodesic *g, double step, double *P, double *r, double *m, int *status);
 

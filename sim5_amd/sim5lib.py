@@ -257,6 +257,14 @@ def geodesic_dm_sign(g, P):
     return float(_c.geodesic_dm_sign(g._rec, P)[0])
 
 
+def geodesic_position_azm(g, r, m, P):
+    return float(_c.geodesic_position_azm(g._rec, r, m, P)[0])
+
+
+def geodesic_timedelay(g, P1, r1, m1, P2, r2, m2):
+    return float(_c.geodesic_timedelay(g._rec, P1, r1, m1, P2, r2, m2)[0])
+
+
 def geodesic_momentum(g, P, r, m, k):
     _arr(k)[:] = _c.geodesic_momentum(g._rec, P, r, m)[0]
 

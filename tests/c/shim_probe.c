@@ -54,5 +54,14 @@ int main(int argc, char **argv)
         }
         printf("# verlet steps %d r_end %.12g carter_err %.3e\n", n, x[1], raytrace_error(x, k, &rtd));
     }
+    /* azimuth and light-travel time along one ray (SIM5 scalar API) */
+    {
+        geodesic gd; int err;
+        geodesic_init_inf(inc, a, 6.0, 5.0, &gd, &err);
+        const double P1 = 0.6 * gd.Rpc, P2 = 1.4 * gd.Rpc;
+        const double r1 = geodesic_position_rad(&gd, P1), m1 = geodesic_position_pol(&gd, P1);
+        printf("# azm %.17g delay %.17g\n", geodesic_position_azm(&gd, r1, m1, P1),
+               geodesic_timedelay(&gd, P1, 0.0, 0.0, P2, 0.0, 0.0));
+    }
     return 0;
 }

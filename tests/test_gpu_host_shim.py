@@ -1,4 +1,5 @@
 """The SIM5 scalar API served by the GPU library (n = 1 batch calls), driven from C."""
+import ctypes as C
 import math
 import os
 import subprocess
@@ -36,8 +37,16 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     m = hit > 0
     assert_close(rec[m, 4], c["r"].ravel()[m], what="r"); assert_close(rec[m, 5], c["g"].ravel()[m], what="g")
     assert_close(rec[m, 6], c["flux"].ravel()[m], floor=1e-9 * c["flux"].max(), what="flux")
-    tail = lines[-1].split()
+    tail = lines[-2].split()
     assert tail[1] == "verlet" and int(tail[3]) > 100 and float(tail[7]) < 1e-2
+    # geodesic_position_azm / geodesic_timedelay through the scalar API against the CPU checker
+    tail = lines[-1].split()
+    gd = ol.Geodesic(); e = C.c_int(0)
+    assert orc.geodesic_init_inf(math.radians(inc), a, 6.0, 5.0, C.byref(gd), C.byref(e))
+    P1, P2 = 0.6 * gd.Rpc, 1.4 * gd.Rpc
+    r1 = orc.geodesic_position_rad(C.byref(gd), P1); m1 = orc.geodesic_position_pol(C.byref(gd), P1)
+    assert abs(float(tail[2]) / orc.geodesic_position_azm(C.byref(gd), r1, m1, P1) - 1) < 1e-9
+    assert abs(float(tail[4]) / orc.geodesic_timedelay(C.byref(gd), P1, 0.0, 0.0, P2, 0.0, 0.0) - 1) < 1e-9
 
 
 def test_batch_example_program(tmp_path, capi):
