@@ -6,12 +6,17 @@ include/sim5gpu.h.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step is one complete image.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
-the SAME image is sharded by 64-row stripes over the ranks (sim5_amd/sharding.py; one kernel launch
-per rank and image) and the finished tiles are gathered to rank 0 by ONE RCCL gather per image, inside
-the timed region; tile buffers are double-buffered so that the gather of image i overlaps the tracing
-of image i+1 (all gathers are complete before the clock stops).  Total work is fixed, so "scaling" is
-"strong" and `value` = 4096*4096*K / max-over-ranks time.
+A step is one complete image per GPU.  Rays are independent, so the path shards without any exchange
+(SURVEY.md 8(e)): with N > 1 (launched by torch.distributed.run, one rank per GPU) every rank traces its
+own complete 4096 x 4096 image -- the shape of a multi-image job such as the inclination scan of
+BASELINE.json configs[4], one image per GPU -- with NO collective on the data path; the images stay in the
+HBM of the GPU that made them.  Per-GPU work is fixed, so "scaling" is "weak" and
+`value` = N * 4096*4096*K / max-over-ranks time (barrier + synchronize on both sides of the timed region).
+
+`--mode stripes` times the other way to use N GPUs, ONE image sharded by 64-row stripes over the ranks
+(sim5_amd/sharding.py; one kernel launch per rank and image) and assembled on rank 0 by ONE RCCL gather
+per image inside the timed region (double-buffered, so the gather of image i overlaps the tracing of
+image i+1; all gathers complete before the clock stops): total work fixed, "scaling": "strong".
 
 Rank 0 prints one JSON line.  At N = 1 it also carries
   roofline:     FP64-VALU roofline of the image kernel.  achieved = W_ell (1.3e3 algorithmic FP64
@@ -72,6 +77,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["images", "stripes"], default="images",
+                    help="N > 1: one complete image per GPU, no collective (default) | one image in row stripes + gather")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,28 +110,47 @@ def main():
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream
     inc = INCL_DEG / 180.0 * math.pi
-    # One launch per rank and image: the rank's 64-row stripes (rank, rank+world, ...) in a single grid.
-    # Tile buffers are [2 planes (F g^4 | g), rows, NX] f32 = one contiguous gather payload; two of them
-    # so that the gather of image i (RCCL, its own stream) overlaps the tracing of image i+1.
-    if world == 1:
+    stripes = world > 1 and args.mode == "stripes"
+    if not stripes:
+        # one complete image per rank: [2 planes (F g^4 | g), NY, NX] f32, resident in this GPU's HBM
         desc = capi.image_desc(NX, NY, SPIN, inc)
+        image = torch.zeros((2, NY, NX), dtype=torch.float32, device=dev)
+
+        def trace(buf):
+            capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
+
+        def step(i):
+            trace(image)
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def last_image():
+            return image
     else:
+        # One launch per rank and image: the rank's 64-row stripes (rank, rank+world, ...) in a single grid.
+        # Tile buffers are [2 planes, rows, NX] f32 = one contiguous gather payload; two of them so that the
+        # gather of image i (RCCL, its own stream) overlaps the tracing of image i+1.
         desc = capi.image_desc(NX, NY, SPIN, inc, y0=rank * sharding.STRIPE, y1=NY,
                                stripe_rows=sharding.STRIPE, stripe_step=world * sharding.STRIPE)
-    assert capi.image_rows(desc) == sharding.local_rows(NY, rank, world)
-    pipe = sharding.TilePipeline(torch, dist, rank, world, NY, NX, dev)
+        assert capi.image_rows(desc) == sharding.local_rows(NY, rank, world)
+        pipe = sharding.TilePipeline(torch, dist, rank, world, NY, NX, dev)
 
-    def trace(buf):
-        capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
+        def trace(buf):
+            capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
 
-    def step(i):
-        pipe.step(trace)
+        def step(i):
+            pipe.step(lambda buf: trace(buf))
 
-    def fence():
-        pipe.drain()
-        if world > 1:
+        def fence():
+            pipe.drain()
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+
+        def last_image():
+            return pipe.last_image()
 
     for i in range(args.warmup):
         step(i)
@@ -132,7 +158,7 @@ def main():
     # HIP events around every kernel launch on rank 0 (on the stream the kernel is launched on)
     ev = [(capi.Event(), capi.Event()) for _ in range(args.steps)] if rank == 0 else None
     if ev:
-        def trace(buf, _i=[0]):                  # noqa: B006 -- the timed flavour of trace()
+        def trace(buf, _i=[0]):                  # noqa: B006,F811 -- the timed flavour of trace()
             a, b = ev[_i[0] % len(ev)]
             a.record(stream)
             capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
@@ -152,19 +178,22 @@ def main():
             dist.destroy_process_group()
         return
 
-    rays = NX * NY
+    rays = NX * NY * (1 if stripes or world == 1 else world)     # rays of one step of the whole job
     value = rays * args.steps / dt
     # sanity: the image that came out is the Kerr disk (known hit count of the reference)
-    img = pipe.last_image()
+    img = last_image()
     hits = int((img[1] > 0).sum().item())
     out = {
         "metric": "null geodesics/sec, 4096x4096 Kerr disk image (a=0.998, i=70)",
         "value": value, "unit": "null geodesics/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if stripes else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "4096x4096 thin-disk image, a=0.998, i=70deg, elliptic-integral path, "
                                "g-factor + Novikov-Thorne flux (BASELINE.json headline / configs[1] at 4096^2)",
-                   "rays_per_step": rays, "parallelism": "row-stripe x%d + 1 RCCL gather" % world if world > 1 else "1 GPU",
+                   "rays_per_step": rays,
+                   "parallelism": ("1 GPU" if world == 1 else
+                                   "row stripes x%d + 1 RCCL gather per image" % world if stripes else
+                                   "%d independent images, one per GPU, no collective" % world),
                    "disk_hits": hits, "disk_hits_reference": 15865362},
     }
     if ev:
