@@ -82,7 +82,15 @@ S5_DEV void flat_connection(double r, double m, Conn& G)                       /
 S5_DEV void kerr_connection(double a, double r, double m, Conn& G)             // ref :233-316
 {
     double rS = 2.0 * r;
+#if S5_FAST
+    // sin(theta) and 1/sin(theta) from one rsq seed (on the axis: 0 and inf, as sqrt and the division give)
+    const double om = 1. - m * m;
+    double s, inv_s;
+    sqrt_rsqrt_pos(om, s, inv_s);
+    if (om == 0.0) { s = 0.0; inv_s = INFINITY; }
+#else
     double s = msqrt(1. - m * m);
+#endif
     double cs = s * m;
     double c2 = m * m;
     double s2 = s * s;
@@ -103,11 +111,22 @@ S5_DEV void kerr_connection(double a, double r, double m, Conn& G)             /
     double R = Rq * Rq;
     double D = r2 - 2. * r + a2;
     double S = r2 + a2c2;
+#if S5_FAST
+    // the three reciprocals from one: 1/(S D R), then products (S, R > 0; D > 0 outside the horizon)
+    const double SD = S * D;
+    const double inv_all = mrcp(SD * R);
+    const double R_1 = SD * inv_all;
+    const double D_1 = (S * R) * inv_all;
+    const double S_1 = (D * R) * inv_all;
+    const double S_3 = S_1 * S_1 * S_1;
+    const double m_s = m * inv_s;
+#else
     double S_1 = mdiv(1., S);
     double S_3 = mdiv(1., S * S * S);
     double D_1 = mdiv(1., D);
     double R_1 = mdiv(1., R);
     double m_s = mdiv(m, s);
+#endif
     double DR_1 = D_1 * R_1;
     double DS_1 = D_1 * S_1;
     double dbl_r2 = 2. * r2;
