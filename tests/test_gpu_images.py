@@ -89,6 +89,22 @@ def test_matches_oracle_other_parameters(capi, strict):
         assert_close(o["flux"], c["flux"], floor=flux_floor(c["flux"]), what="flux")
 
 
+@VARIANTS
+def test_parameter_sweep(capi, strict):
+    """Corners of the parameter box (spin 0 and 1 - 1e-6, inclination 0.5 and 89.9 deg) plus a seeded random
+    sweep: class maps exact, r / g / flux within the bar, against the CPU oracle."""
+    rng = np.random.default_rng(11)
+    cfgs = [(0.0, 1.0), (0.0, 89.0), (0.999999, 89.9), (0.999999, 0.5), (1e-5, 45.0), (0.5, 5.0), (0.998, 85.0), (0.9999, 60.0)]
+    cfgs += [(float(rng.uniform(0, 0.9999)), float(rng.uniform(1, 89))) for _ in range(16)]
+    n = 160
+    for a, inc in cfgs:
+        c = ol.cpu_disk_image("port", n, n, a, inc, nthreads=4, full=True)
+        o = run(capi, n, a, inc, strict=strict)
+        assert np.array_equal(o["cls"], c["cls"]), (a, inc, int((o["cls"] != c["cls"]).sum()))
+        assert_close(o["r"], c["r"], what="r a=%g i=%g" % (a, inc)); assert_close(o["g"], c["g"], what="g a=%g i=%g" % (a, inc))
+        assert_close(o["flux"], c["flux"], floor=flux_floor(c["flux"]), what="flux a=%g i=%g" % (a, inc))
+
+
 def test_ragged_and_tile_shapes(capi):
     """Sizes that are not multiples of the 16x16 tile, single rows, non-square images."""
     base = run(capi, 100, 0.9, 60.0)
