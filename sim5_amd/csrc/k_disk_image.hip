@@ -56,8 +56,9 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
                                          // 8x8 1.701 ms, 16x4 1.700, 32x2 1.710, 64x1 1.750)
 #endif
 #ifndef S5_LB_WAVES
-#define S5_LB_WAVES 2                    // 187 VGPRs, no scratch.  Measured 1/2/3/4 waves per SIMD: 1.502/1.500/1.465/
-                                         // 1.487 ms, but 3 and 4 spill (144 B/lane scratch, 2.2 GB of HBM writes per launch)
+#define S5_LB_WAVES 2                    // a floor only: the kernel needs 111 VGPRs and 40 KB of LDS per workgroup
+                                         // (ladder rungs), so 4 waves/SIMD are resident.  Occupancy is not a lever:
+                                         // 4 -> 6 waves/SIMD (shorter ladder) 0.922 -> 0.915 ms; forcing 8 spills.
 #endif
 constexpr int TILE_W = S5_TILE_W;        // workgroup tile: TILE_W x (256 / TILE_W) pixels
 constexpr int TILE_H = 256 / TILE_W;

@@ -1,9 +1,11 @@
 // s5_thindisk.hpp -- one image-plane ray of the thin-disk problem, fused for the wave64 machine.
 //
-// Same arithmetic as geodesic_init_inf -> geodesic_find_midplane_crossing -> geodesic_position_rad
-// (s5_geod.hpp, i.e. ref: /root/reference/src/sim5kerr-geod.c:42-100, 846-885, 291-357) -- every value is
-// produced by the same expression and the same R_F / sncndn routines -- but arranged so that a wave
-// executes ONE copy of each expensive loop whatever mixture of geodesic classes its lanes hold:
+// Same algorithm as geodesic_init_inf -> geodesic_find_midplane_crossing -> geodesic_position_rad
+// (s5_geod.hpp, i.e. ref: /root/reference/src/sim5kerr-geod.c:42-100, 846-885, 291-357).  In the strict variant
+// every value is produced by the same expression and the same R_F / sncndn routines as there (bit-identical
+// results); the fast variant additionally uses algebraically equal, cheaper forms (#if S5_FAST blocks) and
+// agrees to rounding.  The routine is arranged so that a wave executes ONE copy of each expensive loop
+// whatever mixture of geodesic classes its lanes hold:
 //
 //  * the three or four Carlson R_F evaluations a ray needs (radial integral to the turning point, K(mm),
 //    cn^-1 of the observer's polar position, and for RC rays with a negative argument the second term of
@@ -16,6 +18,10 @@
 //    log forms, ref src/sim5elliptic.c:483-503) are flagged per lane and, if any lane of the wave has one,
 //    re-evaluated by the generic routine out of line -- they keep their exact semantics without costing
 //    registers or instruction-cache on the common path.
+//
+//  * a wave whose lanes all have the same class (the usual case: image neighbours) takes an instantiation of
+//    the second half of the routine with the class as a compile-time constant (thin_disk_finish<.., KNOWN>);
+//  * the Landen ladder keeps its rungs in LDS (sncndn_lds): 256-thread one-dimensional workgroups only.
 //
 // The per-ray state that callers need afterwards (polarization, tests) is returned in ThinRay.
 #pragma once
