@@ -157,7 +157,11 @@ S5_DEV void write_ray_end(const TorusParams& p, const TorusAux& aux, sim5gpu_sto
 // Finished rays are replaced from the global cursor (one atomic per wave and refill pass).  No inter-wave
 // communication: the pool, its tags and the batch list are private to the wave (LDS, 18 KB per wave).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int POOL_SLOTS = 128;
+#ifndef S5_POOL_SLOTS
+#define S5_POOL_SLOTS 128                // rays per wave pool, 65..128 (lane l owns slots l and l + 64)
+#endif
+constexpr int POOL_SLOTS = S5_POOL_SLOTS;
+static_assert(POOL_SLOTS > 64 && POOL_SLOTS <= 128 && POOL_SLOTS % 4 == 0, "pool size");
 #ifndef POOL_KEEP_NUM
 #define POOL_KEEP_NUM 7                   // ... while at least NUM/DEN of its lanes are still stepping
 #define POOL_KEEP_DEN 8
@@ -168,7 +172,7 @@ constexpr int POOL_SLOTS = 128;
 enum : int { PC_X0 = 0, PC_X1, PC_X2, PC_X3, PC_K0, PC_K1, PC_K2, PC_K3, PC_DK0, PC_DK1, PC_DK2, PC_DK3,
              PC_KT, PC_E, PC_I, PC_TAU, NPC };
 enum : int { TAG_EMPTY = 0, TAG_V = 1, TAG_R = 2 };
-constexpr int POOL_WAVE_BYTES = NPC * POOL_SLOTS * 8 + 3 * POOL_SLOTS * 4 + POOL_SLOTS + 128;
+constexpr int POOL_WAVE_BYTES = ((NPC * POOL_SLOTS * 8 + 3 * POOL_SLOTS * 4 + POOL_SLOTS + 64) + 15) / 16 * 16;
 
 S5_DEV void wave_lds_fence()
 {
@@ -197,7 +201,8 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
     const double* __restrict__ sc = start.d;
     const size_t scap = start.cap;
 
-    ptag[lane] = TAG_EMPTY; ptag[lane + 64] = TAG_EMPTY;
+    ptag[lane] = TAG_EMPTY;
+    if (lane + 64 < POOL_SLOTS) ptag[lane + 64] = TAG_EMPTY;
     bool drained = false;                                            // wave-uniform: the cursor ran past the last ray
 
     RayState s;
@@ -215,7 +220,7 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const int slot = lane + 64 * half;
-            const bool want = !drained && (ptag[slot] == TAG_EMPTY);
+            const bool want = !drained && (slot < POOL_SLOTS) && (ptag[slot < POOL_SLOTS ? slot : 0] == TAG_EMPTY);
             const unsigned long long idle = __builtin_amdgcn_ballot_w64(want);
             if (idle) {
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
@@ -256,7 +261,7 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
         wave_lds_fence();
 
         // ---- 2. what is in the pool ----
-        const int t0 = ptag[lane], t1 = ptag[lane + 64];
+        const int t0 = ptag[lane], t1 = (lane + 64 < POOL_SLOTS) ? ptag[lane + 64] : TAG_EMPTY;
         const unsigned long long v0 = __builtin_amdgcn_ballot_w64(t0 == TAG_V), v1 = __builtin_amdgcn_ballot_w64(t1 == TAG_V);
         const unsigned long long q0 = __builtin_amdgcn_ballot_w64(t0 == TAG_R), q1 = __builtin_amdgcn_ballot_w64(t1 == TAG_R);
         const int nV = __builtin_popcountll(v0) + __builtin_popcountll(v1);
