@@ -24,7 +24,7 @@ SOURCES = [("capi_core.hip", "capi_core.o", "strict"), ("capi_batch.hip", "capi_
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 # Both variants round products and sums separately (-ffp-contract=off), as the reference build does
-# (x86-64 baseline, no FMA).  Measured on MI355X (scratch/ablate.sh, 4096^2 headline image): letting
+# (x86-64 baseline, no FMA).  Measured on MI355X (tests/tools/ablate.sh, 4096^2 headline image): letting
 # the compiler contract changed neither the kernel time (1.74 vs 1.71 ms) nor the class map, but raised
 # the worst-pixel error of r from 6e-13 to 2.6e-7 and of g to 1.5e-6 (a cancellation near the horizon
 # that only agrees with the reference when rounded the reference's way), so contraction stays off.

@@ -40,7 +40,7 @@ S5_DEV double hfmac(double a, double b, double c)
 // sqrt for x known to be positive, finite and normal
 S5_DEV double sqrt_pos(double x)
 {
-    // seed accurate to 2^-24.2 (measured on gfx950, scratch/seedacc.hip); one coupled Goldschmidt step takes g
+    // seed accurate to 2^-24.2 (measured on gfx950, tests/tools/seedacc.hip); one coupled Goldschmidt step takes g
     // to ~4e-15, the residual step to < 1 ulp.  h only scales the residual, so the seed's accuracy is enough.
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_torus; rm -rf $OUT; mkdir -p $OUT
-B="python3 scratch/bench_torus.py"
+B="python3 tests/tools/bench_torus.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc1 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR -- $B > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc2 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_INSTS_FLAT -- $B > $OUT/pmc2.log 2>&1

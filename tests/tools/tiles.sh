@@ -1,9 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for cfg in "" "-DS5_KO_FLUX" "-DS5_KO_FLUX -DS5_KO_G" "-DS5_KO_FLUX -DS5_KO_G -DS5_KO_RAD" "-DS5_KO_FLUX -DS5_KO_G -DS5_KO_RAD -DS5_KO_RF"; do
-  rm -f sim5_amd/csrc/_build/*_fast.o
+for cfg in "-DS5_TILE_W=16" "-DS5_TILE_W=32" "-DS5_TILE_W=64" "-DS5_TILE_W=8"; do
+  rm -f sim5_amd/csrc/_build/k_disk_image_fast.o
   S5_FAST_EXTRA="$cfg" python sim5_amd/build.py > /dev/null 2>&1
   echo "=== fast with [$cfg]"
-  python scratch/dbg3.py
+  python tests/tools/dbg3.py
 done
 rm -f sim5_amd/csrc/_build/*_fast.o; python sim5_amd/build.py > /dev/null 2>&1
