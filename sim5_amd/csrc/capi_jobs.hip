@@ -60,7 +60,7 @@ size_t sim5gpu_disk_spectrum_workspace(const sim5gpu_image_desc* desc, int n_ene
     if (!desc || n_energies <= 0 || desc->nx <= 0) return 0;
     size_t nblocks;
     spectrum_grid(desc, nblocks);
-    return nblocks * (size_t)n_energies * sizeof(double);
+    return (nblocks + (nblocks + 63) / 64) * (size_t)n_energies * sizeof(double);      // partial rows + one tree level of scratch
 }
 
 int sim5gpu_disk_spectrum(const sim5gpu_image_desc* desc, int n_energies, const double* d_energies,

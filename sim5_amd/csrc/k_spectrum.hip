@@ -72,7 +72,22 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
             }
         }
     }
+#if S5_FAST
+    // per-pixel factors of the Planck expression, so that a (pixel, energy) pair costs one exp, one division
+    // and a few multiplications: x = E * sT, I_nu g^3 = sL * E^3 / (exp(x) - 1) with
+    //   sT = h kev2freq / (kB f T g),   sL = limbf 2 h kev2freq^4 / (c^2 f^4)   (g^3 from nu^3 cancels the g^3 weight)
+    {
+        const double planck_h = 6.626069e-27, kev2freq = 2.417990e+17, c2 = 8.987554e+20, kB = 1.380650e-16;
+        const bool on = (g > 0.0) && !(T < 1e2);                                 // ref py :76
+        const double f = sp.hardening;
+        const double xs = on ? mdiv(planck_h * kev2freq, kB * f * T * g) : 0.0;
+        const double amp = on ? limbf * mdiv(2.0 * planck_h * (kev2freq * kev2freq * kev2freq) * kev2freq, c2 * (f * f * f * f)) : 0.0;
+        // pixels that contribute nothing keep a harmless exponent (x = E) and amplitude 0: no branch below
+        sT[tid] = on ? xs : 1.0; sG[tid] = on ? 1.0 : 0.0; sL[tid] = amp;
+    }
+#else
     sT[tid] = T; sG[tid] = g; sL[tid] = limbf;
+#endif
     __syncthreads();
 
     // transposed phase: EB energy bins x (256 / EB) pixel sub-sets
@@ -84,6 +99,14 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
         double acc = 0.0;
         if (j < sp.n_energies) {
             const double E = energies[j];
+#if S5_FAST
+            const double E3 = E * E * E;
+            // x capped at 700: exp would overflow to inf, which the Newton division cannot take (the term is 0 to
+            // 300 digits there either way).  Unrolled so that the LDS broadcasts of several pixels are in flight.
+#pragma unroll 4
+            for (int q = grp; q < 256; q += groups)
+                acc += mdiv(sL[q] * E3, mexp(fmin(E * sT[q], 700.0)) - 1.0);
+#else
             for (int q = grp; q < 256; q += groups) {
                 const double gq = sG[q];
                 if (gq > 0.0) {
@@ -92,6 +115,7 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
                         acc += planck_python(Tq, sL[q], sp.hardening, mdiv(E, gq)) * (gq * gq * gq);
                 }
             }
+#endif
         }
         sAcc[tid] = acc;
         __syncthreads();
@@ -105,15 +129,19 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
     }
 }
 
+// one level of the (deterministic) tree sum over workgroup partials: row c of dst = sum of rows
+// [c * SPEC_FAN, (c + 1) * SPEC_FAN) of src, energies across the lanes (coalesced)
+constexpr int SPEC_FAN = 64;
 __global__ __launch_bounds__(256)
-void spectrum_reduce_kernel(const double* __restrict__ partial, size_t nblocks, int n_energies,
-                            double* __restrict__ spectrum)
+void spectrum_reduce_kernel(const double* __restrict__ src, size_t rows, int n_energies, double* __restrict__ dst)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n_energies) return;
+    const size_t r0 = (size_t)blockIdx.y * SPEC_FAN;
+    const size_t r1 = (r0 + SPEC_FAN < rows) ? r0 + SPEC_FAN : rows;
     double tot = 0.0;
-    for (size_t b = 0; b < nblocks; ++b) tot += partial[b * (size_t)n_energies + j];
-    spectrum[j] = tot;
+    for (size_t b = r0; b < r1; ++b) tot += src[b * (size_t)n_energies + j];
+    dst[(size_t)blockIdx.y * n_energies + j] = tot;
 }
 
 } // namespace S5NS
@@ -131,8 +159,20 @@ int s5_launch_disk_spectrum_strict(const s5abi::ImageParams& p, const s5abi::Spe
     hipLaunchKernelGGL(disk_spectrum_kernel, grid, dim3(256), 0, stream, p, sp, energies, partial);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    // tree sum, fan-in 64 per level, ping-pong between the partial rows and the scratch rows behind them
+    // (workspace = (nblocks + ceil(nblocks / 64)) rows); the last level writes the spectrum
     const size_t nblocks = (size_t)grid.x * grid.y;
-    hipLaunchKernelGGL(spectrum_reduce_kernel, dim3((sp.n_energies + 255) / 256), dim3(256), 0, stream,
-                       partial, nblocks, sp.n_energies, spectrum);
-    return (int)hipGetLastError();
+    double* bufs[2] = { partial, partial + nblocks * (size_t)sp.n_energies };
+    size_t rows = nblocks;
+    int cur = 0;
+    for (;;) {
+        const size_t out_rows = (rows + SPEC_FAN - 1) / SPEC_FAN;
+        double* dst = (out_rows == 1) ? spectrum : bufs[cur ^ 1];
+        hipLaunchKernelGGL(spectrum_reduce_kernel, dim3((sp.n_energies + 255) / 256, (unsigned)out_rows), dim3(256), 0, stream,
+                           bufs[cur], rows, sp.n_energies, dst);
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        if (out_rows == 1) break;
+        rows = out_rows; cur ^= 1;
+    }
+    return 0;
 }
