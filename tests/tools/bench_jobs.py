@@ -39,3 +39,19 @@ dE=capi.DeviceBuffer(E.nbytes); dS=capi.DeviceBuffer(E.nbytes); ws=capi.DeviceBu
 fn=lambda: capi._check(capi._lib.sim5gpu_disk_spectrum(C.byref(d), capi.I(E.size), capi.VP(dE.ptr), capi.D(1.7), capi.I(1), capi.VP(dS.ptr), capi.VP(ws.ptr), capi.VP(0)),"spec")
 ms=timeit(fn, reps=5)
 print("spectrum 1024^2 x 128 energies: %.3f ms  %.3e rays/s  %.3e (ray,energy) pairs/s"%(ms, n*n/ms*1e3, n*n*128/ms*1e3))
+# surface search (thick disk H(R) = 0.25 (R - 2), 256-point table), 1024^2 rays
+import ctypes as C
+n=1024; a=0.9; inc=70/180*math.pi
+rmax=20.0
+ax=((np.arange(n)+.5)/n-.5)*2*rmax
+al,be=np.meshgrid(ax,ax); al=al.ravel().copy(); be=be.ravel().copy()
+tR=np.linspace(2.0,60.0,256); tH=0.25*(tR-2.0)
+N=al.size
+b={k:capi.DeviceBuffer(v.nbytes) for k,v in (("tR",tR),("tH",tH),("al",al),("be",be))}
+for k,v in (("tR",tR),("tH",tH),("al",al),("be",be)): b[k].from_numpy(v)
+o={k:capi.DeviceBuffer(N*s) for k,s in (("P",8),("r",8),("m",8),("k",32),("st",4))}
+for strict in (0,1):
+    fn=lambda: capi._check(capi._lib.sim5gpu_disk_surface_rays(capi.D(a),capi.D(inc),capi.I(tR.size),capi.VP(b["tR"].ptr),capi.VP(b["tH"].ptr),capi.SZ(N),capi.VP(b["al"].ptr),capi.VP(b["be"].ptr),capi.VP(o["P"].ptr),capi.VP(o["r"].ptr),capi.VP(o["m"].ptr),capi.VP(o["k"].ptr),capi.VP(o["st"].ptr),capi.I(strict),capi.VP(0)),"surf")
+    ms=timeit(fn,reps=3)
+    st=o["st"].to_numpy(np.int32,(N,))
+    print("surface search 1024^2 %s: %.3f ms  %.3e rays/s  hits %d"%("strict" if strict else "fast",ms,N/ms*1e3,int((st==1).sum())))
