@@ -326,9 +326,18 @@ S5_DEV double omega_from_ell(double ell, const Metric& g)                       
 
 S5_DEV double gfactor_kepler(double r, double a, double l)                                // ref :1128-1141
 {
+#if S5_FAST
+    // Omega_K = 1/(a + r^1.5) and 2/r from one reciprocal
+    const double den = a + r * msqrt(r);
+    const double t = mrcp(den * r);
+    const double Om = r * t;
+    const double w = 1. - a * Om;
+    return mdiv(msqrt(1. - (2. * den * t) * (w * w) - (r * r + a * a) * (Om * Om)), 1. - Om * l);
+#else
     double Om = mdiv(1., a + r * msqrt(r));
     double w = 1. - a * Om;
     return mdiv(msqrt(1. - mdiv(2., r) * (w * w) - (r * r + a * a) * (Om * Om)), 1. - Om * l);
+#endif
 }
 
 S5_DEV void photon_momentum(double a, double r, double m, double l, double q,

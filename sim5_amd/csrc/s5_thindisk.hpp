@@ -163,11 +163,13 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
     // Rpc = pre * inverse-Jacobi(zR | mR); sqAB is reused by r(P)
     double mR, zR, pre, sqAB, rp;
     if (type == T_RR || type == T_RR_DBL) {
-        mR = mdiv((rb - rc_) * (ra - rd_), (rb - rd_) * (ra - rc_));
 #if S5_FAST
+        // 1/sqAB also gives the denominator of the modulus: 1/((ra-rc)(rb-rd)) = (1/sqAB)^2
         sqrt_rsqrt_pos((ra - rc_) * (rb - rd_), sqAB, pre);
+        mR = ((rb - rc_) * (ra - rd_)) * (pre * pre);
         pre = pre + pre;
 #else
+        mR = mdiv((rb - rc_) * (ra - rd_), (rb - rd_) * (ra - rc_));
         sqAB = msqrt((ra - rc_) * (rb - rd_));
         pre = mdiv(2., sqAB);
 #endif
@@ -218,12 +220,17 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
     if (err == GD_OK) {
         if ((m2p <= 0.0) || (m2p >= 1.0)) err = GD_E_MUPLUS;
         else if (q > 0.0) {
+#if S5_FAST
+            // mK = 1/sqrt(a^2 (m2p + m2m)) first; the modulus m2p/(m2p + m2m) is then m2p a^2 mK^2
+            const double rk = rsqrt_pos(a2 * (m2p + m2m));
+            mmT = (m2p * a2) * (rk * rk);
+            if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
+            else if (fabs(p.cos_i) > s_m2p) err = GD_E_MU0;
+            else mK = rk;
+#else
             mmT = mdiv(m2p, m2p + m2m);
             if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
             else if (fabs(p.cos_i) > s_m2p) err = GD_E_MU0;
-#if S5_FAST
-            else mK = rsqrt_pos(a2 * (m2p + m2m));
-#else
             else mK = mdiv(1., msqrt(a2 * (m2p + m2m)));
 #endif
         } else if (q < 0.0) {
