@@ -178,10 +178,11 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
     } else if (type == T_RC) {
         const double Aq = msqrt(sq(ra - rc_) + sq(rd_));
         const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
-        mR = mdiv(sq(Aq + Bq) - sq(ra - rb), 4. * Aq * Bq);
 #if S5_FAST
         sqrt_rsqrt_pos(Aq * Bq, sqAB, pre);
+        mR = (sq(Aq + Bq) - sq(ra - rb)) * (0.25 * (pre * pre));       // 1/(A B) = (1/sqrt(A B))^2
 #else
+        mR = mdiv(sq(Aq + Bq) - sq(ra - rb), 4. * Aq * Bq);
         sqAB = msqrt(Aq * Bq);
         pre = mdiv(1., sqAB);
 #endif
