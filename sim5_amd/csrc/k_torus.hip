@@ -19,6 +19,7 @@
 // with k normalised to k_t = -1 at infinity the local photon energy is -k.U = 1/g, the proper length
 // of a step of affine size dl is dl/g, and per accepted step
 //      dtau = absorb0 * rho * dl / g,     dI = g^4 * emis0 * rho * exp(-tau) * dl / g .
+#include <mutex>
 #include "s5_disk.hpp"
 #include "s5_raytrace.hpp"
 #include "k_torus.hpp"
@@ -125,7 +126,7 @@ S5_DEV void accumulate_transfer(const TorusParams& p, const RayState& s, const d
     tau += p.absorb0 * rho * ds;
 }
 
-S5_DEV void write_ray_end(const TorusParams& p, const TorusAux& aux, sim5gpu_stokes* __restrict__ out, size_t ray,
+S5_DEV void write_ray_end(const TorusAux& aux, sim5gpu_stokes* __restrict__ out, size_t ray,
                           const double x[4], const double k[4], const RayState& s, double I, double tau, float worst)
 {
     sim5gpu_stokes rec = { I, 0.0, 0.0, 0.0, tau };
@@ -341,7 +342,7 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
                                           (s.pass >= p.max_steps);
                         if (done) {
                             s.Q = sc[COL_Q * scap + ray];
-                            write_ray_end(p, aux, out, ray, x, k, s, I, tau, worst);
+                            write_ray_end(aux, out, ray, x, k, s, I, tau, worst);
                             tag = TAG_EMPTY; on = false;
                         }
                     }
@@ -376,6 +377,7 @@ struct TorusWorkspace {
     bool used = false;
 };
 static TorusWorkspace g_ws;
+static std::mutex g_ws_lock;       // jobs from several host threads take turns at the shared workspace
 
 #if S5_FAST
 int launch_torus_fast(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream)
@@ -383,6 +385,7 @@ int launch_torus_fast(const TorusParams& p, sim5gpu_stokes* out, const TorusAux&
 int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAux& aux, hipStream_t stream)
 #endif
 {
+    std::lock_guard<std::mutex> hold(g_ws_lock);
     const size_t n = p.nrays;
     if (n > 0x7ffffff0ull) return (int)hipErrorInvalidValue;            // ray numbers are kept as int in the pool
     const size_t dcol_bytes = (sizeof(double) * NCOL * n + 255) & ~size_t(255);
