@@ -6,11 +6,12 @@
 // i.e. the body of the caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105,
 // for up to max_order crossings, and writes (float)(F g^4) and (float)g.
 //
-// Launch geometry: a 256-thread workgroup covers a 32 x 8 pixel tile, each wave64 a 32 x 2
+// Launch geometry: a 256-thread workgroup covers a 16 x 16 pixel tile, each wave64 a 16 x 4
 // patch of it.  Rays of a wave are image-plane neighbours, so they share the geodesic class and
-// the Carlson trip counts almost always (measured lane utilisation 98 %); each wave row stores 32
-// consecutive f32 = one whole 128-B line per plane.  No input is read in grid mode (alpha, beta follow from the pixel index,
-// ref disk-image.c:57-58); in list mode alpha[]/beta[] are read coalesced, 8 B per lane.
+// the Carlson trip counts almost always (measured lane utilisation 98 %); each wave row stores 16
+// consecutive f32 = half a 128-B line per plane, the workgroup whole lines.  No input is read in grid mode
+// (alpha, beta follow from the pixel index, ref disk-image.c:57-58); in list mode alpha[]/beta[] are read
+// coalesced, 8 B per lane.
 #include "s5_thindisk.hpp"
 #include "kernels.hpp"
 
@@ -51,9 +52,10 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
 }
 
 #ifndef S5_TILE_W
-#define S5_TILE_W 32                     // pixels per wave row: a wave covers 32 x 2 pixels, i.e. each of its
-                                         // f32 stores fills two whole 128-B lines (measured on MI355X, 4096^2:
-                                         // 8x8 1.701 ms, 16x4 1.700, 32x2 1.710, 64x1 1.750)
+#define S5_TILE_W 16                     // pixels per wave row: a wave covers 16 x 4 pixels (64-B store segments).
+                                         // Compact patches keep more waves class-uniform (s5_thindisk.hpp); measured
+                                         // on MI355X, 4096^2, same box: 8x8 0.903 ms, 16x4 0.890, 32x2 0.901-0.906,
+                                         // 64x1 0.909
 #endif
 #ifndef S5_LB_WAVES
 #define S5_LB_WAVES 2                    // a floor only: the kernel needs 111 VGPRs and 40 KB of LDS per workgroup
