@@ -90,6 +90,33 @@ def test_position_azm_and_timedelay(capi, golden):
         assert np.isnan(capi.geodesic_position_azm(rec[bad], np.full(bad.sum(), 5.0), np.zeros(bad.sum()), np.ones(bad.sum()))).all()
 
 
+def test_position_azm_timedelay_random_vs_oracle(capi, oracle):
+    """Beyond the golden set: 4000 seeded geodesics, GPU batch calls against the CPU oracle on the same inputs."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    n = 4000
+    inc = np.radians(rng.uniform(3, 87, n)); a = rng.choice([0.0, 0.2, 0.7, 0.95, 0.998], n)
+    rad = 14.0 * rng.random(n) ** 1.5; ang = rng.uniform(0, 2 * np.pi, n)
+    al, be = rad * np.cos(ang), rad * np.sin(ang)
+    rec, err, ok = capi.geodesic_init_inf(inc, a, al, be)
+    use = (ok == 1) & np.isin(rec["type"], (40, 2))
+    rec = rec[use]; m = int(use.sum())
+    hi = np.where(rec["type"] == 40, 2.0 * rec["Rpc"], rec["Rpc"])
+    P1 = hi * (0.02 + 0.95 * rng.random(m)); P2 = hi * (0.02 + 0.95 * rng.random(m))
+    r1 = capi.geodesic_position_rad(rec, P1); m1 = capi.geodesic_position_pol(rec, P1)
+    phi = capi.geodesic_position_azm(rec, r1, m1, P1)
+    z = np.zeros(m)
+    dt = capi.geodesic_timedelay(rec, P1, z, z, P2, z, z)
+    ref_phi = np.empty(m); ref_dt = np.empty(m)
+    for i in range(m):
+        g = ol.Geodesic.from_buffer_copy(rec[i].tobytes())
+        ref_phi[i] = oracle.geodesic_position_azm(C.byref(g), r1[i], m1[i], P1[i])
+        ref_dt[i] = oracle.geodesic_timedelay(C.byref(g), P1[i], 0.0, 0.0, P2[i], 0.0, 0.0)
+    assert m > 3000
+    assert_close(phi, ref_phi, floor=1e-3, what="position_azm vs oracle")
+    assert_close(dt, ref_dt, floor=1e-3, what="timedelay vs oracle")
+
+
 def test_kerr(capi, golden):
     g = golden("kat_kerr.npz")
     a, r, m = g["a"], g["r"], g["m"]
