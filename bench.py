@@ -97,11 +97,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    # test hook: SIM5_BENCH_ONE_GPU=1 runs all ranks on GPU 0 over gloo, to exercise the N > 1 control flow on a
+    # one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    one_gpu_test = os.environ.get("SIM5_BENCH_ONE_GPU") == "1"
+    if one_gpu_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     from sim5_amd.build import build
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         build()                             # no-op when the in-tree library is up to date
     if world > 1:
@@ -173,7 +181,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
