@@ -122,6 +122,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     inc = INCL_DEG / 180.0 * math.pi
     stripes = world > 1 and args.mode == "stripes"
+    if stripes and one_gpu_test:
+        sys.exit("bench.py: the one-GPU test hook covers --mode images only (gloo cannot gather device tensors asynchronously)")
     if not stripes:
         # one complete image per rank: [2 planes (F g^4 | g), NY, NX] f32, resident in this GPU's HBM
         desc = capi.image_desc(NX, NY, SPIN, inc)
