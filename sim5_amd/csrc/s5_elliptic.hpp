@@ -29,11 +29,17 @@ namespace S5NS {
 //  * lanes stop individually (their result is a function of their own arguments only, whatever the
 //    neighbours in the wave are); the wave leaves the loop when its last lane has converged.
 // ---------------------------------------------------------------------------------------
-S5_DEV double carlson_rf(double x, double y, double z)
+// CHECKED = false: the caller guarantees x, y, z > 0 for every lane whose result it uses (other lanes may carry
+// anything: NaN stops a lane's loop at once, its result is discarded by the caller)
+template <bool CHECKED>
+S5_DEV double carlson_rf_impl(double x, double y, double z)
 {
     const double tol = 0.03, third = 1.0 / 3.0;
-    const bool bad = !(x >= 0.0) || !(y >= 0.0) || !(z >= 0.0);     // sqrt of a negative / NaN -> NaN
-    x = fmax(x, 1e-300); y = fmax(y, 1e-300); z = fmax(z, 1e-300);  // at most one argument may be 0
+    bool bad = false;
+    if (CHECKED) {
+        bad = !(x >= 0.0) || !(y >= 0.0) || !(z >= 0.0);               // sqrt of a negative / NaN -> NaN
+        x = fmax(x, 1e-300); y = fmax(y, 1e-300); z = fmax(z, 1e-300);  // at most one argument may be 0
+    }
     const double A0 = third * (x + y + z);
     const double dx0 = A0 - x, dy0 = A0 - y;
     const double dev = max3abs(dx0, dy0, A0 - z);
@@ -65,8 +71,10 @@ S5_DEV double carlson_rf(double x, double y, double z)
     const double sx = hfma(E2, hfma(E2, -35.0 / 608.0, 1.0 / 16.0), hfma(E3, -15.0 / 272.0, -3.0 / 44.0)); // x E2 E3
     const double ser = hfma(E2, hfma(E3, sx, s2), hfmac(E3, s3, 1.0));
     const double res = ser * pw * sqrt_pos(rA);     // A_n^-1/2 = 2^n (4^n A_n)^-1/2
-    return bad ? NAN : res;
+    return (CHECKED && bad) ? NAN : res;
 }
+S5_DEV double carlson_rf(double x, double y, double z) { return carlson_rf_impl<true>(x, y, z); }
+S5_DEV double carlson_rf_positive(double x, double y, double z) { return carlson_rf_impl<false>(x, y, z); }
 #else
 // ---------------------------------------------------------------------------------------
 // R_F(x,y,z) by the duplication theorem, tolerance 3e-4 and 5th-order series as the reference.
@@ -95,6 +103,7 @@ S5_DEV double carlson_rf(double x, double y, double z)
     double e3 = dx * dy * dz;
     return (1.0 + ((1.0 / 24.0) * e2 - 0.1 - (3.0 / 44.0) * e3) * e2 + (1.0 / 14.0) * e3) / sqrt(mu);
 }
+S5_DEV double carlson_rf_positive(double x, double y, double z) { return carlson_rf(x, y, z); }
 
 #endif
 

@@ -288,7 +288,8 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
 #ifdef S5_KO_RF                  // diagnostic knock-outs: timing-breakdown builds only, never shipped
         const double v = mult * (1.5 + 0.1 * x + 0.01 * y);
 #else
-        const double v = mult * carlson_rf(x, y, 1.0);
+        // plain lanes have x, y > 0 by construction (z^2 < 1, moduli in [0,1)); the others are redone out of line
+        const double v = mult * carlson_rf_positive(x, y, 1.0);
 #endif
         if (slot == 0) res0 = v; else if (slot == 1) res1 = v; else if (slot == 2) res2 = v; else res3 = v;
     }
