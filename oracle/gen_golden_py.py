@@ -142,6 +142,18 @@ def main():
                 w = (R - tR[lo]) / (tR[hi] - tR[lo])
                 return float(tH[lo] + w * (tH[hi] - tH[lo]))
 
+            # the rest of what image() asks of a model (python/sim5diskraytrace.py:176-179, 340-348): slope of
+            # the same piecewise-linear surface, Novikov-Thorne flux and angular momentum of the reference
+            # library (disk_nt_setup is called per case below), a slow radial inflow
+            def dhdr(self, R):
+                if not (R > tR[0]): return 0.0
+                if R >= tR[-1]: return float(tH[-1] / tR[-1])
+                hi = int(np.searchsorted(tR, R, side="left")); lo = hi - 1
+                return float((tH[hi] - tH[lo]) / (tR[hi] - tR[lo]))
+            def flux(self, R): return ref.disk_nt_flux(R)
+            def l(self, R): return ref.disk_nt_ell(R)
+            def vr(self, R): return -0.05 / math.sqrt(R) if R > 1.0 else 0.0
+
         out["surf_R"] = tR; out["surf_H"] = tH
         scases = [(a, inc) for a in (0.5, 0.9) for inc in (30.0, 60.0, 80.0)]
         out["surf_cases"] = np.array(scases)
@@ -158,6 +170,11 @@ def main():
                     rr[j], mm[j], ok[j] = r, m, 1
                     kk[j] = [k[0], k[1], k[2], k[3]]
             out["surf%d_r" % ci] = rr; out["surf%d_m" % ci] = mm; out["surf%d_ok" % ci] = ok; out["surf%d_k" % ci] = kk
+            # DiskRaytrace.image() of the thick disk (python/sim5diskraytrace.py:138-210; non-flat branch :176)
+            ref.disk_nt_setup(10.0, a, 0.1, 0.1, 0)
+            timg = rt.image(inc, rmax_s, Ns)
+            for kq, v in timg.items():
+                out["thk%d_%s" % (ci, kq)] = np.array(v, dtype=np.float64)
     finally:
         os.dup2(saved, 2)
     path = os.path.join(ROOT, "tests", "golden", "py_diskraytrace.npz")

@@ -6,7 +6,7 @@ DiskModel_ThinDisk :70-96).
 Same class and method names, same returned quantities, but every SIM5 call is made ONCE for all rays of
 the image through the batch entry points of the C-ABI (sim5_amd/capi.py) instead of once per pixel
 through SWIG; the surface search for geometrically thick disks is one kernel (sim5gpu_disk_surface_rays).
-image() is implemented for flat disks.
+image() covers flat disks and disks with a tabulated photosphere H(R).
 """
 import math
 
@@ -43,6 +43,39 @@ class DiskModel_ThinDisk:
 
     def dhdr(self, R):
         return np.zeros(np.shape(np.atleast_1d(R)))
+
+
+class DiskModel_Surface(DiskModel_ThinDisk):
+    """A disk with a geometrically thick photosphere given as a table H(R) (R ascending): linear interpolation,
+    H[0] below the table, constant opening angle beyond it -- the definition the surface-search kernel uses.
+    Flux and angular momentum are the Novikov-Thorne ones; `vr` is an optional callable of R.  A model with
+    other profiles derives from this class and overrides flux / l / vr (they receive arrays)."""
+
+    def __init__(self, bh_mass, bh_spin, mdot, alpha, table_R, table_H, vr=None):
+        super().__init__(bh_mass, bh_spin, mdot, alpha)
+        self.name = "tabulated surface"
+        self.tR = np.ascontiguousarray(table_R, dtype=np.float64)
+        self.tH = np.ascontiguousarray(table_H, dtype=np.float64)
+        self._vr = vr
+
+    def surface_table(self):
+        return self.tR, self.tH
+
+    def h(self, R):
+        R = np.atleast_1d(np.asarray(R, dtype=np.float64))
+        inner = np.interp(R, self.tR, self.tH)                   # clamps to H[0] below the table
+        return np.where(R >= self.tR[-1], self.tH[-1] * (R / self.tR[-1]), inner)
+
+    def dhdr(self, R):
+        R = np.atleast_1d(np.asarray(R, dtype=np.float64))
+        hi = np.clip(np.searchsorted(self.tR, R, side="left"), 1, self.tR.size - 1)
+        slope = (self.tH[hi] - self.tH[hi - 1]) / (self.tR[hi] - self.tR[hi - 1])
+        slope = np.where(R > self.tR[0], slope, 0.0)
+        return np.where(R >= self.tR[-1], self.tH[-1] / self.tR[-1], slope)
+
+    def vr(self, R):
+        R = np.atleast_1d(np.asarray(R, dtype=np.float64))
+        return np.zeros(R.shape) if self._vr is None else np.asarray(self._vr(R), dtype=np.float64)
 
 
 class DiskRaytrace:
@@ -113,7 +146,8 @@ class DiskRaytrace:
         c = ((np.arange(N) + .5) / N - 0.5) * 2.0 * rmax
         alpha = np.tile(c, N); beta = np.repeat(c, N)
         dOmega = (2.0 * rmax / N) ** 2 / ((self.bh_mass * grav_radius) / (self.bh_dist * parsec * 1e3)) ** 2
-        geo = self.geodesic(incl, alpha, beta, flat=True)
+        flat = bool(np.all(np.asarray(self.disk.h(1e5)) == 0.0))         # ref :176
+        geo = self.geodesic(incl, alpha, beta, flat=flat)
         out = {k: np.full(N * N, np.nan) for k in ("flux", "gfactor", "mue", "T", "R", "H", "V")}
         sel = geo["ok"].copy()
         r, m = geo["r"], geo["m"]
@@ -133,8 +167,8 @@ class DiskRaytrace:
             out["flux"][idx] = (F[sel] * g ** 4 * l * dOmega)[keep]
             out["gfactor"][idx] = g[keep]
             out["mue"][idx] = np.degrees(np.arccos(e[keep]))
-            out["T"][idx] = (F[sel][keep] / 5.670400e-05) ** 0.25
+            out["T"][idx] = np.asarray(self.disk.t_eff(R[sel]))[keep]
             out["R"][idx] = R[sel][keep]
             out["H"][idx] = (r * m)[sel][keep]
-            out["V"][idx] = 0.0
+            out["V"][idx] = np.asarray(self.disk.vr(R[sel]))[keep]
         return {k: v.reshape(N, N) for k, v in out.items()}

@@ -142,3 +142,25 @@ def test_thick_disk_surface_search(golden, capi, strict):
         R = s["r"][ok] * np.sqrt(1 - s["m"][ok] ** 2); H = s["r"][ok] * s["m"][ok]
         Hd = np.interp(R, g["surf_R"], g["surf_H"])
         assert np.max(np.abs(H - Hd)) < 2e-2
+
+
+@pytest.mark.gpu
+def test_thick_disk_image(golden, capi):
+    """DiskRaytrace.image() for a disk with a tabulated photosphere (surface search kernel + surface tetrad,
+    g-factor and emission angle through the batch calls) against the reference's own Python class run on the
+    same model (oracle/gen_golden_py.py: H(R) table, Novikov-Thorne flux and ell, vr = -0.05/sqrt(R))."""
+    from sim5_amd.diskraytrace import DiskModel_Surface, DiskRaytrace
+    g = golden("py_diskraytrace.npz")
+    Ns, rmax = 12, 30.0
+    for ci, (a, inc) in enumerate(g["surf_cases"]):
+        disk = DiskModel_Surface(10.0, float(a), 0.1, 0.1, g["surf_R"], g["surf_H"],
+                                 vr=lambda R: np.where(R > 1.0, -0.05 / np.sqrt(np.maximum(R, 1e-300)), 0.0))
+        img = DiskRaytrace(10.0, float(a), 10.0, disk).image(float(inc), rmax, Ns)
+        ref = {k: g["thk%d_%s" % (ci, k)] for k in ("flux", "gfactor", "mue", "T", "R", "H", "V")}
+        have = np.isfinite(ref["flux"])
+        assert np.array_equal(np.isfinite(img["flux"]), have), (ci, int((np.isfinite(img["flux"]) != have).sum()))
+        assert have.sum() > 30
+        for k, tol in (("R", 1e-6), ("H", 1e-5), ("gfactor", 1e-6), ("T", 1e-6), ("V", 1e-6), ("flux", 1e-5)):
+            err = np.max(np.abs(img[k][have] - ref[k][have]) / np.maximum(np.abs(ref[k][have]), 1e-3 * np.abs(ref[k][have]).max()))
+            assert err < tol, (ci, k, err)
+        assert np.max(np.abs(img["mue"][have] - ref["mue"][have])) < 1e-3          # degrees
