@@ -45,6 +45,7 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "sim5gpu.h"))
     objs = []
+    cmds = []
     for (src, obj, variant) in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, obj)
@@ -53,10 +54,30 @@ def build(force=False, verbose=False):
             extra = os.environ.get("S5_FAST_EXTRA", "").split() if variant == "fast" else []
             if src == "k_torus.hip":
                 extra = extra + os.environ.get("S5_TORUS_EXTRA", "").split()
-            cmd = [hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            cmds.append([hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o])
+    # the translation units are independent: compile up to 4 at a time (each hipcc peaks at ~1.5 GB)
+    jobs = max(1, min(4, int(os.environ.get("S5_BUILD_JOBS", "4")), os.cpu_count() or 1))
+    running = []
+    def _reap(block):
+        for pr, cmd in list(running):
+            rc = pr.wait() if block else pr.poll()
+            if rc is None:
+                continue
+            running.remove((pr, cmd))
+            if rc != 0:
+                for other, _ in running:
+                    other.wait()
+                raise subprocess.CalledProcessError(rc, cmd)
+    for cmd in cmds:
+        while len(running) >= jobs:
+            _reap(False)
+            if len(running) >= jobs:
+                running[0][0].wait()
+        if verbose:
+            print(" ".join(cmd))
+        running.append((subprocess.Popen(cmd), cmd))
+    while running:
+        _reap(True)
     if force or not _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + \
               ["-o", LIB, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
