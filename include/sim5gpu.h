@@ -348,6 +348,18 @@ int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double *
                               double *d_P, double *d_r, double *d_m, double *d_k, int *d_status,
                               int strict, void *stream);
 
+/* The same search plus the local frame of the disk surface at the point found: g = E_inf / E_local, the cosine
+ * of the emission angle and the local flux, i.e. what the reference's DiskRaytrace.image() derives per pixel
+ * with __tetrad, __gfactor and __emission_angle (python/sim5diskraytrace.py:176-198, 340-390) for a disk model
+ * with this surface (dhdr = slope of the table), Novikov-Thorne flux and angular momentum for
+ * (bh_mass, mdot, disk_spin; disk_spin < 0 = the hole's spin) and radial velocity d_vr[] on the nodes of the
+ * table (NULL = 0).  d_g, d_mue, d_flux are NaN where status = 0; g <= 0 is returned as 0 (ref :360). */
+int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdot, double disk_spin,
+                               int n_table, const double *d_R, const double *d_H, const double *d_vr,
+                               size_t n, const double *d_alpha, const double *d_beta,
+                               double *d_P, double *d_r, double *d_m, double *d_k, int *d_status,
+                               double *d_g, double *d_mue, double *d_flux, int strict, void *stream);
+
 /* Observed spectrum of the thin disk over the pixel grid of `desc` (first-order crossings, as the
  * reference's Python ray tracer: python/sim5diskraytrace.py:96-123, black body of
  * python/sim5diskspectrum.py:54-88): spectrum[j] = sum over pixels of I_nu(E_j / g) g^3, with T_eff from the

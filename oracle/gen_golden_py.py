@@ -131,6 +131,7 @@ def main():
     try:
         tR = 10.0 ** np.linspace(0.0, 3.0, 256)
         tH = np.where(tR > 2.0, 0.25 * (tR - 2.0), 0.0)
+        tV = -0.05 / np.sqrt(tR)                   # a slow radial inflow
 
         class ThickDisk(sim5diskmodel.DiskModel):
             """H(R): linear interpolation of the table, H[0] below it, constant opening angle beyond it
@@ -152,9 +153,14 @@ def main():
                 return float((tH[hi] - tH[lo]) / (tR[hi] - tR[lo]))
             def flux(self, R): return ref.disk_nt_flux(R)
             def l(self, R): return ref.disk_nt_ell(R)
-            def vr(self, R): return -0.05 / math.sqrt(R) if R > 1.0 else 0.0
+            def vr(self, R):                        # nodes tV, interpolated as the surface itself
+                if not (R > tR[0]): return float(tV[0])
+                if R >= tR[-1]: return float(tV[-1])
+                hi = int(np.searchsorted(tR, R, side="left")); lo = hi - 1
+                w = (R - tR[lo]) / (tR[hi] - tR[lo])
+                return float(tV[lo] + w * (tV[hi] - tV[lo]))
 
-        out["surf_R"] = tR; out["surf_H"] = tH
+        out["surf_R"] = tR; out["surf_H"] = tH; out["surf_V"] = tV
         scases = [(a, inc) for a in (0.5, 0.9) for inc in (30.0, 60.0, 80.0)]
         out["surf_cases"] = np.array(scases)
         Ns, rmax_s = 12, 30.0

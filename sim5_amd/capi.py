@@ -692,6 +692,42 @@ def disk_surface_rays(a, incl_rad, table_R, table_H, alpha, beta, strict=False):
             "status": out["st"].to_numpy(np.int32, (n,))}
 
 
+def disk_surface_frame(a, incl_rad, bh_mass, mdot, table_R, table_H, alpha, beta, table_vr=None, disk_spin=-1.0,
+                       strict=False):
+    """Surface search + local frame in one kernel (host arrays in and out):
+    dict(P, r, m, k[n,4], status, g, mue, flux)."""
+    tR = np.ascontiguousarray(table_R, dtype=np.float64).ravel()
+    tH = np.ascontiguousarray(table_H, dtype=np.float64).ravel()
+    al = np.ascontiguousarray(alpha, dtype=np.float64).ravel()
+    be = np.ascontiguousarray(beta, dtype=np.float64).ravel()
+    n = al.size
+    arrays = [("tR", tR), ("tH", tH), ("al", al), ("be", be)]
+    if table_vr is not None:
+        tV = np.ascontiguousarray(table_vr, dtype=np.float64).ravel()
+        if tV.size != tR.size:
+            raise ValueError("table_vr must have the length of table_R")
+        arrays.append(("tV", tV))
+    bufs = {}
+    for name, arr in arrays:
+        bufs[name] = DeviceBuffer(max(arr.nbytes, 8)); bufs[name].from_numpy(arr)
+    out = {k: DeviceBuffer(max(n * s, 8)) for k, s in (("P", 8), ("r", 8), ("m", 8), ("k", 32), ("st", 4),
+                                                       ("g", 8), ("mue", 8), ("flux", 8))}
+    _check(_lib.sim5gpu_disk_surface_frame(D(a), D(incl_rad), D(bh_mass), D(mdot), D(disk_spin), I(tR.size),
+                                           VP(bufs["tR"].ptr), VP(bufs["tH"].ptr),
+                                           VP(bufs["tV"].ptr if "tV" in bufs else 0), SZ(n),
+                                           VP(bufs["al"].ptr), VP(bufs["be"].ptr), VP(out["P"].ptr), VP(out["r"].ptr),
+                                           VP(out["m"].ptr), VP(out["k"].ptr), VP(out["st"].ptr), VP(out["g"].ptr),
+                                           VP(out["mue"].ptr), VP(out["flux"].ptr), I(1 if strict else 0), VP(0)),
+           "sim5gpu_disk_surface_frame")
+    synchronize()
+    res = {"P": out["P"].to_numpy(np.float64, (n,)), "r": out["r"].to_numpy(np.float64, (n,)),
+           "m": out["m"].to_numpy(np.float64, (n,)), "k": out["k"].to_numpy(np.float64, (n, 4)),
+           "status": out["st"].to_numpy(np.int32, (n,))}
+    for k in ("g", "mue", "flux"):
+        res[k] = out[k].to_numpy(np.float64, (n,))
+    return res
+
+
 def torus_image_device(desc, d_stokes, aux=None, stream=None):
     a = None
     if aux:

@@ -42,10 +42,43 @@ int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double* 
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
     SurfaceParams p;
     p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
+    p.tab_vr = nullptr; p.out_g = nullptr; p.out_mue = nullptr; p.out_flux = nullptr;
+    memset(&p.disk, 0, sizeof p.disk);
     hipError_t e = (hipError_t)(strict
         ? s5_launch_disk_surface_strict(p, d_R, d_H, d_alpha, d_beta, d_P, d_r, d_m, d_k, d_status, (hipStream_t)stream)
         : s5_launch_disk_surface_fast(p, d_R, d_H, d_alpha, d_beta, d_P, d_r, d_m, d_k, d_status, (hipStream_t)stream));
     if (e != hipSuccess) { set_error("disk_surface_rays launch", e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdot, double disk_spin,
+                               int n_table, const double* d_R, const double* d_H, const double* d_vr,
+                               size_t n, const double* d_alpha, const double* d_beta,
+                               double* d_P, double* d_r, double* d_m, double* d_k, int* d_status,
+                               double* d_g, double* d_mue, double* d_flux, int strict, void* stream)
+{
+    if (!d_R || !d_H || !d_alpha || !d_beta || !d_P || !d_r || !d_m || !d_status || !d_g || !d_mue || !d_flux) {
+        snprintf(g_err, sizeof g_err, "disk_surface_frame: NULL pointer argument");
+        return SIM5GPU_E_ARG;
+    }
+    if (n_table < 2 || n_table > 4096) {
+        snprintf(g_err, sizeof g_err, "disk_surface_frame: n_table must be in [2, 4096]");
+        return SIM5GPU_E_ARG;
+    }
+    if (!(bh_mass > 0.0) || !(mdot > 0.0)) {
+        snprintf(g_err, sizeof g_err, "disk_surface_frame: need bh_mass > 0 and mdot > 0");
+        return SIM5GPU_E_ARG;
+    }
+    if (n == 0) return SIM5GPU_OK;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    SurfaceParams p;
+    p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
+    p.disk = make_disk_consts(bh_mass, disk_spin >= 0.0 ? disk_spin : a, mdot);
+    p.tab_vr = d_vr; p.out_g = d_g; p.out_mue = d_mue; p.out_flux = d_flux;
+    hipError_t e = (hipError_t)(strict
+        ? s5_launch_disk_surface_strict(p, d_R, d_H, d_alpha, d_beta, d_P, d_r, d_m, d_k, d_status, (hipStream_t)stream)
+        : s5_launch_disk_surface_fast(p, d_R, d_H, d_alpha, d_beta, d_P, d_r, d_m, d_k, d_status, (hipStream_t)stream));
+    if (e != hipSuccess) { set_error("disk_surface_frame launch", e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;
 }
 

@@ -11,7 +11,7 @@
 // The disk surface H(R) is what the reference gets from the Python disk model's h(R).  Here it is a table
 // (R_i ascending, H_i) staged once per workgroup into LDS and interpolated linearly, with a constant opening
 // angle beyond the last point and H[0] below the first; every lane evaluates it many hundred times.
-#include "s5_geod.hpp"
+#include "s5_disk.hpp"
 #include "kernels.hpp"
 
 namespace S5NS {
@@ -19,6 +19,17 @@ namespace S5NS {
 using namespace s5abi;
 
 constexpr int SURF_MAX_TABLE = 4096;        // 2 x 32 KiB of LDS
+
+// slope of the same piecewise-linear surface (what a disk model built on the table returns as dhdr) and
+// the node values of another profile interpolated the same way
+S5_DEV void surface_segment(const double* sR, int n, double R, int& lo, int& hi)
+{
+    lo = 0; hi = n - 1;                      // invariant sR[lo] < R <= sR[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sR[mid] < R) lo = mid; else hi = mid;
+    }
+}
 
 S5_DEV double surface_height(const double* sR, const double* sH, int n, double R)
 {
@@ -116,6 +127,41 @@ void disk_surface_kernel(SurfaceParams p, const double* __restrict__ tabR, const
         } else {
             P = NAN; r = 0.0; m = 0.0;
         }
+    }
+    if (p.out_g) {
+        // local frame of the disk surface at the point found: the reference's __tetrad / __gfactor /
+        // __emission_angle (python/sim5diskraytrace.py:340-390) with the slope of the tabulated surface, the
+        // Novikov-Thorne angular momentum and flux, and the tabulated radial velocity
+        double gfac = NAN, mue = NAN, F = NAN;
+        if (status == 1) {
+            const double R = r * sqrt(1. - m * m);
+            F = disk_flux(p.disk, R);
+            double dhdr = 0.0, V = 0.0;
+            const int nt = p.n_table;
+            if (!(R > sR[0])) { dhdr = 0.0; V = p.tab_vr ? p.tab_vr[0] : 0.0; }
+            else if (R >= sR[nt - 1]) { dhdr = sH[nt - 1] / sR[nt - 1]; V = p.tab_vr ? p.tab_vr[nt - 1] : 0.0; }
+            else {
+                int lo, hi;
+                surface_segment(sR, nt, R, lo, hi);
+                dhdr = (sH[hi] - sH[lo]) / (sR[hi] - sR[lo]);
+                if (p.tab_vr) { const double w = (R - sR[lo]) / (sR[hi] - sR[lo]); V = p.tab_vr[lo] + w * (p.tab_vr[hi] - p.tab_vr[lo]); }
+            }
+            if (!(m > 0.0)) dhdr = 0.0;                                           // ref py :346
+            Metric mt;
+            kerr_metric(p.a, r, m, mt);
+            Tetrad tt;
+            tetrad_surface(mt, omega_from_ell(disk_ell(p.disk, R), mt), V, dhdr, tt);
+            const double e0[4] = { 1.0, 0.0, 0.0, 0.0 }, e2[4] = { 0.0, 0.0, 1.0, 0.0 };
+            double U[4], N[4];
+            on2bl(e0, U, tt);
+            on2bl(e2, N, tt);
+            const double kU = dot(kout, U, mt);
+            gfac = (kout[0] * mt.g00 + kout[3] * mt.g03) / kU;
+            if (!(gfac > 0.0)) gfac = 0.0;                                        // ref py :360
+            mue = dot(kout, N, mt) / kU;
+            if ((mue < 0.0) && (mue > -1e-2)) mue = 1e-3;                         // ref py :387
+        }
+        p.out_g[i] = gfac; p.out_mue[i] = mue; p.out_flux[i] = F;
     }
     outP[i] = P; outR[i] = r; outM[i] = m; outStatus[i] = status;
     if (outK) { outK[4 * i] = kout[0]; outK[4 * i + 1] = kout[1]; outK[4 * i + 2] = kout[2]; outK[4 * i + 3] = kout[3]; }

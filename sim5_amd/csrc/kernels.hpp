@@ -65,6 +65,12 @@ struct SurfaceParams {
     size_t n;
     int n_table;
     double a, incl, sin_i, cos_i;
+    // optional local-frame outputs at the surface point (sim5gpu_disk_surface_frame): NULL = not wanted
+    DiskConsts disk;            // Novikov-Thorne profiles for flux and angular momentum
+    const double* tab_vr;       // radial velocity on the nodes of the surface table, or NULL (= 0)
+    double* out_g;              // E_inf / E_local
+    double* out_mue;            // cosine of the emission angle
+    double* out_flux;           // local flux
 };
 
 } // namespace s5abi

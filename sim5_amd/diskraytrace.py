@@ -51,12 +51,17 @@ class DiskModel_Surface(DiskModel_ThinDisk):
     Flux and angular momentum are the Novikov-Thorne ones; `vr` is an optional callable of R.  A model with
     other profiles derives from this class and overrides flux / l / vr (they receive arrays)."""
 
-    def __init__(self, bh_mass, bh_spin, mdot, alpha, table_R, table_H, vr=None):
+    def __init__(self, bh_mass, bh_spin, mdot, alpha, table_R, table_H, vr=None, table_vr=None):
         super().__init__(bh_mass, bh_spin, mdot, alpha)
         self.name = "tabulated surface"
+        self.bh_mass = bh_mass
         self.tR = np.ascontiguousarray(table_R, dtype=np.float64)
         self.tH = np.ascontiguousarray(table_H, dtype=np.float64)
         self._vr = vr
+        # radial velocity on the nodes of the table, interpolated like the surface; with it (or with no radial
+        # velocity at all) DiskRaytrace.image() runs as ONE kernel (sim5gpu_disk_surface_frame)
+        self.tV = None if table_vr is None else np.ascontiguousarray(table_vr, dtype=np.float64)
+        self.fused = (vr is None) and type(self).flux is DiskModel_ThinDisk.flux and type(self).l is DiskModel_ThinDisk.l
 
     def surface_table(self):
         return self.tR, self.tH
@@ -75,7 +80,11 @@ class DiskModel_Surface(DiskModel_ThinDisk):
 
     def vr(self, R):
         R = np.atleast_1d(np.asarray(R, dtype=np.float64))
-        return np.zeros(R.shape) if self._vr is None else np.asarray(self._vr(R), dtype=np.float64)
+        if self._vr is not None:
+            return np.asarray(self._vr(R), dtype=np.float64)
+        if self.tV is not None:
+            return np.interp(R, self.tR, self.tV)                 # clamps to the end nodes outside the table
+        return np.zeros(R.shape)
 
 
 class DiskRaytrace:
@@ -139,16 +148,35 @@ class DiskRaytrace:
         dOmega = (2.0 * rmax / N) ** 2 * ((self.bh_mass * grav_radius) / (self.bh_dist * parsec * 1e3)) ** 2
         return _c.disk_spectrum(d, energies, hardening=hardening, limb_darkening=limbdk) * dOmega
 
-    def image(self, incl, rmax, N, limbdk=1):
+    def image(self, incl, rmax, N, limbdk=1, fused=True):
         """Disk image (ref :138-210).  incl in degrees; returns the reference's dict of N x N arrays
-        (NaN where the reference leaves None)."""
+        (NaN where the reference leaves None).  fused=False forces the call-by-call path for a DiskModel_Surface."""
         incl = math.radians(max(1.0, incl))
         c = ((np.arange(N) + .5) / N - 0.5) * 2.0 * rmax
         alpha = np.tile(c, N); beta = np.repeat(c, N)
         dOmega = (2.0 * rmax / N) ** 2 / ((self.bh_mass * grav_radius) / (self.bh_dist * parsec * 1e3)) ** 2
         flat = bool(np.all(np.asarray(self.disk.h(1e5)) == 0.0))         # ref :176
-        geo = self.geodesic(incl, alpha, beta, flat=flat)
         out = {k: np.full(N * N, np.nan) for k in ("flux", "gfactor", "mue", "T", "R", "H", "V")}
+        if not flat and getattr(self.disk, "fused", False) and fused:
+            # surface search and local frame in one kernel; the selection rules of ref :174-198 on the host
+            s = _c.disk_surface_frame(self.bh_spin, incl, self.disk.bh_mass, self.disk.mdot, self.disk.tR, self.disk.tH,
+                                      alpha, beta, table_vr=self.disk.tV, disk_spin=self.disk.bh_spin)
+            r, m = s["r"], s["m"]
+            R = r * np.sqrt(1. - m * m)
+            sel = (s["status"] == 1) & (s["flux"] != 0.0) & (s["g"] > 0.0)
+            e = s["mue"][sel]
+            l = (0.5 + 0.75 * e) if limbdk > 0 else np.ones_like(e)
+            e = np.where(e < 0.0, 0.0001, np.where(e > 1.0, 0.9999, e))
+            g = s["g"][sel]; F = s["flux"][sel]
+            out["flux"][sel] = F * g ** 4 * l * dOmega
+            out["gfactor"][sel] = g
+            out["mue"][sel] = np.degrees(np.arccos(e))
+            out["T"][sel] = (F / 5.670400e-05) ** 0.25
+            out["R"][sel] = R[sel]
+            out["H"][sel] = (r * m)[sel]
+            out["V"][sel] = np.asarray(self.disk.vr(R[sel]))
+            return {k: v.reshape(N, N) for k, v in out.items()}
+        geo = self.geodesic(incl, alpha, beta, flat=flat)
         sel = geo["ok"].copy()
         r, m = geo["r"], geo["m"]
         R = r * np.sqrt(1. - m * m)

@@ -153,14 +153,16 @@ def test_thick_disk_image(golden, capi):
     g = golden("py_diskraytrace.npz")
     Ns, rmax = 12, 30.0
     for ci, (a, inc) in enumerate(g["surf_cases"]):
-        disk = DiskModel_Surface(10.0, float(a), 0.1, 0.1, g["surf_R"], g["surf_H"],
-                                 vr=lambda R: np.where(R > 1.0, -0.05 / np.sqrt(np.maximum(R, 1e-300)), 0.0))
-        img = DiskRaytrace(10.0, float(a), 10.0, disk).image(float(inc), rmax, Ns)
+        disk = DiskModel_Surface(10.0, float(a), 0.1, 0.1, g["surf_R"], g["surf_H"], table_vr=g["surf_V"])
+        assert disk.fused
         ref = {k: g["thk%d_%s" % (ci, k)] for k in ("flux", "gfactor", "mue", "T", "R", "H", "V")}
         have = np.isfinite(ref["flux"])
-        assert np.array_equal(np.isfinite(img["flux"]), have), (ci, int((np.isfinite(img["flux"]) != have).sum()))
         assert have.sum() > 30
-        for k, tol in (("R", 1e-6), ("H", 1e-5), ("gfactor", 1e-6), ("T", 1e-6), ("V", 1e-6), ("flux", 1e-5)):
-            err = np.max(np.abs(img[k][have] - ref[k][have]) / np.maximum(np.abs(ref[k][have]), 1e-3 * np.abs(ref[k][have]).max()))
-            assert err < tol, (ci, k, err)
-        assert np.max(np.abs(img["mue"][have] - ref["mue"][have])) < 1e-3          # degrees
+        # one kernel (sim5gpu_disk_surface_frame) and the call-by-call path must both reproduce the reference
+        for fused in (True, False):
+            img = DiskRaytrace(10.0, float(a), 10.0, disk).image(float(inc), rmax, Ns, fused=fused)
+            assert np.array_equal(np.isfinite(img["flux"]), have), (ci, fused, int((np.isfinite(img["flux"]) != have).sum()))
+            for k, tol in (("R", 1e-6), ("H", 1e-5), ("gfactor", 1e-6), ("T", 1e-6), ("V", 1e-6), ("flux", 1e-5)):
+                err = np.max(np.abs(img[k][have] - ref[k][have]) / np.maximum(np.abs(ref[k][have]), 1e-3 * np.abs(ref[k][have]).max()))
+                assert err < tol, (ci, fused, k, err)
+            assert np.max(np.abs(img["mue"][have] - ref["mue"][have])) < 1e-3          # degrees
