@@ -191,6 +191,10 @@ int sim5gpu_tetrad_azimuthal(size_t n, const sim5gpu_metric *metric, const doubl
 int sim5gpu_tetrad_surface(size_t n, const sim5gpu_metric *metric, const double *Omega,
                            const double *V, const double *dhdr, sim5gpu_tetrad *t);
 
+/* vector_norm_to (ref src/sim5kerr.c:553-573): scales each vector (n x 4, in place) to V.V = norm; metric may be
+ * NULL (Minkowski), as in the reference */
+int sim5gpu_vector_norm_to(size_t n, double *v, const double *norm, const sim5gpu_metric *metric);
+
 /* bl2on / on2bl (ref src/sim5kerr.c:926-970); vectors are n x 4 */
 int sim5gpu_bl2on(size_t n, const double *vin, double *vout, const sim5gpu_tetrad *t);
 int sim5gpu_on2bl(size_t n, const double *vin, double *vout, const sim5gpu_tetrad *t);
@@ -198,7 +202,7 @@ int sim5gpu_on2bl(size_t n, const double *vin, double *vout, const sim5gpu_tetra
 /* Carlson R_F and the Jacobi inverses built on it (ref src/sim5elliptic.c:19-52, 218-225,
  * 481-528, 536-598).  which: 0 = rf(x,y,z), 1 = elliptic_k(x), 2 = jacobi_isn(x,y),
  * 3 = jacobi_icn(x,y), 4 = jacobi_itn(x,y), 5 = jacobi_sn(x,y), 6 = jacobi_cn(x,y),
- * 7 = jacobi_dn(x,y), 8 = rd(x,y,z), 9 = rc(x,y), 10 = rj(x,y,z,w) */
+ * 7 = jacobi_dn(x,y), 8 = rd(x,y,z), 9 = rc(x,y), 10 = rj(x,y,z,w), 11 = elliptic_f_sin(x,y) */
 int sim5gpu_elliptic(int which, size_t n, const double *x, const double *y, const double *z,
                      const double *w, double *out);
 

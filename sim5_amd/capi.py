@@ -309,6 +309,15 @@ def integral(name, *args):
     return out
 
 
+def vector_norm_to(v, norm, metric=None):
+    v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1, 4)).copy()
+    n = v.shape[0]
+    norm = _f64(norm, n)
+    _check(_lib.sim5gpu_vector_norm_to(SZ(n), _p(v), _p(norm), _p(metric) if metric is not None else None),
+           "sim5gpu_vector_norm_to")
+    return v
+
+
 def geodesic_follow(g, step, P, r, m):
     g, n = _geod(g)
     step = _f64(step, n)
@@ -472,7 +481,7 @@ def on2bl(v, t):
 
 
 ELLIPTIC = {"rf": 0, "elliptic_k": 1, "jacobi_isn": 2, "jacobi_icn": 3, "jacobi_itn": 4,
-            "jacobi_sn": 5, "jacobi_cn": 6, "jacobi_dn": 7, "rd": 8, "rc": 9, "rj": 10}
+            "jacobi_sn": 5, "jacobi_cn": 6, "jacobi_dn": 7, "rd": 8, "rc": 9, "rj": 10, "elliptic_f_sin": 11}
 
 
 def elliptic(name, x, y=None, z=None, w=None):

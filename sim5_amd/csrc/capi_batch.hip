@@ -310,6 +310,23 @@ int sim5gpu_dotprod(size_t n, const double* v1, const double* v2, const sim5gpu_
     return SIM5GPU_OK;
 }
 
+int sim5gpu_vector_norm_to(size_t n, double* v, const double* norm, const sim5gpu_metric* metric)
+{
+    S5_NEED("vector_norm_to", v && norm);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dv(v, 4 * n), dn(norm, n); DevBuf<Metric> dmt((const Metric*)metric, metric ? n : 0);
+    S5_BUFS_OK("vector_norm_to", dv.ok() && dn.ok() && dmt.ok());
+    double* pv = dv.ptr; const double* pn = dn.ptr; const Metric* pg = dmt.ptr;
+    S5_RUN(n, "vector_norm_to", [=] __device__(size_t i) {                  // ref src/sim5kerr.c:553-573
+        const double u[4] = { pv[4 * i], pv[4 * i + 1], pv[4 * i + 2], pv[4 * i + 3] };
+        const double N = pg ? dot(u, u, pg[i]) : (-u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
+        for (int c = 0; c < 4; ++c) pv[4 * i + c] = u[c] * sqrt(pn[i] / N);
+    });
+    S5_HIP(dv.to_host(v));
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_gfactorK(size_t n, const double* r, const double* a, const double* l, double* g)
 {
     S5_NEED("gfactorK", r && a && l && g);
@@ -421,7 +438,7 @@ int sim5gpu_elliptic(int which, size_t n, const double* x, const double* y, cons
                      const double* w, double* out)
 {
     S5_NEED("elliptic", x && out);
-    if (which < 0 || which > 10) { snprintf(g_err, sizeof g_err, "elliptic: unknown selector %d", which); return SIM5GPU_E_ARG; }
+    if (which < 0 || which > 11) { snprintf(g_err, sizeof g_err, "elliptic: unknown selector %d", which); return SIM5GPU_E_ARG; }
     const bool need_y = (which != 1), need_z = (which == 0 || which == 8 || which == 10), need_w = (which == 10);
     S5_NEED("elliptic", (!need_y || y) && (!need_z || z) && (!need_w || w));
     if (n == 0) return SIM5GPU_OK;
@@ -444,6 +461,7 @@ int sim5gpu_elliptic(int which, size_t n, const double* x, const double* y, cons
         case 8: v = carlson_rd(px[i], py[i], pz[i]); break;
         case 9: v = carlson_rc(px[i], py[i]); break;
         case 10: v = carlson_rj(px[i], py[i], pz[i], pw[i]); break;
+        case 11: v = ell_F_sin(px[i], py[i]); break;
         }
         po[i] = v;
     });

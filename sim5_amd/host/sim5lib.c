@@ -379,6 +379,47 @@ double jacobi_dn(double u, double m) { return s5_ell(7, &u, &m, 0, 0); }
 double rd(double x, double y, double z) { return s5_ell(8, &x, &y, &z, 0); }
 double rc(double x, double y) { return s5_ell(9, &x, &y, 0, 0); }
 double rj(double x, double y, double z, double p) { return s5_ell(10, &x, &y, &z, &p); }
+double elliptic_f_sin(double sin_phi, double m) { return s5_ell(11, &sin_phi, &m, 0, 0); }
+
+/* the integrals under geodesic_position_azm / geodesic_timedelay: sim5gpu_integral(which, 1, nargs, args, out) */
+typedef int (*fn_integral)(int, size_t, int, const double *, double *);
+static double s5_int(int which, int nargs, const double *args)
+{
+    S5_FN(fn_integral, f, "sim5gpu_integral");
+    double out = NAN;
+    s5_check(f(which, 1, nargs, args, &out), "integral");
+    return out;
+}
+#define S5_ARGS(...) (const double[]){ __VA_ARGS__ }
+double elliptic_f_cos(double c, double m) { return s5_int(0, 2, S5_ARGS(c, m)); }
+double elliptic_e_cos(double c, double m) { return s5_int(1, 2, S5_ARGS(c, m)); }
+double elliptic_pi_complete(double n, double m) { return s5_int(2, 2, S5_ARGS(n, m)); }
+double elliptic_pi_cos(double c, double n, double m) { return s5_int(3, 3, S5_ARGS(c, n, m)); }
+double integral_R_r0_re(double a, double b, double c, double d, double X) { return s5_int(12, 5, S5_ARGS(a, b, c, d, X)); }
+double integral_R_r0_re_inf(double a, double b, double c, double d) { return s5_int(13, 4, S5_ARGS(a, b, c, d)); }
+double integral_R_r1_re(double a, double b, double c, double d, double X) { return s5_int(14, 5, S5_ARGS(a, b, c, d, X)); }
+double integral_R_r2_re(double a, double b, double c, double d, double X) { return s5_int(15, 5, S5_ARGS(a, b, c, d, X)); }
+double integral_R_rp_re(double a, double b, double c, double d, double p, double X) { return s5_int(16, 6, S5_ARGS(a, b, c, d, p, X)); }
+double integral_R_rp_re_inf(double a, double b, double c, double d, double p) { return s5_int(17, 5, S5_ARGS(a, b, c, d, p)); }
+double integral_R_r0_cc(double a, double b, sim5complex c, double X) { return s5_int(18, 5, S5_ARGS(a, b, creal(c), cimag(c), X)); }
+double integral_R_r0_cc_inf(double a, double b, sim5complex c) { return s5_int(19, 4, S5_ARGS(a, b, creal(c), cimag(c))); }
+double integral_R_r1_cc(double a, double b, sim5complex c, double X1, double X2) { return s5_int(20, 6, S5_ARGS(a, b, creal(c), cimag(c), X1, X2)); }
+double integral_R_r2_cc(double a, double b, sim5complex c, double X1, double X2) { return s5_int(21, 6, S5_ARGS(a, b, creal(c), cimag(c), X1, X2)); }
+double integral_R_rp_cc2(double a, double b, sim5complex c, double p, double X1, double X2) { return s5_int(22, 7, S5_ARGS(a, b, creal(c), cimag(c), p, X1, X2)); }
+double integral_R_rp_cc2_inf(double a, double b, sim5complex c, double p, double X1) { return s5_int(23, 6, S5_ARGS(a, b, creal(c), cimag(c), p, X1)); }
+double integral_T_m0(double a2, double b2, double X) { return s5_int(24, 3, S5_ARGS(a2, b2, X)); }
+double integral_T_m2(double a2, double b2, double X) { return s5_int(25, 3, S5_ARGS(a2, b2, X)); }
+double integral_T_mp(double a2, double b2, double p, double X) { return s5_int(26, 4, S5_ARGS(a2, b2, p, X)); }
+#undef S5_ARGS
+
+/* ref: src/sim5kerr.c:553-573 */
+typedef int (*fn_vnorm)(size_t, double *, const double *, const sim5metric *);
+void vector_norm_to(double V[4], double norm, sim5metric *m)
+{
+    S5_FN(fn_vnorm, f, "sim5gpu_vector_norm_to");
+    s5_check(f(1, V, &norm, m), "vector_norm_to");
+}
+
 void jacobi_sncndn(double u, double m, double *sn, double *cn, double *dn)
 {
     *sn = jacobi_sn(u, m); *cn = jacobi_cn(u, m); *dn = jacobi_dn(u, m);

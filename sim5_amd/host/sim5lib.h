@@ -126,6 +126,7 @@ typedef struct sim5tetrad sim5tetrad;
 void   kerr_metric(double a, double r, double m, sim5metric *metric);
 void   kerr_connection(double a, double r, double m, double G[4][4][4]);
 double dotprod(double V1[4], double V2[4], sim5metric *m);
+void   vector_norm_to(double V[4], double norm, sim5metric *m);
 void   tetrad_zamo(sim5metric *m, sim5tetrad *t);
 void   tetrad_azimuthal(sim5metric *m, double Omega, sim5tetrad *t);
 void   tetrad_surface(sim5metric *m, double Omega, double V, double dhdr, sim5tetrad *t);
@@ -192,6 +193,28 @@ double jacobi_sn(double u, double m);
 double jacobi_cn(double u, double m);
 double jacobi_dn(double u, double m);
 void   jacobi_sncndn(double u, double m, double *sn, double *cn, double *dn);
+/* Legendre integrals of the 1st-3rd kind and the radial / polar integrals built on them
+   (ref: src/sim5elliptic.h:25-56); a `sim5complex c` is the complex root u + i v */
+double elliptic_f_sin(double sin_phi, double m);
+double elliptic_f_cos(double cos_phi, double m);
+double elliptic_e_cos(double cos_phi, double m);
+double elliptic_pi_complete(double n, double m);
+double elliptic_pi_cos(double cos_phi, double n, double m);
+double integral_R_r0_re(double a, double b, double c, double d, double X);
+double integral_R_r0_cc(double a, double b, sim5complex c, double X);
+double integral_R_r0_re_inf(double a, double b, double c, double d);
+double integral_R_r0_cc_inf(double a, double b, sim5complex c);
+double integral_R_r1_re(double a, double b, double c, double d, double X);
+double integral_R_r1_cc(double a, double b, sim5complex c, double X1, double X2);
+double integral_R_r2_re(double a, double b, double c, double d, double X);
+double integral_R_r2_cc(double a, double b, sim5complex c, double X1, double X2);
+double integral_R_rp_re(double a, double b, double c, double d, double p, double X);
+double integral_R_rp_cc2(double a, double b, sim5complex c, double p, double X1, double X2);
+double integral_R_rp_re_inf(double a, double b, double c, double d, double p);
+double integral_R_rp_cc2_inf(double a, double b, sim5complex c, double p, double X1);
+double integral_T_m0(double a2, double b2, double X);
+double integral_T_m2(double a2, double b2, double X);
+double integral_T_mp(double a2, double b2, double p, double X);
 
 #ifdef __cplusplus
 }

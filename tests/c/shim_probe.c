@@ -63,5 +63,14 @@ int main(int argc, char **argv)
         printf("# azm %.17g delay %.17g\n", geodesic_position_azm(&gd, r1, m1, P1),
                geodesic_timedelay(&gd, P1, 0.0, 0.0, P2, 0.0, 0.0));
     }
+    /* the integrals of sim5elliptic.h and vector_norm_to through the scalar API */
+    {
+        sim5metric mt; kerr_metric(a, 7.0, 0.3, &mt);
+        double V[4] = { 0.0, 0.3, 0.1, 0.02 };
+        vector_norm_to(V, 1.0, &mt);
+        printf("# ints %.17g %.17g %.17g %.17g %.17g %.17g\n", elliptic_f_sin(0.7, 0.4), elliptic_pi_cos(0.35, -1.7, 0.62),
+               integral_R_rp_cc2(4.0, 1.5, 0.8 + 1.1 * I, 1.2, 4.5, 30.0), integral_T_mp(3.0, 0.7, 1.0, -0.4),
+               dotprod(V, V, &mt), V[1]);
+    }
     return 0;
 }

@@ -37,10 +37,17 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     m = hit > 0
     assert_close(rec[m, 4], c["r"].ravel()[m], what="r"); assert_close(rec[m, 5], c["g"].ravel()[m], what="g")
     assert_close(rec[m, 6], c["flux"].ravel()[m], floor=1e-9 * c["flux"].max(), what="flux")
-    tail = lines[-2].split()
+    tail = lines[-3].split()
     assert tail[1] == "verlet" and int(tail[3]) > 100 and float(tail[7]) < 1e-2
-    # geodesic_position_azm / geodesic_timedelay through the scalar API against the CPU checker
+    # the integrals of sim5elliptic.h and vector_norm_to through the scalar API
     tail = lines[-1].split()
+    assert tail[1] == "ints"
+    want = [orc.elliptic_f_sin(0.7, 0.4), orc.elliptic_pi_cos(0.35, -1.7, 0.62),
+            orc.integral_R_rp_cc2(4.0, 1.5, 0.8, 1.1, 1.2, 4.5, 30.0), orc.integral_T_mp(3.0, 0.7, 1.0, -0.4), 1.0]
+    for got, ref in zip(tail[2:7], want):
+        assert abs(float(got) / ref - 1) < 1e-9, (got, ref)
+    # geodesic_position_azm / geodesic_timedelay through the scalar API against the CPU checker
+    tail = lines[-2].split()
     gd = ol.Geodesic(); e = C.c_int(0)
     assert orc.geodesic_init_inf(math.radians(inc), a, 6.0, 5.0, C.byref(gd), C.byref(e))
     P1, P2 = 0.6 * gd.Rpc, 1.4 * gd.Rpc
