@@ -227,7 +227,7 @@ S5_DEV double dot(const double u[4], const double v[4], const Metric& g)        
 
 S5_DEV void normalize_to(double v[4], double norm, const Metric& g)             // ref :553-573
 {
-    double f = sqrt(norm / dot(v, v, g));
+    double f = msqrt(mdiv(norm, dot(v, v, g)));
     v[0] *= f; v[1] *= f; v[2] *= f; v[3] *= f;
 }
 
@@ -242,11 +242,11 @@ S5_DEV void clear_tetrad(Tetrad& t)
 S5_DEV void tetrad_zamo(const Metric& g, Tetrad& t)                             // ref :678-711
 {
     clear_tetrad(t);
-    t.e[0][0] = sqrt(g.g33 / (sq(g.g03) - g.g33 * g.g00));
-    t.e[0][3] = -t.e[0][0] * g.g03 / g.g33;
-    t.e[1][1] = 1. / sqrt(g.g11);
-    t.e[2][2] = -1. / sqrt(g.g22);
-    t.e[3][3] = 1. / sqrt(g.g33);
+    t.e[0][0] = msqrt(mdiv(g.g33, sq(g.g03) - g.g33 * g.g00));
+    t.e[0][3] = mdiv(-t.e[0][0] * g.g03, g.g33);
+    t.e[1][1] = mdiv(1., msqrt(g.g11));
+    t.e[2][2] = mdiv(-1., msqrt(g.g22));
+    t.e[3][3] = mdiv(1., msqrt(g.g33));
     t.metric = g;
 }
 
@@ -254,39 +254,39 @@ S5_DEV void tetrad_azimuthal(const Metric& g, double Omega, Tetrad& t)          
 {
     if (Omega == 0.0) { tetrad_zamo(g, t); return; }
     double g00 = g.g00, g33 = g.g33, g03 = g.g03;
-    double U0 = sqrt(-1.0 / (g00 + 2. * Omega * g03 + sq(Omega) * g33));
+    double U0 = msqrt(mdiv(-1.0, g00 + 2. * Omega * g03 + sq(Omega) * g33));
     double U3 = U0 * Omega;
     clear_tetrad(t);
     t.e[0][0] = U0;
     t.e[0][3] = U3;
-    t.e[1][1] = sqrt(1. / g.g11);
-    t.e[2][2] = -sqrt(1. / g.g22);
+    t.e[1][1] = msqrt(mdiv(1., g.g11));
+    t.e[2][2] = -msqrt(mdiv(1., g.g22));
     double k1 = (g03 * U3 + g00 * U0);
     double k2 = (g33 * U3 + g03 * U0);
-    t.e[3][0] = -(k1 >= 0.0 ? +1.0 : -1.0) * k2 /
-                sqrt((g33 * g00 - g03 * g03) * (g00 * U0 * U0 + g33 * U3 * U3 + 2.0 * g03 * U0 * U3));
-    t.e[3][3] = t.e[3][0] * (-k1 / k2);
+    t.e[3][0] = mdiv(-(k1 >= 0.0 ? +1.0 : -1.0) * k2,
+                     msqrt((g33 * g00 - g03 * g03) * (g00 * U0 * U0 + g33 * U3 * U3 + 2.0 * g03 * U0 * U3)));
+    t.e[3][3] = t.e[3][0] * mdiv(-k1, k2);
     t.metric = g;
 }
 
 S5_DEV void tetrad_surface(const Metric& g, double Omega, double V, double dhdr, Tetrad& t) // ref :818-921
 {
     double g00 = g.g00, g11 = g.g11, g22 = g.g22, g33 = g.g33, g03 = g.g03;
-    double S0r = 1.0 / sqrt(g11 + g22 * sq(dhdr));
+    double S0r = mdiv(1.0, msqrt(g11 + g22 * sq(dhdr)));
     double S0h = S0r * dhdr;
-    double ur = V / sqrt(1. - V * V) / sqrt(g11);
+    double ur = mdiv(mdiv(V, msqrt(1. - V * V)), msqrt(g11));
     double v = (V >= 0.0 ? +1.0 : -1.0) *
-               sqrt((sq(ur / S0r) * (-g00 - 2. * Omega * g03 - sq(Omega) * g33)) / (1. + sq(ur / S0r)));
+               msqrt(mdiv(sq(mdiv(ur, S0r)) * (-g00 - 2. * Omega * g03 - sq(Omega) * g33), 1. + sq(mdiv(ur, S0r))));
     t.e[0][0] = 1.0; t.e[0][1] = v * S0r; t.e[0][2] = v * S0h; t.e[0][3] = Omega;
     normalize_to(t.e[0], -1.0, g);
     t.e[1][0] = (v * t.e[0][0]);
-    t.e[1][1] = (v * t.e[0][1] + S0r / t.e[0][0]);
-    t.e[1][2] = (v * t.e[0][2] + S0h / t.e[0][0]);
+    t.e[1][1] = (v * t.e[0][1] + mdiv(S0r, t.e[0][0]));
+    t.e[1][2] = (v * t.e[0][2] + mdiv(S0h, t.e[0][0]));
     t.e[1][3] = (v * t.e[0][3]);
     normalize_to(t.e[1], 1.0, g);
     t.e[2][0] = 0.0; t.e[2][1] = dhdr; t.e[2][2] = -1.0; t.e[2][3] = 0.0;
     normalize_to(t.e[2], 1.0, g);
-    t.e[3][0] = -(g03 + g33 * Omega) / (g00 + g03 * Omega);
+    t.e[3][0] = mdiv(-(g03 + g33 * Omega), g00 + g03 * Omega);
     t.e[3][1] = 0.0; t.e[3][2] = 0.0; t.e[3][3] = 1.0;
     normalize_to(t.e[3], 1.0, g);
     t.metric = g;
@@ -321,7 +321,7 @@ S5_DEV double ell_kepler(double r, double a)                                    
 
 S5_DEV double omega_from_ell(double ell, const Metric& g)                                 // ref :1101-1111
 {
-    return -(g.g03 + ell * g.g00) / (g.g33 + ell * g.g03);
+    return mdiv(-(g.g03 + ell * g.g00), g.g33 + ell * g.g03);
 }
 
 S5_DEV double gfactor_kepler(double r, double a, double l)                                // ref :1128-1141
@@ -347,14 +347,14 @@ S5_DEV void photon_momentum(double a, double r, double m, double l, double q,
     double S = r2 + a2 * m2;
     double D = r2 - 2. * r + a2;
     double R = sq(r2 + a2 - a * l) - D * (sq(l - a) + q);
-    double M = q - l2 * m2 / (1. - m2) + a2 * m2;
+    double M = q - mdiv(l2 * m2, 1. - m2) + a2 * m2;
     if ((M < 0.0) && (-M < 1e-8)) M = 0.0;
     if ((R < 0.0) && (-R < 1e-8)) R = 0.0;
     if (M < 0.0) { k[0] = k[1] = k[2] = k[3] = NAN; return; }
-    k[0] = +1 / S * (-a * (a * (1. - m2) - l) + (r2 + a2) / D * (r2 + a2 - a * l));
-    k[1] = +1 / S * sqrt(R);
-    k[2] = +1 / S * sqrt(M);
-    k[3] = +1 / S * (-a + l / (1. - m2) + a / D * (r2 + a2 - a * l));
+    k[0] = mdiv(+1, S) * (-a * (a * (1. - m2) - l) + mdiv(r2 + a2, D) * (r2 + a2 - a * l));
+    k[1] = mdiv(+1, S) * msqrt(R);
+    k[2] = mdiv(+1, S) * msqrt(M);
+    k[3] = mdiv(+1, S) * (-a + mdiv(l, 1. - m2) + mdiv(a, D) * (r2 + a2 - a * l));
     if (r_sign < 0.0) k[1] = -k[1];
     if (m_sign < 0.0) k[2] = -k[2];
 }

@@ -11,7 +11,7 @@ S5_DEV void polarization_constant(const double k[4], const double f[4], const Me
 {
     const double a = g.a, m = g.m, r = g.r;
     const double A1 = (k[0] * f[1] - k[1] * f[0]) + a * (1. - m * m) * (k[1] * f[3] - k[3] * f[1]);
-    const double A2 = sqrt(1. - m * m) * ((r * r + a * a) * (k[3] * f[2] - k[2] * f[3]) - a * (k[0] * f[2] - k[2] * f[0]));
+    const double A2 = msqrt(1. - m * m) * ((r * r + a * a) * (k[3] * f[2] - k[2] * f[3]) - a * (k[0] * f[2] - k[2] * f[0]));
     wp[0] = +r * A1 - a * m * A2;
     wp[1] = -r * A2 - a * m * A1;
 }
@@ -20,28 +20,28 @@ S5_DEV void polarization_vector(const double k[4], const double wp[2], const Met
 {
     const double a = g.a, r = g.r;
     double m = g.m;
-    double s = sqrt(1.0 - m * m);
+    double s = msqrt(1.0 - m * m);
     const double ra2 = r * r + a * a;
     const double r2 = r * r;
     const double a2 = a * a;
     double s2 = 1.0 - m * m;
     if (s < 1e-12) { s = 1e-12; s2 = 1e-24; m = 1.0 - 0.5 * s; }
-    const double A1 = (+r * wp[0] - a * m * wp[1]) / (r * r + a * a * m * m);
-    const double A2 = (-r * wp[1] - a * m * wp[0]) / (r * r + a * a * m * m);
+    const double A1 = mdiv(+r * wp[0] - a * m * wp[1], r * r + a * a * m * m);
+    const double A2 = mdiv(-r * wp[1] - a * m * wp[0], r * r + a * a * m * m);
     f[0] = 0.0;
-    f[3] = (
+    f[3] = mdiv(
              + g.g11 * A1 * k[1] * (s * r2 * k[3] + s * a2 * k[3] - s * a * k[0])
              + g.g22 * A2 * k[2] * (k[0] - a * s2 * k[3])
-           ) / (
+           , (
              + sq(k[0]) * g.g33 * (s * k[3] * a)
              + sq(k[0]) * g.g03 * (s * k[0] * a - s * r2 * k[3] - s * a2 * k[3] - a2 * s * s2 * k[3])
              + sq(k[1]) * g.g11 * a * s * s2 * (+r2 * k[3] + a2 * k[3] - a * k[0])
              + sq(k[2]) * g.g22 * (a2 * a * s * s2 * k[3] + r2 * a * s * s2 * k[3] - s * r2 * k[0] - s * a2 * k[0])
              + sq(k[3]) * g.g33 * s * (k[3] * a * s2 * r2 + k[3] * a2 * a * s2 - k[0] * r2 - k[0] * a2 - a2 * s2 * k[0])
              + sq(k[3]) * g.g03 * a * s * s2 * (r2 * k[0] + a2 * k[0])
-           );
-    f[1] = (A1 - a * s * s * k[1] * f[3]) / (k[0] - a * s * s * k[3]);
-    f[2] = (A2 + s * k[2] * f[3] * ra2) / (s * k[3] * ra2 - s * a * k[0]);
+           ));
+    f[1] = mdiv(A1 - a * s * s * k[1] * f[3], k[0] - a * s * s * k[3]);
+    f[2] = mdiv(A2 + s * k[2] * f[3] * ra2, s * k[3] * ra2 - s * a * k[0]);
     normalize_to(f, 1.0, g);
 }
 
@@ -57,8 +57,8 @@ S5_DEV double polarization_angle_rotation(double a, double sin_i, double alpha, 
 {
     const double S = -alpha - a * sin_i;
     const double T = +beta;
-    const double X = (-S * wp[1] - T * wp[0]) / (S * S + T * T);
-    const double Y = (-S * wp[0] + T * wp[1]) / (S * S + T * T);
+    const double X = mdiv(-S * wp[1] - T * wp[0], S * S + T * T);
+    const double Y = mdiv(-S * wp[0] + T * wp[1], S * S + T * T);
     return matan2(Y, X);
 }
 
