@@ -46,8 +46,8 @@ struct GeodCache {
     bool   valid;
 };
 
-S5_DEV double pol_integral(const Geod& g, double x) { return g.mK * inv_cn(x / sqrt(g.m2p), g.mm); }  // ref :29
-S5_DEV double pol_inverse(const Geod& g, double T) { return sqrt(g.m2p) * jac_cn(T / g.mK, g.mm); }   // ref :30
+S5_DEV double pol_integral(const Geod& g, double x) { return g.mK * inv_cn(mdiv(x, msqrt(g.m2p)), g.mm); }  // ref :29
+S5_DEV double pol_inverse(const Geod& g, double T) { return msqrt(g.m2p) * jac_cn(mdiv(T, g.mK), g.mm); }   // ref :30
 
 // ---------------------------------------------------------------------------------------
 // roots of R(r), geodesic class, pericentre and the radial integral to infinity  (ref :986-1104)
@@ -140,12 +140,12 @@ S5_DEV bool radial_roots(Geod& g, double r0, int& err)
         g.Rpc = mdiv(1., msqrt(Aq * Bq)) * inv_cn(mdiv(Aq - Bq, Aq + Bq), mm);
     } else {
         const double b1 = g.r1[0], b2 = g.r3[0], a1 = g.r1[1], a2c = g.r3[1];
-        const double Aq = sqrt(sq(b1 - b2) + sq(a1 + a2c));
-        const double Bq = sqrt(sq(b1 - b2) + sq(a1 - a2c));
-        const double g1 = sqrt((4. * sq(a1) - sq(Aq - Bq)) / (sq(Aq + Bq) - 4. * sq(a1)));
-        const double mm = 4. * Aq * Bq / sq(Aq + Bq);
+        const double Aq = msqrt(sq(b1 - b2) + sq(a1 + a2c));
+        const double Bq = msqrt(sq(b1 - b2) + sq(a1 - a2c));
+        const double g1 = msqrt(mdiv(4. * sq(a1) - sq(Aq - Bq), sq(Aq + Bq) - 4. * sq(a1)));
+        const double mm = mdiv(4. * Aq * Bq, sq(Aq + Bq));
         g.rp = b1 - a1 * g1;
-        g.Rpc = 2. / (Aq + Bq) * inv_tn(-1. / g1, mm);
+        g.Rpc = mdiv(2., Aq + Bq) * inv_tn(mdiv(-1., g1), mm);
     }
     return true;
 }
@@ -221,28 +221,28 @@ S5_DEV double P_int(const Geod& g, double r, int ppc)
     if (r == g.rp) return g.Rpc;
     if (g.type == T_RR || g.type == T_RR_BH) {
         const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
-        const double mm = ((r2 - r3) * (r1 - r4)) / ((r2 - r4) * (r1 - r3));
-        const double z = (g.type == T_RR) ? sqrt(((r2 - r4) * (r - r1)) / ((r1 - r4) * (r - r2)))
-                                          : sqrt((r1 - r3) / (r2 - r3) * (r2 - r) / (r1 - r));
-        const double R = 2. / sqrt((r1 - r3) * (r2 - r4)) * inv_sn(z, mm);
+        const double mm = mdiv((r2 - r3) * (r1 - r4), (r2 - r4) * (r1 - r3));
+        const double z = (g.type == T_RR) ? msqrt(mdiv((r2 - r4) * (r - r1), (r1 - r4) * (r - r2)))
+                                          : msqrt(mdiv(mdiv(r1 - r3, r2 - r3) * (r2 - r), r1 - r));
+        const double R = mdiv(2., msqrt((r1 - r3) * (r2 - r4))) * inv_sn(z, mm);
         return (ppc) ? g.Rpc + R : g.Rpc - R;
     }
     if (g.type == T_RC) {
         const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
-        const double A = sqrt(sq(r1 - u) + sq(v));
-        const double B = sqrt(sq(r2 - u) + sq(v));
-        const double mm = (sq(A + B) - sq(r1 - r2)) / (4. * A * B);
-        const double R = 1. / sqrt(A * B) *
-                         inv_cn(((A - B) * r + r1 * B - r2 * A) / ((A + B) * r - r1 * B - r2 * A), mm);
+        const double A = msqrt(sq(r1 - u) + sq(v));
+        const double B = msqrt(sq(r2 - u) + sq(v));
+        const double mm = mdiv(sq(A + B) - sq(r1 - r2), 4. * A * B);
+        const double R = mdiv(1., msqrt(A * B)) *
+                         inv_cn(mdiv((A - B) * r + r1 * B - r2 * A, (A + B) * r - r1 * B - r2 * A), mm);
         return g.Rpc - R;
     }
     if (g.type == T_CC) {
         const double b1 = g.r1[0], b2 = g.r3[0], a1 = g.r1[1], a2c = g.r3[1];
-        const double A = sqrt(sq(b1 - b2) + sq(a1 + a2c));
-        const double B = sqrt(sq(b1 - b2) + sq(a1 - a2c));
-        const double g1 = sqrt((4. * sq(a1) - sq(A - B)) / (sq(A + B) - 4. * sq(a1)));
-        const double mm = 4. * A * B / sq(A + B);
-        const double R = 2. / (A + B) * inv_tn((r - b1 + a1 * g1) / (a1 + b1 * g1 - g1 * r), mm);
+        const double A = msqrt(sq(b1 - b2) + sq(a1 + a2c));
+        const double B = msqrt(sq(b1 - b2) + sq(a1 - a2c));
+        const double g1 = msqrt(mdiv(4. * sq(a1) - sq(A - B), sq(A + B) - 4. * sq(a1)));
+        const double mm = mdiv(4. * A * B, sq(A + B));
+        const double R = mdiv(2., A + B) * inv_tn(mdiv(r - b1 + a1 * g1, a1 + b1 * g1 - g1 * r), mm);
         return g.Rpc - R;
     }
     return NAN;
@@ -371,8 +371,8 @@ S5_DEV void follow(const Geod& g, double step, double& P, double& r, double& m, 
 {
     const double cap = 5e-2;
     for (int it = 0; it < 100000; ++it) {
-        const double truestep = step / fabs(step) * fmin(fabs(step), cap * sqrt(r));
-        P = P + truestep / (sq(r) + sq(g.a * m));
+        const double truestep = mdiv(step, fabs(step)) * fmin(fabs(step), cap * msqrt(r));
+        P = P + mdiv(truestep, sq(r) + sq(g.a * m));
         r = position_rad(g, P);
         m = position_pol(g, P);
         if (r < 1.01 * r_horizon(g.a)) { status = 0; return; }
