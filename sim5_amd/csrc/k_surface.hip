@@ -11,6 +11,7 @@
 // The disk surface H(R) is what the reference gets from the Python disk model's h(R).  Here it is a table
 // (R_i ascending, H_i) staged once per workgroup into LDS and interpolated linearly, with a constant opening
 // angle beyond the last point and H[0] below the first; every lane evaluates it many hundred times.
+#define S5_LADDER_IN_LDS 1            // 256-thread 1-D workgroups: Landen rungs of position_rad / position_pol in LDS
 #include "s5_disk.hpp"
 #include "kernels.hpp"
 
@@ -44,7 +45,10 @@ S5_DEV double surface_height(const double* sR, const double* sH, int n, double R
     return sH[lo] + w * (sH[hi] - sH[lo]);
 }
 
-__global__ __launch_bounds__(256, 2)
+#ifndef S5_SURF_WAVES
+#define S5_SURF_WAVES 2
+#endif
+__global__ __launch_bounds__(256, S5_SURF_WAVES)
 void disk_surface_kernel(SurfaceParams p, const double* __restrict__ tabR, const double* __restrict__ tabH,
                          const double* __restrict__ alpha, const double* __restrict__ beta,
                          double* __restrict__ outP, double* __restrict__ outR, double* __restrict__ outM,

@@ -404,8 +404,15 @@ S5_DEV void sncndn_lds(double u, double m, double& sn, double& cn, double& dn)
     sncndn_with(lad, u, m, sn, cn, dn);
 }
 
-S5_DEV double jac_sn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return s; }
-S5_DEV double jac_cn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return c; }
-S5_DEV double jac_dn(double u, double m) { double s, c, d; sncndn(u, m, s, c, d); return d; }
+// A kernel launched with 256-thread one-dimensional workgroups may define S5_LADDER_IN_LDS before including the
+// headers: the generic routines (position_rad, position_pol, ...) then keep the ladder rungs in LDS as well.
+#ifdef S5_LADDER_IN_LDS
+#define S5_SNCNDN sncndn_lds
+#else
+#define S5_SNCNDN sncndn
+#endif
+S5_DEV double jac_sn(double u, double m) { double s, c, d; S5_SNCNDN(u, m, s, c, d); return s; }
+S5_DEV double jac_cn(double u, double m) { double s, c, d; S5_SNCNDN(u, m, s, c, d); return c; }
+S5_DEV double jac_dn(double u, double m) { double s, c, d; S5_SNCNDN(u, m, s, c, d); return d; }
 
 } // namespace S5NS
