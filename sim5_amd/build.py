@@ -38,12 +38,33 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def _fingerprint(files, extra):
+    """Content hash of everything the library is built from: a copied tree (gpurun snapshot, checkout) keeps the
+    prebuilt library whatever happened to the modification times."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(files):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(repr(extra).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "sim5gpu.h"))
+    sources = sorted(set(os.path.join(CSRC, src) for (src, _, _) in SOURCES))
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    fp = _fingerprint(headers + sources + [os.path.abspath(__file__)],
+                      (FLAGS, VARIANT, os.environ.get("S5_FAST_EXTRA", ""), os.environ.get("S5_TORUS_EXTRA", "")))
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
+        return LIB
+    if os.path.exists(stamp):
+        os.remove(stamp)
     objs = []
     cmds = []
     for (src, obj, variant) in SOURCES:
@@ -84,6 +105,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    with open(stamp, "w") as fh:
+        fh.write(fp + "\n")
     return LIB
 
 
