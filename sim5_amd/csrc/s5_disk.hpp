@@ -18,7 +18,7 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
 {
     if (r <= d.rms) return 0.0;
     const double a = d.a;
-    const double x = msqrt(r);
+    const double x = sqrt_pos(r);                     // r > rms > 0
 #if S5_FAST
     // same expression with the constant divisors replaced by their host-computed reciprocals and the two
     // prefactor divisions merged into one

@@ -341,7 +341,7 @@ S5_DEV void sncndn_with(Ladder& lad, double u, double m, double& sn, double& cn,
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         if (climbing) {
-            emc = msqrt(emc);
+            emc = sqrt_pos(emc);                // 0 < 1 - m <= 1, and products of positive means after that
             lad.put(i, a, emc);
             c = 0.5 * (a + emc);
             if (fabs(a - emc) <= conv * a) { climbing = false; top = i; }

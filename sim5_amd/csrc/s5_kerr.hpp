@@ -328,7 +328,7 @@ S5_DEV double gfactor_kepler(double r, double a, double l)                      
 {
 #if S5_FAST
     // Omega_K = 1/(a + r^1.5) and 2/r from one reciprocal
-    const double den = a + r * msqrt(r);
+    const double den = a + r * sqrt_pos(r);
     const double t = mrcp(den * r);
     const double Om = r * t;
     const double w = 1. - a * Om;

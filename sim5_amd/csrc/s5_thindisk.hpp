@@ -93,8 +93,8 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
 #if S5_FAST
         // Z^2 = (F^2 - X)/54^2 = 4 E^3/54^2, so Z^(1/3) = sqrt(E)/3: one square root instead of a square
         // root and a cube root; atan2 is scale-free, so the divisions by 54 drop out as well
-        const double z = matan2(msqrt(-X), F);
-        A = msqrt(E) * (2. / 3.) * mcos_third(z);
+        const double z = matan2(sqrt_pos(-X), F);                    // X < 0 here, and then E > 0
+        A = sqrt_pos(E) * (2. / 3.) * mcos_third(z);
 #else
         const double sX = S5_DIVC(msqrt(-X), 54.);
         const double F54 = S5_DIVC(F, 54.);
@@ -272,13 +272,13 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
         double x, y, mult;
         if (slot == 0) {
             const double z2 = zT * zT;
-            if (type == T_RC) { x = z2; y = 1.0 - mR * (1. - z2); mult = msqrt(1. - z2); }
+            if (type == T_RC) { x = z2; y = 1.0 - mR * (1. - z2); mult = sqrt_pos(1. - z2); }     // plain lanes: z2 < 1
             else { x = 1.0 - z2; y = 1.0 - mR * zT * zT; mult = zT; }      // (m z) z, as ref :485
         } else if (slot == 1) {
             x = 0.0; y = 1.0 - mmT; mult = 1.0;
         } else if (slot == 2) {
             const double z2 = u_i * u_i;
-            x = z2; y = 1.0 - mmT * (1. - z2); mult = msqrt(1. - z2);
+            x = z2; y = 1.0 - mmT * (1. - z2); mult = sqrt_pos(1. - z2);
         } else {
             double m3 = mdiv(mR, mR - 1.);              // modulus of the second term (ref :513, :280)
             if (m3 == 1.0) m3 = 0.99999999;
