@@ -146,3 +146,36 @@ def test_torus_kernel_matches_cpu_integration(capi):
     # rounding differences in cos/acos may shift a float threshold for a few rays; the bulk must agree
     assert same_steps >= 0.97 * len(res), same_steps
     assert np.isfinite(S[:, 0]).all() and (S[:, 0] >= 0).all() and S[:, 0].max() > 0
+
+
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+def test_polarized_parameter_sweep(capi, strict):
+    """Polarization angle and g over a seeded sweep of spins / inclinations, GPU kernel against the CPU
+    oracle's recipe (oracle/cpu_driver.c:cpu_polarized_rays run on our restatement) on the same rays."""
+    import ctypes as C
+    drv = C.CDLL(ol.DRIVER_SO)
+    D, I, VP = C.c_double, C.c_int, C.c_void_p
+    drv.cpu_polarized_rays.argtypes = [C.c_char_p, C.c_char_p, D, D, D, I, VP, VP, VP, VP, VP, VP]
+    drv.cpu_polarized_rays.restype = I
+    rng = np.random.default_rng(5)
+    n = 96
+    for a, inc in [(0.0, 20.0), (0.5, 45.0), (0.998, 80.0)] + [(float(rng.uniform(0, 0.999)), float(rng.uniform(5, 85))) for _ in range(5)]:
+        d = capi.image_desc(n, n, a, math.radians(inc), pol_degree=0.1, strict=strict)
+        N = n * n
+        st = capi.DeviceBuffer(3 * N * 8); chi = capi.DeviceBuffer(N * 8); gg = capi.DeviceBuffer(N * 8)
+        capi.disk_image_polarized_device(d, st.ptr, chi.ptr, aux={"g": gg.ptr})
+        capi.synchronize()
+        CH = chi.to_numpy(np.float64, (N,)); G = gg.to_numpy(np.float64, (N,))
+        rmax = ol.Oracle().r_ms(a) + 8.0
+        c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+        al = np.ascontiguousarray(np.tile(c, n)); be = np.ascontiguousarray(np.repeat(c, n))
+        rchi = np.zeros(N); rr = np.zeros(N); rg = np.zeros(N); rwp = np.zeros((N, 2))
+        rc = drv.cpu_polarized_rays(ol.ORACLE_SO.encode(), b"orc_", a, math.radians(inc), -1.0, N, al.ctypes.data, be.ctypes.data,
+                                    rchi.ctypes.data, rr.ctypes.data, rg.ctypes.data, rwp.ctypes.data)
+        assert rc == 0
+        assert np.array_equal(np.isnan(CH), np.isnan(rchi)), (a, inc, int((np.isnan(CH) != np.isnan(rchi)).sum()))
+        m = ~np.isnan(rchi)
+        assert m.sum() > 1000
+        dchi = np.angle(np.exp(1j * (CH[m] - rchi[m])))
+        assert np.max(np.abs(dchi)) < 1e-6, (a, inc, float(np.max(np.abs(dchi))))
+        assert_close(G[m], rg[m], what="g a=%g i=%g" % (a, inc))
