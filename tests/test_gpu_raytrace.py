@@ -179,3 +179,31 @@ def test_polarized_parameter_sweep(capi, strict):
         dchi = np.angle(np.exp(1j * (CH[m] - rchi[m])))
         assert np.max(np.abs(dchi)) < 1e-6, (a, inc, float(np.max(np.abs(dchi))))
         assert_close(G[m], rg[m], what="g a=%g i=%g" % (a, inc))
+
+
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+def test_torus_kernel_parameter_sweep(capi, strict):
+    """Step counts and end points of the march kernel against the oracle's raytrace() loop for other spins,
+    inclinations and precisions than the C4 configuration, both arithmetic variants."""
+    n, r0 = 16, 100.0
+    orc = ol.Oracle()
+    for a, inc, prec in [(0.2, 30.0, 1.0), (0.998, 80.0, 1.0), (0.6, 55.0, 0.1), (0.9, 70.0, 0.01)]:
+        d = torus_desc(capi, n, a, inc, r0=r0, precision=prec, max_steps=50000)
+        if strict:
+            d.img.flags = 1
+        S, steps, xe, ce, me = run_torus(capi, d)
+        rmax = orc.r_ms(a) + 8.0
+        c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+        cases = [(a, inc / 180.0 * math.pi, c[ix], c[iy], r0, prec, 0) for iy in range(n) for ix in range(n)]
+        res = gga.verlet_traces(ol.ORACLE_SO, "orc_", cases, 50000)
+        same = 0
+        for i, (m, tr, xs, ks, car) in enumerate(res):
+            if m <= 0:
+                assert steps[i] == 0
+                continue
+            same += int(m == steps[i])
+            if m == steps[i]:
+                assert abs(xe[i, 1] - tr[m - 1, 1]) <= 1e-6 * max(1.0, abs(tr[m - 1, 1])), (a, inc, prec, i)
+        print("torus sweep a=%g i=%g precision=%g %s: %d of %d rays with identical step counts" % (a, inc, prec, "strict" if strict else "fast", same, len(res)))
+        assert same >= (0.99 if strict else 0.95) * len(res), (a, inc, prec, strict, same, len(res))
+        assert np.isfinite(S[:, 0]).all()
