@@ -207,6 +207,8 @@ typedef struct {
     void (*rt_step)(double *, double *, double *, rtd_t *);
     double (*rt_error)(double *, double *, rtd_t *);
     double (*r_ms)(double);
+    void (*flat_metric)(double, double, metric_t *);
+    double (*Omega_from_ell)(double, metric_t *);
 } api_t;
 
 static void *sym(void *h, const char *prefix, const char *name)
@@ -239,6 +241,8 @@ static int load_api(const char *libpath, const char *prefix, api_t *A, void **ho
     A->rt_step = sym(h, prefix, "raytrace");
     A->rt_error = sym(h, prefix, "raytrace_error");
     A->r_ms = sym(h, prefix, "r_ms");
+    A->flat_metric = sym(h, prefix, "flat_metric");
+    A->Omega_from_ell = sym(h, prefix, "Omega_from_ell");
     void **p = (void **)A;
     for (size_t i = 0; i < sizeof(api_t) / sizeof(void *); i++)
         if (!p[i]) { fprintf(stderr, "cpu_driver: missing symbol #%zu in %s\n", i, libpath); return -2; }
@@ -331,4 +335,87 @@ int cpu_verlet_trace(const char *libpath, const char *prefix, double a, double i
     }
     if (carter) *carter = A.rt_error(x, k, &rtd);
     return n;
+}
+
+
+/*
+ * The C4 job on the host: n rays (alpha[i], beta[i]) started at r0 as in cpu_verlet_trace, advanced by the
+ * library's raytrace() until they leave (r_in, r_out), rtd.error > max_error or max_steps calls were made, with
+ * the radiative transfer through the torus accumulated after every call.  The integrator is the checker
+ * library's (the unmodified reference with prefix "", our restatement with "orc_"); the transfer model is this
+ * project's own (the reference has none) and is restated here in plain C from its
+ * definition in DESIGN.md section 7: fluid on circular orbits of constant specific angular momentum ell
+ * (Omega = Omega_from_ell, ref src/sim5kerr.c:1101), density rho = exp(-((R-R_t)^2+z^2)/(2 w^2)) cut at
+ * 36 * 2w^2 (shape 0) or 1 inside r <= w (shape 1), g = E_inf / (-k.U), and per step of affine length dl
+ *      dtau = absorb0 rho dl/g ,   dI = g^4 emis0 rho exp(-tau) dl/g .
+ * Outputs per ray (any may be NULL): steps (0 = the ray could not be started), x_end[4], k_end[4], I, tau,
+ * raytrace_error() at the end, largest rtd.error seen.
+ */
+int cpu_torus_rays(const char *libpath, const char *prefix, double a, double inc_rad, int n,
+                   const double *alpha, const double *beta, double r0, double precision, int options,
+                   double dl_max, double r_in, double r_out, double max_error, int max_steps,
+                   int shape, double torus_r, double torus_w, double torus_l, double emis0, double absorb0,
+                   int *steps, double *x_end, double *k_end, double *I_out, double *tau_out,
+                   double *carter, float *max_step_error)
+{
+    api_t A; void *h;
+    int rc = load_api(libpath, prefix, &A, &h);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        geod_t gd; int err = 0;
+        double x[4] = { 0.0, r0, 0.0, 0.0 }, k[4] = { 0.0, 0.0, 0.0, 0.0 };
+        double I = 0.0, tau = 0.0, car = NAN;
+        float worst = 0.0f;
+        int made = 0;
+        A.init_inf(inc_rad, a, alpha[i], beta[i], &gd, &err);
+        if (!err && r0 > gd.rp) {
+            double P0 = A.P_int(&gd, r0, 0);
+            x[2] = A.pos_pol(&gd, P0);
+            A.momentum(&gd, P0, r0, x[2], k);
+            if (!isnan(k[0]) && !isnan(x[2])) {
+                rtd_t rtd;
+                memset(&rtd, 0, sizeof rtd);
+                A.rt_prepare(a, x, k, precision, options, &rtd);
+                while (made < max_steps) {
+                    double dl = dl_max;
+                    A.rt_step(x, k, &dl, &rtd);
+                    made++;
+                    if (rtd.error > worst) worst = rtd.error;
+                    /* transfer over the step just taken, evaluated at its end point */
+                    double rho;
+                    if (shape == 1) rho = (x[1] <= torus_w) ? 1.0 : 0.0;
+                    else {
+                        double R = x[1] * sqrt(1. - x[2] * x[2]), z = x[1] * x[2];
+                        double d2 = (R - torus_r) * (R - torus_r) + z * z, w2 = 2. * torus_w * torus_w;
+                        rho = (d2 < 36. * w2) ? exp(-d2 / w2) : 0.0;
+                    }
+                    if (rho > 0.0) {
+                        metric_t g;
+                        if (rtd.opt_gr) A.kerr_metric(a, x[1], x[2], &g); else A.flat_metric(x[1], x[2], &g);
+                        double Om = A.Omega_from_ell(torus_l, &g);
+                        double nrm = -(g.g00 + 2. * Om * g.g03 + Om * Om * g.g33);
+                        if (nrm > 0.0) {
+                            double ut = 1. / sqrt(nrm);
+                            double k_t = k[0] * g.g00 + k[3] * g.g03, k_f = k[3] * g.g33 + k[0] * g.g03;
+                            double gfac = rtd.E / (ut * (k_t + Om * k_f));
+                            double ds = dl / gfac, g2 = gfac * gfac;
+                            double att = (absorb0 == 0.0) ? 1.0 : exp(-tau);
+                            I += (g2 * g2) * emis0 * rho * att * ds;
+                            tau += absorb0 * rho * ds;
+                        }
+                    }
+                    if (!(x[1] > r_in) || !(x[1] < r_out) || (rtd.error > max_error)) break;
+                }
+                car = A.rt_error(x, k, &rtd);
+            }
+        }
+        if (steps) steps[i] = made;
+        if (x_end) for (int c = 0; c < 4; c++) x_end[4 * i + c] = x[c];
+        if (k_end) for (int c = 0; c < 4; c++) k_end[4 * i + c] = k[c];
+        if (I_out) I_out[i] = I;
+        if (tau_out) tau_out[i] = tau;
+        if (carter) carter[i] = car;
+        if (max_step_error) max_step_error[i] = worst;
+    }
+    return 0;
 }

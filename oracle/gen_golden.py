@@ -150,6 +150,93 @@ def kat_geodesic(ref, rng):
 
 
 # ------------------------------------------------------------------------------------------
+def kat_init_src():
+    """geodesic_init_src (ref src/sim5kerr-geod.c:106-173) on the round trip the reference's own (disabled)
+    unit test intends, ref src/sim5unittests.c:171-255: init_inf -> a point of the trajectory (the equatorial
+    crossing or a random position integral, before and after the pericentre) -> position_rad / position_pol ->
+    geodesic_momentum (photon_momentum with the signs of the branch) -> init_src, which must give back the
+    inclination and the impact parameters.  Spin 0 exercises the 1e-8 clamp (:126; init_inf clamps to 1e-4, :71).
+    A second block feeds photons with random directions in the ZAMO frame (captured, bound and escaping rays,
+    both ppc values), which reaches the error returns and the RR_BH class (r0 = r in the root classification)."""
+    ref = ol.Reference()
+    rng = np.random.default_rng(20261005)
+    rows = []          # (a, r, m, k0..k3, ppc, origin, inc, alpha, beta)
+    for a in [0.0, 1e-5, 0.099, 0.5, 0.9, 0.998]:
+        for inc in [deg(10.0), deg(35.0), deg(60.0), deg(80.0)]:
+            made = 0
+            while made < 60:
+                rad = (ref.r_ms(a) + 8.0) * rng.random() ** 1.3 + 0.05
+                ang = rng.uniform(0, 2 * math.pi)
+                al, be = rad * math.cos(ang), rad * math.sin(ang)
+                g = ol.Geodesic(); C.memset(C.byref(g), 0, 240); e = C.c_int(-1)
+                if not ref.geodesic_init_inf(inc, a, al, be, C.byref(g), C.byref(e)) or g.type not in (40, 2):
+                    continue
+                kind = made % 3
+                if kind == 0:                                          # the equatorial crossing (m = 0 exactly or to rounding)
+                    P = ref.geodesic_find_midplane_crossing(C.byref(g), 0)
+                elif kind == 1:                                        # a point before the pericentre
+                    P = g.Rpc * (0.03 + 0.94 * rng.random())
+                else:                                                  # after it (RR only; RC rays end in the hole)
+                    P = g.Rpc * (1.03 + 0.94 * rng.random()) if g.type == 40 else g.Rpc * (0.03 + 0.94 * rng.random())
+                if not (P == P):
+                    continue
+                r = ref.geodesic_position_rad(C.byref(g), P)
+                m = ref.geodesic_position_pol(C.byref(g), P)
+                if not (r == r and m == m) or r < 1.02 * ref.r_bh(a):
+                    continue
+                k = ol.D4()
+                ref.geodesic_momentum(C.byref(g), P, r, m, k)
+                if math.isnan(k[0]):
+                    continue
+                rows.append((a, r, m, k[0], k[1], k[2], k[3], 1 if P > g.Rpc else 0, 0, inc, al, be))
+                made += 1
+    for _ in range(400):
+        a = float(rng.choice([0.0, 0.3, 0.9, 0.998]))
+        r = ref.r_bh(a) * (1.05 + 12.0 * rng.random() ** 2)
+        m = rng.uniform(-0.95, 0.95)
+        mt = ol.Metric(); t = ol.Tetrad()
+        ref.kerr_metric(a, r, m, C.byref(mt)); ref.tetrad_zamo(C.byref(mt), C.byref(t))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        k = ol.D4(); ref.on2bl(ol.D4(1.0, *d), k, C.byref(t))
+        rows.append((a, r, m, k[0], k[1], k[2], k[3], int(rng.integers(0, 2)), 1, np.nan, np.nan, np.nan))
+    # edge cases: photons in the equatorial plane (q = 0 -> GD_ERROR_Q_RANGE), photons at a polar turning point off
+    # the plane (k^theta = 0: |m| = mu_plus up to rounding), nearly radial photons close to the axis (q < 0, the
+    # vortical branch of geodesic_priv_T_roots) and photons aimed along the local photon orbit (r1 ~ r2)
+    for j in range(160):
+        a = float(rng.choice([0.5, 0.9, 0.998]))
+        r = ref.r_bh(a) * (1.2 + 8.0 * rng.random())
+        kind = j % 4
+        if kind == 0:
+            m = 0.0; d = np.array([rng.normal(), 0.0, rng.normal()])
+        elif kind == 1:
+            m = rng.uniform(-0.9, 0.9); d = np.array([rng.normal(), 0.0, rng.normal()])
+        elif kind == 2:
+            m = rng.choice([-1.0, 1.0]) * rng.uniform(0.8, 0.995); d = np.array([rng.choice([-1.0, 1.0]), 0.02 * rng.normal(), 0.02 * rng.normal()])
+        else:
+            m = rng.uniform(-0.3, 0.3); r = ref.r_bh(a) * rng.uniform(1.3, 2.2); d = np.array([1e-3 * rng.normal(), 0.2 * rng.normal(), rng.choice([-1.0, 1.0])])
+        d /= np.linalg.norm(d)
+        mt = ol.Metric(); t = ol.Tetrad()
+        ref.kerr_metric(a, r, m, C.byref(mt)); ref.tetrad_zamo(C.byref(mt), C.byref(t))
+        k = ol.D4(); ref.on2bl(ol.D4(1.0, *d), k, C.byref(t))
+        rows.append((a, r, m, k[0], k[1], k[2], k[3], int(rng.integers(0, 2)), 2, np.nan, np.nan, np.nan))
+    inp = np.array(rows)
+    n = len(inp)
+    dump = np.zeros((n, 240), np.uint8); err = np.zeros(n, np.int32); ok = np.zeros(n, np.int32)
+    for i in range(n):
+        g = ol.Geodesic(); C.memset(C.byref(g), 0, 240); e = C.c_int(-1)
+        k = ol.D4(*inp[i, 3:7])
+        ok[i] = ref.geodesic_init_src(inp[i, 0], inp[i, 1], inp[i, 2], k, int(inp[i, 7]), C.byref(g), C.byref(e))
+        err[i] = e.value
+        dump[i] = np.frombuffer(ol.struct_bytes(g), np.uint8)
+    rec = np.frombuffer(dump.tobytes(), dtype=np.dtype([("f", np.float64, 30)]))["f"]
+    rt = inp[:, 8] == 0
+    back = np.abs(rec[rt & (ok == 1), 4] - np.cos(inp[rt & (ok == 1), 9]))
+    print("   init_src: %d records, ok %d, round-trip rays %d, worst |cos_i - cos(incl)| %.2e; err codes %s" % (
+        n, ok.sum(), rt.sum(), back.max(), np.unique(err).tolist()))
+    save("kat_init_src.npz", inp=inp, dump=dump, err=err, ok=ok)
+
+
+# ------------------------------------------------------------------------------------------
 def kat_kerr(ref, rng):
     n = 600
     a = rng.choice([0.0, 0.1, 0.5, 0.9, 0.998], n)
@@ -494,6 +581,35 @@ def polarized():
          chi=chi, r=r, g=g, wp=wp)
 
 
+def torus_c4():
+    """C4 (BASELINE.json configs[3]: 1024^2 optically thin torus, raytrace() + transfer) on a decimated subset of the
+    SAME 1024^2 pixel grid, integrated by the unmodified reference's raytrace() with the build-defined transfer
+    accumulated per step (oracle/cpu_driver.c:cpu_torus_rays): every 16th pixel without absorption, the same rays
+    with absorption (absorb0 = 0.3: the exp(-tau) branch), and the same view as a 16 x 16 image at precision 0.01."""
+    import gen_golden_access as gga
+    n, a, inc = 1024, 0.9, deg(70.0)
+    rmax = ol.Reference().r_ms(a) + 8.0
+    c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+    out = {"n": np.array([n]), "a": np.array([a]), "inc_deg": np.array([70.0])}
+    for tag, dec, kw in (("thin", 16, {}), ("absorb", 16, {"absorb0": 0.3}), ("fine", 64, {"precision": 0.01, "max_steps": 50000})):
+        if tag == "fine":                                  # a 16 x 16 image of the same view (all its pixels)
+            idx = np.arange(16)
+            grid = ((idx + .5) / 16 - 0.5) * 2.0 * rmax
+        else:
+            idx = np.arange(dec // 2, n, dec)
+            grid = c
+        ix, iy = np.meshgrid(idx, idx)
+        r = gga.torus_rays(ol.REF_SO, "", a, inc, grid[ix.ravel()], grid[iy.ravel()], **kw)
+        out["%s_ix" % tag] = ix.ravel().astype(np.int32); out["%s_iy" % tag] = iy.ravel().astype(np.int32)
+        for k, v in r.items():
+            if tag == "absorb" and k not in ("I", "tau"):
+                continue                               # the trajectory is the one of "thin"
+            out["%s_%s" % (tag, k)] = v
+        print("   torus %s: %d rays, %.1f steps/ray, I max %.4g, tau max %.4g" % (
+            tag, len(r["I"]), r["steps"].mean(), r["I"].max(), r["tau"].max()))
+    save("torus_c4.npz", **out)
+
+
 def main():
     if not ol.have_reference():
         sys.exit("oracle/_ref/libsim5ref.so missing: run `make -C oracle` in the build container")
@@ -507,6 +623,12 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "azimuth":      # only the newest fixture
             kat_azimuth(ref)
             return
+        if len(sys.argv) > 1 and sys.argv[1] == "init_src":
+            kat_init_src()
+            return
+        if len(sys.argv) > 1 and sys.argv[1] == "torus":
+            torus_c4()
+            return
         kat_elliptic(ref, rng)
         kat_geodesic(ref, rng)
         kat_kerr(ref, rng)
@@ -516,6 +638,8 @@ def main():
         polarized()
         images()
         kat_azimuth(ref)
+        kat_init_src()
+        torus_c4()
     finally:
         os.dup2(saved, 2)
 

@@ -182,7 +182,10 @@ class DeviceBuffer:
         _check(_lib.sim5gpu_memcpy_h2d(VP(self.ptr), _p(arr), SZ(arr.nbytes)), "sim5gpu_memcpy_h2d")
 
     def zero(self):
-        _check(_lib.sim5gpu_memset(VP(self.ptr), I(0), SZ(self.nbytes)), "sim5gpu_memset")
+        self.fill(0)
+
+    def fill(self, byte):
+        _check(_lib.sim5gpu_memset(VP(self.ptr), I(int(byte)), SZ(self.nbytes)), "sim5gpu_memset")
 
     def free(self):
         if self.ptr:

@@ -128,23 +128,77 @@ def test_fast_and_strict_variants_agree(capi):
     assert_close(f["flux"], s["flux"], rtol=1e-6, floor=flux_floor(s["flux"]), what="flux")
 
 
-def test_row_tile_sharding_equals_whole_image(capi, golden):
-    """C5 geometry (8192^2, 8 inclinations): 8 row tiles concatenated == one launch; sampled pixels
-    against the reference."""
+@VARIANTS
+def test_c5_all_inclinations_row_tiles(capi, golden, strict):
+    """BASELINE.json configs[4]: 8192^2, a = 0.998, the 8 inclinations 10..80 deg, each image traced as 8 row tiles
+    (the shards of an 8-GPU job): every 64th pixel in x and y against the reference (classes exact, r / g / flux
+    within the bar), hit counts of the tiles add up to the whole image's, and (one inclination) the tiles put
+    together are bit-identical to the image traced in one launch."""
     g = golden("img_c5_8192_sampled.npz")
     n = 8192
-    for inc in (10, 40, 80):
-        tiles = [run(capi, n, 0.998, float(inc), full=True, y0=k * n // 8, y1=(k + 1) * n // 8) for k in range(8)]
-        cls = np.concatenate([t["cls"] for t in tiles]); r = np.concatenate([t["r"] for t in tiles])
-        gg = np.concatenate([t["g"] for t in tiles]); fl = np.concatenate([t["flux"] for t in tiles])
-        sl = (slice(32, None, 64), slice(0, None, 64))
-        assert np.array_equal(cls[sl], g["cls_%d" % inc])
-        assert_close(r[sl], g["r_%d" % inc], what="r"); assert_close(gg[sl], g["g_%d" % inc], what="g")
-        assert_close(fl[sl], g["flux_%d" % inc], floor=flux_floor(g["flux_%d" % inc]), what="flux")
-        if inc == 40:
-            whole = run(capi, n, 0.998, float(inc), full=False)
-            assert np.array_equal(whole["image_g"], np.concatenate([t["image_g"] for t in tiles]))
-            assert np.array_equal(whole["image_f"], np.concatenate([t["image_f"] for t in tiles]))
+    for inc in range(10, 90, 10):
+        parts = {k: [] for k in ("cls", "r", "g", "flux")}
+        hits = 0
+        planes = []
+        for k in range(8):
+            t = run(capi, n, 0.998, float(inc), full=True, y0=k * n // 8, y1=(k + 1) * n // 8, strict=strict)
+            for key in parts:
+                parts[key].append(t[key][32::64, ::64].copy())        # tile height 1024: global rows 32, 96, ...
+            hits += int(np.isin(t["cls"], HIT).sum())
+            if inc == 40 and not strict:
+                planes.append((t["image_f"], t["image_g"]))
+            del t
+        cls, r, gg, fl = (np.concatenate(parts[k]) for k in ("cls", "r", "g", "flux"))
+        assert np.array_equal(cls, g["cls_%d" % inc]), (inc, int((cls != g["cls_%d" % inc]).sum()))
+        assert_close(r, g["r_%d" % inc], what="r i=%d" % inc); assert_close(gg, g["g_%d" % inc], what="g i=%d" % inc)
+        assert_close(fl, g["flux_%d" % inc], floor=flux_floor(g["flux_%d" % inc]), what="flux i=%d" % inc)
+        whole = run(capi, n, 0.998, float(inc), full=False, strict=strict)
+        assert int((whole["image_g"] > 0).sum()) == hits
+        if planes:
+            assert np.array_equal(whole["image_f"], np.concatenate([p[0] for p in planes]))
+            assert np.array_equal(whole["image_g"], np.concatenate([p[1] for p in planes]))
+        del whole, planes
+
+
+@VARIANTS
+def test_headline_flux_error_distribution(capi, strict):
+    """The 4096^2 headline image, EVERY pixel against the CPU oracle, without the floor the other flux assertions use:
+    how many pixels exceed 1e-6 relative, the largest error and where it sits.  F(r) is a difference of O(1) log terms
+    that cancels towards the inner edge (ref src/sim5disk-nt.c:129-135), so a pure relative error is unbounded as
+    F -> 0 for ANY two libms; on this image the innermost pixel with flux sits 5e-6 r_g outside the zero-flux band and
+    the unfloored 1e-6 bar still holds for every pixel.  r and g: unfloored, every pixel."""
+    import json, os
+    n, a, inc = 4096, 0.998, 70.0
+    c = ol.cpu_disk_image("port", n, n, a, inc, nthreads=min(16, os.cpu_count() or 1), full=True)
+    o = run(capi, n, a, inc, strict=strict)
+    assert np.array_equal(o["cls"], c["cls"])
+    hit = np.isin(c["cls"], HIT)
+    er = np.abs(o["r"][hit] - c["r"][hit]) / c["r"][hit]
+    eg = np.abs(o["g"][hit] - c["g"][hit]) / c["g"][hit]
+    assert er.max() < 1e-6 and eg.max() < 1e-6
+    F, Fo, r = c["flux"][hit], o["flux"][hit], c["r"][hit]
+    assert np.array_equal(F == 0, Fo == 0)                   # the zero-flux band r_ms <= r <= (float)(r_ms + 1e-3)
+    pos = F > 0
+    ef = np.abs(Fo[pos] - F[pos]) / F[pos]
+    rin = float(r[pos].min()); peak = float(F.max())
+    edges = [0, 1e-12, 1e-10, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, np.inf]
+    hist = np.histogram(ef, bins=edges)[0].tolist()
+    over = ef > 1e-6
+    worst = int(np.argmax(ef))
+    rep = {"variant": "strict" if strict else "fast", "pixels_with_flux": int(pos.sum()), "bin_edges": [str(e) for e in edges],
+           "counts": hist, "over_1e-6": int(over.sum()), "max_rel_err": float(ef.max()),
+           "r_of_max": float(r[pos][worst]), "r_inner": rin, "max_r_over_rin_minus_1_of_pixels_over_1e-6":
+           float((r[pos][over] / rin - 1).max()) if over.any() else 0.0,
+           "max_abs_err_over_peak": float(np.abs(Fo[pos] - F[pos]).max() / peak),
+           "max_rel_err_r": float(er.max()), "max_rel_err_g": float(eg.max())}
+    print("flux error distribution (unfloored):", json.dumps(rep))
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(outdir):
+        with open(os.path.join(outdir, "flux_error_hist_%s.json" % rep["variant"]), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    # measured on MI355X: no pixel above 6e-8 (fast) / 9e-9 (strict) -- the north-star bar holds without any floor
+    assert ef.max() < 1e-6, rep
+    assert rep["max_abs_err_over_peak"] < 1e-9
 
 
 def test_striped_launch_equals_separate_stripes(capi):

@@ -10,6 +10,11 @@ from gpuutil import REL, assert_close
 
 pytestmark = pytest.mark.gpu
 
+# share of rays whose raytrace() call count must equal the CPU loop's.  Step counts are integer work decided by
+# float thresholds (ref src/sim5raytrace.c:213,220); the strict variant reproduces the reference's arithmetic.
+STEP_MATCH_STRICT = 1.0
+STEP_MATCH_FAST = 0.98
+
 
 def test_prepare_and_single_step(capi, golden):
     g = golden("kat_raytrace_api.npz")
@@ -92,15 +97,59 @@ def torus_desc(capi, n, a, inc_deg, **kw):
     return d
 
 
-def run_torus(capi, d):
+def run_torus(capi, d, full=False):
     n = d.img.nx * (d.img.y1 - d.img.y0)
     st = capi.DeviceBuffer(n * 40); steps = capi.DeviceBuffer(n * 4); xe = capi.DeviceBuffer(n * 32)
-    ce = capi.DeviceBuffer(n * 8); me = capi.DeviceBuffer(n * 4)
+    ce = capi.DeviceBuffer(n * 8); me = capi.DeviceBuffer(n * 4); ke = capi.DeviceBuffer(n * 32)
+    # sentinels: a ray the job does not write keeps them
+    st.fill(0xff); steps.fill(0xff)
     capi.torus_image_device(d, st.ptr, aux={"steps": steps.ptr, "x_end": xe.ptr, "carter_error": ce.ptr,
-                                            "max_step_error": me.ptr})
+                                            "max_step_error": me.ptr, "k_end": ke.ptr})
     capi.synchronize()
-    return (st.to_numpy(np.float64, (n, 5)), steps.to_numpy(np.int32, (n,)), xe.to_numpy(np.float64, (n, 4)),
-            ce.to_numpy(np.float64, (n,)), me.to_numpy(np.float32, (n,)))
+    out = (st.to_numpy(np.float64, (n, 5)), steps.to_numpy(np.int32, (n,)), xe.to_numpy(np.float64, (n, 4)),
+           ce.to_numpy(np.float64, (n,)), me.to_numpy(np.float32, (n,)))
+    return out + (ke.to_numpy(np.float64, (n, 4)),) if full else out
+
+
+def compare_rays(tag, S, steps, xe, ke, ref, need_same):
+    """GPU rays against the CPU integration of the same rays (dict of oracle/cpu_driver.c:cpu_torus_rays arrays):
+    step counts, and for rays with identical counts the end point (all four coordinates), the end momentum and
+    the transfer integrals I and tau within 1e-6."""
+    same = steps == ref["steps"]
+    print("%s: %d of %d rays with identical step counts (the others differ by %s steps)" % (
+        tag, int(same.sum()), same.size, sorted(set((steps - ref["steps"])[~same].tolist()))[:8]))
+    assert same.sum() >= need_same * same.size, (tag, int(same.sum()), same.size)
+    assert np.array_equal(steps == 0, ref["steps"] == 0)
+    m = same & (steps > 0)
+    strict = " strict" in tag
+    worst = {}
+
+    def check(name, got, want, floor=0.0):
+        # Bar 1e-6 (north_star) for every ray in the strict variant.  The fast variant evaluates the polar update in
+        # another (algebraically equal) form: its rounding differs from the reference's in the last bit of every step,
+        # and a ray that winds around the photon orbit (1 000+ steps instead of ~520) amplifies that exponentially --
+        # such rays are ill-conditioned for any two implementations.  Fast: 99.9 % of the rays within 1e-6, all within
+        # 1e-5; the worst value is printed.
+        e = np.abs(got - want) / np.maximum(np.abs(want), floor)
+        worst[name] = float(e.max()) if e.size else 0.0
+        if strict:
+            assert e.max() <= REL, "%s %s: max rel err %.3e" % (tag, name, e.max())
+        else:
+            assert (e <= REL).mean() >= 0.999 and e.max() <= 1e-5, "%s %s: %d of %d rays above 1e-6, max %.3e" % (
+                tag, name, int((e > REL).sum()), e.size, e.max())
+
+    # t and phi are sums over the whole ray (|t| ~ 200, |phi| up to a few turns), r and cos(theta) are O(1..100)
+    check("t_end", xe[m, 0], ref["x_end"][m, 0], 1.0)
+    check("r_end", xe[m, 1], ref["x_end"][m, 1])
+    check("cos(theta)_end", xe[m, 2], ref["x_end"][m, 2], 1e-2)
+    check("phi_end", xe[m, 3], ref["x_end"][m, 3], 1.0)
+    for c, floor in ((0, 0.0), (1, 1e-2), (2, 1e-4), (3, 1e-4)):          # k^t ~ 1, k^r ~ 1, k^theta, k^phi ~ 1e-2 at r ~ 100
+        check("k_end[%d]" % c, ke[m, c], ref["k_end"][m, c], floor)
+    check("Stokes I", S[m, 0], ref["I"][m], 1e-6 * float(ref["I"].max()))
+    check("tau", S[m, 4], ref["tau"][m], 1e-6 * max(float(ref["tau"].max()), 1e-300))
+    print("   worst relative differences:", {k: "%.1e" % v for k, v in worst.items()})
+    assert (S[:, 1:4] == 0).all()
+    return same
 
 
 def test_torus_flat_space_uniform_sphere(capi):
@@ -124,28 +173,88 @@ def test_torus_flat_space_uniform_sphere(capi):
     assert (steps[sel] > 3000).all() and (xe[sel, 1] > 40.0).all()
 
 
-def test_torus_kernel_matches_cpu_integration(capi):
-    """Kerr, a=0.9: final position and step count per ray against the oracle's own step loop;
-    optically thin torus intensity against the same accumulation done on the CPU trace."""
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+@pytest.mark.parametrize("absorb0", [0.0, 0.3], ids=["thin", "absorbing"])
+def test_torus_kernel_matches_cpu_integration(capi, strict, absorb0):
+    """Kerr, a = 0.9, a 24 x 24 image: per ray the step count, the end point (t, r, cos theta, phi), the end momentum
+    and the transfer integrals I and tau against the oracle's raytrace() loop with the same per-step accumulation done
+    on the CPU (oracle/cpu_driver.c:cpu_torus_rays); with and without absorption (the exp(-tau) branch)."""
     n, a, inc, r0 = 24, 0.9, 70.0, 100.0
-    d = torus_desc(capi, n, a, inc, r0=r0)
-    S, steps, xe, ce, me = run_torus(capi, d)
-    orc = ol.Oracle()
-    rmax = orc.r_ms(a) + 8.0
+    d = torus_desc(capi, n, a, inc, r0=r0, absorb0=absorb0)
+    if strict:
+        d.img.flags = 1
+    S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
+    rmax = ol.Oracle().r_ms(a) + 8.0
     c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
-    cases = [(a, inc / 180.0 * math.pi, c[ix], c[iy], r0, 1.0, 0) for iy in range(n) for ix in range(n)]
-    res = gga.verlet_traces(ol.ORACLE_SO, "orc_", cases, 20000)
-    same_steps = 0
-    for i, (m, tr, xs, ks, car) in enumerate(res):
-        if m <= 0:
-            assert steps[i] == 0
-            continue
-        same_steps += int(m == steps[i])
-        if m == steps[i]:
-            assert abs(xe[i, 1] - tr[m - 1, 1]) <= 1e-6 * max(1.0, abs(tr[m - 1, 1])), (i, xe[i], tr[m - 1, :4])
-    # rounding differences in cos/acos may shift a float threshold for a few rays; the bulk must agree
-    assert same_steps >= 0.97 * len(res), same_steps
-    assert np.isfinite(S[:, 0]).all() and (S[:, 0] >= 0).all() and S[:, 0].max() > 0
+    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), np.tile(c, n), np.repeat(c, n), r0=r0, absorb0=absorb0)
+    compare_rays("24x24 %s absorb0=%g" % ("strict" if strict else "fast", absorb0), S, steps, xe, ke, ref,
+                 STEP_MATCH_STRICT if strict else STEP_MATCH_FAST)
+    assert (S[:, 0] >= 0).all() and S[:, 0].max() > 1.0
+    if absorb0 > 0:
+        assert S[:, 4].max() > 1.0            # optically thick lines of sight are in the sample
+
+
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+def test_c4_full_size(capi, golden, strict):
+    """BASELINE.json configs[3] at its full size: 1024 x 1024 rays through the torus (the real job: 2 048 persistent
+    waves, cursor refill, ~5.4e8 raytrace() calls).  Every ray: written exactly once (sentinels gone, the counters
+    of the job add up), started (r0 = 100 is outside every pericentre of this image), ended for one of the three
+    reasons of the stop rule, Carter constant conserved to the level of the reference on the same rays.  Every 16th
+    pixel of the SAME grid (4 096 rays): step counts, end point, end momentum, I and tau against the unmodified
+    reference's raytrace() loop (golden torus_c4.npz), without and with absorption."""
+    g = golden("torus_c4.npz")
+    n, a, inc, r0 = int(g["n"][0]), float(g["a"][0]), float(g["inc_deg"][0]), 100.0
+    rbh = 1.0 + math.sqrt(1.0 - a * a)
+    for tag, absorb0 in (("thin", 0.0), ("absorb", 0.3)):
+        d = torus_desc(capi, n, a, inc, r0=r0, absorb0=absorb0)
+        if strict:
+            d.img.flags = 1
+        S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
+        N = n * n
+        assert not np.isnan(S).any(), "%d rays were never written" % int(np.isnan(S[:, 0]).sum())
+        assert (steps >= 0).all() and (steps < 20000).all()
+        # rays the start-up rejects (here 134 rays near beta = 0 whose photon_momentum() at r0 is NaN in the reference,
+        # ref src/sim5kerr.c:1183-1188): the CPU loop rejects exactly the same ones
+        unstarted = np.nonzero(steps == 0)[0]
+        print("%d of %d rays not started" % (unstarted.size, N))
+        assert unstarted.size < 256
+        if unstarted.size and tag == "thin":
+            rmax = ol.Oracle().r_ms(a) + 8.0
+            c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+            u = unstarted[:256]
+            o = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), c[u % n], c[u // n], r0=r0)
+            assert (o["steps"] == 0).all(), (u[o["steps"] != 0][:8], o["steps"][o["steps"] != 0][:8])
+            assert (S[unstarted] == 0).all()
+        started = steps > 0
+        inside = started & (xe[:, 1] > 1.05 * rbh) & (xe[:, 1] < 1.01 * r0)
+        assert (me[inside] > 1e-2).all()                 # a ray that stopped inside the domain stopped on its error
+        assert np.isfinite(ce[started]).all() and np.isfinite(xe[started]).all() and np.isfinite(ke[started]).all()
+        assert (S[:, 0] >= 0).all() and (S[:, 4] >= 0).all()
+        sel = g["thin_iy"].astype(np.int64) * n + g["thin_ix"]
+        ref = {k: g["thin_" + k] for k in ("steps", "x_end", "k_end", "carter", "max_step_error")}
+        ref["I"] = g[tag + "_I"]; ref["tau"] = g[tag + "_tau"]
+        name = "C4 1024^2 %s %s" % ("strict" if strict else "fast", tag)
+        same = compare_rays(name, S[sel], steps[sel], xe[sel], ke[sel], ref, STEP_MATCH_STRICT if strict else STEP_MATCH_FAST)
+        # conservation: the Carter-constant error of the GPU rays is the reference's on the same rays
+        assert_close(ce[sel][same], ref["carter"][same], floor=1e-3, rtol=1e-3, what=name + " raytrace_error")
+        print("%s: %.1f steps/ray, %.3g raytrace() calls, I max %.4g, |dQ/Q| median %.2e, 99.9%% %.2e, max %.2e; rays stopped by "
+              "their error inside the domain: %d" % (name, steps.mean(), float(steps.sum()), S[:, 0].max(),
+                                                     np.median(ce[started]), np.quantile(ce[started], 0.999), ce[started].max(), int(inside.sum())))
+        assert np.median(ce[started]) < 2.0 * np.median(ref["carter"])
+
+
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+def test_c4_grid_fine_precision(capi, golden, strict):
+    """The C4 view as a 16 x 16 image at precision 0.01 (~4 100 steps per ray) against the reference's loop."""
+    g = golden("torus_c4.npz")
+    n, a, inc = int(g["n"][0]), float(g["a"][0]), float(g["inc_deg"][0])
+    d = torus_desc(capi, 16, a, inc, precision=0.01, max_steps=50000)
+    if strict:
+        d.img.flags = 1
+    S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
+    ref = {k: g["fine_" + k] for k in ("steps", "x_end", "k_end", "I", "tau")}
+    compare_rays("C4 grid, precision 0.01, %s" % ("strict" if strict else "fast"), S, steps, xe, ke, ref,
+                 STEP_MATCH_STRICT if strict else STEP_MATCH_FAST)
 
 
 @pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
@@ -205,5 +314,5 @@ def test_torus_kernel_parameter_sweep(capi, strict):
             if m == steps[i]:
                 assert abs(xe[i, 1] - tr[m - 1, 1]) <= 1e-6 * max(1.0, abs(tr[m - 1, 1])), (a, inc, prec, i)
         print("torus sweep a=%g i=%g precision=%g %s: %d of %d rays with identical step counts" % (a, inc, prec, "strict" if strict else "fast", same, len(res)))
-        assert same >= (0.99 if strict else 0.95) * len(res), (a, inc, prec, strict, same, len(res))
+        assert same >= (STEP_MATCH_STRICT if strict else STEP_MATCH_FAST) * len(res), (a, inc, prec, strict, same, len(res))
         assert np.isfinite(S[:, 0]).all()

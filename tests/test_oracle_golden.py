@@ -86,6 +86,36 @@ def test_geodesic_records(oracle, golden):
     assert exact == nok, "only %d of %d records are byte-identical with the reference" % (exact, nok)
 
 
+def test_geodesic_init_src_records(oracle, golden):
+    """geodesic_init_src (ref src/sim5kerr-geod.c:106-173): 2 000 records from the reference -- the round trip
+    init_inf -> point of the trajectory -> momentum -> init_src of ref src/sim5unittests.c:171-255 (both sides of the
+    pericentre, spin 0 for the 1e-8 clamp), random ZAMO-frame photons (RR_BH, CC, captured rays) and the error
+    returns (q = 0, mu_plus and mu_0 out of range).  Byte level: return value, error code and every field the
+    reference writes (the first 200 bytes of the record; the rest is never written)."""
+    g = golden("kat_init_src.npz")
+    inp = g["inp"]
+    exact = 0
+    for i in range(len(inp)):
+        gd = ol.Geodesic(); C.memset(C.byref(gd), 0, 240)
+        e = C.c_int(-1)
+        ok = oracle.geodesic_init_src(inp[i, 0], inp[i, 1], inp[i, 2], ol.D4(*inp[i, 3:7]), int(inp[i, 7]),
+                                      C.byref(gd), C.byref(e))
+        assert ok == g["ok"][i] and e.value == g["err"][i], (i, ok, e.value, g["ok"][i], g["err"][i])
+        same = ol.struct_bytes(gd)[:200] == g["dump"][i].tobytes()[:200]
+        if not same:
+            ref = ol.Geodesic.from_buffer_copy(g["dump"][i].tobytes())
+            assert (gd.nrr, gd.type) == (ref.nrr, ref.type), i
+            for f in GEOD_F64:
+                close(getattr(gd, f), getattr(ref, f), what="init_src.%s[%d]" % (f, i))
+        exact += same
+    assert exact == len(inp), "only %d of %d init_src records are byte-identical with the reference" % (exact, len(inp))
+    # the round trip gives the observer back (the reference's own acceptance test, ref src/sim5unittests.c:239)
+    rt = (inp[:, 8] == 0) & (inp[:, 0] > 1e-3)
+    rec = np.frombuffer(g["dump"].tobytes(), dtype=np.dtype([("f", np.float64, 30)]))["f"]
+    assert np.max(np.abs(rec[rt, 4] - np.cos(inp[rt, 9]))) < 1e-5
+    assert np.max(np.abs(rec[rt, 1] - inp[rt, 10])) < 1e-4 and np.max(np.abs(rec[rt, 2] - inp[rt, 11])) < 1e-4
+
+
 AZM_FUNCS = ["elliptic_f_cos", "elliptic_e_cos", "elliptic_pi_complete", "elliptic_pi_cos", "integral_C2",
              "integral_C2_cos", "integral_Z1", "integral_Z2", "integral_Rm1", "integral_Rm2", "integral_R1",
              "integral_R2", "integral_R_r0_re", "integral_R_r0_re_inf", "integral_R_r1_re", "integral_R_r2_re",
@@ -264,3 +294,23 @@ def test_polarized_recipe(golden):
     assert np.array_equal(np.isnan(chi), np.isnan(g["chi"]))
     close(chi, g["chi"], rtol=1e-13, what="chi"); close(r, g["r"], what="r"); close(gg, g["g"], what="g")
     close(wp, g["wp"], rtol=1e-12, what="kappa")
+
+
+def test_torus_c4_port_equals_reference(golden):
+    """C4 subset (every 16th pixel of the 1024^2 grid, and the view as a 16 x 16 image at precision 0.01): our restatement's
+    raytrace() loop with the per-step transfer (oracle/cpu_driver.c:cpu_torus_rays) against the same loop over the
+    unmodified reference (golden torus_c4.npz): step counts, end states and transfer integrals bit for bit."""
+    import gen_golden_access as gga
+    g = golden("torus_c4.npz")
+    n, a, inc = int(g["n"][0]), float(g["a"][0]), math.radians(float(g["inc_deg"][0]))
+    rmax = ol.Oracle().r_ms(a) + 8.0
+    c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+    for tag, kw in (("thin", {}), ("absorb", {"absorb0": 0.3}), ("fine", {"precision": 0.01, "max_steps": 50000})):
+        src = "thin" if tag == "absorb" else tag
+        sel = slice(None, None, 4) if tag != "fine" else slice(None)          # a quarter of the 4 096 rays is enough here
+        grid = c if tag != "fine" else ((np.arange(16) + .5) / 16 - 0.5) * 2.0 * rmax       # "fine": a 16 x 16 image
+        o = gga.torus_rays(ol.ORACLE_SO, "orc_", a, inc, grid[g[src + "_ix"]][sel], grid[g[src + "_iy"]][sel], **kw)
+        for k in ("steps", "x_end", "k_end", "I", "tau", "carter", "max_step_error"):
+            key = "%s_%s" % (tag if k in ("I", "tau") else src, k)
+            assert np.array_equal(o[k], g[key][sel], equal_nan=True), (tag, k)
+    assert g["absorb_tau"].max() > 5 and g["thin_I"].max() > 20
