@@ -4,29 +4,34 @@ a 4096 x 4096 thin-disk image of a Kerr black hole (a = 0.998, i = 70 deg), elli
 path, one GPU lane per ray (hand-written HIP, sim5_amd/csrc), through the C-ABI of
 include/sim5gpu.h.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c5] [--mode stripes|images]
 
-A step is one complete image per GPU.  Rays are independent, so the path shards without any exchange
-(SURVEY.md 8(e)): with N > 1 (launched by torch.distributed.run, one rank per GPU) every rank traces its
-own complete 4096 x 4096 image -- the shape of a multi-image job such as the inclination scan of
-BASELINE.json configs[4], one image per GPU -- with NO collective on the data path; the images stay in the
-HBM of the GPU that made them.  Per-GPU work is fixed, so "scaling" is "weak" and
-`value` = N * 4096*4096*K / max-over-ranks time (barrier + synchronize on both sides of the timed region).
+N = 1: a step is one complete image.
+N > 1 (launched by torch.distributed.run, one rank per GPU), default `--mode stripes`, the split BASELINE.json's
+north_star names: ONE image per step, its rows dealt to the ranks in 64-row stripes round-robin
+(sim5_amd/sharding.py; one kernel launch per rank and image) and assembled on rank 0 by ONE RCCL gather per image
+INSIDE the timed region (both planes of a rank's stripes are one contiguous payload; double-buffered, so the
+gather of image i overlaps the tracing of image i+1; every gather has completed before the clock stops).  Total
+work is fixed: "scaling": "strong", `value` = rays of one image * K / max-over-ranks time.
+`--mode images` (opt-in) is the other way to use N GPUs: N independent images, one per GPU, no collective
+("scaling": "weak").
+`--workload c5` is BASELINE.json configs[4]: a step is the inclination scan 10..80 deg of 8192 x 8192 images
+(8 images, 5.4e8 rays), each image striped over the ranks and gathered like the headline image.
 
-`--mode stripes` times the other way to use N GPUs, ONE image sharded by 64-row stripes over the ranks
-(sim5_amd/sharding.py; one kernel launch per rank and image) and assembled on rank 0 by ONE RCCL gather
-per image inside the timed region (double-buffered, so the gather of image i overlaps the tracing of
-image i+1; all gathers complete before the clock stops): total work fixed, "scaling": "strong".
-
-Rank 0 prints one JSON line.  At N = 1 it also carries
-  roofline:     FP64-VALU roofline of the image kernel.  achieved = W_ell (1.3e3 algorithmic FP64
-                operations per ray) x rays per launch / mean kernel time measured
-                with HIP events on the launch stream; peak = 78.6 TFLOP/s FP64 vector (256 CU x 128
-                FLOP/clk x 2.4 GHz).  The path is scalar ODE/special-function work: no MFMA, and HBM
-                traffic is 8 B/ray of output (reported next to it as hbm_*).
-  cpu_baseline: the unmodified reference (oracle/_ref/libsim5ref.so, built from the reference
-                sources in the build container; falls back to our C port when absent) timed on this
-                box's host cores over a bounded row sample of the same image.
+Rank 0 prints one JSON line.  Beside the contract's fields it carries
+  roofline:     FP64-VALU roofline of the image kernel on rank 0.  achieved = W_ell (1.3e3 algorithmic FP64
+                operations per ray) x rays per launch / mean kernel time measured with HIP events
+                on the launch stream; peak = 78.6 TFLOP/s FP64 vector (256 CU x 128 FLOP/clk x 2.4 GHz).  The
+                path is scalar ODE/special-function work: no MFMA, and HBM traffic is 8 B/ray of output (hbm_*).
+  per_rank:     N > 1: mean kernel ms of every rank (HIP events, timed region) and the time of one gather measured
+                on its own after the timed region (rank 0, the receiver), so compute and exchange can be told apart.
+  cpu_baseline: N = 1: the unmodified reference (oracle/_ref/libsim5ref.so, built from the reference sources in the
+                build container; our C port when absent) timed on this box's host cores over a bounded row sample
+                of the same image; `cores` = the cores this process may run on (sched_getaffinity).
+  extra:        the other BASELINE.json configurations, timed after the headline's timed region (a few launches
+                each): C2, C3 (polarized), C4 (torus, raytrace() steps), C5 (N = 1: one 8192^2 image per inclination;
+                N > 1: the whole striped + gathered scan), each with kernel ms, rays/s and its roofline fraction.
+`ok` is false (and the exit code 1) if the image that came out does not have the reference's disk-hit count.
 """
 import argparse
 import json
@@ -38,40 +43,171 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NX = NY = 4096
 SPIN, INCL_DEG = 0.998, 70.0
 W_ELL = 1.3e3                     # algorithmic FP64 ops per elliptic thin-disk ray (an estimate)
 # the same quantity counted exactly on the reference binary (oracle/opcount.c, profiles/r01_opcount_image.json):
 # 363 add + 207 sub + 419 mul + 165 div + 152 sqrt + 308 compare + 11 x87 + 139 library calls per ray
 W_ELL_MEASURED = 1764.8
+W_POL = 3.0e2                     # polarization add-on per ray
+W_STEP = 7.5e2                    # algorithmic FP64 ops per raytrace() step, Verlet part
+W_STEP_MEASURED = 1354.0          # counted on the reference incl. its RK4 fallbacks (profiles/r01_opcount_verlet.json)
 PEAK_FP64_VALU_TFLOPS = 78.6      # 256 CU x 128 FLOP/clk x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0
+HEADLINE_HITS = 15865362          # disk hits of the reference on the headline image
+C5_INCLINATIONS = (10, 20, 30, 40, 50, 60, 70, 80)
 
 
-def cpu_baseline(budget_s=12.0):
+def reference_hits_c5():
+    """Disk-hit counts of the reference on the eight 8192^2 images (tests/golden/c5_hit_counts.json, data)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "c5_hit_counts.json")) as fh:
+            return {int(k): v["hits_image_g_gt_0"] for k, v in json.load(fh)["counts"].items()}
+    except Exception:
+        return {}
+
+
+def cpu_baseline(nx, ny, budget_s=12.0):
     """Reference (or port) on the host cores over a bounded sample of the headline image."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as ol
     kind = "reference" if ol.have_reference() else "port"
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     # calibrate on 1/128 of the rows, then size the sample for ~budget_s of wall time
-    cal = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=cores, full=False)
+    cal = ol.cpu_disk_image(kind, nx, ny, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=cores, full=False)
     rate = cal["rays"] / max(cal["seconds"], 1e-6)
-    rows = int(min(NY, max(32, budget_s * rate / NX)))
-    stride = max(1, NY // rows)
+    rows = int(min(ny, max(32, budget_s * rate / nx)))
+    stride = max(1, ny // rows)
     rays = 0
     secs = 0.0
     reps = 0
     while secs < 0.6 * budget_s and reps < 64:       # on many-core hosts one pass is short: repeat it
-        run = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=stride // 2, ystride=stride, nthreads=cores, full=False)
+        run = ol.cpu_disk_image(kind, nx, ny, SPIN, INCL_DEG, y0=stride // 2, ystride=stride, nthreads=cores, full=False)
         rays += run["rays"]; secs += run["seconds"]; reps += 1
-    one = ol.cpu_disk_image(kind, NX, NY, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=1, full=False)
+    one = ol.cpu_disk_image(kind, nx, ny, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=1, full=False)
+    single = one["rays"] / one["seconds"]
     return {
         "value": rays / secs, "unit": "null geodesics/s", "cores": cores, "kind": kind,
         "sample": "every %d-th row of the %dx%d image, %d pass(es), %d rays, %d threads, %.1f s wall" % (
-            stride, NX, NY, reps, rays, cores, secs),
-        "single_thread_value": one["rays"] / one["seconds"],
+            stride, nx, ny, reps, rays, cores, secs),
+        "single_thread_value": single, "parallel_speedup": (rays / secs) / single,
+        "os_cpu_count": os.cpu_count(),
     }
+
+
+class ImageJob:
+    """One thin-disk image (or this rank's stripes of it) per call of trace(): descriptor + launch."""
+
+    def __init__(self, capi, sharding, n, incl_deg, rank, world, striped, stream):
+        self.capi, self.n, self.stream = capi, n, stream
+        inc = incl_deg / 180.0 * math.pi
+        if striped:
+            self.desc = capi.image_desc(n, n, SPIN, inc, y0=rank * sharding.STRIPE, y1=n,
+                                        stripe_rows=sharding.STRIPE, stripe_step=world * sharding.STRIPE)
+            assert capi.image_rows(self.desc) == sharding.local_rows(n, rank, world)
+        else:
+            self.desc = capi.image_desc(n, n, SPIN, inc)
+        self.rays = capi.image_rows(self.desc) * n          # rays of one launch of this rank
+        self.events = None
+        self.used = 0
+
+    def trace(self, buf):
+        if self.events is not None and self.used < len(self.events):
+            a, b = self.events[self.used]
+            self.used += 1
+            a.record(self.stream)
+            self.capi.disk_image_device(self.desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=self.stream)
+            b.record(self.stream)
+        else:
+            self.capi.disk_image_device(self.desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=self.stream)
+
+    def start_timing(self, launches):
+        """HIP events (created here, outside the timed region) around the next `launches` launches"""
+        self.events = [(self.capi.Event(), self.capi.Event()) for _ in range(launches)]
+        self.used = 0
+
+    def collect(self):
+        """mean kernel ms over the launches recorded since start_timing() (waits for them)"""
+        kms = [a.elapsed_ms(b) for (a, b) in (self.events or [])[:self.used]]
+        self.events = None
+        return sum(kms) / len(kms) if kms else float("nan")
+
+
+def timed_kernel(capi, stream, launch, reps, warm=1):
+    """mean ms per launch, HIP events on the launch stream"""
+    for _ in range(warm):
+        launch()
+    e0, e1 = capi.Event(), capi.Event()
+    e0.record(stream)
+    for _ in range(reps):
+        launch()
+    e1.record(stream)
+    return e0.elapsed_ms(e1) / reps
+
+
+def extra_configs(torch, capi, dev, stream):
+    """The other BASELINE.json configurations on ONE GPU, a few launches each (well under a second in total)."""
+    out = {}
+    rad = math.pi / 180.0
+    # C2: 1024^2, a = 0.998, i = 70: g-factor + flux
+    n = 1024
+    img = torch.zeros((2, n, n), dtype=torch.float32, device=dev)
+    d = capi.image_desc(n, n, 0.998, 70.0 * rad)
+    ms = timed_kernel(capi, stream, lambda: capi.disk_image_device(d, img[0].data_ptr(), img[1].data_ptr(), stream=stream), 20, 3)
+    out["c2_1024_thin_disk"] = {"kernel": "disk_image_grid_kernel", "kernel_ms": ms, "rays": n * n, "rays_per_s": n * n / ms * 1e3,
+                                "roofline_frac": n * n * W_ELL / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                "disk_hits": int((img[1] > 0).sum().item()), "disk_hits_reference": 991579}
+    # C3: 2048^2, a = 0.9, i = 70, Stokes I, Q, U in f64
+    n = 2048
+    st = torch.zeros((3, n, n), dtype=torch.float64, device=dev)
+    gpl = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    d = capi.image_desc(n, n, 0.9, 70.0 * rad, pol_degree=0.1)
+    ms = timed_kernel(capi, stream, lambda: capi.disk_image_polarized_device(d, st.data_ptr(), None, aux={"g": gpl.data_ptr()},
+                                                                             stream=stream), 10, 2)
+    out["c3_2048_polarized"] = {"kernel": "disk_image_polarized_kernel", "kernel_ms": ms, "rays": n * n, "rays_per_s": n * n / ms * 1e3,
+                                "roofline_frac": n * n * (W_ELL + W_POL) / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                "disk_hits": int((gpl > 0).sum().item()), "disk_hits_reference": 3871553 + 5993}
+    del st, gpl
+    # C4: 1024^2 rays through the torus, raytrace() steps at precision 1.0 with transfer
+    n = 1024
+    N = n * n
+    stokes = torch.zeros((N, 5), dtype=torch.float64, device=dev)
+    steps = torch.zeros((N,), dtype=torch.int32, device=dev)
+    td = capi.TorusDesc(img=capi.image_desc(n, n, 0.9, 70.0 * rad), r0=100.0, dl_max=1e9, precision=1.0, options=0,
+                        max_steps=20000, max_error=1e-2, r_stop_in=1.05, r_stop_out=1.01, shape=0, torus_r=8.0,
+                        torus_w=2.0, torus_l=3.5, emis0=1.0, absorb0=0.0)
+    ms = timed_kernel(capi, stream, lambda: capi.torus_image_device(td, stokes.data_ptr(), aux={"steps": steps.data_ptr()},
+                                                                    stream=stream), 3, 1)
+    tot = int(steps.sum(dtype=torch.int64).item())
+    out["c4_1024_torus_verlet"] = {"kernel": "torus_start_kernel + torus_pool_kernel", "job_ms": ms, "rays": N, "rays_per_s": N / ms * 1e3,
+                                   "raytrace_calls": tot, "steps_per_ray": tot / N, "steps_per_s": tot / ms * 1e3,
+                                   "roofline_frac": tot * W_STEP / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                   "roofline_frac_with_counted_flops": tot * W_STEP_MEASURED / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                   "stokes_I_sum": float(stokes[:, 0].sum().item())}
+    del stokes, steps
+    return out
+
+
+def c5_on_one_gpu(torch, capi, dev, stream):
+    n = 8192
+    img = torch.zeros((2, n, n), dtype=torch.float32, device=dev)
+    ref = reference_hits_c5()
+    per = {}
+    tot = 0.0
+    ok = True
+    for inc in C5_INCLINATIONS:
+        d = capi.image_desc(n, n, 0.998, inc * math.pi / 180.0)
+        ms = timed_kernel(capi, stream, lambda: capi.disk_image_device(d, img[0].data_ptr(), img[1].data_ptr(), stream=stream), 2, 1)
+        hits = int((img[1] > 0).sum().item())
+        per[str(inc)] = {"kernel_ms": ms, "rays_per_s": n * n / ms * 1e3, "disk_hits": hits, "disk_hits_reference": ref.get(inc)}
+        ok = ok and (ref.get(inc) is None or ref[inc] == hits)
+        tot += ms
+    return {"kernel": "disk_image_grid_kernel", "images": len(C5_INCLINATIONS), "rays": len(C5_INCLINATIONS) * n * n, "scan_ms": tot,
+            "rays_per_s": len(C5_INCLINATIONS) * n * n / tot * 1e3,
+            "roofline_frac": len(C5_INCLINATIONS) * n * n * W_ELL / (tot * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+            "per_inclination": per, "hits_ok": ok}
 
 
 def main():
@@ -80,8 +216,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["images", "stripes"], default="images",
-                    help="N > 1: one complete image per GPU, no collective (default) | one image in row stripes + gather")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C2/C3/C4/C5 timings after the headline region")
+    ap.add_argument("--workload", choices=["headline", "c5"], default="headline")
+    ap.add_argument("--mode", choices=["stripes", "images"], default="stripes",
+                    help="N > 1: one image in row stripes + one RCCL gather per image (default) | one complete image per GPU, no collective")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,8 +235,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    # test hook: SIM5_BENCH_ONE_GPU=1 runs all ranks on GPU 0 over gloo, to exercise the N > 1 control flow on a
-    # one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    # test hook: SIM5_BENCH_ONE_GPU=1 runs all ranks on GPU 0 over gloo (tiles staged through the host for the gather),
+    # to exercise the N > 1 control flow on a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
     one_gpu_test = os.environ.get("SIM5_BENCH_ONE_GPU") == "1"
     if one_gpu_test:
         local_rank = 0
@@ -119,130 +257,186 @@ def main():
     capi.set_device(local_rank)
 
     dev = torch.device("cuda", local_rank)
+    cdev = "cpu" if one_gpu_test else dev   # where small control tensors of a collective live
     stream = torch.cuda.current_stream().cuda_stream
-    inc = INCL_DEG / 180.0 * math.pi
-    stripes = world > 1 and args.mode == "stripes"
-    if stripes and one_gpu_test:
-        sys.exit("bench.py: the one-GPU test hook covers --mode images only (gloo cannot gather device tensors asynchronously)")
-    if not stripes:
-        # one complete image per rank: [2 planes (F g^4 | g), NY, NX] f32, resident in this GPU's HBM
-        desc = capi.image_desc(NX, NY, SPIN, inc)
-        image = torch.zeros((2, NY, NX), dtype=torch.float32, device=dev)
+    striped = world > 1 and args.mode == "stripes"
+    c5 = args.workload == "c5"
+    n = 8192 if c5 else 4096
+    inclinations = C5_INCLINATIONS if c5 else (INCL_DEG,)
+    jobs = [ImageJob(capi, sharding, n, inc, rank, world, striped, stream) for inc in inclinations]
+    pipe = sharding.TilePipeline(torch, dist, rank, world if striped else 1, n, n, dev, host_staged=one_gpu_test)
 
-        def trace(buf):
-            capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
+    def step(i):
+        for job in jobs:                    # one image per inclination: trace my stripes, gather (overlapped)
+            pipe.step(job.trace)
 
-        def step(i):
-            trace(image)
-
-        def fence():
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        def last_image():
-            return image
-    else:
-        # One launch per rank and image: the rank's 64-row stripes (rank, rank+world, ...) in a single grid.
-        # Tile buffers are [2 planes, rows, NX] f32 = one contiguous gather payload; two of them so that the
-        # gather of image i (RCCL, its own stream) overlaps the tracing of image i+1.
-        desc = capi.image_desc(NX, NY, SPIN, inc, y0=rank * sharding.STRIPE, y1=NY,
-                               stripe_rows=sharding.STRIPE, stripe_step=world * sharding.STRIPE)
-        assert capi.image_rows(desc) == sharding.local_rows(NY, rank, world)
-        pipe = sharding.TilePipeline(torch, dist, rank, world, NY, NX, dev)
-
-        def trace(buf):
-            capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
-
-        def step(i):
-            pipe.step(lambda buf: trace(buf))
-
-        def fence():
-            pipe.drain()
+    def fence():
+        pipe.drain()
+        if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
-
-        def last_image():
-            return pipe.last_image()
+        torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
     fence()
-    # HIP events around every kernel launch on rank 0 (on the stream the kernel is launched on)
-    ev = [(capi.Event(), capi.Event()) for _ in range(args.steps)] if rank == 0 else None
-    if ev:
-        def trace(buf, _i=[0]):                  # noqa: B006,F811 -- the timed flavour of trace()
-            a, b = ev[_i[0] % len(ev)]
-            a.record(stream)
-            capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=stream)
-            b.record(stream)
-            _i[0] += 1
+    for job in jobs:
+        job.start_timing(args.steps)        # HIP events around every launch of the timed region, on every rank
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     dt = time.perf_counter() - t0
+    kavg = [job.collect() for job in jobs]  # mean kernel ms per image of the step, this rank
+    kstep = sum(kavg)                       # kernel ms per step, this rank
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, kstep], dtype=torch.float64, device=cdev)
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)
+        dt = max(float(v[0].item()) for v in allv)
+        per_rank = {"kernel_ms_per_step": [float(v[1].item()) for v in allv],
+                    "rays_per_launch": [sharding.local_rows(n, r, world) * n if striped else n * n for r in range(world)]}
+    # one gather on its own (not overlapped), after the timed region: the exchange time next to the compute time
+    if striped:
+        gms = []
+        for _ in range(3):
+            pipe.drain(); torch.cuda.synchronize(); dist.barrier()
+            g0 = time.perf_counter()
+            pipe.gather(0, async_op=False)
+            torch.cuda.synchronize()
+            gms.append(1e3 * (time.perf_counter() - g0))
+        per_rank["gather_ms_alone"] = min(gms)          # meaningful on rank 0 (the receiver); rank 0 reports its own
+        per_rank["gather_payload_bytes_per_rank"] = 2 * sharding.max_local_rows(n, world) * n * 4
     if rank != 0:
+        extra = None
+        if world > 1 and not args.no_extra and not c5 and striped:
+            run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test)
         if world > 1:
             dist.destroy_process_group()
         return
 
-    rays = NX * NY * (1 if stripes or world == 1 else world)     # rays of one step of the whole job
+    images_per_step = len(inclinations) * (1 if striped or world == 1 else world)
+    rays = n * n * images_per_step                     # rays of one step of the whole job
     value = rays * args.steps / dt
-    # sanity: the image that came out is the Kerr disk (known hit count of the reference, BASELINE.md)
-    img = last_image()
+    # sanity: the image that came out is the Kerr disk (known hit count of the reference)
+    img = pipe.last_image()
     hits = int((img[1] > 0).sum().item())
+    hits_ref = reference_hits_c5().get(inclinations[-1]) if c5 else HEADLINE_HITS
+    ok = hits_ref is None or hits == hits_ref
+    if c5:
+        workload = ("8192x8192 thin-disk images, a=0.998, inclination scan 10..80 deg (8 images per step), elliptic-integral "
+                    "path, g-factor + Novikov-Thorne flux (BASELINE.json configs[4])")
+    else:
+        workload = ("4096x4096 thin-disk image, a=0.998, i=70deg, elliptic-integral path, g-factor + Novikov-Thorne flux "
+                    "(BASELINE.json headline / configs[1] at 4096^2)")
     out = {
-        "metric": "null geodesics/sec, 4096x4096 Kerr disk image (a=0.998, i=70)",
+        "metric": "null geodesics/sec, 4096x4096 Kerr disk image (a=0.998, i=70)" if not c5 else
+                  "null geodesics/sec, 8192x8192 Kerr disk images x 8 inclinations (a=0.998)",
         "value": value, "unit": "null geodesics/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if stripes else "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "4096x4096 thin-disk image, a=0.998, i=70deg, elliptic-integral path, "
-                               "g-factor + Novikov-Thorne flux (BASELINE.json headline / configs[1] at 4096^2)",
-                   "rays_per_step": rays,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "strong" if (striped or world == 1) else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ok": ok,
+        "config": {"workload": workload, "rays_per_step": rays,
                    "parallelism": ("1 GPU" if world == 1 else
-                                   "row stripes x%d + 1 RCCL gather per image" % world if stripes else
+                                   "64-row stripes round-robin over %d GPUs + 1 RCCL gather per image (%d per step), overlapped "
+                                   "with the next image" % (world, len(inclinations)) if striped else
                                    "%d independent images, one per GPU, no collective" % world),
-                   "disk_hits": hits, "disk_hits_reference": 15865362},
+                   "disk_hits": hits, "disk_hits_reference": hits_ref},
     }
-    if ev:
-        rays_launch = capi.image_rows(desc) * NX             # rays of one launch of rank 0 (its stripes)
-        kms = [a.elapsed_ms(b) for (a, b) in ev]
-        kavg = sum(kms) / len(kms)
-        achieved = rays_launch * W_ELL / (kavg * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {
-            "bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-            "kernel": "disk_image_grid_kernel", "kernel_ms_avg": kavg, "algorithmic_flops_per_ray": W_ELL,
-            "rays_per_launch": rays_launch, "per": "GPU (rank 0)",
-            "algorithmic_flops_per_ray_counted_on_reference": W_ELL_MEASURED,
-            "achieved_with_counted_flops": achieved * W_ELL_MEASURED / W_ELL,
-            "frac_with_counted_flops": achieved * W_ELL_MEASURED / W_ELL / PEAK_FP64_VALU_TFLOPS,
-            "hbm_algorithmic_bytes_per_launch": rays_launch * 8,
-            "hbm_achieved_GBps": rays_launch * 8 / (kavg * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
-            "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output",
-        }
-        if world > 1:
-            out["roofline"]["traffic"] = None          # the PMC traffic figure was collected for the 1-GPU launch
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline()
-            except Exception as e:                       # the baseline is a report, never a blocker
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if world == 1:
+        out["scaling"] = "strong"
+    rays_launch = sum(job.rays for job in jobs)            # rays rank 0 traces per step
+    achieved = rays_launch * W_ELL / (kstep * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and world == 1 and not c5:      # the PMC traffic figure was collected for the 1-GPU headline launch
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out["roofline"] = {
+        "bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+        "kernel": "disk_image_grid_kernel", "kernel_ms_avg": kstep / len(jobs), "algorithmic_flops_per_ray": W_ELL,
+        "rays_per_launch": rays_launch // len(jobs), "per": "GPU (rank 0)",
+        "algorithmic_flops_per_ray_counted_on_reference": W_ELL_MEASURED,
+        "achieved_with_counted_flops": achieved * W_ELL_MEASURED / W_ELL,
+        "frac_with_counted_flops": achieved * W_ELL_MEASURED / W_ELL / PEAK_FP64_VALU_TFLOPS,
+        "hbm_algorithmic_bytes_per_launch": rays_launch // len(jobs) * 8,
+        "hbm_achieved_GBps": rays_launch * 8 / (kstep * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+        "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output",
+    }
+    if per_rank:
+        out["per_rank"] = per_rank
+    if not args.no_extra and not c5:
+        try:
+            if world == 1:
+                extra = extra_configs(torch, capi, dev, stream)
+                extra["c5_8192_x8_inclinations"] = c5_on_one_gpu(torch, capi, dev, stream)
+                ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
+            elif striped:
+                extra = {"c5_8192_x8_inclinations": run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test)}
+                ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
+            else:
+                extra = None
+            if extra:
+                out["extra"] = extra
+                out["ok"] = ok
+        except Exception as e:                             # the extras are a report, never a blocker for the headline line
+            out["extra"] = {"error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline and not c5:
+        try:
+            out["cpu_baseline"] = cpu_baseline(n, n)
+        except Exception as e:                             # the baseline is a report, never a blocker
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
+def run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, reps=2):
+    """BASELINE.json configs[4] on all ranks: 8192^2 x 8 inclinations, each image in 64-row stripes over the ranks
+    and gathered to rank 0 with one collective per image, overlapped with the tracing of the next image.  Called by
+    every rank (collective); rank 0 returns the record."""
+    n = 8192
+    jobs = [ImageJob(capi, sharding, n, inc, rank, world, True, stream) for inc in C5_INCLINATIONS]
+    pipe = sharding.TilePipeline(torch, dist, rank, world, n, n, dev, host_staged=one_gpu_test)
+    ref = reference_hits_c5()
+    hits = {}
+
+    def scan(check):
+        for job, inc in zip(jobs, C5_INCLINATIONS):
+            pipe.step(job.trace)
+            if check and rank == 0:
+                pipe.drain()
+                hits[inc] = int((pipe.last_image()[1] > 0).sum().item())
+        pipe.drain()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    scan(True)                               # warm-up pass, also the hit-count check of every image
+    for job in jobs:
+        job.start_timing(reps)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        scan(False)
+    dt = time.perf_counter() - t0
+    k = sum(job.collect() for job in jobs)
+    t = torch.tensor([dt, k], dtype=torch.float64, device=cdev)
+    allv = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allv, t)
+    if rank != 0:
+        return None
+    dt = max(float(v[0].item()) for v in allv)
+    rays = len(C5_INCLINATIONS) * n * n
+    return {"images": len(C5_INCLINATIONS), "rays": rays, "scan_ms": 1e3 * dt / reps, "rays_per_s": rays * reps / dt,
+            "n_gpus": world, "gathers_per_scan": len(C5_INCLINATIONS),
+            "gather_payload_bytes_per_rank": 2 * sharding.max_local_rows(n, world) * n * 4,
+            "kernel_ms_per_scan_per_rank": [float(v[1].item()) for v in allv],
+            "disk_hits": {str(k_): v for k_, v in hits.items()},
+            "hits_ok": all(ref.get(i) is None or ref[i] == h for i, h in hits.items())}
 
 
 if __name__ == "__main__":

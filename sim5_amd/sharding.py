@@ -49,18 +49,24 @@ class TilePipeline:
     """Double-buffered "trace my stripes, gather them to rank 0" loop shared by bench.py and the CPU
     (gloo) test.  `trace(buffer)` must enqueue the work that fills `buffer` ([2, rows_max, nx] tensor);
     the gather of image i is issued asynchronously and overlaps the tracing of image i+1; `drain()`
-    waits for every outstanding gather.  With world == 1 there is no gather and a single buffer."""
+    waits for every outstanding gather.  With world == 1 there is no gather and a single buffer.
 
-    def __init__(self, torch, dist, rank, world, ny, nx, device, dtype=None):
+    host_staged=True is the one-GPU test hook of bench.py: the tile is copied to the host and gathered
+    synchronously over gloo (RCCL refuses two ranks on one device); same control flow, same buffers."""
+
+    def __init__(self, torch, dist, rank, world, ny, nx, device, dtype=None, host_staged=False):
         self.dist, self.rank, self.world, self.ny = dist, rank, world, ny
+        self.host_staged = host_staged and world > 1
         dtype = dtype or torch.float32
         rows_max = max_local_rows(ny, world)
         self.nbuf = 2 if world > 1 else 1
         self.tiles = [torch.zeros((2, rows_max, nx), dtype=dtype, device=device) for _ in range(self.nbuf)]
-        self.gathered = [[torch.zeros_like(self.tiles[0]) for _ in range(world)] for _ in range(self.nbuf)] \
-            if (world > 1 and rank == 0) else [None] * self.nbuf
+        gdev = "cpu" if self.host_staged else device
+        self.gathered = [[torch.zeros((2, rows_max, nx), dtype=dtype, device=gdev) for _ in range(world)]
+                         for _ in range(self.nbuf)] if (world > 1 and rank == 0) else [None] * self.nbuf
         self.pending = [None] * self.nbuf
         self.count = 0
+        self.gathers = 0
 
     def step(self, trace):
         b = self.count % self.nbuf
@@ -69,8 +75,18 @@ class TilePipeline:
             self.pending[b] = None
         trace(self.tiles[b])
         if self.world > 1:
-            self.pending[b] = self.dist.gather(self.tiles[b], self.gathered[b], dst=0, async_op=True)
+            self.gather(b)
         self.count += 1
+
+    def gather(self, b, async_op=True):
+        """ONE collective per image: both planes of this rank's stripes in a single contiguous payload."""
+        if self.host_staged:
+            self.dist.gather(self.tiles[b].cpu(), self.gathered[b], dst=0)
+        else:
+            w = self.dist.gather(self.tiles[b], self.gathered[b], dst=0, async_op=async_op)
+            if async_op:
+                self.pending[b] = w
+        self.gathers += 1
 
     def drain(self):
         for b in range(self.nbuf):

@@ -1,0 +1,61 @@
+"""bench.py end to end on the GPU box: the one-GPU line, and the N > 1 control flow (row stripes + one gather per
+image, the per-rank record, the striped C5 scan) exercised with two ranks on GPU 0 through the bench's test hook
+(SIM5_BENCH_ONE_GPU=1: gloo, tiles staged through the host -- RCCL refuses two ranks on one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    rows = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert rows, out[-2000:]
+    return json.loads(rows[-1])
+
+
+def _port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_single_gpu_line_carries_every_config():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = _line(r.stdout)
+    assert o["ok"] is True and o["n_gpus"] == 1 and o["config"]["disk_hits"] == 15865362
+    assert o["roofline"]["frac"] > 0.2 and o["roofline"]["rays_per_launch"] == 4096 * 4096
+    x = o["extra"]
+    assert x["c2_1024_thin_disk"]["disk_hits"] == x["c2_1024_thin_disk"]["disk_hits_reference"]
+    assert x["c3_2048_polarized"]["disk_hits"] == x["c3_2048_polarized"]["disk_hits_reference"]
+    assert 500 < x["c4_1024_torus_verlet"]["steps_per_ray"] < 540 and x["c4_1024_torus_verlet"]["stokes_I_sum"] > 0
+    c5 = x["c5_8192_x8_inclinations"]
+    assert c5["hits_ok"] and len(c5["per_inclination"]) == 8
+    assert all(v["disk_hits"] == v["disk_hits_reference"] for v in c5["per_inclination"].values())
+
+
+@pytest.mark.parametrize("mode", ["stripes", "images"])
+def test_two_ranks_on_one_gpu(mode):
+    env = dict(os.environ, SIM5_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    o = _line(r.stdout)
+    assert o["ok"] is True and o["n_gpus"] == 2 and o["config"]["disk_hits"] == 15865362
+    if mode == "stripes":
+        assert o["scaling"] == "strong" and o["config"]["rays_per_step"] == 4096 * 4096
+        pr = o["per_rank"]
+        assert len(pr["kernel_ms_per_step"]) == 2 and sum(pr["rays_per_launch"]) == 4096 * 4096
+        assert pr["gather_ms_alone"] > 0
+        c5 = o["extra"]["c5_8192_x8_inclinations"]
+        assert c5["hits_ok"] and c5["n_gpus"] == 2 and len(c5["disk_hits"]) == 8 and c5["gathers_per_scan"] == 8
+    else:
+        assert o["scaling"] == "weak" and o["config"]["rays_per_step"] == 2 * 4096 * 4096

@@ -64,13 +64,13 @@ def _worker(rank, world, port, ny, nx, q):
     dist.destroy_process_group()
 
 
-def _pipeline_worker(rank, world, port, ny, nx, nimages, q):
+def _pipeline_worker(rank, world, port, ny, nx, nimages, q, host_staged=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    pipe = sharding.TilePipeline(torch, dist, rank, world, ny, nx, torch.device("cpu"))
+    pipe = sharding.TilePipeline(torch, dist, rank, world, ny, nx, torch.device("cpu"), host_staged=host_staged)
     state = {"img": 0}
 
     def trace(buf):                               # stand-in kernel: value = image number * 1e6 + row * nx + col
@@ -93,14 +93,15 @@ def _pipeline_worker(rank, world, port, ny, nx, nimages, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nimages", [1, 4, 5])
-def test_overlapped_gather_pipeline_gloo(nimages):
-    """The bench's double-buffered trace/gather loop with world size 2 on CPU."""
+@pytest.mark.parametrize("nimages,host_staged", [(1, False), (4, False), (5, False), (3, True)])
+def test_overlapped_gather_pipeline_gloo(nimages, host_staged):
+    """The bench's double-buffered trace/gather loop with world size 2 on CPU (host_staged: the synchronous,
+    host-staged gather of bench.py's one-GPU test hook)."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 200, 16, nimages, q)) for r in range(2)]
+    ps = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 200, 16, nimages, q, host_staged)) for r in range(2)]
     for p in ps:
         p.start()
     ok = q.get(timeout=120)
