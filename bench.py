@@ -66,15 +66,37 @@ def reference_hits_c5():
         return {}
 
 
+def usable_cores():
+    """(cores this process may actually use, how that was found): the scheduler affinity mask, capped by the
+    cgroup CPU quota of the container when there is one (cpu.max = "quota period" under cgroup v2)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except Exception:
+            continue
+    cores = aff if quota is None else max(1, min(aff, int(math.ceil(quota))))
+    return cores, {"sched_getaffinity": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count()}
+
+
 def cpu_baseline(nx, ny, budget_s=12.0):
     """Reference (or port) on the host cores over a bounded sample of the headline image."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as ol
     kind = "reference" if ol.have_reference() else "port"
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores, how = usable_cores()
     # calibrate on 1/128 of the rows, then size the sample for ~budget_s of wall time
     cal = ol.cpu_disk_image(kind, nx, ny, SPIN, INCL_DEG, y0=16, ystride=128, nthreads=cores, full=False)
     rate = cal["rays"] / max(cal["seconds"], 1e-6)
@@ -93,7 +115,7 @@ def cpu_baseline(nx, ny, budget_s=12.0):
         "sample": "every %d-th row of the %dx%d image, %d pass(es), %d rays, %d threads, %.1f s wall" % (
             stride, nx, ny, reps, rays, cores, secs),
         "single_thread_value": single, "parallel_speedup": (rays / secs) / single,
-        "os_cpu_count": os.cpu_count(),
+        "cores_found_by": how,
     }
 
 

@@ -167,6 +167,10 @@ int sim5gpu_photon_motion_constants(size_t n, const double *a, const double *r, 
                                     const double *k, double *L, double *Q);
 int sim5gpu_photon_carter_const(size_t n, const double *k, const sim5gpu_metric *metric, double *Q);
 
+/* r_mb, r_ph: marginally bound and photon orbit (ref src/sim5kerr.c:1007-1034; used by examples/01-kerr-spacetime) */
+int sim5gpu_r_mb(size_t n, const double *a, double *r);
+int sim5gpu_r_ph(size_t n, const double *a, double *r);
+
 /* r_bh, r_ms, OmegaK, ellK, Omega_from_ell, dotprod (ref src/sim5kerr.c:981, 994, 1037, 1050, 1101, 609);
  * dotprod: metric == NULL means the Minkowski product -v0w0 + v1w1 + v2w2 + v3w3, as in SIM5 */
 int sim5gpu_r_bh(size_t n, const double *a, double *r);
@@ -228,11 +232,18 @@ int sim5gpu_geodesic_timedelay(size_t n, const sim5gpu_geodesic *g, const double
  * 24 integral_T_m0(a2,b2,X)              25 integral_T_m2(a2,b2,X)             26 integral_T_mp(a2,b2,p,X) */
 int sim5gpu_integral(int which, size_t n, int nargs, const double *args, double *out);
 
-/* Novikov-Thorne disk (ref src/sim5disk-nt.c:37-146, 260-266).  As in SIM5 the disk model
- * is process-global state set once by disk_nt_setup; options must be 0 (mdot-parametrised). */
-int sim5gpu_disk_nt_setup(double M, double a, double mdot, double alpha, int options);
+/* Novikov-Thorne disk (ref src/sim5disk-nt.c:37-266, 371-385).  As in SIM5 the disk model is process-global state
+ * set once by disk_nt_setup.  options: 0 = mdot_or_L is the accretion rate; SIM5GPU_DISK_NT_OPTION_LUMINOSITY
+ * (= DISK_NT_OPTION_LUMINOSITY, ref src/sim5disk-nt.h:17) = it is the luminosity and the accretion rate is found by
+ * the reference's bisection over disk_nt_lumi().  disk_nt_lumi is the reference's Simpson integral of the flux
+ * (ref :151-188), its integrand evaluated on the device; disk_nt_sigma the column density (ref :204-250). */
+#define SIM5GPU_DISK_NT_OPTION_LUMINOSITY 1
+int sim5gpu_disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int options);
 int sim5gpu_disk_nt_r_min(double *r_min);
+int sim5gpu_disk_nt_mdot(double *mdot);
+int sim5gpu_disk_nt_lumi(double *lumi);
 int sim5gpu_disk_nt_flux(size_t n, const double *r, double *flux);
+int sim5gpu_disk_nt_sigma(size_t n, const double *r, double *sigma);
 int sim5gpu_disk_nt_ell(size_t n, const double *r, double *ell);
 
 /* raytrace_prepare / raytrace / raytrace_error (ref src/sim5raytrace.c:44-94, 109-245,

@@ -309,6 +309,32 @@ def kat_disk(ref, rng):
     save("kat_disk.npz", **out)
 
 
+def kat_disk_model():
+    """The rest of the Novikov-Thorne module the reference's callers use (python/sim5diskmodel.py:77-90, disk_nt_dump):
+    disk_nt_mdot, disk_nt_lumi (Simpson rule over the flux), disk_nt_sigma, for set-ups by accretion rate and by
+    luminosity (DISK_NT_OPTION_LUMINOSITY: bisection for mdot, ref src/sim5disk-nt.c:371-385); and r_ph, r_mb of
+    examples/01-kerr-spacetime (ref src/sim5kerr.c:1007-1034)."""
+    ref = ol.Reference()
+    setups = [(10.0, 0.0, 0.1, 0.1, 0), (10.0, 0.998, 0.1, 0.1, 0), (3.7e6, 0.7, 0.31, 0.05, 0), (10.0, 0.9, 1.0, 0.1, 0),
+              (10.0, 0.5, 0.3, 0.1, 1), (1e8, 0.9, 1.5, 0.02, 1), (5.0, 0.3, 0.01, 0.1, 1), (10.0, 0.998, 0.05, 0.1, 1)]
+    out = {"setups": np.array(setups)}
+    for j, (M, a, x, al, opt) in enumerate(setups):
+        ref.disk_nt_setup(M, a, x, al, int(opt))
+        rmin = ref.disk_nt_r_min()
+        r = np.concatenate([[rmin - 1e-2, rmin - 1e-4], rmin * 10.0 ** np.linspace(1e-6, 3.3, 240)])
+        out["r_%d" % j] = r
+        out["sigma_%d" % j] = np.array([ref.disk_nt_sigma(v) for v in r])
+        out["flux_%d" % j] = np.array([ref.disk_nt_flux(v) for v in r])
+        out["mdot_%d" % j] = np.array([ref.disk_nt_mdot()])
+        out["lumi_%d" % j] = np.array([ref.disk_nt_lumi()])
+        out["rmin_%d" % j] = np.array([rmin])
+        print("   disk %s: mdot %.9g lumi %.9g" % ((M, a, x, al, opt), out["mdot_%d" % j][0], out["lumi_%d" % j][0]))
+    a = np.concatenate([np.arange(0.0, 1.0, 0.01), [0.998, 0.999999]])     # the loop of examples/01-kerr-spacetime + extremes
+    out.update(spin=a, r_ph=np.array([ref.r_ph(v) for v in a]), r_mb=np.array([ref.r_mb(v) for v in a]),
+               r_ms=np.array([ref.r_ms(v) for v in a]), r_bh=np.array([ref.r_bh(v) for v in a]))
+    save("kat_disk_model.npz", **out)
+
+
 # ------------------------------------------------------------------------------------------
 def kat_polar(ref, rng):
     n = 400
@@ -626,6 +652,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "init_src":
             kat_init_src()
             return
+        if len(sys.argv) > 1 and sys.argv[1] == "disk_model":
+            kat_disk_model()
+            return
         if len(sys.argv) > 1 and sys.argv[1] == "torus":
             torus_c4()
             return
@@ -640,6 +669,7 @@ def main():
         kat_azimuth(ref)
         kat_init_src()
         torus_c4()
+        kat_disk_model()
     finally:
         os.dup2(saved, 2)
 

@@ -599,6 +599,10 @@ double orc_integral_T_mp(double a2, double b2, double p, double X)
 /* ref: src/sim5kerr.c:981-984 */
 double orc_r_bh(double a) { return 1. + sqrt(1. - SQ(a)); }
 
+/* ref: src/sim5kerr.c:1007-1034 */
+double orc_r_mb(double a) { return (2. - a) + 2. * sqrt(1. - a); }
+double orc_r_ph(double a) { return 2.0 * (1.0 + cos(2. / 3. * acos(-a))); }
+
 /* ISCO radius (prograde branch only, cbrt); ref: src/sim5kerr.c:994-1004 */
 double orc_r_ms(double a)
 {
@@ -1436,6 +1440,118 @@ double orc_disk_nt_ell(const orc_disk_nt *d, double r)
     double a = d->spin;
     r = fmax(d->rms, r);
     return (r * r - 2. * a * sqrt(r) + a * a) / (sqrt(r) * r - 2. * sqrt(r) + a);
+}
+
+/* ref: src/sim5disk-nt.c:193-199 */
+double orc_disk_nt_mdot(const orc_disk_nt *d) { return d->mdot; }
+
+/* Column density of the two inner zones; ref: src/sim5disk-nt.c:204-250.  Note 3.*(x1-a)*(x1-a)/... here
+ * against 3.*sqr(x1-a)/... in the flux: the products associate differently. */
+double orc_disk_nt_sigma(const orc_disk_nt *d, double r)
+{
+    if (r < d->rms) return 0.0;
+    double a = d->spin;
+    double x = sqrt(r);
+    double x0 = sqrt(d->rms);
+    double x1 = +2. * cos(1. / 3. * acos(a) - M_PI / 3.);
+    double x2 = +2. * cos(1. / 3. * acos(a) + M_PI / 3.);
+    double x3 = -2. * cos(1. / 3. * acos(a));
+    double xA = 1. + SQ(a) / SQ(r) + 2. * SQ(a) / (r * r * r);
+    double xB = 1. + a / (x * x * x);
+    double xC = 1. - 3. / (x * x) + 2. * a / (x * x * x);
+    double xD = 1. - 2. / r + SQ(a) / SQ(r);
+    double xE = 1. + 4. * SQ(a) / SQ(r) - 4. * SQ(a) / (r * r * r) + 3. * (a * a * a * a) / (r * r * r * r);
+    double f0 = x - x0 - 1.5 * a * log(x / x0);
+    double f1 = 3. * (x1 - a) * (x1 - a) / (x1 * (x1 - x2) * (x1 - x3)) * log((x - x1) / (x0 - x1));
+    double f2 = 3. * (x2 - a) * (x2 - a) / (x2 * (x2 - x1) * (x2 - x3)) * log((x - x2) / (x0 - x2));
+    double f3 = 3. * (x3 - a) * (x3 - a) / (x3 * (x3 - x2) * (x3 - x1)) * log((x - x3) / (x0 - x3));
+    double xL = (1. + a / (x * x * x)) / sqrt(1. - 3. / (x * x) + 2. * a / (x * x * x)) / x * (f0 - f1 - f2 - f3);
+    const double Mdot_Edd = 2.225475942e+18;                       /* ref: src/sim5const.h:49 */
+    double xMdot = d->mdot * d->mass * Mdot_Edd / 1e17;
+    double r_im = 40. * (pow(d->alpha, 2. / 21.) / pow(d->mass / 3., 2. / 3.) * pow(xMdot, 16. / 20.)) * pow(xA, 20. / 21.) *
+                  pow(xB, -36. / 21.) * pow(xD, -8. / 21.) * pow(xE, -10. / 21.) * pow(xL, 16. / 21.);
+    double Sigma;
+    if (r < r_im)
+        Sigma = 20. * (d->mass / 3.) / xMdot / d->alpha * sqrt(r * r * r) * 1. / (xA * xA) * pow(xB, 3.) * sqrt(xC) * xE * 1. / xL;
+    else
+        Sigma = 5e4 * pow(d->mass / 3., -2. / 5.) * pow(xMdot, 3. / 5.) * pow(d->alpha, -4. / 5.) * pow(r, -3. / 5.) *
+                pow(xB, -4. / 5.) * sqrt(xC) * pow(xD, -4. / 5.) * pow(xL, 3. / 5.);
+    return Sigma;
+}
+
+/* integrand of the luminosity integral over log r; ref: src/sim5disk-nt.c:167-179 */
+static double lumi_integrand(const orc_disk_nt *d, double log_r)
+{
+    double a = d->spin;
+    double r = exp(log_r);
+    double gtt = -1. + 2. / r;
+    double gtf = -2. * a / r;
+    /* sqr(disk_nt_bh_spin) on the float static is a FLOAT product (no promotion), then widened */
+    double a2f = (double)(d->spin * d->spin);
+    double gff = SQ(r) + a2f + 2. * a2f / r;
+    double Omega = 1. / (a + pow(r, 1.5));
+    double U_t = sqrt(-1.0 / (gtt + 2. * Omega * gtf + SQ(Omega) * gff)) * (gtt + Omega * gtf);
+    double F = orc_disk_nt_flux(d, r);
+    return 2. * M_PI * r * 2.0 * (-U_t) * F * r;
+}
+
+/* Total luminosity in Eddington units: Simpson rule built on the refined trapezoid rule
+ * (ref: src/sim5disk-nt.c:151-188; src/sim5integration.c:26-52 stage rule with its running abscissa
+ * x += del, :96-133 Simpson with NMAX 23, accuracy 1e-5, at least 4 stages). */
+double orc_disk_nt_lumi(const orc_disk_nt *d)
+{
+    const float disk_rmax = 1e5;
+    const double lo = log(d->rms), hi = log(disk_rmax), acc = 1e-5;
+    double s = 0.0, st = 0.0, ost = -1.e50, os = -1.e50;
+    int n;
+    for (n = 1; n <= 23; n++) {
+        if (n == 1) {
+            st = 0.5 * (hi - lo) * (lumi_integrand(d, hi) + lumi_integrand(d, lo));
+        } else {
+            int it = 1, j;
+            for (j = 1; j < n - 1; j++) it <<= 1;
+            double tnm = (double)it, del = (hi - lo) / tnm, x = lo + 0.5 * del, sum = 0.0;
+            for (j = 1; j <= it; j++, x += del) sum += lumi_integrand(d, x);
+            st = 0.5 * (st + del * sum);
+        }
+        s = (4. * st - ost) / 3.;
+        if (n > 3) {
+            if ((fabs(s - os) < acc * fabs(os)) || ((s == 0.) && (os == 0.))) break;
+        }
+        os = s;
+        ost = st;
+    }
+    const double grav_radius = 1.476716e+05, L_Edd = 1.257142540e+38;   /* ref: src/sim5const.h:32,51 */
+    double L = s * SQ(d->mass * grav_radius);
+    return L / (L_Edd * d->mass);
+}
+
+/* set-up with the reference's options word: bit 0 (DISK_NT_OPTION_LUMINOSITY, ref src/sim5disk-nt.h:17) reads
+ * mdot_or_L as a luminosity and finds the accretion rate by bisection on [0, 100] to 1e-6
+ * (ref: src/sim5disk-nt.c:37-78, :371-385; src/sim5roots.c:21-63).  The trial rate goes through the float static. */
+void orc_disk_nt_setup_opt(orc_disk_nt *d, double M, double a, double mdot_or_L, double alpha, int options)
+{
+    d->mass = M;
+    d->spin = a;
+    d->rms = orc_disk_nt_r_min(d);
+    d->alpha = alpha;
+    d->options = options;
+    if (!(options & 1)) { d->mdot = mdot_or_L; return; }
+    const double L0 = mdot_or_L, x1 = 0.0, x2 = 100.0, xacc = 1e-6;
+    double dx, f, fmid, xmid, rtb;
+    long j;
+    d->mdot = x2; fmid = L0 - orc_disk_nt_lumi(d);
+    d->mdot = x1; f = L0 - orc_disk_nt_lumi(d);
+    if ((f * fmid) >= 0.0) { d->mdot = 0.0; return; }
+    if (f < 0.0) { rtb = x1; dx = x2 - x1; } else { rtb = x2; dx = x1 - x2; }
+    for (j = 0; j < 500; j++) {
+        dx = dx * 0.5;
+        xmid = rtb + dx;
+        d->mdot = xmid; fmid = L0 - orc_disk_nt_lumi(d);
+        if (fmid <= 0.0) rtb = xmid;
+        if ((fabs(dx) < xacc) || (fmid == 0.0)) break;
+    }
+    d->mdot = (j >= 500) ? 0.0 : rtb;
 }
 
 /* ================================================================================== */

@@ -111,6 +111,8 @@ double orc_integral_T_mp(double a2, double b2, double p, double X);
 /* --- Kerr spacetime (reference src/sim5kerr.c) ------------------------------------ */
 double orc_r_bh(double a);
 double orc_r_ms(double a);
+double orc_r_mb(double a);
+double orc_r_ph(double a);
 void   orc_flat_metric(double r, double m, orc_metric *g);
 void   orc_kerr_metric(double a, double r, double m, orc_metric *g);
 void   orc_kerr_metric_contravariant(double a, double r, double m, orc_metric *g);
@@ -156,6 +158,10 @@ void   orc_disk_nt_setup(orc_disk_nt *d, double M, double a, double mdot, double
 double orc_disk_nt_r_min(const orc_disk_nt *d);
 double orc_disk_nt_flux(const orc_disk_nt *d, double r);
 double orc_disk_nt_ell(const orc_disk_nt *d, double r);
+double orc_disk_nt_mdot(const orc_disk_nt *d);
+double orc_disk_nt_sigma(const orc_disk_nt *d, double r);
+double orc_disk_nt_lumi(const orc_disk_nt *d);
+void   orc_disk_nt_setup_opt(orc_disk_nt *d, double M, double a, double mdot_or_L, double alpha, int options);
 
 /* --- step-wise integrator (reference src/sim5raytrace.c) --------------------------- */
 void   orc_raytrace_prepare(double bh_spin, double x[4], double k[4], double precision,

@@ -375,6 +375,14 @@ def r_ms(a):
     return _unary(_lib.sim5gpu_r_ms, "sim5gpu_r_ms", a)
 
 
+def r_mb(a):
+    return _unary(_lib.sim5gpu_r_mb, "sim5gpu_r_mb", a)
+
+
+def r_ph(a):
+    return _unary(_lib.sim5gpu_r_ph, "sim5gpu_r_ph", a)
+
+
 def OmegaK(r, a):
     r = _f64(r).ravel()
     a = _f64(a, r.size)
@@ -509,6 +517,25 @@ def disk_nt_r_min():
     v = D(0.0)
     _check(_lib.sim5gpu_disk_nt_r_min(C.byref(v)), "sim5gpu_disk_nt_r_min")
     return v.value
+
+
+def disk_nt_mdot():
+    v = D(0.0)
+    _check(_lib.sim5gpu_disk_nt_mdot(C.byref(v)), "sim5gpu_disk_nt_mdot")
+    return v.value
+
+
+def disk_nt_lumi():
+    v = D(0.0)
+    _check(_lib.sim5gpu_disk_nt_lumi(C.byref(v)), "sim5gpu_disk_nt_lumi")
+    return v.value
+
+
+def disk_nt_sigma(r):
+    r = _f64(r).ravel()
+    out = np.empty(r.size)
+    _check(_lib.sim5gpu_disk_nt_sigma(SZ(r.size), _p(r), _p(out)), "sim5gpu_disk_nt_sigma")
+    return out
 
 
 def disk_nt_flux(r):

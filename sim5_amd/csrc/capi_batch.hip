@@ -4,6 +4,7 @@
 // calling the same device routines the image kernels inline -> download.  These exist so that a
 // host program written against the SIM5 scalar API (and the parity tests) can reach each routine
 // through the C-ABI; throughput work goes through the whole-job kernels instead.
+#include <vector>
 #include "capi_util.hpp"
 #include "s5_disk.hpp"
 #include "s5_raytrace.hpp"
@@ -41,6 +42,54 @@ static int arg_error(const char* fn)
 #define S5_DEVICE_OR_FAIL() do { if (!have_device()) return SIM5GPU_E_NO_DEVICE; } while (0)
 #define S5_BUFS_OK(fn, cond) do { if (!(cond)) { snprintf(g_err, sizeof g_err, "%s: device allocation/copy failed", fn); return SIM5GPU_E_HIP; } } while (0)
 #define S5_RUN(n, what, ...) do { int rc_ = run_map(n, __VA_ARGS__, what); if (rc_) return rc_; } while (0)
+
+// Total disk luminosity in Eddington units (ref src/sim5disk-nt.c:151-188): the reference's Simpson rule on the
+// refined trapezoid rule (src/sim5integration.c:26-52 stage rule with its running abscissa x += del, :96-133:
+// at most 23 stages, relative accuracy 1e-5, at least 4 stages).  The abscissae of a stage are generated on the
+// host exactly as the reference's loop does, the integrand (flux, u_t) is evaluated for the whole stage in one
+// launch, the values are summed in the reference's order.
+int disk_lumi(const DiskConsts& d, double* lumi)
+{
+    const float disk_rmax = 1e5;
+    const double lo = log(d.rms), hi = log((double)disk_rmax), acc = 1e-5;
+    double s = 0.0, st = 0.0, ost = -1.e50, os = -1.e50;
+    std::vector<double> x, f;
+    for (int n = 1; n <= 23; n++) {
+        double del = 0.0;
+        x.clear();
+        if (n == 1) { x.push_back(hi); x.push_back(lo); }
+        else {
+            int it = 1;
+            for (int j = 1; j < n - 1; j++) it <<= 1;
+            del = (hi - lo) / (double)it;
+            double xx = lo + 0.5 * del;
+            for (int j = 1; j <= it; j++, xx += del) x.push_back(xx);
+        }
+        const size_t m = x.size();
+        f.resize(m);
+        {
+            DevBuf<double> dx(x.data(), m), df(m);
+            S5_BUFS_OK("disk_nt_lumi", dx.ok() && df.ok());
+            const double* px = dx.ptr; double* pf = df.ptr; const DiskConsts dd = d;
+            S5_RUN(m, "disk_nt_lumi", [=] __device__(size_t i) { pf[i] = disk_lumi_integrand(dd, px[i]); });
+            S5_HIP(df.to_host(f.data()));
+        }
+        if (n == 1) st = 0.5 * (hi - lo) * (f[0] + f[1]);
+        else {
+            double sum = 0.0;
+            for (size_t j = 0; j < m; j++) sum += f[j];
+            st = 0.5 * (st + del * sum);
+        }
+        s = (4. * st - ost) / 3.;
+        if (n > 3 && ((fabs(s - os) < acc * fabs(os)) || ((s == 0.) && (os == 0.)))) break;
+        os = s;
+        ost = st;
+    }
+    const double grav_radius = 1.476716e+05, L_Edd = 1.257142540e+38;      // ref src/sim5const.h:32,51
+    const double L = s * ((d.mass * grav_radius) * (d.mass * grav_radius));
+    *lumi = L / (L_Edd * d.mass);
+    return SIM5GPU_OK;
+}
 
 } // namespace s5
 
@@ -260,6 +309,8 @@ int NAME(size_t n, const double* x, double* out)                                
 }
 S5_UNARY_FN(sim5gpu_r_bh, r_horizon(v))
 S5_UNARY_FN(sim5gpu_r_ms, r_isco(v))
+S5_UNARY_FN(sim5gpu_r_mb, (2. - v) + 2. * sqrt(1. - v))                    // ref src/sim5kerr.c:1007-1017
+S5_UNARY_FN(sim5gpu_r_ph, 2.0 * (1.0 + cos(2. / 3. * acos(-v))))          // ref src/sim5kerr.c:1020-1031
 #undef S5_UNARY_FN
 
 #define S5_BINARY_FN(NAME, EXPR)                                                               \
@@ -564,6 +615,20 @@ int sim5gpu_disk_nt_flux(size_t n, const double* r, double* flux)
     const double* pr = dr.ptr; double* pf = df.ptr; const DiskConsts d = g_disk;
     S5_RUN(n, "disk_nt_flux", [=] __device__(size_t i) { pf[i] = disk_flux(d, pr[i]); });
     S5_HIP(df.to_host(flux));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_nt_sigma(size_t n, const double* r, double* sigma)
+{
+    S5_NEED("disk_nt_sigma", r && sigma);
+    if (!g_disk.ready) { snprintf(g_err, sizeof g_err, "disk_nt_setup has not been called"); return SIM5GPU_E_NOT_SETUP; }
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dr(r, n), ds(n);
+    S5_BUFS_OK("disk_nt_sigma", dr.ok() && ds.ok());
+    const double* pr = dr.ptr; double* ps = ds.ptr; const DiskConsts d = g_disk;
+    S5_RUN(n, "disk_nt_sigma", [=] __device__(size_t i) { ps[i] = disk_sigma(d, pr[i]); });
+    S5_HIP(ds.to_host(sigma));
     return SIM5GPU_OK;
 }
 

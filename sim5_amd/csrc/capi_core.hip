@@ -43,10 +43,16 @@ static double host_r_ms(double a)
 
 // Fold everything that depends only on (M, a, mdot) -- float-rounded as the reference's statics are
 // -- into DiskConsts (ref src/sim5disk-nt.c:37-78 setup, :91-105 r_min, :122-135 flux constants).
-DiskConsts make_disk_consts(double M, double a_in, double mdot)
+void disk_set_mdot(DiskConsts& d, double mdot)
+{
+    d.mdot = (float)mdot;                                  // the reference keeps it in a float static
+    d.scale = 9.1721376255e+28 * d.mdot / d.mass;
+}
+
+DiskConsts make_disk_consts(double M, double a_in, double mdot, double alpha)
 {
     DiskConsts d;
-    const float f_mass = (float)M, f_spin = (float)a_in, f_mdot = (float)mdot;
+    const float f_mass = (float)M, f_spin = (float)a_in, f_mdot = (float)mdot, f_alpha = (float)alpha;
     const double a = f_spin;
     const double sga = (a >= 0.0) ? +1. : -1.;
     const double z1 = 1. + pow(1. - a * a, 1. / 3.) * (pow(1. + a, 1. / 3.) + pow(1. - a, 1. / 3.));
@@ -69,6 +75,8 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot)
     d.mass = f_mass;
     d.inv_x0 = 1.0 / d.x0; d.inv_d1 = 1.0 / d.d1; d.inv_d2 = 1.0 / d.d2; d.inv_d3 = 1.0 / d.d3;
     d.scale = 9.1721376255e+28 * d.mdot / d.mass;
+    d.alpha = f_alpha;
+    d.a2f = (double)(f_spin * f_spin);
     d.ready = 1;
     return d;
 }
@@ -205,15 +213,57 @@ int sim5gpu_event_destroy(void* event)
 }
 
 // ---- disk model (process-global, like SIM5) -------------------------------------------------
-int sim5gpu_disk_nt_setup(double M, double a, double mdot, double alpha, int options)
+int sim5gpu_disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int options)
 {
-    (void)alpha;
-    if (options != 0) {
-        snprintf(g_err, sizeof g_err, "disk_nt_setup: only options=0 (mdot-parametrised) is supported");
+    if (options & ~SIM5GPU_DISK_NT_OPTION_LUMINOSITY) {
+        snprintf(g_err, sizeof g_err, "disk_nt_setup: unknown option bits 0x%x", options);
         return SIM5GPU_E_ARG;
     }
-    g_disk = make_disk_consts(M, a, mdot);
+    DiskConsts d = make_disk_consts(M, a, mdot_or_L, alpha);
+    if (options & SIM5GPU_DISK_NT_OPTION_LUMINOSITY) {
+        // the accretion rate whose integrated luminosity is mdot_or_L: the reference's bisection on [0, 100] to
+        // 1e-6 (ref src/sim5disk-nt.c:371-385, src/sim5roots.c:21-63); every trial luminosity is the Simpson
+        // integral of disk_lumi(), evaluated on the device
+        if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+        const double L0 = mdot_or_L, x1 = 0.0, x2 = 100.0, xacc = 1e-6;
+        double dx, f, fmid, xmid, rtb, L;
+        int rc, j;
+        disk_set_mdot(d, x2); if ((rc = disk_lumi(d, &L)) != 0) return rc; fmid = L0 - L;
+        disk_set_mdot(d, x1); if ((rc = disk_lumi(d, &L)) != 0) return rc; f = L0 - L;
+        if ((f * fmid) >= 0.0) {
+            disk_set_mdot(d, 0.0);                       // not bracketed: the reference ends with mdot = 0
+        } else {
+            if (f < 0.0) { rtb = x1; dx = x2 - x1; } else { rtb = x2; dx = x1 - x2; }
+            for (j = 0; j < 500; j++) {
+                dx = dx * 0.5;
+                xmid = rtb + dx;
+                disk_set_mdot(d, xmid);
+                if ((rc = disk_lumi(d, &L)) != 0) return rc;
+                fmid = L0 - L;
+                if (fmid <= 0.0) rtb = xmid;
+                if ((fabs(dx) < xacc) || (fmid == 0.0)) break;
+            }
+            disk_set_mdot(d, (j >= 500) ? 0.0 : rtb);
+        }
+    }
+    g_disk = d;
     return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_nt_mdot(double* mdot)
+{
+    if (!mdot) return SIM5GPU_E_ARG;
+    if (!g_disk.ready) { snprintf(g_err, sizeof g_err, "disk_nt_setup has not been called"); return SIM5GPU_E_NOT_SETUP; }
+    *mdot = g_disk.mdot;
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_disk_nt_lumi(double* lumi)
+{
+    if (!lumi) return SIM5GPU_E_ARG;
+    if (!g_disk.ready) { snprintf(g_err, sizeof g_err, "disk_nt_setup has not been called"); return SIM5GPU_E_NOT_SETUP; }
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    return disk_lumi(g_disk, lumi);
 }
 
 int sim5gpu_disk_nt_r_min(double* r_min)
@@ -234,6 +284,7 @@ int sim5gpu_image_rows(const sim5gpu_image_desc* desc)
 {
     if (!desc || desc->y1 <= desc->y0) return 0;
     if (desc->stripe_rows <= 0) return desc->y1 - desc->y0;
+    if (desc->stripe_step < desc->stripe_rows) return 0;       // overlapping or non-advancing stripes: rejected by the launchers
     int rows = 0;
     for (int y = desc->y0; y < desc->y1; y += desc->stripe_step)
         rows += (y + desc->stripe_rows <= desc->y1) ? desc->stripe_rows : desc->y1 - y;

@@ -21,6 +21,8 @@ struct DiskConsts {
     double mdot, mass;   // (double)(float) values                               ref :145
     // reciprocals and the overall scale, folded on the host for the fast variant
     double inv_x0, inv_d1, inv_d2, inv_d3, scale;
+    double alpha;        // (double)(float) viscosity parameter (disk_nt_sigma only)  ref :31,59
+    double a2f;          // (double)((float)spin * (float)spin): sqr() of the float static in disk_nt_lumi  ref :172-173
     int    ready;
 };
 

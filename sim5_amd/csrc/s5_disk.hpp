@@ -45,4 +45,45 @@ S5_DEV double disk_ell(const DiskConsts& d, double r)                  // ref :2
     return (r * r - 2. * a * sqrt(r) + a * a) / (sqrt(r) * r - 2. * sqrt(r) + a);
 }
 
+// Column density of the two inner zones (ref :204-250), the reference's expressions term by term
+// (3.*(x1-a)*(x1-a)/... associates differently from the flux's 3.*sqr(x1-a)/..., so the prefactors are formed here).
+S5_DEV double disk_sigma(const DiskConsts& d, double r)
+{
+    if (r < d.rms) return 0.0;
+    const double a = d.a;
+    const double x = sqrt(r);
+    const double x0 = d.x0, x1 = d.x1, x2 = d.x2, x3 = d.x3;
+    const double xA = 1. + (a * a) / (r * r) + 2. * (a * a) / (r * r * r);
+    const double xB = 1. + a / (x * x * x);
+    const double xC = 1. - 3. / (x * x) + 2. * a / (x * x * x);
+    const double xD = 1. - 2. / r + (a * a) / (r * r);
+    const double xE = 1. + 4. * (a * a) / (r * r) - 4. * (a * a) / (r * r * r) + 3. * (a * a * a * a) / (r * r * r * r);
+    const double f0 = x - x0 - 1.5 * a * log(x / x0);
+    const double f1 = 3. * (x1 - a) * (x1 - a) / (x1 * (x1 - x2) * (x1 - x3)) * log((x - x1) / (x0 - x1));
+    const double f2 = 3. * (x2 - a) * (x2 - a) / (x2 * (x2 - x1) * (x2 - x3)) * log((x - x2) / (x0 - x2));
+    const double f3 = 3. * (x3 - a) * (x3 - a) / (x3 * (x3 - x2) * (x3 - x1)) * log((x - x3) / (x0 - x3));
+    const double xL = (1. + a / (x * x * x)) / sqrt(1. - 3. / (x * x) + 2. * a / (x * x * x)) / x * (f0 - f1 - f2 - f3);
+    const double xMdot = d.mdot * d.mass * 2.225475942e+18 / 1e17;                  // Mdot_Edd, ref src/sim5const.h:49
+    const double r_im = 40. * (pow(d.alpha, 2. / 21.) / pow(d.mass / 3., 2. / 3.) * pow(xMdot, 16. / 20.)) * pow(xA, 20. / 21.) *
+                        pow(xB, -36. / 21.) * pow(xD, -8. / 21.) * pow(xE, -10. / 21.) * pow(xL, 16. / 21.);
+    if (r < r_im)
+        return 20. * (d.mass / 3.) / xMdot / d.alpha * sqrt(r * r * r) * 1. / (xA * xA) * pow(xB, 3.) * sqrt(xC) * xE * 1. / xL;
+    return 5e4 * pow(d.mass / 3., -2. / 5.) * pow(xMdot, 3. / 5.) * pow(d.alpha, -4. / 5.) * pow(r, -3. / 5.) *
+           pow(xB, -4. / 5.) * sqrt(xC) * pow(xD, -4. / 5.) * pow(xL, 3. / 5.);
+}
+
+// integrand of the luminosity integral over log r: 2 pi r 2 (-U_t) F(r) r  (ref :167-179)
+S5_DEV double disk_lumi_integrand(const DiskConsts& d, double log_r)
+{
+    const double a = d.a;
+    const double r = exp(log_r);
+    const double gtt = -1. + 2. / r;
+    const double gtf = -2. * a / r;
+    const double gff = r * r + d.a2f + 2. * d.a2f / r;
+    const double Omega = 1. / (a + pow(r, 1.5));
+    const double U_t = sqrt(-1.0 / (gtt + 2. * Omega * gtf + (Omega * Omega) * gff)) * (gtt + Omega * gtf);
+    const double F = disk_flux(d, r);
+    return 2. * M_PI * r * 2.0 * (-U_t) * F * r;
+}
+
 } // namespace S5NS

@@ -226,6 +226,8 @@ void on2bl(double Vin[4], double Vout[4], sim5tetrad *t)
 
 double r_bh(double a) { S5_FN(fn_d1, f, "sim5gpu_r_bh"); double r = NAN; s5_check(f(1, &a, &r), "r_bh"); return r; }
 double r_ms(double a) { S5_FN(fn_d1, f, "sim5gpu_r_ms"); double r = NAN; s5_check(f(1, &a, &r), "r_ms"); return r; }
+double r_mb(double a) { S5_FN(fn_d1, f, "sim5gpu_r_mb"); double r = NAN; s5_check(f(1, &a, &r), "r_mb"); return r; }
+double r_ph(double a) { S5_FN(fn_d1, f, "sim5gpu_r_ph"); double r = NAN; s5_check(f(1, &a, &r), "r_ph"); return r; }
 double OmegaK(double r, double a) { S5_FN(fn_d2, f, "sim5gpu_OmegaK"); double o = NAN; s5_check(f(1, &r, &a, &o), "OmegaK"); return o; }
 double ellK(double r, double a) { S5_FN(fn_d2, f, "sim5gpu_ellK"); double o = NAN; s5_check(f(1, &r, &a, &o), "ellK"); return o; }
 
@@ -293,11 +295,16 @@ double raytrace_error(double x[4], double k[4], raytrace_data *rtd)
     return e;
 }
 
+/* the arguments of the last set-up, as the reference keeps them (floats), for the header of disk_nt_dump only */
+static float s5_disk_M = 10.0, s5_disk_a = 0.0, s5_disk_alpha = 0.1;
+static int s5_disk_options = 0;
+
 int disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int options)
 {
     typedef int (*fn)(double, double, double, double, int);
     S5_FN(fn, f, "sim5gpu_disk_nt_setup");
     s5_check(f(M, a, mdot_or_L, alpha, options), "disk_nt_setup");
+    s5_disk_M = M; s5_disk_a = a; s5_disk_alpha = alpha; s5_disk_options = options;
     return 0;
 }
 
@@ -312,8 +319,66 @@ double disk_nt_r_min(void)
     return r;
 }
 
+static double disk_nt_r_min_f(void) { return (float)disk_nt_r_min(); }     /* the float static disk_nt_disk_rms */
+double disk_nt_vr(double r) { (void)r; return 0.0; }                          /* ref src/sim5disk-nt.c:253-303 */
+double disk_nt_h(double r) { (void)r; return 0.0; }
+double disk_nt_dhdr(double r) { (void)r; return 0.0; }
+
 double disk_nt_flux(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_flux"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_flux"); return o; }
 double disk_nt_ell(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_ell"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_ell"); return o; }
+double disk_nt_sigma(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_sigma"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_sigma"); return o; }
+
+double disk_nt_mdot(void)
+{
+    typedef int (*fn)(double *);
+    S5_FN(fn, f, "sim5gpu_disk_nt_mdot");
+    double v = NAN;
+    s5_check(f(&v), "disk_nt_mdot");
+    return v;
+}
+
+double disk_nt_lumi(void)
+{
+    typedef int (*fn)(double *);
+    S5_FN(fn, f, "sim5gpu_disk_nt_lumi");
+    double v = NAN;
+    s5_check(f(&v), "disk_nt_lumi");
+    return v;
+}
+
+/* radial profile dump in the reference's layout (ref src/sim5disk-nt.c:310-360): header with the model parameters,
+ * then one line per radius from the inner edge to 2000 r_g in steps of 5 %; the whole profile is two batch calls */
+void disk_nt_dump(char *filename)
+{
+    FILE *stream = stdout;
+    if (filename) stream = fopen(filename, "w");
+    if (!stream) { fprintf(stderr, "disk_nt_dump: cannot open output (%s)\n", filename); return; }
+    const float disk_rmax = 2000.;
+    double rr[512], fl[512], sg[512], el[512];
+    size_t n = 0;
+    double r;
+    for (r = (float)disk_nt_r_min_f(); r < disk_rmax && n < 512; r *= 1.05) rr[n++] = r;
+    { S5_FN(fn_d1, f, "sim5gpu_disk_nt_flux"); s5_check(f(n, rr, fl), "disk_nt_flux"); }
+    { S5_FN(fn_d1, f, "sim5gpu_disk_nt_sigma"); s5_check(f(n, rr, sg), "disk_nt_sigma"); }
+    { S5_FN(fn_d1, f, "sim5gpu_disk_nt_ell"); s5_check(f(n, rr, el), "disk_nt_ell"); }
+    fprintf(stream, "# (sim5disk-nt) dump\n");
+    fprintf(stream, "#-------------------------------------------\n");
+    fprintf(stream, "# M        = %.4f\n", s5_disk_M);
+    fprintf(stream, "# a        = %.4f\n", s5_disk_a);
+    fprintf(stream, "# rmin     = %.4f\n", (float)disk_nt_r_min_f());
+    fprintf(stream, "# rmax     = %.4f\n", disk_rmax);
+    fprintf(stream, "# alpha    = %.4f\n", s5_disk_alpha);
+    fprintf(stream, "# options  = %d\n", s5_disk_options);
+    fprintf(stream, "# L        = %e\n", disk_nt_lumi());
+    fprintf(stream, "# mdot     = %e\n", disk_nt_mdot());
+    fprintf(stream, "#-------------------------------------------\n");
+    fprintf(stream, "# r   flux   sigma   ell   vr   H   dH/dr\n");
+    fprintf(stream, "#-------------------------------------------\n");
+    for (size_t i = 0; i < n; i++)
+        fprintf(stream, "%e  %e  %e  %e  %e  %e  %e\n", rr[i], fl[i], sg[i], el[i], 0.0, 0.0, 0.0);
+    fflush(stream);
+    if (filename) fclose(stream);
+}
 
 sim5complex polarization_constant(double k[4], double f[4], sim5metric *metric)
 {

@@ -134,6 +134,8 @@ void   bl2on(double Vin[4], double Vout[4], sim5tetrad *t);
 void   on2bl(double Vin[4], double Vout[4], sim5tetrad *t);
 double r_bh(double a);
 double r_ms(double a);
+double r_mb(double a);
+double r_ph(double a);
 double OmegaK(double r, double a);
 double ellK(double r, double a);
 double Omega_from_ell(double ell, sim5metric *m);
@@ -168,7 +170,14 @@ int    disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int opt
 void   disk_nt_done(void);
 double disk_nt_r_min(void);
 double disk_nt_flux(double r);
+double disk_nt_lumi(void);
+double disk_nt_mdot(void);
+double disk_nt_sigma(double r);
 double disk_nt_ell(double r);
+double disk_nt_vr(double r);
+double disk_nt_h(double r);
+double disk_nt_dhdr(double r);
+void   disk_nt_dump(char *filename);
 
 /* ---- polarization, radiation ---- */
 typedef struct stokes_params { double i, q, u, v, tau; } stokes_params;

@@ -165,6 +165,14 @@ def r_ms(a):
     return float(_c.r_ms([a])[0])
 
 
+def r_mb(a):
+    return float(_c.r_mb([a])[0])
+
+
+def r_ph(a):
+    return float(_c.r_ph([a])[0])
+
+
 def OmegaK(r, a):
     return float(_c.OmegaK([r], a)[0])
 
@@ -291,6 +299,18 @@ def disk_nt_r_min():
 
 def disk_nt_flux(r):
     return float(_c.disk_nt_flux([r])[0])
+
+
+def disk_nt_lumi():
+    return _c.disk_nt_lumi()
+
+
+def disk_nt_mdot():
+    return _c.disk_nt_mdot()
+
+
+def disk_nt_sigma(r):
+    return float(_c.disk_nt_sigma([r])[0])
 
 
 def disk_nt_ell(r):

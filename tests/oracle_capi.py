@@ -24,7 +24,35 @@ def _b(x, n):
 
 
 def disk_nt_setup(M, a, mdot, alpha, options=0):
-    _orc().disk_nt_setup(M, a, mdot, alpha)
+    _orc().disk_nt_setup(M, a, mdot, alpha, options)
+
+
+def disk_nt_mdot():
+    return _orc().disk_nt_mdot()
+
+
+def disk_nt_lumi():
+    return _orc().disk_nt_lumi()
+
+
+def disk_nt_sigma(r):
+    return np.array([_orc().disk_nt_sigma(v) for v in np.atleast_1d(r)])
+
+
+def r_ms(a):
+    return np.array([_orc().r_ms(v) for v in np.atleast_1d(a)])
+
+
+def r_bh(a):
+    return np.array([_orc().r_bh(v) for v in np.atleast_1d(a)])
+
+
+def r_mb(a):
+    return np.array([_orc().r_mb(v) for v in np.atleast_1d(a)])
+
+
+def r_ph(a):
+    return np.array([_orc().r_ph(v) for v in np.atleast_1d(a)])
 
 
 def disk_nt_r_min():
@@ -56,11 +84,22 @@ def _gd(rec):
 
 
 def geodesic_find_midplane_crossing(g, order):
-    return np.array([_orc().geodesic_find_midplane_crossing(C.byref(_gd(r)), int(order)) for r in g])
+    return np.array([_orc().geodesic_find_midplane_crossing(C.byref(_gd(r)), int(order)) for r in np.atleast_1d(g)])
 
 
 def geodesic_position_rad(g, P):
-    return np.array([_orc().geodesic_position_rad(C.byref(_gd(r)), p) for r, p in zip(g, P)])
+    g = np.atleast_1d(g)
+    return np.array([_orc().geodesic_position_rad(C.byref(_gd(r)), p) for r, p in zip(g, _b(P, g.size))])
+
+
+def geodesic_position_pol(g, P):
+    g = np.atleast_1d(g)
+    return np.array([_orc().geodesic_position_pol(C.byref(_gd(r)), p) for r, p in zip(g, _b(P, g.size))])
+
+
+def geodesic_P_int(g, r, ppc):
+    g = np.atleast_1d(g)
+    return np.array([_orc().geodesic_P_int(C.byref(_gd(rec)), rr, int(pp)) for rec, rr, pp in zip(g, _b(r, g.size), _b(ppc, g.size))])
 
 
 def photon_momentum(a, r, m, l, q, rs, ms):
@@ -87,11 +126,13 @@ def _met(rec):
 
 
 def Omega_from_ell(ell, metric):
+    metric = np.atleast_1d(metric)
     ell = _b(ell, metric.size)
     return np.array([_orc().Omega_from_ell(ell[i], C.byref(_met(metric[i]))) for i in range(metric.size)])
 
 
 def tetrad_surface(metric, Om, V, dhdr):
+    metric = np.atleast_1d(metric)
     n = metric.size
     Om, V, dhdr = _b(Om, n), _b(V, n), _b(dhdr, n)
     out = np.zeros(n, dtype=TETRAD_DTYPE)
@@ -103,6 +144,7 @@ def tetrad_surface(metric, Om, V, dhdr):
 
 def on2bl(v, tetrad):
     v = np.asarray(v, dtype=np.float64).reshape(-1, 4)
+    tetrad = np.atleast_1d(tetrad)
     out = np.zeros_like(v)
     for i in range(v.shape[0]):
         t = ol.Tetrad.from_buffer_copy(tetrad[i].tobytes()); vo = ol.D4()
@@ -112,4 +154,5 @@ def on2bl(v, tetrad):
 
 def dotprod(v1, v2, metric):
     v1 = np.asarray(v1).reshape(-1, 4); v2 = np.asarray(v2).reshape(-1, 4)
+    metric = np.atleast_1d(metric)
     return np.array([_orc().dotprod(ol.D4(*v1[i]), ol.D4(*v2[i]), C.byref(_met(metric[i]))) for i in range(v1.shape[0])])

@@ -82,7 +82,7 @@ _COMMON = {
     "jacobi_isn": (D, [D, D]), "jacobi_icn": (D, [D, D]), "jacobi_itn": (D, [D, D]),
     "jacobi_sncndn": (None, [D, D, PD, PD, PD]),
     "jacobi_sn": (D, [D, D]), "jacobi_cn": (D, [D, D]), "jacobi_dn": (D, [D, D]),
-    "r_bh": (D, [D]), "r_ms": (D, [D]),
+    "r_bh": (D, [D]), "r_ms": (D, [D]), "r_mb": (D, [D]), "r_ph": (D, [D]),
     "flat_metric": (None, [D, D, PM]),
     "kerr_metric": (None, [D, D, D, PM]),
     "kerr_metric_contravariant": (None, [D, D, D, PM]),
@@ -174,12 +174,27 @@ class Oracle(_Lib):
         L.orc_disk_nt_ell.restype = D
         L.orc_disk_pixel.argtypes = [PDN, D, D, D, D, D, C.POINTER(Pixel)]
         L.orc_disk_pixel.restype = None
+        L.orc_disk_nt_setup_opt.argtypes = [PDN, D, D, D, D, I]
+        L.orc_disk_nt_setup_opt.restype = None
+        for name in ("orc_disk_nt_mdot", "orc_disk_nt_lumi"):
+            getattr(L, name).argtypes = [PDN]
+            getattr(L, name).restype = D
+        L.orc_disk_nt_sigma.argtypes = [PDN, D]
+        L.orc_disk_nt_sigma.restype = D
         self.disk = DiskNT()
 
-    def disk_nt_setup(self, M, a, mdot, alpha, options=0):
-        assert options == 0
-        self.lib.orc_disk_nt_setup(C.byref(self.disk), M, a, mdot, alpha)
+    def disk_nt_setup(self, M, a, mdot_or_L, alpha, options=0):
+        self.lib.orc_disk_nt_setup_opt(C.byref(self.disk), M, a, mdot_or_L, alpha, options)
         return 0
+
+    def disk_nt_mdot(self):
+        return self.lib.orc_disk_nt_mdot(C.byref(self.disk))
+
+    def disk_nt_lumi(self):
+        return self.lib.orc_disk_nt_lumi(C.byref(self.disk))
+
+    def disk_nt_sigma(self, r):
+        return self.lib.orc_disk_nt_sigma(C.byref(self.disk), r)
 
     def disk_nt_r_min(self):
         return self.lib.orc_disk_nt_r_min(C.byref(self.disk))
@@ -209,10 +224,17 @@ class Reference(_Lib):
         L.disk_nt_flux.restype = D
         L.disk_nt_ell.argtypes = [D]
         L.disk_nt_ell.restype = D
+        L.disk_nt_mdot.restype = D
+        L.disk_nt_lumi.restype = D
+        L.disk_nt_sigma.argtypes = [D]
+        L.disk_nt_sigma.restype = D
         self.disk_nt_setup = L.disk_nt_setup
         self.disk_nt_r_min = L.disk_nt_r_min
         self.disk_nt_flux = L.disk_nt_flux
         self.disk_nt_ell = L.disk_nt_ell
+        self.disk_nt_mdot = L.disk_nt_mdot
+        self.disk_nt_lumi = L.disk_nt_lumi
+        self.disk_nt_sigma = L.disk_nt_sigma
 
 
 def have_reference():

@@ -56,6 +56,39 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     assert abs(float(tail[4]) / orc.geodesic_timedelay(C.byref(gd), P1, 0.0, 0.0, P2, 0.0, 0.0) - 1) < 1e-9
 
 
+def test_radii_and_disk_report_program(tmp_path, capi, golden):
+    """tests/c/disk_dump.c through the scalar API: the radii of example 01, the disk report incl. a set-up by
+    luminosity, and disk_nt_dump's table (ref src/sim5disk-nt.c:310-360) against the reference's numbers."""
+    exe = str(tmp_path / "dump")
+    subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", "disk_dump.c"), os.path.join(ROOT, "src", "sim5lib.c"),
+                    "-I", os.path.join(ROOT, "src"), "-o", exe, "-lm", "-O3", "-w", "-fgnu89-inline"], check=True)
+    env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    g = golden("kat_disk_model.npz")
+    spin = g["spin"]
+    for ln in [l for l in lines if l.startswith("radii")]:
+        v = [float(t) for t in ln.split()[1:]]
+        i = int(np.argmin(np.abs(spin - v[0])))
+        for got, ref in zip(v[1:], (g["r_bh"][i], g["r_ph"][i], g["r_mb"][i], g["r_ms"][i])):
+            assert abs(got - ref) <= 1e-12 * max(1.0, abs(ref)), ln
+    m0 = [float(t) for t in [l for l in lines if l.startswith("model0")][0].split()[1:]]
+    assert m0[0] == g["mdot_3"][0] and abs(m0[1] / g["lumi_3"][0] - 1) < 1e-6 and m0[2] == g["rmin_3"][0]
+    m1 = [float(t) for t in [l for l in lines if l.startswith("model1")][0].split()[1:]]
+    assert abs(m1[0] / g["mdot_4"][0] - 1) < 1e-6 and abs(m1[1] / g["lumi_4"][0] - 1) < 1e-6
+    assert [l for l in lines if l.startswith("zeros")][0].split()[1:] == ["0", "0", "0"]
+    # the dump: header of the LAST set-up (luminosity option), then r flux sigma ell 0 0 0 per radius
+    assert "# options  = 1" in lines and any(l.startswith("# L        = 3.0000") for l in lines)
+    rows = np.array([[float(t) for t in l.split()] for l in lines if l and l[0].isdigit()])
+    assert rows.shape[1] == 7 and rows.shape[0] > 100 and (rows[:, 4:] == 0).all()
+    assert abs(rows[0, 0] - np.float32(g["rmin_4"][0])) < 1e-6 and np.allclose(rows[1:, 0] / rows[:-1, 0], 1.05, rtol=1e-6)
+    orc = ol.Oracle(); orc.disk_nt_setup(10.0, 0.5, 0.3, 0.1, 1)
+    want = np.array([[orc.disk_nt_flux(r), orc.disk_nt_sigma(r), orc.disk_nt_ell(r)] for r in rows[:, 0]])
+    ok = want[:, 0] > 0
+    assert np.allclose(rows[ok, 1:4], want[ok], rtol=5e-6, atol=0)           # "%e" keeps 7 digits
+
+
 def test_batch_example_program(tmp_path, capi):
     """examples/disk_image_batch.c: the reference example's output format from one library call."""
     exe = str(tmp_path / "batch")

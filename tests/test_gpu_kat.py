@@ -189,6 +189,30 @@ def test_disk_nt(capi, golden):
     assert_close(capi.disk_nt_flux(g["r_x"]), g["flux_x"], floor=1e-9 * g["flux_x"].max(), what="flux (other M, mdot)")
 
 
+def test_disk_model_rest(capi, golden):
+    """The rest of the Novikov-Thorne module and the orbit radii of example 01 (ref src/sim5disk-nt.c:151-250,
+    371-385; src/sim5kerr.c:1007-1034) against the reference: disk_nt_mdot exact (a float), disk_nt_lumi (Simpson
+    integral, integrand on the device), disk_nt_sigma, the luminosity-parametrised set-up (bisection), r_ph, r_mb."""
+    g = golden("kat_disk_model.npz")
+    for j, (M, a, x, al, opt) in enumerate(g["setups"]):
+        capi.disk_nt_setup(float(M), float(a), float(x), float(al), int(opt))
+        if opt:
+            assert abs(capi.disk_nt_mdot() / g["mdot_%d" % j][0] - 1) < 1e-6, (j, capi.disk_nt_mdot(), g["mdot_%d" % j][0])
+        else:
+            assert capi.disk_nt_mdot() == g["mdot_%d" % j][0]
+        assert abs(capi.disk_nt_lumi() / g["lumi_%d" % j][0] - 1) < 1e-6, (j, capi.disk_nt_lumi(), g["lumi_%d" % j][0])
+        assert capi.disk_nt_r_min() == g["rmin_%d" % j][0]
+        sg = capi.disk_nt_sigma(g["r_%d" % j]); ref = g["sigma_%d" % j]
+        assert np.array_equal(sg == 0, ref == 0)
+        if not opt:
+            assert_close(sg, ref, what="disk_nt_sigma %d" % j)
+        else:       # sigma depends on the accretion rate the bisection found (agrees to 1e-6, see above)
+            assert_close(sg, ref, rtol=5e-6, what="disk_nt_sigma %d" % j)
+    assert_close(capi.r_ph(g["spin"]), g["r_ph"], floor=1e-9, what="r_ph")
+    assert_close(capi.r_mb(g["spin"]), g["r_mb"], floor=1e-9, what="r_mb")
+    assert_close(capi.r_ms(g["spin"]), g["r_ms"], what="r_ms"); assert_close(capi.r_bh(g["spin"]), g["r_bh"], what="r_bh")
+
+
 def test_polarization_and_blackbody(capi, golden):
     g = golden("kat_polar.npz")
     met = np.frombuffer(np.ascontiguousarray(g["metric"]).tobytes(), dtype=capi.METRIC_DTYPE)

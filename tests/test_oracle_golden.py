@@ -314,3 +314,23 @@ def test_torus_c4_port_equals_reference(golden):
             key = "%s_%s" % (tag if k in ("I", "tau") else src, k)
             assert np.array_equal(o[k], g[key][sel], equal_nan=True), (tag, k)
     assert g["absorb_tau"].max() > 5 and g["thin_I"].max() > 20
+
+
+def test_disk_model_rest(oracle, golden):
+    """disk_nt_mdot / disk_nt_lumi / disk_nt_sigma incl. the luminosity-parametrised set-up (bisection over the Simpson
+    integral of the flux), and r_ph / r_mb: bit for bit against the reference."""
+    g = golden("kat_disk_model.npz")
+    for j, (M, a, x, al, opt) in enumerate(g["setups"]):
+        oracle.disk_nt_setup(M, a, x, al, int(opt))
+        assert oracle.disk_nt_mdot() == g["mdot_%d" % j][0], j
+        assert oracle.disk_nt_lumi() == g["lumi_%d" % j][0], j
+        close(oracle.disk_nt_r_min(), g["rmin_%d" % j][0], rtol=0, what="r_min")
+        close([oracle.disk_nt_sigma(r) for r in g["r_%d" % j]], g["sigma_%d" % j], rtol=0, what="sigma %d" % j)
+        close([oracle.disk_nt_flux(r) for r in g["r_%d" % j]], g["flux_%d" % j], rtol=0, what="flux %d" % j)
+        assert g["sigma_%d" % j][0] == 0 and g["sigma_%d" % j][2] > 0
+    close([oracle.r_ph(a) for a in g["spin"]], g["r_ph"], rtol=0, what="r_ph")
+    close([oracle.r_mb(a) for a in g["spin"]], g["r_mb"], rtol=0, what="r_mb")
+    # luminosity set-ups give back the luminosity asked for (the reference's bisection stops at 1e-6 in mdot)
+    for j, (M, a, x, al, opt) in enumerate(g["setups"]):
+        if opt:
+            assert abs(g["lumi_%d" % j][0] / x - 1) < 1e-4
