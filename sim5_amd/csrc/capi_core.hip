@@ -82,7 +82,7 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot, double alpha)
 }
 
 // validate a job description and turn it into the kernel argument block
-int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p)
+int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_disk)
 {
     if (!desc) { snprintf(g_err, sizeof g_err, "image descriptor is NULL"); return SIM5GPU_E_ARG; }
     if (desc->nx <= 0 || desc->ny <= 0 || desc->y0 < 0 || desc->y1 > desc->ny || desc->y0 >= desc->y1) {
@@ -92,6 +92,10 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p)
     }
     if (desc->stripe_rows < 0 || (desc->stripe_rows > 0 && desc->stripe_step < desc->stripe_rows)) {
         snprintf(g_err, sizeof g_err, "bad striping stripe_rows=%d stripe_step=%d", desc->stripe_rows, desc->stripe_step);
+        return SIM5GPU_E_ARG;
+    }
+    if (need_disk && (!(desc->bh_mass > 0.0) || !(desc->mdot > 0.0))) {     // a zero-initialised descriptor would give inf / NaN fluxes
+        snprintf(g_err, sizeof g_err, "image descriptor needs bh_mass > 0 and mdot > 0 (got %g, %g)", desc->bh_mass, desc->mdot);
         return SIM5GPU_E_ARG;
     }
     memset(&p, 0, sizeof p);

@@ -129,7 +129,7 @@ int sim5gpu_torus_image(const sim5gpu_torus_desc* desc, sim5gpu_stokes* d_stokes
 {
     if (!desc || !d_stokes) { snprintf(g_err, sizeof g_err, "torus_image: NULL pointer argument"); return SIM5GPU_E_ARG; }
     ImageParams ip;
-    int rc = fill_image_params(&desc->img, ip);
+    int rc = fill_image_params(&desc->img, ip, false);       // image geometry only: the disk fields are unused
     if (rc) return rc;
     if (!(desc->r0 > 0.0) || !(desc->precision > 0.0) || desc->max_steps < 1) {
         snprintf(g_err, sizeof g_err, "torus_image: need r0 > 0, precision > 0, max_steps >= 1");

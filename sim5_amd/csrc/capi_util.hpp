@@ -18,7 +18,7 @@ int  have_device();
 DiskConsts make_disk_consts(double M, double a, double mdot, double alpha = 0.1);
 void disk_set_mdot(DiskConsts& d, double mdot);
 int  disk_lumi(const DiskConsts& d, double* lumi);          // capi_batch.hip: Simpson rule, integrand on the device
-int  fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p);
+int  fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_disk = true);
 
 #define S5_HIP(call)                                                          \
     do {                                                                      \
@@ -33,23 +33,38 @@ int  fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p);
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, used = 0;
+    size_t demand = 0;          // bytes asked for by the call in progress, including buffers that did not fit
+    size_t want = 0;            // largest demand of any call so far: the arena grows to it between calls
     int live = 0;
+    int dev = -1;               // device the block lives on; a thread that switches device gets a new block
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; used = 0; }
     void* take(size_t bytes)
     {
         bytes = (bytes + 255) & ~size_t(255);
-        if (used + bytes > cap) {
-            if (live != 0) return nullptr;                 // cannot move buffers that are in use
-            if (base) (void)hipFree(base);
-            size_t want = cap ? cap * 2 : (size_t)1 << 20;
-            while (want < bytes) want *= 2;
-            if (hipMalloc((void**)&base, want) != hipSuccess) { base = nullptr; cap = 0; return nullptr; }
-            cap = want; used = 0;
+        if (live == 0) {                                       // first buffer of a call: the block may be replaced
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (cur != dev) { release(); dev = cur; }
+            demand = 0;
+            size_t need = want > bytes ? want : bytes;
+            if (need > cap) {
+                release();
+                size_t grow = (size_t)1 << 20;
+                while (grow < need) grow *= 2;
+                if (hipMalloc((void**)&base, grow) != hipSuccess) { base = nullptr; cap = 0; demand += bytes; return nullptr; }
+                cap = grow;
+            }
         }
+        demand += bytes;
+        if (used + bytes > cap) return nullptr;                // cannot move buffers that are in use: one-off hipMalloc
         void* p = base + used;
         used += bytes; ++live;
         return p;
     }
-    void give() { if (--live == 0) used = 0; }
+    // a buffer of the call that did not come from the block (fallback allocation) has been released
+    void call_done() { if (demand > want) want = demand; }
+    void give() { if (--live == 0) { used = 0; call_done(); } }
+    ~Arena() { release(); }                                    // thread exit: the block goes back
 };
 Arena& arena();
 
@@ -76,7 +91,7 @@ struct DevBuf {
     ~DevBuf()
     {
         if (!ptr) return;
-        if (from_arena) arena().give(); else (void)hipFree(ptr);
+        if (from_arena) arena().give(); else { (void)hipFree(ptr); arena().call_done(); }
     }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;

@@ -375,8 +375,11 @@ struct TorusWorkspace {
     size_t cap = 0;
     hipStream_t last = nullptr;
     bool used = false;
+    bool attr_set = false;         // dynamic-LDS limit of the march kernel raised on this device
 };
-static TorusWorkspace g_ws;
+constexpr int MAX_DEVICES = 64;
+static TorusWorkspace g_ws_dev[MAX_DEVICES];   // one workspace per device: a process that switches device never hands
+                                               // a kernel on GPU B memory that lives on GPU A
 static std::mutex g_ws_lock;       // jobs from several host threads take turns at the shared workspace
 
 #if S5_FAST
@@ -386,12 +389,16 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
 #endif
 {
     std::lock_guard<std::mutex> hold(g_ws_lock);
+    int dev = 0;
+    hipError_t e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return (int)hipErrorInvalidDevice;
+    TorusWorkspace& g_ws = g_ws_dev[dev];
     const size_t n = p.nrays;
     if (n > 0x7ffffff0ull) return (int)hipErrorInvalidValue;            // ray numbers are kept as int in the pool
     const size_t dcol_bytes = (sizeof(double) * NCOL * n + 255) & ~size_t(255);
     const size_t ok_bytes = (sizeof(int) * n + 255) & ~size_t(255);
     const size_t need = dcol_bytes + ok_bytes + 256;
-    hipError_t e;
     if (g_ws.used && g_ws.last != stream) {
         if ((e = hipStreamSynchronize(g_ws.last)) != hipSuccess) return (int)e;
     }
@@ -418,17 +425,15 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
 
     // persistent grid: 2 workgroups of 4 waves per CU (VGPR-bound occupancy 2 waves/SIMD; 2 x 71 KB of LDS),
     // never more waves than 128-ray pools to fill
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
+    int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     size_t blocks_b = (size_t)cus * S5_MARCH_WAVES;
     const size_t needed = (n + 4 * POOL_SLOTS - 1) / (4 * POOL_SLOTS);
     if (blocks_b > needed) blocks_b = needed;
     const size_t lds = 4 * (size_t)POOL_WAVE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!g_ws.attr_set) {
         if ((e = hipFuncSetAttribute((const void*)torus_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
-        attr_set = true;
+        g_ws.attr_set = true;
     }
     hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(256), lds, stream, p, start, ok, cursor, out, aux);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;

@@ -85,8 +85,10 @@ def test_radii_and_disk_report_program(tmp_path, capi, golden):
     assert abs(rows[0, 0] - np.float32(g["rmin_4"][0])) < 1e-6 and np.allclose(rows[1:, 0] / rows[:-1, 0], 1.05, rtol=1e-6)
     orc = ol.Oracle(); orc.disk_nt_setup(10.0, 0.5, 0.3, 0.1, 1)
     want = np.array([[orc.disk_nt_flux(r), orc.disk_nt_sigma(r), orc.disk_nt_ell(r)] for r in rows[:, 0]])
-    ok = want[:, 0] > 0
-    assert np.allclose(rows[ok, 1:4], want[ok], rtol=5e-6, atol=0)           # "%e" keeps 7 digits
+    # "%e" keeps 7 digits of r as well: compare away from the inner edge, where F and Sigma are steep functions of r
+    ok = rows[:, 0] > 1.5 * rows[0, 0]
+    assert ok.sum() > 100 and np.allclose(rows[ok, 1:4], want[ok], rtol=2e-5, atol=0)
+    assert rows[0, 1] == 0 and rows[1, 1] > 0                                 # F = 0 on the inner edge itself
 
 
 def test_batch_example_program(tmp_path, capi):

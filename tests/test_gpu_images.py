@@ -252,6 +252,16 @@ def test_rejects_bad_arguments(capi):
     d = capi.image_desc(16, 16, 0.5, 1.0, y0=8, y1=4)
     with pytest.raises(capi.Sim5GpuError):
         capi.disk_image(d)
+    # a zero-initialised disk (bh_mass = mdot = 0) is a descriptor error, not an image of NaNs
+    with pytest.raises(capi.Sim5GpuError):
+        capi.disk_image(capi.image_desc(16, 16, 0.5, 1.0, bh_mass=0.0))
+    with pytest.raises(capi.Sim5GpuError):
+        capi.disk_image(capi.image_desc(16, 16, 0.5, 1.0, mdot=0.0))
+    # stripes that do not advance are rejected instead of looping
+    d = capi.image_desc(64, 64, 0.5, 1.0, stripe_rows=16, stripe_step=0)
+    assert capi.image_rows(d) == 0
+    with pytest.raises(capi.Sim5GpuError):
+        capi.disk_image(d)
     # out-of-range physics is a per-ray status, not an API failure: spin > 1-1e-6 rejects every ray
     o = capi.disk_image(capi.image_desc(16, 16, 0.9999999, 1.0), full=True)
     assert (o["cls"] == 0).all() and (o["image_f"] == 0).all()
