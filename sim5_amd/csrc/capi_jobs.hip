@@ -152,6 +152,7 @@ int sim5gpu_torus_image(const sim5gpu_torus_desc* desc, sim5gpu_stokes* d_stokes
     p.r_stop_in = desc->r_stop_in > 0.0 ? desc->r_stop_in : 1.05;
     p.r_stop_out = desc->r_stop_out > 0.0 ? desc->r_stop_out : 1.01;
     p.torus_r = desc->torus_r; p.torus_w = desc->torus_w; p.torus_l = desc->torus_l;
+    p.inv_2w2 = 1.0 / (2. * desc->torus_w * desc->torus_w); p.cut_d2 = 36. * (2. * desc->torus_w * desc->torus_w);
     p.emis0 = desc->emis0; p.absorb0 = desc->absorb0;
     TorusAux aux = { nullptr, nullptr, nullptr, nullptr, nullptr };
     if (d_aux) {

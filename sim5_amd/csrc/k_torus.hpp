@@ -13,6 +13,7 @@ struct TorusParams {
     int options, max_steps, shape;
     double max_error, r_stop_in, r_stop_out;
     double torus_r, torus_w, torus_l, emis0, absorb0;
+    double inv_2w2, cut_d2;       // 1 / (2 w^2) and 36 * 2 w^2, folded on the host (fast variant)
 };
 
 struct TorusAux {

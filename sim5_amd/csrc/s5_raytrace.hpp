@@ -68,9 +68,9 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
 // 32.  The sums are accumulated in the reference's order ((k1 + 2 k2) + 2 k3) + k4 and the stage-0
 // operations with a zero offset / unit weight are exact, so every rounding is the reference's.
 #ifdef S5_RK4_NOINLINE
-static __device__ __noinline__ void rk4_step(double x[4], double k[4], double dl, RayState& s)
+static __device__ __noinline__ void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g)
 #else
-S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s)
+S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g)
 #endif
 {
     Conn G;
@@ -110,10 +110,16 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s)
         k[i] += S5_DIVC(dl, 6.) * sk[i];
     }
     x[2] = mcos(x[2]);
+    // g: the KERR metric at the new point, also in flat mode (ref :305); returned for the caller's transfer step
+#if S5_FAST
+    if (s.opt_gr) kerr_metric_connection(s.bh_spin, x[1], x[2], g, G);
+    else { flat_connection(x[1], x[2], G); kerr_metric(s.bh_spin, x[1], x[2], g); }
+    transport_self(G, k, s.dk);
+#else
     rt_connection(s, x[1], x[2], G);
     transport_self(G, k, s.dk);
-    Metric g;
-    kerr_metric(s.bh_spin, x[1], x[2], g);          // Kerr metric also in flat mode, ref :302
+    kerr_metric(s.bh_spin, x[1], x[2], g);
+#endif
     const double kt1 = k[0] * g.g00 + k[3] * g.g03;
     s.error = (float)rel_diff(kt1, kt0);
 }
@@ -128,15 +134,29 @@ S5_DEV double next_step_size(const double k[4], double step_cap, const RayState&
 {
     const double tiny = 1e-40;
     const double* dk = s.dk;
+#if S5_FAST
+    // eps / (sum_i |dk_i| / (|k_i| + tiny) + tiny) over the common denominator: one division instead of five.
+    // The product of the four denominators cannot leave the normal range for a null vector (k^t is O(1)); if it
+    // ever did, the reference's form below is taken.
+    const double d0 = fabs(k[0]) + tiny, d1 = fabs(k[1]) + tiny, d2 = fabs(k[2]) + tiny, d3 = fabs(k[3]) + tiny;
+    const double d01 = d0 * d1, d23 = d2 * d3;
+    const double den = d01 * d23;
+    const double num = (fabs(dk[0]) * d1 + fabs(dk[1]) * d0) * d23 + (fabs(dk[2]) * d3 + fabs(dk[3]) * d2) * d01;
+    double stepsize = mdiv(s.step_epsilon * den, num + tiny * den);
+    if (!(den > 1e-250) || !(den < 1e250))
+        stepsize = mdiv(s.step_epsilon,
+            mdiv(fabs(dk[0]), d0) + mdiv(fabs(dk[1]), d1) + mdiv(fabs(dk[2]), d2) + mdiv(fabs(dk[3]), d3) + tiny);
+#else
     const double stepsize = mdiv(s.step_epsilon,
         mdiv(fabs(dk[0]), fabs(k[0]) + tiny) + mdiv(fabs(dk[1]), fabs(k[1]) + tiny) +
         mdiv(fabs(dk[2]), fabs(k[2]) + tiny) + mdiv(fabs(dk[3]), fabs(k[3]) + tiny) + tiny);
+#endif
     double dl = fmin(step_cap, stepsize);
     if (dl < 1e-3) dl = 1e-3;
     return dl;
 }
 
-S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl, RayState& s)
+S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl, RayState& s, Metric& g)
 {
     double xp[4], kh[4], kp[4], kq[4];
     const double* dk = s.dk;
@@ -164,15 +184,61 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
     for (int i = 0; i < 4; ++i) kh[i] = k[i] + dk[i] * half_dl;          // the reference updates k in place
 
     S5_FENCE();
-    Metric g;
     Conn G;
+#if S5_FAST
+    if (s.opt_gr) kerr_metric_connection(s.bh_spin, xp[1], xp[2], g, G);
+    else { flat_metric(xp[1], xp[2], g); flat_connection(xp[1], xp[2], G); }
+#else
     rt_metric(s, xp[1], xp[2], g);
     S5_FENCE();
     rt_connection(s, xp[1], xp[2], G);
+#endif
     S5_FENCE();
 #pragma unroll
     for (int i = 0; i < 4; ++i) kp[i] = kh[i] + dk[i] * half_dl;
 
+#if S5_FAST
+    // The corrector's convergence measure k_frac_error = sum_i |kp_i - kq_i| / (|kq_i| + 1e-40), accumulated in
+    // float (ref :199-210), is only ever COMPARED (with 1e-5 to iterate again, with 1e-4 to reject the step,
+    // ref :213,220).  The comparisons are made on the exact rational N/D > T as N > T D (no division); the float
+    // accumulation differs from the exact sum by < 3e-7 relative, so whenever N/D is within 1e-6 of a threshold
+    // the reference's own float sequence is evaluated and decides (`near`, rare).  Decisions are identical.
+    bool again = true, reject = false;
+#pragma unroll
+    for (int iter = 0; iter < 3; ++iter) {
+        if (again) {
+            double acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kq[i] = kp[i];
+            transport_self(G, kq, acc);              // G (k_a k_b): the ten products once instead of (G k_a) k_b per entry
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kp[i] = kh[i] + acc[i] * half_dl;
+            const double tiny = 1e-40;
+            const double d0 = fabs(kq[0]) + tiny, d1 = fabs(kq[1]) + tiny, d2 = fabs(kq[2]) + tiny, d3 = fabs(kq[3]) + tiny;
+            const double n0 = fabs(kp[0] - kq[0]), n1 = fabs(kp[1] - kq[1]), n2 = fabs(kp[2] - kq[2]), n3 = fabs(kp[3] - kq[3]);
+            const double d01 = d0 * d1, d23 = d2 * d3;
+            const double D = d01 * d23;
+            const double N = (n0 * d1 + n1 * d0) * d23 + (n2 * d3 + n3 * d2) * d01;
+            const double T1 = 1e-2 * 1e-3, T2 = 1e-2 * 1e-2, slack = 1e-6;
+            again = N > (T1 * (1. + slack)) * D;
+            reject = N > (T2 * (1. + slack)) * D;
+            const bool sure = (again || !(N >= (T1 * (1. - slack)) * D)) && (reject || !(N >= (T2 * (1. - slack)) * D)) &&
+                              (D > 1e-250) && (D < 1e250) && (N == N);
+            if (!sure) {
+                float kerr = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kerr = (float)((double)kerr + rel_diff(kp[i], kq[i]));
+                again = (double)kerr > T1;
+                reject = (double)kerr > T2;
+            }
+        }
+        S5_FENCE();
+    }
+    const double kt = kp[0] * g.g00 + kp[3] * g.g03;
+    const double kk = fabs(dot(kp, kp, g));
+    s.error = (float)fmax(rel_diff(kt, s.kt), kk);
+    if (reject || ((double)s.error > 1e-2 * 1e-2)) return false;
+#else
     float kerr = 0.0f;
     bool again = true;
 #pragma unroll
@@ -197,9 +263,14 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
     const double kk = fabs(dot(kp, kp, g));
     s.error = (float)fmax(rel_diff(kt, s.kt), kk);
     if (((double)kerr > 1e-2 * 1e-2) || ((double)s.error > 1e-2 * 1e-2)) return false;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x[i] = xp[i]; k[i] = kp[i]; }
+#if S5_FAST
+    transport_self(G, kp, s.dk);
+#else
     geodesic_accel(G, kp, s.dk);
+#endif
     s.kt = kt;
     return true;
 }
@@ -208,7 +279,8 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
 S5_DEV void raytrace_step(double x[4], double k[4], double& step, RayState& s)
 {
     double dl;
-    if (!verlet_attempt(x, k, step, dl, s)) rk4_step(x, k, dl, s);
+    Metric g;
+    if (!verlet_attempt(x, k, step, dl, s, g)) rk4_step(x, k, dl, s, g);
     step = dl;
 }
 
