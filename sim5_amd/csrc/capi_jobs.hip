@@ -1,4 +1,5 @@
 // capi_jobs.hip -- C-ABI of the polarized thin-disk image and of the step-wise torus ray tracer.
+#include <vector>
 #include "capi_util.hpp"
 #include "k_torus.hpp"
 #include <math.h>
@@ -25,6 +26,25 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     return SIM5GPU_OK;
 }
 
+// The surface table must have strictly ascending radii: equal neighbours would divide by zero in the interpolation
+// and a descending pair breaks the bisection.  The table (<= 32 KB) is read back on the job's stream and checked
+// before the launch, so a bad table is an argument error of this call and not NaNs in its output.
+static int check_surface_table(const char* fn, int n_table, const double* d_R, hipStream_t stream)
+{
+    std::vector<double> h((size_t)n_table);
+    hipError_t e = hipMemcpyAsync(h.data(), d_R, sizeof(double) * (size_t)n_table, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { set_error(fn, e); return SIM5GPU_E_HIP; }
+    for (int i = 1; i < n_table; i++)
+        if (!(h[i] > h[i - 1])) {
+            snprintf(g_err, sizeof g_err, "%s: the radii of the surface table must be strictly ascending (R[%d] = %g, R[%d] = %g)",
+                     fn, i - 1, h[i - 1], i, h[i]);
+            return SIM5GPU_E_ARG;
+        }
+    if (!(h[0] == h[0])) { snprintf(g_err, sizeof g_err, "%s: NaN in the surface table", fn); return SIM5GPU_E_ARG; }
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double* d_R, const double* d_H,
                               size_t n, const double* d_alpha, const double* d_beta,
                               double* d_P, double* d_r, double* d_m, double* d_k, int* d_status,
@@ -40,6 +60,7 @@ int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double* 
     }
     if (n == 0) return SIM5GPU_OK;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    { int rc = check_surface_table("disk_surface_rays", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
     SurfaceParams p;
     p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
     p.tab_vr = nullptr; p.out_g = nullptr; p.out_mue = nullptr; p.out_flux = nullptr;
@@ -71,6 +92,7 @@ int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdo
     }
     if (n == 0) return SIM5GPU_OK;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    { int rc = check_surface_table("disk_surface_frame", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
     SurfaceParams p;
     p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
     p.disk = make_disk_consts(bh_mass, disk_spin >= 0.0 ? disk_spin : a, mdot);

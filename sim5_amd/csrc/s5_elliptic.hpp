@@ -314,27 +314,33 @@ struct LadderLds {
     S5_DEV double get_g(int i) const { return base[(2 * i + 1) * 256]; }
 };
 
-template <class Ladder>
-S5_DEV void sncndn_with(Ladder& lad, double u, double m, double& sn, double& cn, double& dn)
+// The routine in two halves.  The climb (the AGM rungs) depends on the modulus only; the descent takes the
+// argument u.  A caller that evaluates sn/cn/dn many times for ONE modulus (a geodesic's r(P) and mu(P): the
+// moduli are constants of the ray) climbs once and keeps the rungs; sncndn_with below is climb + descent, so
+// both uses run the same operations in the same order.
+struct LadderState {
+    double c;        // the last arithmetic mean, multiplies the argument
+    double d;        // scale of the flipped (m > 1) branch
+    int top;         // index of the last rung
+    bool flipped;
+    bool degenerate; // 1 - m == 0 after the clamp: unreachable, kept for parity
+};
+
+template <class Ladder, int NR = LADDER_RUNGS>
+S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
 {
     if (m == 1.0) m = 0.999999999;
     const double conv = 1.0e-8;
     double emc = 1.0 - m;
-    if (emc == 0.0) {                          // unreachable after the clamp above; kept for parity
-        cn = 1.0 / cosh(u);
-        dn = cn;
-        sn = tanh(u);
-        return;
-    }
-    double d = 1.0;
-    const bool flipped = emc < 0.0;
-    if (flipped) {
-        d = 1.0 - emc;
+    st.d = 1.0; st.c = 0.0; st.top = NR - 1; st.flipped = false;
+    st.degenerate = (emc == 0.0);
+    if (st.degenerate) return;
+    st.flipped = emc < 0.0;
+    if (st.flipped) {
+        double d = 1.0 - emc;
         emc /= -1.0 / d;
-        d = msqrt(d);
-        u *= d;
+        st.d = msqrt(d);
     }
-    constexpr int NR = LADDER_RUNGS;
     double a = 1.0, c = 0.0;
     int top = NR - 1;
     bool climbing = true;
@@ -349,6 +355,21 @@ S5_DEV void sncndn_with(Ladder& lad, double u, double m, double& sn, double& cn,
         }
         if (!wave_any(climbing)) break;        // rungs above are never read (i <= top below)
     }
+    st.c = c; st.top = top;
+}
+
+template <class Ladder, int NR = LADDER_RUNGS>
+S5_DEV void ladder_descend(const Ladder& lad, const LadderState& st, double u, double& sn, double& cn, double& dn)
+{
+    if (st.degenerate) {
+        cn = 1.0 / cosh(u);
+        dn = cn;
+        sn = tanh(u);
+        return;
+    }
+    if (st.flipped) u *= st.d;
+    const int top = st.top;
+    double a, c = st.c;
     u *= c;
     double s0, c0;
     msincos(u, s0, c0);
@@ -382,13 +403,35 @@ S5_DEV void sncndn_with(Ladder& lad, double u, double m, double& sn, double& cn,
         sn = (s0 >= 0.0 ? a : -a);
         cn = c * sn;
     }
-    if (flipped) {
+    if (st.flipped) {
         a = dn;
         dn = cn;
         cn = a;
-        sn = mdiv(sn, d);
+        sn = mdiv(sn, st.d);
     }
 }
+
+template <class Ladder>
+S5_DEV void sncndn_with(Ladder& lad, double u, double m, double& sn, double& cn, double& dn)
+{
+    LadderState st;
+    ladder_climb(lad, m, st);
+    ladder_descend(lad, st, u, sn, cn, dn);
+}
+
+// Rungs a double-precision modulus can need: with 0 <= m < 1 the AGM reaches |a - g| <= 1e-8 a at rung index 7 at
+// the latest (m = 1 - 2^-53 and the m == 1 clamp included; scanned in tests/tools, same count for both variants), so a
+// ladder kept for a known-valid modulus stores 8 rungs instead of the reference's array of 13.
+constexpr int LADDER_RUNGS_VALID = 8;
+
+// rungs of one lane in LDS with a caller-chosen lane stride (workgroup size): element k at base[k * STRIDE]
+template <int STRIDE>
+struct LadderLdsAt {
+    double* base;
+    S5_DEV void put(int i, double av, double gv) { base[(2 * i) * STRIDE] = av; base[(2 * i + 1) * STRIDE] = gv; }
+    S5_DEV double get_a(int i) const { return base[(2 * i) * STRIDE]; }
+    S5_DEV double get_g(int i) const { return base[(2 * i + 1) * STRIDE]; }
+};
 
 S5_DEV void sncndn(double u, double m, double& sn, double& cn, double& dn)
 {

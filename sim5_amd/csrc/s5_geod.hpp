@@ -366,6 +366,104 @@ S5_DEV bool init_src(double a, double r, double m, const double k[4], int ppc, G
     return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// r(P) and mu(P) of ONE geodesic evaluated many times (geodesic_follow walks, surface searches).
+// Everything in position_rad / position_pol that does not depend on P is a constant of the ray: the two
+// elliptic moduli (hence the AGM rungs of their Landen ladders), the root combinations, sqrt(m2p), the polar
+// phase bookkeeping.  GeodTrack forms them once -- with the very expressions of position_rad / position_pol
+// above, so each later value is the one those routines return, bit for bit -- and keeps the rungs of the two
+// ladders in LDS (LadderLdsAt<STRIDE>: 2 x LADDER_RUNGS_VALID x 16 B = 256 B per lane; the moduli of a valid
+// geodesic are in [0, 1)).  An evaluation is then one sincos and
+// the descent of the ladder instead of ~10 square roots of the climb plus the divisions of the constants.
+// ---------------------------------------------------------------------------------------
+template <int STRIDE>
+struct GeodTrack {
+    LadderLdsAt<STRIDE> lad_r, lad_m;
+    LadderState st_r, st_m;
+    // radial part
+    int type;
+    double Rpc, rp;
+    double fac;                  // RR: sqrt((r2-r4)(r1-r3));  RC: sqrt(A B)
+    double c0, c1, c2, c3;       // RR: r1 (r2-r4), r2 (r1-r4), r2-r4, r1-r4;  RC: r2 A - r1 B, r2 A + r1 B, A - B, A + B
+    // polar part
+    bool escapes_;
+    double sq_m2p, mK, Tpp, Tip, beta;
+
+    S5_DEV void build(const Geod& g, double* lds_lane)
+    {
+        lad_r.base = lds_lane;
+        lad_m.base = lds_lane + 2 * LADDER_RUNGS_VALID * STRIDE;
+        type = g.type; Rpc = g.Rpc; rp = g.rp;
+        st_r.degenerate = false; st_r.flipped = false; st_r.c = 0.0; st_r.d = 1.0; st_r.top = 0;
+        fac = c0 = c1 = c2 = c3 = 0.0;
+        if (g.type == T_RR) {
+            const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
+            const double m4 = mdiv((r2 - r3) * (r1 - r4), (r2 - r4) * (r1 - r3));
+            fac = msqrt((r2 - r4) * (r1 - r3));
+            c0 = r1 * (r2 - r4); c1 = r2 * (r1 - r4); c2 = r2 - r4; c3 = r1 - r4;
+            ladder_climb<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, m4, st_r);
+        } else if (g.type == T_RC) {
+            const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
+            const double A = msqrt(sq(r1 - u) + sq(v));
+            const double B = msqrt(sq(r2 - u) + sq(v));
+            const double m2 = mdiv(sq(A + B) - sq(r1 - r2), 4. * A * B);
+            fac = msqrt(A * B);
+            c0 = r2 * A - r1 * B; c1 = r2 * A + r1 * B; c2 = A - B; c3 = A + B;
+            ladder_climb<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, m2, st_r);
+        }
+        escapes_ = escapes(g);
+        sq_m2p = msqrt(g.m2p); mK = g.mK; Tpp = g.Tpp; Tip = g.Tip; beta = g.beta;
+        ladder_climb<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_m, g.mm, st_m);
+    }
+
+    S5_DEV double rad(double P) const                               // = position_rad(g, P)
+    {
+        if ((P <= 0.0) || (P >= 2. * Rpc)) return NAN;
+        if (P == Rpc) return rp;
+        double sn, cn, dn;
+        if (type == T_RR) {
+            const double x4 = 0.5 * fabs(P - Rpc) * fac;
+            ladder_descend<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, st_r, x4, sn, cn, dn);
+            const double sn2 = sn * sn;
+            return mdiv(c0 - c1 * sn2, c2 - c3 * sn2);
+        }
+        if (type == T_RC) {
+            if (P > Rpc) return NAN;
+            ladder_descend<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, st_r, fac * (Rpc - P), sn, cn, dn);
+            return mdiv(c0 - c1 * cn, c2 - c3 * cn);
+        }
+        return NAN;
+    }
+
+    S5_DEV double pol(double P) const                               // = position_pol(g, P)
+    {
+        if (!escapes_) return NAN;
+        double sdm = (beta >= 0.0) ? +1.0 : -1.0;
+        double T = (sdm > 0.0) ? -(Tpp - Tip) : -(Tip);
+        for (int it = 0; it < 4096 && (P > T + Tpp); ++it) { T += Tpp; sdm = -sdm; }
+        double sn, cn, dn;
+        ladder_descend<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_m, st_m, mdiv(P - T, mK), sn, cn, dn);
+        return -sdm * (sq_m2p * cn);
+    }
+
+    // one call of geodesic_follow on the tracked geodesic  (ref :891-925)
+    S5_DEV void follow(double a, double step, double& P, double& r, double& m, int& status) const
+    {
+        const double cap = 5e-2;
+        for (int it = 0; it < 100000; ++it) {
+            const double truestep = mdiv(step, fabs(step)) * fmin(fabs(step), cap * msqrt(r));
+            P = P + mdiv(truestep, sq(r) + sq(a * m));
+            r = rad(P);
+            m = pol(P);
+            if (r < 1.01 * r_horizon(a)) { status = 0; return; }
+            if ((P < 0.0) || (P > 2. * Rpc)) { status = 0; return; }
+            step -= truestep;
+            if (!(fabs(step) > 1e-5)) break;
+        }
+        status = 1;
+    }
+};
+
 // one call of geodesic_follow  (ref :891-925)
 S5_DEV void follow(const Geod& g, double step, double& P, double& r, double& m, int& status)
 {

@@ -145,6 +145,36 @@ def test_thick_disk_surface_search(golden, capi, strict):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+def test_surface_table_of_maximum_size_and_bad_tables(golden, capi, strict):
+    """The accepted maximum of 4096 table nodes (2 x 32 KB of LDS next to the ladders: more than the 64 KB a kernel
+    gets without asking) in both variants: the same piecewise-linear surface sampled on 4096 nodes that contain the
+    256 original ones gives the same intersection points.  Tables whose radii do not ascend are an argument error."""
+    g = golden("py_diskraytrace.npz")
+    tR, tH = g["surf_R"], g["surf_H"]
+    fine = np.unique(np.concatenate([tR, np.exp(np.linspace(np.log(tR[0]), np.log(tR[-1]), 4096 - len(tR) + 64))]))[:4096]
+    fine = np.unique(np.concatenate([tR, fine]))
+    fine = np.concatenate([tR, np.setdiff1d(fine, tR)[: 4096 - len(tR)]]); fine.sort()
+    assert fine.size == 4096 and np.isin(tR, fine).all()
+    fH = np.interp(fine, tR, tH)
+    a, inc = g["surf_cases"][1]
+    base = capi.disk_surface_rays(float(a), math.radians(float(inc)), tR, tH, g["surf_alpha"], g["surf_beta"], strict=strict)
+    big = capi.disk_surface_rays(float(a), math.radians(float(inc)), fine, fH, g["surf_alpha"], g["surf_beta"], strict=strict)
+    assert np.array_equal(base["status"], big["status"]) and (base["status"] == 1).sum() > 50
+    ok = base["status"] == 1
+    # same surface to rounding of the interpolation; the walk compares heights with thresholds, so a ray may stop one
+    # sub-step apart -- both ends lie within the search accuracy of the surface
+    assert np.max(np.abs(big["r"][ok] - base["r"][ok])) < 2e-2 and np.median(np.abs(big["r"][ok] - base["r"][ok])) < 1e-9
+    for bad in (np.concatenate([tR[:10], tR[9:]]), tR[::-1].copy()):          # a repeated node; descending radii
+        with pytest.raises(capi.Sim5GpuError):
+            capi.disk_surface_rays(float(a), math.radians(float(inc)), bad, np.interp(bad, tR, tH), g["surf_alpha"], g["surf_beta"],
+                                   strict=strict)
+    with pytest.raises(capi.Sim5GpuError):
+        capi.disk_surface_rays(float(a), math.radians(float(inc)), np.linspace(1, 50, 4097), np.zeros(4097), g["surf_alpha"],
+                               g["surf_beta"], strict=strict)
+
+
+@pytest.mark.gpu
 def test_thick_disk_image(golden, capi):
     """DiskRaytrace.image() for a disk with a tabulated photosphere (surface search kernel + surface tetrad,
     g-factor and emission angle through the batch calls) against the reference's own Python class run on the
