@@ -375,6 +375,42 @@ S5_DEV void ladder_descend(const Ladder& lad, const LadderState& st, double u, d
     msincos(u, s0, c0);
     sn = s0; cn = c0; dn = 1.0;
     if (s0 != 0.0) {
+#if S5_FAST
+        // The descent a <- c a;  c <- dn c;  dn <- (g_i + a)/(b_i + a);  a <- c/b_i  carried as fractions
+        //   a = A/al, c = C/ga, dn = N/D:   dn' = (g_i ga al + C A)/(b_i ga al + C A),  c' = N C/(D ga),  a'' = c'/b_i
+        // -- seven multiplications per rung and no division; cot(u c) enters as cos/sin without being divided, and
+        // sn = |ga| / sqrt(C^2 + ga^2), cn = C sign(ga) / sqrt(C^2 + ga^2) leave through ONE reciprocal square root.
+        // Only the ratios matter and C^2 + ga^2 is roughly cubed by a rung (it starts in [1/4, 1]), so every second rung
+        // the pair (C, ga) is rescaled by the exact power of two that brings ga's exponent back to zero.
+        double A = c0, al = s0, C = c * c0, ga = s0, N = 1.0, D = 1.0;
+#pragma unroll
+        for (int i = NR - 1; i >= 0; --i) {
+            if (wave_any(i <= top)) {          // rungs no lane of the wave reached are skipped
+                if (i <= top) {
+                    const double b = lad.get_a(i), g = lad.get_g(i);
+                    const double t1 = C * A, t2 = ga * al;
+                    const double Nn = g * t2 + t1, Dn = b * t2 + t1;
+                    C = N * C;
+                    ga = D * ga;
+                    if ((i & 1) == 0) {
+                        const int e = -__builtin_amdgcn_frexp_exp(fabs(C) + fabs(ga));
+                        C = __builtin_amdgcn_ldexp(C, e);
+                        ga = __builtin_amdgcn_ldexp(ga, e);
+                    }
+                    A = C;
+                    al = ga * b;
+                    N = Nn; D = Dn;
+                }
+            }
+        }
+        const double rs = rsqrt_pos(C * C + ga * ga);
+        a = fabs(ga) * rs;
+        sn = (s0 >= 0.0 ? a : -a);
+        cn = (ga >= 0.0 ? C : -C) * rs;
+        if (!(s0 >= 0.0)) cn = -cn;
+        dn = mdiv(N, D);
+        c = 0.0;
+#else
         a = mdiv(c0, s0);
         c *= a;
 #pragma unroll
@@ -384,24 +420,15 @@ S5_DEV void ladder_descend(const Ladder& lad, const LadderState& st, double u, d
                     const double b = lad.get_a(i);
                     a *= c;
                     c *= dn;
-#if S5_FAST
-                    const double t = mrcp((b + a) * b);      // one reciprocal for both quotients
-                    dn = (lad.get_g(i) + a) * b * t;
-                    a = c * (b + a) * t;
-#else
                     dn = mdiv(lad.get_g(i) + a, b + a);
                     a = mdiv(c, b);
-#endif
                 }
             }
         }
-#if S5_FAST
-        a = rsqrt_pos(c * c + 1.0);
-#else
         a = mdiv(1.0, msqrt(c * c + 1.0));
-#endif
         sn = (s0 >= 0.0 ? a : -a);
         cn = c * sn;
+#endif
     }
     if (st.flipped) {
         a = dn;
