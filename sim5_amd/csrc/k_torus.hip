@@ -117,22 +117,24 @@ S5_DEV void accumulate_transfer(const TorusParams& p, const RayState& s, const M
     else {
         const double R = x[1] * msqrt(1. - x[2] * x[2]), z = x[1] * x[2];
         const double d2 = sq(R - p.torus_r) + z * z;
-        rho = (d2 < p.cut_d2) ? exp(-d2 * p.inv_2w2) : 0.0;
+        rho = (d2 < p.cut_d2) ? mexp(-d2 * p.inv_2w2) : 0.0;
     }
     if (!(rho > 0.0)) return;
-    const double Om = omega_from_ell(p.torus_l, g);
-    const double nrm = -(g.g00 + 2. * Om * g.g03 + Om * Om * g.g33);
-    if (!(nrm > 0.0)) return;
-    const double ut = rsqrt_pos(nrm);
+    // Omega = A/B, u^t = |B| / sqrt(Q) with Q = -(g00 B^2 + 2 A B g03 + A^2 g33): the orbit is time-like iff Q > 0, and
+    // g = E / (u^t (k_t + Omega k_phi)) = E sign(B) sqrt(Q) / (k_t B + A k_phi) -- one square root and one division
+    const double A = -(g.g03 + p.torus_l * g.g00), B = g.g33 + p.torus_l * g.g03;
+    const double Q = -(g.g00 * (B * B) + 2. * (A * B) * g.g03 + (A * A) * g.g33);
+    if (!(Q > 0.0)) return;
     const double k_t = k[0] * g.g00 + k[3] * g.g03;
     const double k_f = k[3] * g.g33 + k[0] * g.g03;
-    const double gfac = mdiv(s.E, ut * (k_t + Om * k_f));
+    const double sQ = sqrt_pos(Q);
+    const double gfac = mdiv((B >= 0.0 ? s.E : -s.E) * sQ, k_t * B + A * k_f);
     if (p.absorb0 == 0.0) {
         I += (gfac * gfac * gfac) * (p.emis0 * rho) * dl_taken;
     } else {
         const double ds = mdiv(dl_taken, gfac);
         const double g2 = gfac * gfac;
-        I += (g2 * g2) * p.emis0 * rho * exp(-tau) * ds;
+        I += (g2 * g2) * p.emis0 * rho * mexp(-tau) * ds;
         tau += p.absorb0 * rho * ds;
     }
 #else

@@ -77,7 +77,16 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
     double xp[4], ki[4], di[4], sx[4], sk[4];
     const double h = 0.5 * dl;
     const double kt0 = s.kt;
+#if S5_FAST
+    // The reference integrates the polar ANGLE: acos at the start, cos of every stage angle and of the result
+    // (ref :269-298).  With m = cos(theta), sn = sin(theta) = sqrt(1 - m^2) (theta in [0, pi]) every cosine it needs is
+    // cos(theta + d) = m cos d - sn sin d for a small offset d: one bounded sincos per stage, no acos.
+    const double m0 = x[2];
+    const double sn0 = msqrt(1. - m0 * m0);
+    x[2] = 0.0;                                   // x[2] and xp[2] now hold the OFFSET from theta
+#else
     x[2] = macos(x[2]);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ki[i] = 0.0; di[i] = 0.0; sx[i] = 0.0; sk[i] = 0.0; }
 #pragma unroll 1
@@ -94,7 +103,9 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
 #pragma unroll
             for (int i = 0; i < 4; ++i) di[i] = s.dk[i];
         } else {
-            rt_connection(s, xp[1], mcos(xp[2]), G);
+            double sd, cd;
+            msincos(xp[2], sd, cd);
+            rt_connection(s, xp[1], m0 * cd - sn0 * sd, G);
             transport_self(G, ki, di);
         }
 #else
@@ -109,13 +120,18 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
         x[i] += S5_DIVC(dl, 6.) * sx[i];
         k[i] += S5_DIVC(dl, 6.) * sk[i];
     }
-    x[2] = mcos(x[2]);
     // g: the KERR metric at the new point, also in flat mode (ref :305); returned for the caller's transfer step
 #if S5_FAST
+    {
+        double sd, cd;
+        msincos(x[2], sd, cd);
+        x[2] = m0 * cd - sn0 * sd;
+    }
     if (s.opt_gr) kerr_metric_connection(s.bh_spin, x[1], x[2], g, G);
     else { flat_connection(x[1], x[2], G); kerr_metric(s.bh_spin, x[1], x[2], g); }
     transport_self(G, k, s.dk);
 #else
+    x[2] = mcos(x[2]);
     rt_connection(s, x[1], x[2], G);
     transport_self(G, k, s.dk);
     kerr_metric(s.bh_spin, x[1], x[2], g);
