@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <string.h>
 #include "../../include/sim5gpu.h"
 #include "kernels.hpp"
 #include "s5_config.hpp"
@@ -64,7 +65,31 @@ struct Arena {
     // a buffer of the call that did not come from the block (fallback allocation) has been released
     void call_done() { if (demand > want) want = demand; }
     void give() { if (--live == 0) { used = 0; call_done(); } }
-    ~Arena() { release(); }                                    // thread exit: the block goes back
+
+    // Small batches (the n = 1 calls of the SIM5 scalar API, sim5_amd/host/sim5lib.c) are staged in page-locked host
+    // memory that the GPU reads and writes in place over the bus: a call is then one launch and one synchronisation
+    // instead of a blocking hipMemcpy per argument (measured through tests/c/shim_probe.c: 373 -> see INTEGRATION.md
+    // us per ray).  Any device of the process can address the block, so it is not tied to the current device.
+    char* pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0;
+    int pin_live = 0;
+    static constexpr size_t PIN_BLOCK = 256 << 10, PIN_LIMIT = 16 << 10;
+    void* take_pinned(size_t bytes)
+    {
+        if (bytes > PIN_LIMIT) return nullptr;
+        bytes = (bytes + 63) & ~size_t(63);
+        if (!pin) {
+            if (pin_cap == (size_t)-1) return nullptr;                       // tried before, not available
+            if (hipHostMalloc((void**)&pin, PIN_BLOCK, hipHostMallocDefault) != hipSuccess) { pin = nullptr; pin_cap = (size_t)-1; return nullptr; }
+            pin_cap = PIN_BLOCK;
+        }
+        if (pin_used + bytes > pin_cap) return nullptr;
+        void* p = pin + pin_used;
+        pin_used += bytes; ++pin_live;
+        return p;
+    }
+    void give_pinned() { if (--pin_live == 0) pin_used = 0; }
+    ~Arena() { release(); if (pin) (void)hipHostFree(pin); }   // thread exit: the blocks go back
 };
 Arena& arena();
 
@@ -75,9 +100,12 @@ struct DevBuf {
     size_t n = 0;
     bool failed = false;
     bool from_arena = false;
+    bool pinned = false;            // ptr is page-locked host memory the kernel accesses in place
     void alloc()
     {
         if (!n) return;
+        ptr = (T*)arena().take_pinned(n * sizeof(T));
+        if (ptr) { pinned = true; return; }
         ptr = (T*)arena().take(n * sizeof(T));
         if (ptr) { from_arena = true; return; }
         if (hipMalloc((void**)&ptr, n * sizeof(T)) != hipSuccess) { ptr = nullptr; failed = true; }
@@ -86,12 +114,14 @@ struct DevBuf {
     DevBuf(const T* host, size_t count) : n(host ? count : 0)
     {
         alloc();
-        if (ptr && hipMemcpy(ptr, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) failed = true;
+        if (ptr && pinned) memcpy(ptr, host, n * sizeof(T));
+        else if (ptr && hipMemcpy(ptr, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) failed = true;
     }
     ~DevBuf()
     {
         if (!ptr) return;
-        if (from_arena) arena().give(); else { (void)hipFree(ptr); arena().call_done(); }
+        if (pinned) arena().give_pinned();
+        else if (from_arena) arena().give(); else { (void)hipFree(ptr); arena().call_done(); }
     }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -99,6 +129,7 @@ struct DevBuf {
     hipError_t to_host(T* host) const
     {
         if (!n || !host || !ptr) return hipSuccess;
+        if (pinned) { memcpy(host, ptr, n * sizeof(T)); return hipSuccess; }      // the kernel has been waited for (run_map)
         return hipMemcpy(host, ptr, n * sizeof(T), hipMemcpyDeviceToHost);
     }
 };
