@@ -57,6 +57,28 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     json.dump({"hbm_bytes_per_launch": 2 * fetch + write, "source": "profiles/%s_pmc.json" % tag,
                "note": "2*FETCH_SIZE + WRITE_SIZE, KiB->B, per launch of " + KERNEL},
               open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+# the default bench command (headline + the other configurations): per-kernel statistics as rocprofv3 prints them, and the
+# headline launches picked out of its kernel trace by their grid (256 x 256 workgroups of 256 threads: X = 65536, Y = 256)
+dstats = glob.glob(os.path.join(src, "stats_default_cmd", "*", "*kernel_stats.csv"))
+if dstats:
+    rows = list(csv.reader(open(dstats[0])))
+    with open(os.path.join(root, "profiles", tag + "_kernel_stats_default_cmd.csv"), "w") as f:
+        w = csv.writer(f)
+        for r in rows[:16]:
+            w.writerow([c[:160] for c in r])
+dtrace = glob.glob(os.path.join(src, "stats_default_cmd", "*", "*kernel_trace.csv"))
+if dtrace:
+    hd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(dtrace[0]))
+          if KERNEL in r["Kernel_Name"] and r.get("Grid_Size_X") == "65536" and r.get("Grid_Size_Y") == "256"]
+    out["default_cmd_headline_launches"] = {"launches": len(hd), "kernel_ns_avg": sum(hd) / len(hd) if hd else None}
+dl = os.path.join(src, "stats_default_cmd.log")
+if os.path.exists(dl):
+    for line in open(dl):
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                out["bench_default_cmd_under_rocprof"] = json.loads(line)
+            except Exception:
+                pass
 bj = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(bj):
     try:
