@@ -11,8 +11,10 @@
 //  * loops leave as soon as no lane of the wave needs another pass (wave vote), lanes that are
 //    done keep their value under predication -- rays of one wave are neighbours on the image
 //    plane, so their trip counts differ by at most one or two;
-//  * the Landen ladder of sncndn lives in registers (fully unrolled, level index compile-time),
-//    never in scratch or LDS.
+//  * the Landen ladder of sncndn is fully unrolled (rung index compile-time) and its rungs are kept by a storage
+//    policy: registers for the generic per-ray routines (LadderRegs), LDS for the whole-image and surface kernels
+//    (LadderLds / LadderLdsAt); never scratch.  The routine comes in two halves, climb (modulus only) and descent
+//    (argument), so a caller with a fixed modulus climbs once (GeodTrack, s5_geod.hpp).
 #pragma once
 #include "s5_trig.hpp"
 
