@@ -4,6 +4,8 @@
 #include "capi_util.hpp"
 #include <math.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 namespace s5 {
 
@@ -77,8 +79,120 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot, double alpha)
     d.scale = 9.1721376255e+28 * d.mdot / d.mass;
     d.alpha = f_alpha;
     d.a2f = (double)(f_spin * f_spin);
+    d.ftab = nullptr; d.ft_wmin = 0.0; d.ft_inv_dw = 0.0;
     d.ready = 1;
     return d;
+}
+
+// ---- radial profile table of the Novikov-Thorne flux (fast variant) ---------------------------------------
+// F(r) is a closed form with four logarithms (ref src/sim5disk-nt.c:110-146) and, per pixel, the second most expensive
+// block of the image kernel after r(P).  Up to the scale mdot/M it is a function of the radius and of the spin only, so
+// the host tabulates  T(w) = F / (scale (x - x0)),  x = sqrt(r), w = x0 / x  -- smooth and bounded on (0, 1]: F vanishes
+// linearly at x0 = sqrt of the reference's float-rounded inner edge, which is 1e-3 outside the true ISCO -- as FT_N
+// polynomials of degree FT_DEG in the local coordinate of FT_N equal intervals of w in [x0 / 16, 1]: Chebyshev
+// interpolation of the reference's formula evaluated in long double, 1e-10 of T at a = 0.998, 3e-13 at a <= 0.9
+// (checked in tests/test_gpu_images.py against the closed form on the device).  The kernels keep the closed form where
+// the table must not be used: within 2e-4 of x0, where the reference's own double evaluation is a rounding-noise
+// pattern that parity has to reproduce, and beyond x = 16.  8 KB per spin, kept per device for the last few spins.
+namespace {
+struct FluxTable { int dev; double a; double* ptr; };
+FluxTable g_ftab[16];
+int g_ftab_n = 0, g_ftab_next = 0;
+std::mutex g_ftab_lock;
+
+// returns the largest relative error of the fit, probed at four points inside every interval
+double build_flux_table(const DiskConsts& d, double wmin, std::vector<double>& tab)
+{
+    typedef long double ld;
+    const ld a = d.a, x0 = d.x0, x1 = d.x1, x2 = d.x2, x3 = d.x3;
+    const ld p1 = 3.L * (x1 - a) * (x1 - a) / (x1 * (x1 - x2) * (x1 - x3));
+    const ld p2 = 3.L * (x2 - a) * (x2 - a) / (x2 * (x2 - x1) * (x2 - x3));
+    const ld p3 = 3.L * (x3 - a) * (x3 - a) / (x3 * (x3 - x1) * (x3 - x2));
+    const ld pi = 3.14159265358979323846264338327950288L;
+    auto T = [&](ld w) -> ld {
+        const ld x = x0 / w;
+        const ld f0 = x - x0 - 1.5L * a * logl(x / x0);
+        const ld f1 = p1 * logl((x - x1) / (x0 - x1));
+        const ld f2 = p2 * logl((x - x2) / (x0 - x2));
+        const ld f3 = p3 * logl((x - x3) / (x0 - x3));
+        const ld F = 1.L / (4.L * pi * x * x) * 1.5L / (x * x * (x * x * x - 3.L * x + 2.L * a)) * (f0 - f1 - f2 - f3);
+        return F / (x - x0);
+    };
+    constexpr int K = s5abi::FT_DEG + 1;
+    double worst = 0.0;
+    tab.assign((size_t)s5abi::FT_N * K, 0.0);
+    const ld dw = (1.L - (ld)wmin) / s5abi::FT_N;
+    for (int i = 0; i < s5abi::FT_N; i++) {
+        const ld lo = (ld)wmin + dw * i, mid = lo + 0.5L * dw, half = 0.5L * dw;
+        ld y[K], c[K];
+        for (int k = 0; k < K; k++) y[k] = T(mid + half * cosl(pi * (k + 0.5L) / K));     // Chebyshev nodes (interior)
+        for (int j = 0; j < K; j++) {                                                      // Chebyshev coefficients
+            ld sacc = 0.L;
+            for (int k = 0; k < K; k++) sacc += y[k] * cosl(pi * j * (k + 0.5L) / K);
+            c[j] = sacc * (j == 0 ? 1.L : 2.L) / K;
+        }
+        // to monomials in tau: T_0 = 1, T_1 = tau, T_{n+1} = 2 tau T_n - T_{n-1}
+        ld m[K] = { 0 }, tm1[K] = { 0 }, tm0[K] = { 0 }, tn[K];
+        tm1[0] = 1.L; tm0[1] = 1.L;
+        for (int q = 0; q < K; q++) m[q] += c[0] * tm1[q];
+        if (K > 1) for (int q = 0; q < K; q++) m[q] += c[1] * tm0[q];
+        for (int n = 2; n < K; n++) {
+            for (int q = 0; q < K; q++) tn[q] = (q > 0 ? 2.L * tm0[q - 1] : 0.L) - tm1[q];
+            for (int q = 0; q < K; q++) { m[q] += c[n] * tn[q]; tm1[q] = tm0[q]; tm0[q] = tn[q]; }
+        }
+        for (int q = 0; q < K; q++) tab[(size_t)i * K + q] = (double)m[q];
+        for (int j = 0; j < 4; j++) {
+            const ld tau = -0.9L + 0.6L * j;
+            ld w = mid + half * tau;
+            if (w >= 1.L) continue;
+            double acc = tab[(size_t)i * K + K - 1];
+            for (int q = K - 2; q >= 0; q--) acc = acc * (double)tau + tab[(size_t)i * K + q];
+            const ld ref = T(w);
+            const double err = (double)fabsl(((ld)acc - ref) / ref);
+            if (!(err <= worst)) worst = err;
+        }
+    }
+    return worst;
+}
+} // namespace
+
+int attach_flux_table(DiskConsts& d)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SIM5GPU_E_HIP;
+    std::lock_guard<std::mutex> hold(g_ftab_lock);
+    const double wmin = d.x0 / 16.0;
+    d.ft_wmin = wmin;
+    d.ft_inv_dw = (double)s5abi::FT_N / (1.0 - wmin);
+    for (int i = 0; i < g_ftab_n; i++)
+        if (g_ftab[i].dev == dev && g_ftab[i].a == d.a) { d.ftab = g_ftab[i].ptr; return SIM5GPU_OK; }
+    std::vector<double> tab;
+    const double fit_error = build_flux_table(d, wmin, tab);
+    double* ptr = nullptr;
+    // towards a = 1 the inner edge approaches the logarithmic singularity at x1 and the uniform grid stops resolving
+    // the profile (1e-10 at a = 0.998, 1e-8 at 0.9995): such spins keep the closed form (remembered as a NULL table)
+    const bool usable = (fit_error <= 2e-9);
+    hipError_t e = hipSuccess;
+    if (usable) {
+        e = hipMalloc((void**)&ptr, tab.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(ptr, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { if (ptr) (void)hipFree(ptr); set_error("flux table", e); return SIM5GPU_E_HIP; }
+    int slot = -1;
+    if (g_ftab_n < 16) slot = g_ftab_n++;
+    else {
+        // a table of THIS device goes (round robin); a kernel still reading it was queued before this call: wait for the device
+        for (int k = 0; k < 16 && slot < 0; k++) {
+            const int c = (g_ftab_next + k) % 16;
+            if (g_ftab[c].dev == dev) { slot = c; g_ftab_next = (c + 1) % 16; }
+        }
+        if (slot < 0) { if (ptr) (void)hipFree(ptr); d.ftab = nullptr; return SIM5GPU_OK; }     // cache full of other devices' tables: closed form
+        (void)hipDeviceSynchronize();
+        if (g_ftab[slot].ptr) (void)hipFree(g_ftab[slot].ptr);
+    }
+    g_ftab[slot].dev = dev; g_ftab[slot].a = d.a; g_ftab[slot].ptr = ptr;
+    d.ftab = ptr;
+    return SIM5GPU_OK;
 }
 
 // validate a job description and turn it into the kernel argument block
@@ -310,6 +424,7 @@ int sim5gpu_disk_image(const sim5gpu_image_desc* desc, float* d_image_f, float* 
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
     p.img_f = d_image_f; p.img_g = d_image_g;
     attach_aux(p, d_aux);
     hipError_t e = (hipError_t)((desc->flags & SIM5GPU_IMG_STRICT) ? s5_launch_disk_image_strict(p, (hipStream_t)stream)
@@ -335,6 +450,7 @@ int sim5gpu_disk_rays(const sim5gpu_image_desc* desc, size_t n, const double* d_
     if (rc) return rc;
     if (n == 0) return SIM5GPU_OK;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
     p.img_f = d_image_f; p.img_g = d_image_g;
     p.alpha = d_alpha; p.beta = d_beta; p.n = n;
     attach_aux(p, d_aux);

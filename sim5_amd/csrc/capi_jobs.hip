@@ -17,6 +17,7 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
     p.stokes = d_stokes;
     p.chi = d_chi;
     if (d_aux) { p.cls = d_aux->cls; p.gtype = d_aux->gtype; p.r = d_aux->r; p.g = d_aux->g; p.flux = d_aux->flux; }
@@ -96,6 +97,7 @@ int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdo
     SurfaceParams p;
     p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
     p.disk = make_disk_consts(bh_mass, disk_spin >= 0.0 ? disk_spin : a, mdot);
+    if (!strict) { int rc = attach_flux_table(p.disk); if (rc) return rc; }
     p.tab_vr = d_vr; p.out_g = d_g; p.out_mue = d_mue; p.out_flux = d_flux;
     hipError_t e = (hipError_t)(strict
         ? s5_launch_disk_surface_strict(p, d_R, d_H, d_alpha, d_beta, d_P, d_r, d_m, d_k, d_status, (hipStream_t)stream)
@@ -130,6 +132,7 @@ int sim5gpu_disk_spectrum(const sim5gpu_image_desc* desc, int n_energies, const 
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
     p.max_order = 1;                  // the Python ray tracer uses the first crossing only
     p.rms = 0.0;                      // and lets the disk model decide (zero flux inside its inner edge)
     SpectrumParams sp;

@@ -11,6 +11,8 @@ namespace s5abi {
 enum : int { PX_ERROR = 0, PX_NAN0 = 1, PX_HIT0 = 2, PX_NAN1 = 3, PX_HIT1 = 4, PX_MISS = 5 };
 
 // Novikov-Thorne disk folded to constants on the host (see s5_disk.hpp); wave-uniform (SGPRs)
+constexpr int FT_N = 128, FT_DEG = 7;
+
 struct DiskConsts {
     double a;            // (double)(float)spin                                  ref :27-28,51
     double rms;          // (double)(float)(r_ms_pow(a) + 1e-3): inner edge     ref :58,91-105
@@ -23,6 +25,11 @@ struct DiskConsts {
     double inv_x0, inv_d1, inv_d2, inv_d3, scale;
     double alpha;        // (double)(float) viscosity parameter (disk_nt_sigma only)  ref :31,59
     double a2f;          // (double)((float)spin * (float)spin): sqr() of the float static in disk_nt_lumi  ref :172-173
+    // Radial profile table of the fast variant (DEVICE memory, made once per spin by the host, s5_disk.hpp): F(r) /
+    // (scale (x - x0)) as piecewise polynomials of degree FT_DEG on FT_N equal intervals of w = x0 / x, x = sqrt(r),
+    // covering x0 <= x <= 16; NULL = evaluate the closed form
+    const double* ftab;
+    double ft_wmin, ft_inv_dw;
     int    ready;
 };
 

@@ -13,12 +13,13 @@
 namespace S5NS {
 
 using s5abi::DiskConsts;
+using s5abi::FT_N;
+using s5abi::FT_DEG;
 
-S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :110-146
+// the closed form, ref :110-146
+S5_DEV double disk_flux_closed_form(const DiskConsts& d, double r, double x)
 {
-    if (r <= d.rms) return 0.0;
     const double a = d.a;
-    const double x = sqrt_pos(r);                     // r > rms > 0
 #if S5_FAST
     // same expression with the constant divisors replaced by their host-computed reciprocals and the two
     // prefactor divisions merged into one
@@ -35,6 +36,41 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
     const double f3 = d.p3 * mlog(mdiv(x - d.x3, d.d3));
     const double F = mdiv(mdiv(1., 4. * M_PI * r) * 1.5, x * x * (x * x * x - 3. * x + 2. * a)) * (f0 - f1 - f2 - f3);
     return mdiv(9.1721376255e+28 * F * d.mdot, d.mass);
+#endif
+}
+
+S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :110-146
+{
+    if (r <= d.rms) return 0.0;
+#if S5_FAST
+    // The radial profile from the host's table (kernels.hpp, capi_core.hip: F / (scale (x - x0)) as polynomials of
+    // degree FT_DEG on FT_N equal intervals of w = x0 / x): one reciprocal square root, eight loads of one 64-byte
+    // row, seven FMAs -- instead of four logarithms and a division.  Lanes the table must not serve -- within 2e-4
+    // of the inner edge in x, where the reference's own double evaluation is rounding noise that parity reproduces,
+    // and beyond x = 16 -- take the closed form, their wave with them.
+    double x, rx;
+    sqrt_rsqrt_pos(r, x, rx);                         // r > rms > 0
+    const double t = x - d.x0;
+    const double w = d.x0 * rx;
+    const bool tab = (d.ftab != nullptr) && (t > 2e-4) && (w > d.ft_wmin);
+    double F = 0.0;
+    if (tab) {
+        const double u = (w - d.ft_wmin) * d.ft_inv_dw;
+        int i = (int)u;
+        i = i < FT_N - 1 ? i : FT_N - 1;
+        const double tau = 2.0 * (u - (double)i) - 1.0;
+        const double* c = d.ftab + (size_t)i * (FT_DEG + 1);
+        double acc = c[FT_DEG];
+#pragma unroll
+        for (int k = FT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
+        F = d.scale * (t * acc);
+    }
+    if (wave_any(!tab)) {
+        if (!tab) F = disk_flux_closed_form(d, r, x);
+    }
+    return F;
+#else
+    return disk_flux_closed_form(d, r, sqrt_pos(r));
 #endif
 }
 
