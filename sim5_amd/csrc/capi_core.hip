@@ -100,32 +100,23 @@ FluxTable g_ftab[16];
 int g_ftab_n = 0, g_ftab_next = 0;
 std::mutex g_ftab_lock;
 
-// returns the largest relative error of the fit, probed at four points inside every interval
-double build_flux_table(const DiskConsts& d, double wmin, std::vector<double>& tab)
+// f on [lo, hi] as N polynomials of degree DEG in the local coordinate tau in [-1, 1] of N equal intervals: Chebyshev
+// interpolation (DEG + 1 interior nodes per interval, long double), converted to monomials for a Horner evaluation on
+// the device; tab[i * (DEG + 1) + q] = coefficient of tau^q in interval i.  Returns the largest relative error of the
+// double-precision Horner evaluation, probed at four points inside every interval.
+template <int N, int DEG, class Fn>
+double fit_piecewise(Fn f, long double lo_all, long double hi_all, std::vector<double>& tab)
 {
     typedef long double ld;
-    const ld a = d.a, x0 = d.x0, x1 = d.x1, x2 = d.x2, x3 = d.x3;
-    const ld p1 = 3.L * (x1 - a) * (x1 - a) / (x1 * (x1 - x2) * (x1 - x3));
-    const ld p2 = 3.L * (x2 - a) * (x2 - a) / (x2 * (x2 - x1) * (x2 - x3));
-    const ld p3 = 3.L * (x3 - a) * (x3 - a) / (x3 * (x3 - x1) * (x3 - x2));
     const ld pi = 3.14159265358979323846264338327950288L;
-    auto T = [&](ld w) -> ld {
-        const ld x = x0 / w;
-        const ld f0 = x - x0 - 1.5L * a * logl(x / x0);
-        const ld f1 = p1 * logl((x - x1) / (x0 - x1));
-        const ld f2 = p2 * logl((x - x2) / (x0 - x2));
-        const ld f3 = p3 * logl((x - x3) / (x0 - x3));
-        const ld F = 1.L / (4.L * pi * x * x) * 1.5L / (x * x * (x * x * x - 3.L * x + 2.L * a)) * (f0 - f1 - f2 - f3);
-        return F / (x - x0);
-    };
-    constexpr int K = s5abi::FT_DEG + 1;
+    constexpr int K = DEG + 1;
     double worst = 0.0;
-    tab.assign((size_t)s5abi::FT_N * K, 0.0);
-    const ld dw = (1.L - (ld)wmin) / s5abi::FT_N;
-    for (int i = 0; i < s5abi::FT_N; i++) {
-        const ld lo = (ld)wmin + dw * i, mid = lo + 0.5L * dw, half = 0.5L * dw;
+    tab.assign((size_t)N * K, 0.0);
+    const ld dw = (hi_all - lo_all) / N;
+    for (int i = 0; i < N; i++) {
+        const ld lo = lo_all + dw * i, mid = lo + 0.5L * dw, half = 0.5L * dw;
         ld y[K], c[K];
-        for (int k = 0; k < K; k++) y[k] = T(mid + half * cosl(pi * (k + 0.5L) / K));     // Chebyshev nodes (interior)
+        for (int k = 0; k < K; k++) y[k] = f(mid + half * cosl(pi * (k + 0.5L) / K));     // Chebyshev nodes (interior)
         for (int j = 0; j < K; j++) {                                                      // Chebyshev coefficients
             ld sacc = 0.L;
             for (int k = 0; k < K; k++) sacc += y[k] * cosl(pi * j * (k + 0.5L) / K);
@@ -143,18 +134,76 @@ double build_flux_table(const DiskConsts& d, double wmin, std::vector<double>& t
         for (int q = 0; q < K; q++) tab[(size_t)i * K + q] = (double)m[q];
         for (int j = 0; j < 4; j++) {
             const ld tau = -0.9L + 0.6L * j;
-            ld w = mid + half * tau;
-            if (w >= 1.L) continue;
+            const ld w = mid + half * tau;
+            if (w >= hi_all) continue;
             double acc = tab[(size_t)i * K + K - 1];
             for (int q = K - 2; q >= 0; q--) acc = acc * (double)tau + tab[(size_t)i * K + q];
-            const ld ref = T(w);
+            const ld ref = f(w);
             const double err = (double)fabsl(((ld)acc - ref) / ref);
             if (!(err <= worst)) worst = err;
         }
     }
     return worst;
 }
+
+// returns the largest relative error of the fit
+double build_flux_table(const DiskConsts& d, double wmin, std::vector<double>& tab)
+{
+    typedef long double ld;
+    const ld a = d.a, x0 = d.x0, x1 = d.x1, x2 = d.x2, x3 = d.x3;
+    const ld p1 = 3.L * (x1 - a) * (x1 - a) / (x1 * (x1 - x2) * (x1 - x3));
+    const ld p2 = 3.L * (x2 - a) * (x2 - a) / (x2 * (x2 - x1) * (x2 - x3));
+    const ld p3 = 3.L * (x3 - a) * (x3 - a) / (x3 * (x3 - x1) * (x3 - x2));
+    const ld pi = 3.14159265358979323846264338327950288L;
+    auto T = [&](ld w) -> ld {
+        const ld x = x0 / w;
+        const ld f0 = x - x0 - 1.5L * a * logl(x / x0);
+        const ld f1 = p1 * logl((x - x1) / (x0 - x1));
+        const ld f2 = p2 * logl((x - x2) / (x0 - x2));
+        const ld f3 = p3 * logl((x - x3) / (x0 - x3));
+        const ld F = 1.L / (4.L * pi * x * x) * 1.5L / (x * x * (x * x * x - 3.L * x + 2.L * a)) * (f0 - f1 - f2 - f3);
+        return F / (x - x0);
+    };
+    return fit_piecewise<s5abi::FT_N, s5abi::FT_DEG>(T, (long double)wmin, 1.L, tab);
+}
+
+// K(m), complete elliptic integral of the first kind, as KT_N polynomials of degree KT_DEG on [0, KT_MMAX]
+// (the image kernels' fast variant; the AGM evaluation stays for larger moduli).  Universal: one table per device.
+double build_K_table(std::vector<double>& tab)
+{
+    typedef long double ld;
+    const ld pi = 3.14159265358979323846264338327950288L;
+    auto K = [&](ld m) -> ld {
+        ld a = 1.L, b = sqrtl(1.L - m);
+        for (int it = 0; it < 40 && fabsl(a - b) > 1e-19L * a; it++) { const ld an = 0.5L * (a + b); b = sqrtl(a * b); a = an; }
+        return pi / (a + b);
+    };
+    return fit_piecewise<s5abi::KT_N, s5abi::KT_DEG>(K, 0.L, (ld)s5abi::KT_MMAX, tab);
+}
 } // namespace
+
+// universal K(m) table, one per device (never freed: 8 KB)
+static const double* g_ktab[64];
+
+int attach_K_table(ImageParams& p)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SIM5GPU_E_HIP;
+    if (dev < 0 || dev >= 64) return SIM5GPU_OK;                       // no table: the kernels use the AGM
+    std::lock_guard<std::mutex> hold(g_ftab_lock);
+    if (!g_ktab[dev]) {
+        std::vector<double> tab;
+        const double fit_error = build_K_table(tab);
+        if (!(fit_error <= 1e-15)) return SIM5GPU_OK;
+        double* ptr = nullptr;
+        hipError_t e = hipMalloc((void**)&ptr, tab.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(ptr, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (ptr) (void)hipFree(ptr); set_error("K table", e); return SIM5GPU_E_HIP; }
+        g_ktab[dev] = ptr;
+    }
+    p.ktab = g_ktab[dev];
+    return SIM5GPU_OK;
+}
 
 int attach_flux_table(DiskConsts& d)
 {
@@ -424,7 +473,7 @@ int sim5gpu_disk_image(const sim5gpu_image_desc* desc, float* d_image_f, float* 
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
-    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.img_f = d_image_f; p.img_g = d_image_g;
     attach_aux(p, d_aux);
     hipError_t e = (hipError_t)((desc->flags & SIM5GPU_IMG_STRICT) ? s5_launch_disk_image_strict(p, (hipStream_t)stream)
@@ -450,7 +499,7 @@ int sim5gpu_disk_rays(const sim5gpu_image_desc* desc, size_t n, const double* d_
     if (rc) return rc;
     if (n == 0) return SIM5GPU_OK;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
-    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.img_f = d_image_f; p.img_g = d_image_g;
     p.alpha = d_alpha; p.beta = d_beta; p.n = n;
     attach_aux(p, d_aux);

@@ -17,7 +17,7 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
-    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.stokes = d_stokes;
     p.chi = d_chi;
     if (d_aux) { p.cls = d_aux->cls; p.gtype = d_aux->gtype; p.r = d_aux->r; p.g = d_aux->g; p.flux = d_aux->flux; }
@@ -132,7 +132,7 @@ int sim5gpu_disk_spectrum(const sim5gpu_image_desc* desc, int n_energies, const 
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
-    if (!(desc->flags & SIM5GPU_IMG_STRICT) && (rc = attach_flux_table(p.disk)) != 0) return rc;
+    if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.max_order = 1;                  // the Python ray tracer uses the first crossing only
     p.rms = 0.0;                      // and lets the disk model decide (zero flux inside its inner edge)
     SpectrumParams sp;

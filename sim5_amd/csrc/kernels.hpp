@@ -12,6 +12,8 @@ enum : int { PX_ERROR = 0, PX_NAN0 = 1, PX_HIT0 = 2, PX_NAN1 = 3, PX_HIT1 = 4, P
 
 // Novikov-Thorne disk folded to constants on the host (see s5_disk.hpp); wave-uniform (SGPRs)
 constexpr int FT_N = 128, FT_DEG = 7;
+constexpr int KT_N = 128, KT_DEG = 7;          // K(m) table: [0, KT_MMAX] in KT_N intervals, degree KT_DEG
+constexpr double KT_MMAX = 0.9;
 
 struct DiskConsts {
     double a;            // (double)(float)spin                                  ref :27-28,51
@@ -44,6 +46,7 @@ struct ImageParams {
     double inv_nx, inv_ny, ny_over_nx; // 1/nx, 1/ny, ny/nx (host doubles; used by the fast variant)
     double inv_2a2;                    // 1 / (2 max(a, 1e-4)^2)              (fast variant)
     double pol_degree;
+    const double* ktab;                // K(m) table of the fast variant (DEVICE memory, capi_core.hip) or NULL
     DiskConsts disk;
     // outputs (tile-local, row-major)
     float*   img_f;

@@ -39,17 +39,33 @@ S5_DEV double disk_flux_closed_form(const DiskConsts& d, double r, double x)
 #endif
 }
 
+#if S5_FAST
+S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx);
+#endif
+
 S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :110-146
 {
     if (r <= d.rms) return 0.0;
 #if S5_FAST
+    double x, rx;
+    sqrt_rsqrt_pos(r, x, rx);                         // r > rms > 0
+    return disk_flux_x(d, r, x, rx);
+#else
+    return disk_flux_closed_form(d, r, sqrt_pos(r));
+#endif
+}
+
+#if S5_FAST
+// the same with x = sqrt(r) and 1/x supplied by the caller (the g-factor of the same point needs sqrt(r) too)
+S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
+{
+    if (r <= d.rms) return 0.0;
+    {
     // The radial profile from the host's table (kernels.hpp, capi_core.hip: F / (scale (x - x0)) as polynomials of
     // degree FT_DEG on FT_N equal intervals of w = x0 / x): one reciprocal square root, eight loads of one 64-byte
     // row, seven FMAs -- instead of four logarithms and a division.  Lanes the table must not serve -- within 2e-4
     // of the inner edge in x, where the reference's own double evaluation is rounding noise that parity reproduces,
     // and beyond x = 16 -- take the closed form, their wave with them.
-    double x, rx;
-    sqrt_rsqrt_pos(r, x, rx);                         // r > rms > 0
     const double t = x - d.x0;
     const double w = d.x0 * rx;
     const bool tab = (d.ftab != nullptr) && (t > 2e-4) && (w > d.ft_wmin);
@@ -69,10 +85,9 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
         if (!tab) F = disk_flux_closed_form(d, r, x);
     }
     return F;
-#else
-    return disk_flux_closed_form(d, r, sqrt_pos(r));
-#endif
+    }
 }
+#endif
 
 S5_DEV double disk_ell(const DiskConsts& d, double r)                  // ref :260-266
 {

@@ -404,6 +404,18 @@ S5_DEV double omega_from_ell(double ell, const Metric& g)                       
     return mdiv(-(g.g03 + ell * g.g00), g.g33 + ell * g.g03);
 }
 
+#if S5_FAST
+// with x = sqrt(r) supplied by the caller
+S5_DEV double gfactor_kepler_x(double r, double x, double a, double l)
+{
+    const double den = a + r * x;
+    const double t = mrcp(den * r);
+    const double Om = r * t;
+    const double w = 1. - a * Om;
+    return mdiv(msqrt(1. - (2. * den * t) * (w * w) - (r * r + a * a) * (Om * Om)), 1. - Om * l);
+}
+#endif
+
 S5_DEV double gfactor_kepler(double r, double a, double l)                                // ref :1128-1141
 {
 #if S5_FAST

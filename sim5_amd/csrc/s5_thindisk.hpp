@@ -297,7 +297,25 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
     double Rint = res0;
     if (type == T_RC && need3) Rint = mdiv(2., msqrt(1. - mR)) * res3 + res0;
 #if S5_F_AGMK
-    res1 = ell_K(mmT);
+    {
+        // K(mm): from the table (kernels.hpp KT_*: 128 polynomials of degree 7 on [0, 0.9], 2e-16) where it reaches,
+        // by the arithmetic-geometric mean elsewhere (the lanes' wave with them)
+        const bool tab = (p.ktab != nullptr) && (mmT >= 0.0) && (mmT < KT_MMAX);
+        if (tab) {
+            const double u = mmT * ((double)KT_N / KT_MMAX);
+            int i = (int)u;
+            i = i < KT_N - 1 ? i : KT_N - 1;
+            const double tau = 2.0 * (u - (double)i) - 1.0;
+            const double* c = p.ktab + (size_t)i * (KT_DEG + 1);
+            double acc = c[KT_DEG];
+#pragma unroll
+            for (int k = KT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
+            res1 = acc;
+        }
+        if (wave_any(!tab)) {
+            if (!tab) res1 = ell_K(mmT);
+        }
+    }
 #endif
     double K = res1;
     double icn_i = res2;
@@ -380,6 +398,15 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
             }
         }
     }
+#if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX)
+    if (out.cls == PX_HIT0 || out.cls == PX_HIT1) {
+        double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
+        sqrt_rsqrt_pos(out.r, x, rx);                 // r >= rms > 0
+        out.g = gfactor_kepler_x(out.r, x, a_in, l);
+        out.flux = disk_flux_x(p.disk, out.r, x, rx);
+    }
+    return;
+#endif
     if (out.cls == PX_HIT0 || out.cls == PX_HIT1) {
 #ifdef S5_KO_G
         out.g = 0.5 + 1e-3 * out.r;
