@@ -31,9 +31,14 @@ void disk_image_polarized_kernel(ImageParams p)
     const int iy = p.stripe_rows > 0 ? p.y0 + (lr / p.stripe_rows) * p.stripe_step + lr % p.stripe_rows
                                      : p.y0 + lr;
 
+#if S5_FAST
+    const double alpha = (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;       // as the unpolarized kernel
+    const double beta = (((double)(iy) + .5) * p.inv_ny - 0.5) * 2.0 * p.rmax * p.ny_over_nx;
+#else
     const double alpha = (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
     const double beta = (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax *
                         ((double)p.ny / (double)p.nx);
+#endif
     const size_t npix = (size_t)p.nrows * (size_t)p.nx;
     const size_t o = (size_t)lr * (size_t)p.nx + (size_t)ix;
 
@@ -60,11 +65,25 @@ void disk_image_polarized_kernel(ImageParams p)
         on2bl(floc, fv, tt);
         normalize_to(fv, 1.0, mt);
         polarization_constant(k, fv, mt, wp);
+#if S5_FAST
+        // chi = atan2(Y, X) with X, Y sharing the positive denominator S^2 + T^2 (ref src/sim5polarization.c:279-283):
+        // the angle needs neither division, cos 2chi = (X^2 - Y^2)/(X^2 + Y^2) and sin 2chi = 2XY/(X^2 + Y^2) need no
+        // angle at all; atan2 is evaluated only when the caller asked for the chi plane.
+        {
+            const double S = -alpha - p.a * p.sin_i, T = +beta;
+            const double Xn = -S * wp[1] - T * wp[0], Yn = -S * wp[0] + T * wp[1];
+            const double rn = mrcp(Xn * Xn + Yn * Yn);
+            Q = p.pol_degree * I * ((Xn - Yn) * (Xn + Yn) * rn);
+            U = p.pol_degree * I * (2.0 * Xn * Yn * rn);
+            if (p.chi) chi = matan2(Yn, Xn);
+        }
+#else
         chi = polarization_angle_rotation(p.a, p.sin_i, alpha, beta, wp);
         double s2c, c2c;
         msincos(2.0 * chi, s2c, c2c);
         Q = p.pol_degree * I * c2c;
         U = p.pol_degree * I * s2c;
+#endif
     }
     p.stokes[o] = I;
     p.stokes[npix + o] = Q;
