@@ -93,8 +93,12 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
 #if S5_FAST
         // Z^2 = (F^2 - X)/54^2 = 4 E^3/54^2, so Z^(1/3) = sqrt(E)/3: one square root instead of a square
         // root and a cube root; atan2 is scale-free, so the divisions by 54 drop out as well
+#ifdef S5_KO_TRIG
+        A = sqrt_pos(E) * (2. / 3.) * (0.9 + 1e-9 * F);
+#else
         const double z = matan2(sqrt_pos(-X), F);                    // X < 0 here, and then E > 0
         A = sqrt_pos(E) * (2. / 3.) * mcos_third(z);
+#endif
 #else
         const double sX = S5_DIVC(msqrt(-X), 54.);
         const double F54 = S5_DIVC(F, 54.);
