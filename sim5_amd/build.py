@@ -72,16 +72,23 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, obj)
         objs.append(o)
-        if force or not _newer(o, [s] + headers):
-            extra = os.environ.get("S5_FAST_EXTRA", "").split() if variant == "fast" else []
-            if src == "k_torus.hip":
-                extra = extra + os.environ.get("S5_TORUS_EXTRA", "").split()
-                if variant == "fast":
-                    # the march kernel of the fast variant lets the compiler fuse a*b+c (measured on MI355X: C4 job
-                    # 39.7 -> 37.0 ms, step counts identical to the reference's on every ray of the test sets; the
-                    # cancellation that rules contraction out for the image kernels is not on this path)
-                    extra = extra + ["-ffp-contract=fast"] + os.environ.get("S5_TORUS_FAST_EXTRA", "").split()
-            cmds.append([hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o])
+        extra = os.environ.get("S5_FAST_EXTRA", "").split() if variant == "fast" else []
+        if src == "k_torus.hip":
+            extra = extra + os.environ.get("S5_TORUS_EXTRA", "").split()
+            if variant == "fast":
+                # the march kernel of the fast variant lets the compiler fuse a*b+c (measured on MI355X: C4 job
+                # 39.7 -> 37.0 ms, step counts identical to the reference's on every ray of the test sets; the
+                # cancellation that rules contraction out for the image kernels is not on this path)
+                extra = extra + ["-ffp-contract=fast"] + os.environ.get("S5_TORUS_FAST_EXTRA", "").split()
+        cmd = [hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o]
+        # an object is reused only if it is newer than its sources AND was compiled by this very command line
+        # (experiment flags from the environment must not survive in objects a later build links)
+        cmdfile = o + ".cmd"
+        same_cmd = os.path.exists(cmdfile) and open(cmdfile).read() == " ".join(cmd)
+        if force or not same_cmd or not _newer(o, [s] + headers):
+            if os.path.exists(cmdfile):
+                os.remove(cmdfile)
+            cmds.append(cmd)
     # the translation units are independent: compile up to 4 at a time (each hipcc peaks at ~1.5 GB)
     jobs = max(1, min(4, int(os.environ.get("S5_BUILD_JOBS", "4")), os.cpu_count() or 1))
     running = []
@@ -105,7 +112,10 @@ def build(force=False, verbose=False):
         running.append((subprocess.Popen(cmd), cmd))
     while running:
         _reap(True)
-    if force or not _newer(LIB, objs):
+    for cmd in cmds:
+        with open(cmd[-1] + ".cmd", "w") as fh:
+            fh.write(" ".join(cmd))
+    if force or cmds or not _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + \
               ["-o", LIB, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
         if verbose:
