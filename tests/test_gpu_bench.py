@@ -59,3 +59,11 @@ def test_two_ranks_on_one_gpu(mode):
         assert c5["hits_ok"] and c5["n_gpus"] == 2 and len(c5["disk_hits"]) == 8 and c5["gathers_per_scan"] == 8
     else:
         assert o["scaling"] == "weak" and o["config"]["rays_per_step"] == 2 * 4096 * 4096
+
+
+def test_rccl_collectives_of_the_bench_with_one_rank():
+    """The real `nccl` (= RCCL) backend with a world of one rank: async gather of the kernel's output tile issued on
+    torch's stream, barrier, all_gather, synchronous gather -- the calls bench.py makes for N > 1 (tests/tools/nccl_world1.py)."""
+    r = subprocess.run([sys.executable, os.path.join("tests", "tools", "nccl_world1.py")], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600, env=dict(os.environ, MASTER_PORT=str(_port())))
+    assert r.returncode == 0 and "nccl world=1 ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
