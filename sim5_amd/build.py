@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
     stamp = os.path.join(LIBDIR, "build.stamp")
     fp = _fingerprint(headers + sources + [os.path.abspath(__file__)],
                       (FLAGS, VARIANT, os.environ.get("S5_FAST_EXTRA", ""), os.environ.get("S5_TORUS_EXTRA", ""),
-                       os.environ.get("S5_TORUS_FAST_EXTRA", "")))
+                       os.environ.get("S5_TORUS_FAST_EXTRA", ""), os.environ.get("S5_SURF_FAST_EXTRA", "")))
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
         return LIB
     if os.path.exists(stamp):
@@ -80,6 +80,8 @@ def build(force=False, verbose=False):
                 # 39.7 -> 37.0 ms, step counts identical to the reference's on every ray of the test sets; the
                 # cancellation that rules contraction out for the image kernels is not on this path)
                 extra = extra + ["-ffp-contract=fast"] + os.environ.get("S5_TORUS_FAST_EXTRA", "").split()
+        if src == "k_surface.hip" and variant == "fast":
+            extra = extra + os.environ.get("S5_SURF_FAST_EXTRA", "").split()
         cmd = [hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o]
         # an object is reused only if it is newer than its sources AND was compiled by this very command line
         # (experiment flags from the environment must not survive in objects a later build links)

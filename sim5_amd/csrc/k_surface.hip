@@ -15,7 +15,22 @@
 // The walk evaluates r(P) and mu(P) of ONE geodesic about a thousand times.  Both are Jacobi functions whose moduli
 // are constants of the ray, so the AGM rungs of the two Landen ladders are climbed once per ray and kept in LDS
 // (GeodTrack, s5_geod.hpp): a sub-step costs two ladder descents instead of two full sncndn evaluations
-// (ref src/sim5kerr-geod.c:891-960, geodesic_follow only changes P).  Dynamic LDS = surface table + ladders.
+// (ref src/sim5kerr-geod.c:891-960, geodesic_follow only changes P).  In the fast variant most sub-steps do not even
+// descend: consecutive points are close, so the two triples (sn, cn, dn) are advanced by the addition theorems
+// (GeodTrack::Along) and the full evaluation re-anchors them every 24 sub-steps.
+//
+// FOUR kernels per job, the per-ray state between them in a workspace in HBM (the geodesic record and ~100 B of walk
+// state per ray): a register allocation is the maximum over everything a kernel inlines, and the set-up (closed-form
+// quartic, Carlson integrals, inverse-cn special cases) needs 256 VGPRs and spills, while the loop that does the work
+// -- the sub-step of geodesic_follow, ~550 per ray -- needs half of that.
+//   surface_setup_kernel   geodesic_init_inf, search for the starting radius                      (once)
+//   surface_walk_kernel    the hot loop only: sub-steps until the ray leaves the walk            (4 rounds; a second
+//                          instance with full-depth ladders for the few near-critical rays runs beside it)
+//   surface_slow_kernel    equatorial crossing, retry from further out                            (4 rounds; rare)
+//   surface_finish_kernel  photon momentum, local frame of the surface                            (once)
+// A ray retries at most three times (ref py :258), so four walk/slow rounds finish every ray; later rounds find almost
+// nothing to do and return at once.
+#include <mutex>
 #include "s5_disk.hpp"
 #include "kernels.hpp"
 
@@ -49,19 +64,144 @@ S5_DEV double surface_height(const double* sR, const double* sH, int n, double R
     return sH[lo] + w * (sH[hi] - sH[lo]);
 }
 
-// the two ladders of a lane take 2 x 2 x LADDER_RUNGS_VALID x 8 B = 256 B of LDS: 64 KB per workgroup, two
-// workgroups (8 waves) per CU next to a surface table of up to ~1 000 nodes
+// The two ladders of a lane take 2 x 2 x rungs x 8 B of LDS.  The set-up kernel keeps all 8 rungs a double-precision
+// modulus can need (64 KB per workgroup; it runs once).  The walk kernel keeps 6 -- enough unless a modulus is within
+// 3e-6 of 1, i.e. the ray within ~1e-6 of the critical curve -- so that three workgroups (48 KB + table each) share a
+// CU: 3 waves per SIMD at its 143 VGPRs.  The set-up marks the rays that need the deeper ladder (`deep`); those are
+// walked by the slow kernel, which keeps all 8 (same values: a converged ladder is the same ladder).
 constexpr int SURF_BLOCK = 256;
+constexpr int WALK_RUNGS = 6;
 constexpr size_t SURF_LADDER_BYTES = (size_t)2 * 2 * LADDER_RUNGS_VALID * SURF_BLOCK * sizeof(double);
-#ifndef S5_SURF_WAVES
-#define S5_SURF_WAVES 2
-#endif
+constexpr size_t WALK_LADDER_BYTES = (size_t)2 * 2 * WALK_RUNGS * SURF_BLOCK * sizeof(double);
 
-__global__ __launch_bounds__(SURF_BLOCK, S5_SURF_WAVES)
-void disk_surface_kernel(SurfaceParams p, const double* __restrict__ tabR, const double* __restrict__ tabH,
-                         const double* __restrict__ alpha, const double* __restrict__ beta,
-                         double* __restrict__ outP, double* __restrict__ outR, double* __restrict__ outM,
-                         double* __restrict__ outK, int* __restrict__ outStatus)
+enum : int { ST_GROW, ST_FOLLOW, ST_MID, ST_DONE };
+enum : int { FWD, BACK_FULL, BACK_HALF };
+
+// walk state of one ray between the kernels
+struct WalkState {
+    double P, r, m, H1, Hd, step, fstep, step_factor, r0;
+    long walk_it;
+    int state, purpose, iteration, grow, sub_it, found, deep, pad;
+};
+
+struct SurfaceWork {                 // the job's workspace (device): one record of each per ray
+    Geod* gd;
+    GeodCache* cache;
+    WalkState* ws;
+};
+
+S5_DEV double first_r0(const Geod& gd, int iteration, double alpha_beta, double cos_view)          // ref py :265
+{
+    return fmax(fmax(200.0, 1.1 * gd.rp), (0.5 + iteration) * alpha_beta / cos_view);
+}
+
+// start of a walk step (ref py :297-299): the step towards the surface, then geodesic_follow(step)
+S5_DEV void begin_forward(WalkState& w)
+{
+    const double accuracy = 1e-2;
+    if (w.walk_it >= 2000000) { w.state = ST_DONE; return; }                 // neither found nor failed: failed (:331)
+    ++w.walk_it;
+    w.step = fmax(accuracy / 2., fmin((w.H1 - w.Hd) / 2., 0.5 * (sqrt(w.r) - 0.99) * w.step_factor));
+    w.fstep = w.step; w.purpose = FWD; w.sub_it = 0; w.state = ST_FOLLOW;
+}
+
+// one pass of the search for the starting radius (ref py :272-280) with r(P), mu(P) supplied by the caller
+S5_DEV void grow_step(WalkState& w, double Pe, double re, double me, const double* sR, const double* sH, int n_table)
+{
+    const double R1 = re * sqrt(1. - me * me);
+    w.H1 = re * me;
+    w.Hd = surface_height(sR, sH, n_table, R1);
+    if ((w.Hd < w.H1) || (w.r0 > 5e6) || (w.grow + 1 >= 64)) {
+        if (!(w.Hd < w.H1)) w.state = ST_DONE;                                // :283 (Hd >= H1, or NaN): failed
+        else { w.P = Pe; w.r = re; w.m = me; w.step_factor = 1.0; w.walk_it = 0; begin_forward(w); }
+    } else { w.r0 = 2.0 * w.r0; ++w.grow; }
+}
+
+// The walk: sub-steps of geodesic_follow (ref c :903-924) and the decisions after each call (ref py :296-331) until
+// the ray leaves it -- found, failed, equatorial crossing or retry from further out.  `ev` supplies r(P) and mu(P).
+template <class Eval>
+S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clamped, double twoRpc, double rp,
+                        double alpha_beta, double cos_view, const double* sR, const double* sH, int n_table)
+{
+    const double accuracy = 1e-2;                                            // ref py :268
+    const double rbh = r_horizon(a_in);
+    const double rbh_follow = 1.01 * r_horizon(a_clamped);                   // geodesic_follow's own limit, ref c :913
+#if S5_FAST
+    // r, mu along the walk by the addition theorems (GeodTrack::Along), re-anchored by the full evaluation every
+    // ANCHOR_EVERY sub-steps of the WAVE (a wave-uniform count, so that the lanes take the expensive branch together)
+    // and whenever a lane's sub-step is too long for the series
+#ifndef S5_ANCHOR_EVERY
+#define S5_ANCHOR_EVERY 24
+#endif
+    constexpr int ANCHOR_EVERY = S5_ANCHOR_EVERY;
+    typename Eval::Along along;
+    int since_anchor = ANCHOR_EVERY;
+#endif
+    for (long guard = 0; guard < 400000000L; ++guard) {
+        const bool walking = (w.state == ST_FOLLOW);
+        if (!wave_any(walking)) break;
+#if S5_FAST
+        double truestep = 0.0, dP = 0.0;
+        if (walking) {
+            truestep = copysign(fmin(fabs(w.fstep), 5e-2 * msqrt(w.r)), w.fstep);      // step/|step| = +-1 exactly
+            const double am = a_clamped * w.m;
+            dP = mdiv(truestep, fma(w.r, w.r, am * am));
+            w.P = w.P + dP;
+        }
+        const bool anchor_now = (since_anchor >= ANCHOR_EVERY) || wave_any(walking && !ev.step_is_small(dP));
+        since_anchor = anchor_now ? 1 : since_anchor + 1;
+#endif
+        if (walking) {
+            // one sub-step of geodesic_follow, c :904-924
+#if S5_FAST
+            if (anchor_now) ev.anchor(w.P, along, w.r, w.m);
+            else ev.advance(dP, w.P, along, w.r, w.m);
+#else
+            const double truestep = mdiv(w.fstep, fabs(w.fstep)) * fmin(fabs(w.fstep), 5e-2 * msqrt(w.r));
+            w.P = w.P + mdiv(truestep, sq(w.r) + sq(a_clamped * w.m));
+            w.r = ev.rad(w.P);
+            w.m = ev.pol(w.P);
+#endif
+            int ended = 0, st = 1;
+            if (w.r < rbh_follow) { ended = 1; st = 0; }
+            else if ((w.P < 0.0) || (w.P > twoRpc)) { ended = 1; st = 0; }
+            else {
+                w.fstep -= truestep;
+                ++w.sub_it;
+                if (!(fabs(w.fstep) > 1e-5) || w.sub_it >= 100000) ended = 1;
+            }
+            if (ended) {
+                if (w.purpose == BACK_HALF) { w.found = 1; w.state = ST_DONE; }       // :309-311
+                else if (w.purpose == BACK_FULL) { w.step_factor = w.step_factor / 5.; begin_forward(w); }   // :312-314
+                else if (!st) w.state = ST_DONE;                                      // :301 failed
+                else {
+                    const double R1 = w.r * sqrt(1. - w.m * w.m);
+                    w.H1 = w.r * w.m;
+                    w.Hd = surface_height(sR, sH, n_table, R1);
+                    if (w.H1 <= w.Hd) {                                               // surface hit? :307
+                        if (w.step < accuracy) { w.fstep = -w.step / 2.; w.purpose = BACK_HALF; }
+                        else { w.fstep = -w.step; w.purpose = BACK_FULL; }
+                        w.sub_it = 0;
+                    }
+                    else if (w.H1 < 1e-4) w.state = ST_MID;                           // equatorial plane hit? :316
+                    else if (w.r < 1.05 * rbh) w.state = ST_DONE;                     // :324
+                    else if (w.r > 1.1 * w.r0) {                                      // :325 retry from further out
+                        ++w.iteration;
+                        if (w.iteration > 3) w.state = ST_DONE;
+                        else { w.r0 = fmax(fmax(200.0, 1.1 * rp), (0.5 + w.iteration) * alpha_beta / cos_view); w.grow = 0; w.state = ST_GROW; }
+                    }
+                    else if (w.m < 0.0) w.state = ST_DONE;                            // :326
+                    else if (w.step < accuracy / 2.) w.state = ST_DONE;               // :327
+                    else begin_forward(w);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SURF_BLOCK)
+void surface_setup_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH,
+                          const double* __restrict__ alpha, const double* __restrict__ beta)
 {
     extern __shared__ double lds[];
     double* sLad = lds;                                              // [2 ladders][2 * LADDER_RUNGS_VALID][SURF_BLOCK]
@@ -69,131 +209,134 @@ void disk_surface_kernel(SurfaceParams p, const double* __restrict__ tabR, const
     double* sH = sR + p.n_table;
     for (int i = threadIdx.x; i < p.n_table; i += SURF_BLOCK) { sR[i] = tabR[i]; sH[i] = tabH[i]; }
     __syncthreads();
-
     const size_t i = (size_t)blockIdx.x * SURF_BLOCK + threadIdx.x;
     if (i >= p.n) return;
-
-    int status = 0;                          // 1 = surface point found, 0 = no intersection / error
-    double P = NAN, r = 0.0, m = 0.0;
-    double kout[4] = { NAN, NAN, NAN, NAN };
 
     Geod gd;
     GeodCache cache;
     int err = 0;
+    WalkState w;
+    w.P = NAN; w.r = 0.0; w.m = 0.0; w.H1 = NAN; w.Hd = NAN; w.step = 0.0; w.fstep = 0.0; w.step_factor = 1.0; w.r0 = 0.0;
+    w.walk_it = 0; w.state = ST_DONE; w.purpose = FWD; w.iteration = 0; w.grow = 0; w.sub_it = 0; w.found = 0; w.deep = 0; w.pad = 0;
     const bool ok = init_inf(p.incl, p.sin_i, p.cos_i, p.a, alpha[i], beta[i], gd, err, cache);
     if (ok) {
         GeodTrack<SURF_BLOCK> trk;
         trk.build(gd, sLad + threadIdx.x);
-        const double accuracy = 1e-2;                                            // ref py :268
-        const double rbh = r_horizon(p.a);
-        const double rbh_follow = 1.01 * r_horizon(gd.a);                        // geodesic_follow's own limit, ref c :913
+        w.deep = (trk.st_r.top >= WALK_RUNGS || trk.st_m.top >= WALK_RUNGS) ? 1 : 0;
         const double disk_theta = atan(surface_height(sR, sH, p.n_table, 1e6) / 1e6);   // :263
         const double alpha_beta = sqrt(gd.alpha * gd.alpha + gd.beta * gd.beta);
         const double cos_view = cos(gd.incl + disk_theta);
-
-        // The three nested loops of the reference (retry from further out :258, walk :296, sub-steps of
-        // geodesic_follow c :903) flattened into ONE loop whose body evaluates r(P), mu(P) exactly once: whatever
-        // a lane is doing -- looking for its starting radius, stepping down the geodesic, backing up after a hit,
-        // taking the equatorial crossing -- the wave shares the one inlined copy of the two ladder descents.  Per
-        // ray the sequence of calls, operands and decisions is the reference's.
-        enum : int { ST_GROW, ST_FOLLOW, ST_MID, ST_DONE };
-        enum : int { FWD, BACK_FULL, BACK_HALF };
-        int state = ST_GROW, purpose = FWD, iteration = 0, grow = 0, sub_it = 0;
-        long walk_it = 0;
-        bool found = false;
-        double r0 = fmax(fmax(200.0, 1.1 * gd.rp), (0.5 + iteration) * alpha_beta / cos_view);        // :265
-        double H1 = NAN, Hd = NAN, step = 0.0, fstep = 0.0, truestep = 0.0, step_factor = 1.0;
-
-        // start of a walk step (:297-299): the step towards the surface, then geodesic_follow(step)
-        auto begin_forward = [&]() {
-            if (walk_it >= 2000000) { state = ST_DONE; return; }                 // neither found nor failed: failed (:331)
-            ++walk_it;
-            step = fmax(accuracy / 2., fmin((H1 - Hd) / 2., 0.5 * (sqrt(r) - 0.99) * step_factor));
-            fstep = step; purpose = FWD; sub_it = 0; state = ST_FOLLOW;
-        };
-
-        // Two phases per round.  The slow one serves lanes that look for their starting radius (P_int: a Carlson
-        // integral) or take the equatorial crossing (inverse cn with its special cases) -- once or twice per ray; the
-        // hot one is the sub-step of geodesic_follow, ~300 times per ray, and carries none of that code or its
-        // registers.  A lane that leaves the hot phase (retry from further out, equatorial crossing, done) idles
-        // until the wave's hot phase ends.
-        for (int round = 0; round < 64; ++round) {
-            if (!wave_any(state != ST_DONE)) break;
-            for (int guard = 0; guard < 4096; ++guard) {
-                const bool slow = (state == ST_GROW) || (state == ST_MID);
-                if (!wave_any(slow)) break;
-                if (slow) {
-                    if (state == ST_GROW) {                                      // :272-280
-                        const double Pe = P_int(gd, r0, 0);
-                        const double re = trk.rad(Pe), me = trk.pol(Pe);
-                        const double R1 = re * sqrt(1. - me * me);
-                        H1 = re * me;
-                        Hd = surface_height(sR, sH, p.n_table, R1);
-                        if ((Hd < H1) || (r0 > 5e6) || (grow + 1 >= 64)) {
-                            if (!(Hd < H1)) state = ST_DONE;                      // :283 (Hd >= H1, or NaN): failed
-                            else { P = Pe; r = re; m = me; step_factor = 1.0; walk_it = 0; begin_forward(); }
-                        } else { r0 = 2.0 * r0; ++grow; }
-                    } else {                                                     // :317-320
-                        P = midplane_crossing(gd, 0, cache);
-                        r = trk.rad(P);
-                        m = trk.pol(P);
-                        found = true; state = ST_DONE;
-                    }
-                }
-            }
-            for (long guard = 0; guard < 400000000L; ++guard) {
-                if (!wave_any(state == ST_FOLLOW)) break;
-                if (state == ST_FOLLOW) {
-                    // one sub-step of geodesic_follow, c :904-924
-                    truestep = mdiv(fstep, fabs(fstep)) * fmin(fabs(fstep), 5e-2 * msqrt(r));
-                    P = P + mdiv(truestep, sq(r) + sq(gd.a * m));
-                    r = trk.rad(P);
-                    m = trk.pol(P);
-                    int ended = 0, st = 1;
-                    if (r < rbh_follow) { ended = 1; st = 0; }
-                    else if ((P < 0.0) || (P > 2. * trk.Rpc)) { ended = 1; st = 0; }
-                    else {
-                        fstep -= truestep;
-                        ++sub_it;
-                        if (!(fabs(fstep) > 1e-5) || sub_it >= 100000) ended = 1;
-                    }
-                    if (ended) {
-                        if (purpose == BACK_HALF) { found = true; state = ST_DONE; }       // :309-311
-                        else if (purpose == BACK_FULL) { step_factor = step_factor / 5.; begin_forward(); }   // :312-314
-                        else if (!st) state = ST_DONE;                                    // :301 failed
-                        else {
-                            const double R1 = r * sqrt(1. - m * m);
-                            H1 = r * m;
-                            Hd = surface_height(sR, sH, p.n_table, R1);
-                            if (H1 <= Hd) {                                               // surface hit? :307
-                                if (step < accuracy) { fstep = -step / 2.; purpose = BACK_HALF; }
-                                else { fstep = -step; purpose = BACK_FULL; }
-                                sub_it = 0;
-                            }
-                            else if (H1 < 1e-4) state = ST_MID;                           // equatorial plane hit? :316
-                            else if (r < 1.05 * rbh) state = ST_DONE;                     // :324
-                            else if (r > 1.1 * r0) {                                      // :325 retry from further out
-                                ++iteration;
-                                if (iteration > 3) state = ST_DONE;
-                                else {
-                                    r0 = fmax(fmax(200.0, 1.1 * trk.rp), (0.5 + iteration) * alpha_beta / cos_view);
-                                    grow = 0; state = ST_GROW;
-                                }
-                            }
-                            else if (m < 0.0) state = ST_DONE;                            // :326
-                            else if (step < accuracy / 2.) state = ST_DONE;               // :327
-                            else begin_forward();
-                        }
-                    }
-                }
+        w.state = ST_GROW;
+        w.r0 = first_r0(gd, 0, alpha_beta, cos_view);
+        for (int guard = 0; guard < 64; ++guard) {
+            if (!wave_any(w.state == ST_GROW)) break;
+            if (w.state == ST_GROW) {
+                const double Pe = P_int(gd, w.r0, 0);                        // :272
+                grow_step(w, Pe, trk.rad(Pe), trk.pol(Pe), sR, sH, p.n_table);
             }
         }
-        if (found && !isnan(r) && !isnan(P)) {                                   // ref py :244-248
-            status = 1;
-            photon_momentum(p.a, r, m, gd.l, gd.q, gd.Rpc - P, 1.0, kout);       // :250
-        } else {
-            P = NAN; r = 0.0; m = 0.0;
+        if (w.state == ST_GROW) w.state = ST_DONE;
+    } else {
+        gd.type = -1;
+    }
+    wk.gd[i] = gd; wk.cache[i] = cache; wk.ws[i] = w;
+}
+
+#ifndef S5_SURF_WAVES
+#define S5_SURF_WAVES 3
+#endif
+// NST = WALK_RUNGS, DEEP = false: the rays whose ladders fit (nearly all);  NST = LADDER_RUNGS_VALID, DEEP = true: the
+// few that need the full ladders (64 KB of LDS per workgroup; launched beside the other on a second stream)
+template <int NST, bool DEEP>
+__global__ __launch_bounds__(SURF_BLOCK, DEEP ? 2 : S5_SURF_WAVES)
+void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH)
+{
+    extern __shared__ double lds[];
+    double* sLad = lds;                                              // [2 ladders][2 * NST][SURF_BLOCK]
+    double* sR = lds + (size_t)2 * 2 * NST * SURF_BLOCK;
+    double* sH = sR + p.n_table;
+    const size_t i = (size_t)blockIdx.x * SURF_BLOCK + threadIdx.x;
+    const size_t ic = (i < p.n) ? i : 0;
+    const bool mine = (i < p.n) && (wk.ws[ic].state == ST_FOLLOW) && ((wk.ws[ic].deep != 0) == DEEP);
+    if (!__syncthreads_or(mine)) return;                             // nothing to walk in this workgroup
+    for (int j = threadIdx.x; j < p.n_table; j += SURF_BLOCK) { sR[j] = tabR[j]; sH[j] = tabH[j]; }
+    __syncthreads();
+    if (!mine) return;
+
+    WalkState w = wk.ws[i];
+    GeodTrack<SURF_BLOCK, NST> trk;
+    double a_clamped, alpha_beta, cos_view;
+    {
+        const Geod gd = wk.gd[i];
+        trk.build(gd, sLad + threadIdx.x);
+        a_clamped = gd.a;
+        const double disk_theta = atan(surface_height(sR, sH, p.n_table, 1e6) / 1e6);
+        alpha_beta = sqrt(gd.alpha * gd.alpha + gd.beta * gd.beta);
+        cos_view = cos(gd.incl + disk_theta);
+    }
+    follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, trk.rp, alpha_beta, cos_view, sR, sH, p.n_table);
+    wk.ws[i] = w;
+}
+
+// the rare steps: equatorial crossing (ref py :317-320) and a new search for the starting radius after the ray
+// escaped (:325 -> :265-280), through the generic per-ray routines (same values as the tracked ones, s5_geod.hpp)
+__global__ __launch_bounds__(SURF_BLOCK)
+void surface_slow_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH)
+{
+    extern __shared__ double lds[];
+    double* sR = lds;
+    double* sH = sR + p.n_table;
+    const size_t i = (size_t)blockIdx.x * SURF_BLOCK + threadIdx.x;
+    const int st0 = (i < p.n) ? wk.ws[i].state : ST_DONE;
+    const bool mine = (st0 == ST_GROW) || (st0 == ST_MID);
+    if (!__syncthreads_or(mine)) return;
+    for (int j = threadIdx.x; j < p.n_table; j += SURF_BLOCK) { sR[j] = tabR[j]; sH[j] = tabH[j]; }
+    __syncthreads();
+    if (!mine) return;
+    WalkState w = wk.ws[i];
+    const Geod gd = wk.gd[i];
+    if (w.state == ST_MID) {
+        const GeodCache cache = wk.cache[i];
+        w.P = midplane_crossing(gd, 0, cache);
+        w.r = position_rad(gd, w.P);
+        w.m = position_pol(gd, w.P);
+        w.found = 1; w.state = ST_DONE;
+    } else {
+        for (int guard = 0; guard < 64 && w.state == ST_GROW; ++guard) {
+            const double Pe = P_int(gd, w.r0, 0);
+            grow_step(w, Pe, position_rad(gd, Pe), position_pol(gd, Pe), sR, sH, p.n_table);
         }
+        if (w.state == ST_GROW) w.state = ST_DONE;
+    }
+    wk.ws[i] = w;
+}
+
+__global__ __launch_bounds__(SURF_BLOCK)
+void surface_finish_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH,
+                           double* __restrict__ outP, double* __restrict__ outR, double* __restrict__ outM,
+                           double* __restrict__ outK, int* __restrict__ outStatus)
+{
+    extern __shared__ double lds[];
+    double* sR = lds;
+    double* sH = sR + p.n_table;
+    if (p.out_g) {
+        for (int j = threadIdx.x; j < p.n_table; j += SURF_BLOCK) { sR[j] = tabR[j]; sH[j] = tabH[j]; }
+        __syncthreads();
+    }
+    const size_t i = (size_t)blockIdx.x * SURF_BLOCK + threadIdx.x;
+    if (i >= p.n) return;
+    const WalkState w = wk.ws[i];
+    int status = 0;
+    double P = w.P, r = w.r, m = w.m;
+    double kout[4] = { NAN, NAN, NAN, NAN };
+    if (w.found && !isnan(r) && !isnan(P)) {                                     // ref py :244-248
+        const Geod gd = wk.gd[i];
+        status = 1;
+        photon_momentum(p.a, r, m, gd.l, gd.q, gd.Rpc - P, 1.0, kout);           // :250
+    } else if (wk.gd[i].type == -1) {
+        P = NAN; r = 0.0; m = 0.0;                                               // rejected by geodesic_init_inf
+    } else {
+        P = NAN; r = 0.0; m = 0.0;
     }
     if (p.out_g) {
         // local frame of the disk surface at the point found: the reference's __tetrad / __gfactor /
@@ -236,6 +379,16 @@ void disk_surface_kernel(SurfaceParams p, const double* __restrict__ tabR, const
 
 } // namespace S5NS
 
+namespace {
+// workspace of the surface job: one grow-only device allocation per device (a job on another stream than the previous one
+// first waits for that stream, so two jobs never share it)
+struct SurfaceWorkspace {
+    char* base = nullptr; size_t cap = 0; hipStream_t last = nullptr; bool used = false; bool attr_set = false;
+    hipStream_t side = nullptr;              // the deep-ladder walk runs here, beside the main walk
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+}
+
 #if S5_FAST
 int s5_launch_disk_surface_fast(const s5abi::SurfaceParams& p, const double* tabR, const double* tabH,
 #else
@@ -245,21 +398,55 @@ int s5_launch_disk_surface_strict(const s5abi::SurfaceParams& p, const double* t
                                   double* k, int* status, hipStream_t stream)
 {
     using namespace S5NS;
-    const unsigned blocks = (unsigned)((p.n + SURF_BLOCK - 1) / SURF_BLOCK);
-    const size_t lds = SURF_LADDER_BYTES + 2 * sizeof(double) * (size_t)p.n_table;
-    // more than 64 KB of dynamic LDS has to be allowed once per device
-    static bool attr_set[64] = {};
+    static SurfaceWorkspace g_ws[64];
+    static std::mutex g_lock;
+    std::lock_guard<std::mutex> hold(g_lock);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
-        e = hipFuncSetAttribute((const void*)disk_surface_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(SURF_LADDER_BYTES + 2 * sizeof(double) * (size_t)SURF_MAX_TABLE));
-        if (e != hipSuccess) return (int)e;
-        attr_set[dev] = true;
+    SurfaceWorkspace& W = g_ws[dev];
+    const size_t n = p.n;
+    const size_t b_gd = (sizeof(Geod) * n + 255) & ~size_t(255), b_ca = (sizeof(GeodCache) * n + 255) & ~size_t(255);
+    const size_t b_ws = (sizeof(WalkState) * n + 255) & ~size_t(255);
+    const size_t need = b_gd + b_ca + b_ws;
+    if (W.used && W.last != stream) { if ((e = hipStreamSynchronize(W.last)) != hipSuccess) return (int)e; }
+    if (need > W.cap) {
+        if (W.base) { if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e; (void)hipFree(W.base); W.base = nullptr; W.cap = 0; }
+        if ((e = hipMalloc((void**)&W.base, need)) != hipSuccess) return (int)e;
+        W.cap = need;
     }
-    hipLaunchKernelGGL(disk_surface_kernel, dim3(blocks), dim3(SURF_BLOCK), lds, stream, p, tabR, tabH, alpha, beta,
-                       P, r, m, k, status);
+    W.last = stream; W.used = true;
+    SurfaceWork wk;
+    wk.gd = (Geod*)W.base; wk.cache = (GeodCache*)(W.base + b_gd); wk.ws = (WalkState*)(W.base + b_gd + b_ca);
+
+    const unsigned blocks = (unsigned)((n + SURF_BLOCK - 1) / SURF_BLOCK);
+    const size_t tab_bytes = 2 * sizeof(double) * (size_t)p.n_table;
+    const size_t lds_lad = SURF_LADDER_BYTES + tab_bytes, lds_walk = WALK_LADDER_BYTES + tab_bytes;
+    auto walk = surface_walk_kernel<WALK_RUNGS, false>;
+    auto walk_deep = surface_walk_kernel<LADDER_RUNGS_VALID, true>;
+    if (!W.attr_set) {            // more than 64 KB of dynamic LDS has to be allowed once per device
+        const int most = (int)(SURF_LADDER_BYTES + 2 * sizeof(double) * (size_t)SURF_MAX_TABLE);
+        if ((e = hipFuncSetAttribute((const void*)surface_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, most)) != hipSuccess) return (int)e;
+        if ((e = hipFuncSetAttribute((const void*)walk, hipFuncAttributeMaxDynamicSharedMemorySize, most)) != hipSuccess) return (int)e;
+        if ((e = hipFuncSetAttribute((const void*)walk_deep, hipFuncAttributeMaxDynamicSharedMemorySize, most)) != hipSuccess) return (int)e;
+        if ((e = hipStreamCreateWithFlags(&W.side, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+        if ((e = hipEventCreateWithFlags(&W.fork, hipEventDisableTiming)) != hipSuccess) return (int)e;
+        if ((e = hipEventCreateWithFlags(&W.join, hipEventDisableTiming)) != hipSuccess) return (int)e;
+        W.attr_set = true;
+    }
+    hipLaunchKernelGGL(surface_setup_kernel, dim3(blocks), dim3(SURF_BLOCK), lds_lad, stream, p, wk, tabR, tabH, alpha, beta);
+    for (int round = 0; round < 4; ++round) {                       // a ray retries at most three times (ref py :258)
+        // fork: the few rays with deep ladders walk on the side stream (a handful of waves, latency bound) while the
+        // rest walk here; join before the slow steps
+        if ((e = hipEventRecord(W.fork, stream)) != hipSuccess) return (int)e;
+        if ((e = hipStreamWaitEvent(W.side, W.fork, 0)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(walk_deep, dim3(blocks), dim3(SURF_BLOCK), lds_lad, W.side, p, wk, tabR, tabH);
+        if ((e = hipEventRecord(W.join, W.side)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(walk, dim3(blocks), dim3(SURF_BLOCK), lds_walk, stream, p, wk, tabR, tabH);
+        if ((e = hipStreamWaitEvent(stream, W.join, 0)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(surface_slow_kernel, dim3(blocks), dim3(SURF_BLOCK), tab_bytes, stream, p, wk, tabR, tabH);
+    }
+    hipLaunchKernelGGL(surface_finish_kernel, dim3(blocks), dim3(SURF_BLOCK), tab_bytes, stream, p, wk, tabR, tabH, P, r, m, k, status);
     return (int)hipGetLastError();
 }

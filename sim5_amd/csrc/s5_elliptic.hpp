@@ -326,6 +326,7 @@ struct LadderState {
     int top;         // index of the last rung
     bool flipped;
     bool degenerate; // 1 - m == 0 after the clamp: unreachable, kept for parity
+    bool incomplete; // the AGM had not converged when the NR rungs were used up (a caller with a short ladder checks)
 };
 
 template <class Ladder, int NR = LADDER_RUNGS>
@@ -334,7 +335,7 @@ S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
     if (m == 1.0) m = 0.999999999;
     const double conv = 1.0e-8;
     double emc = 1.0 - m;
-    st.d = 1.0; st.c = 0.0; st.top = NR - 1; st.flipped = false;
+    st.d = 1.0; st.c = 0.0; st.top = NR - 1; st.flipped = false; st.incomplete = false;
     st.degenerate = (emc == 0.0);
     if (st.degenerate) return;
     st.flipped = emc < 0.0;
@@ -357,7 +358,7 @@ S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
         }
         if (!wave_any(climbing)) break;        // rungs above are never read (i <= top below)
     }
-    st.c = c; st.top = top;
+    st.c = c; st.top = top; st.incomplete = climbing;
 }
 
 template <class Ladder, int NR = LADDER_RUNGS>

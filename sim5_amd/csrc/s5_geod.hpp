@@ -372,13 +372,13 @@ S5_DEV bool init_src(double a, double r, double m, const double k[4], int ppc, G
 // elliptic moduli (hence the AGM rungs of their Landen ladders), the root combinations, sqrt(m2p), the polar
 // phase bookkeeping.  GeodTrack forms them once -- with the very expressions of position_rad / position_pol
 // above, so each later value is the one those routines return, bit for bit -- and keeps the rungs of the two
-// ladders in LDS (LadderLdsAt<STRIDE>: 2 x LADDER_RUNGS_VALID x 16 B = 256 B per lane; the moduli of a valid
-// geodesic are in [0, 1)).  An evaluation is then one sincos and
+// ladders in LDS (LadderLdsAt<STRIDE>: 2 x NST x 16 B per lane; NST = 8 serves every modulus in [0, 1), a shorter
+// ladder serves all but the rays within 3e-6 of the critical curve and reports those through deep()).  An evaluation is then one sincos and
 // the descent of the ladder instead of ~10 square roots of the climb plus the divisions of the constants.
 // ---------------------------------------------------------------------------------------
-template <int STRIDE>
+template <int STRIDE, int NST = LADDER_RUNGS_VALID>
 struct GeodTrack {
-    LadderLdsAt<STRIDE> lad_r, lad_m;
+    LadderLdsAt<STRIDE> lad_r, lad_m;            // NST rungs each; deep() tells whether NST were enough
     LadderState st_r, st_m;
     // radial part
     int type;
@@ -392,16 +392,18 @@ struct GeodTrack {
     S5_DEV void build(const Geod& g, double* lds_lane)
     {
         lad_r.base = lds_lane;
-        lad_m.base = lds_lane + 2 * LADDER_RUNGS_VALID * STRIDE;
+        lad_m.base = lds_lane + 2 * NST * STRIDE;
         type = g.type; Rpc = g.Rpc; rp = g.rp;
         st_r.degenerate = false; st_r.flipped = false; st_r.c = 0.0; st_r.d = 1.0; st_r.top = 0;
         fac = c0 = c1 = c2 = c3 = 0.0;
+        double m_rad = 0.0;
         if (g.type == T_RR) {
             const double r1 = g.r1[0], r2 = g.r2[0], r3 = g.r3[0], r4 = g.r4[0];
             const double m4 = mdiv((r2 - r3) * (r1 - r4), (r2 - r4) * (r1 - r3));
             fac = msqrt((r2 - r4) * (r1 - r3));
             c0 = r1 * (r2 - r4); c1 = r2 * (r1 - r4); c2 = r2 - r4; c3 = r1 - r4;
-            ladder_climb<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, m4, st_r);
+            ladder_climb<LadderLdsAt<STRIDE>, NST>(lad_r, m4, st_r);
+            m_rad = m4;
         } else if (g.type == T_RC) {
             const double r1 = g.r1[0], r2 = g.r2[0], u = g.r3[0], v = g.r3[1];
             const double A = msqrt(sq(r1 - u) + sq(v));
@@ -409,12 +411,22 @@ struct GeodTrack {
             const double m2 = mdiv(sq(A + B) - sq(r1 - r2), 4. * A * B);
             fac = msqrt(A * B);
             c0 = r2 * A - r1 * B; c1 = r2 * A + r1 * B; c2 = A - B; c3 = A + B;
-            ladder_climb<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, m2, st_r);
+            ladder_climb<LadderLdsAt<STRIDE>, NST>(lad_r, m2, st_r);
+            m_rad = m2;
         }
         escapes_ = escapes(g);
         sq_m2p = msqrt(g.m2p); mK = g.mK; Tpp = g.Tpp; Tip = g.Tip; beta = g.beta;
-        ladder_climb<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_m, g.mm, st_m);
+        ladder_climb<LadderLdsAt<STRIDE>, NST>(lad_m, g.mm, st_m);
+#if S5_FAST
+        build_along(g, m_rad);
+#else
+        (void)m_rad;
+#endif
     }
+
+    // true if a ladder did not converge within the NST rungs kept (moduli within 3e-6 of 1 need 7 or 8): the caller
+    // must not use rad() / pol() then
+    S5_DEV bool deep() const { return st_r.incomplete || st_m.incomplete; }
 
     S5_DEV double rad(double P) const                               // = position_rad(g, P)
     {
@@ -423,13 +435,13 @@ struct GeodTrack {
         double sn, cn, dn;
         if (type == T_RR) {
             const double x4 = 0.5 * fabs(P - Rpc) * fac;
-            ladder_descend<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, st_r, x4, sn, cn, dn);
+            ladder_descend<LadderLdsAt<STRIDE>, NST>(lad_r, st_r, x4, sn, cn, dn);
             const double sn2 = sn * sn;
             return mdiv(c0 - c1 * sn2, c2 - c3 * sn2);
         }
         if (type == T_RC) {
             if (P > Rpc) return NAN;
-            ladder_descend<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_r, st_r, fac * (Rpc - P), sn, cn, dn);
+            ladder_descend<LadderLdsAt<STRIDE>, NST>(lad_r, st_r, fac * (Rpc - P), sn, cn, dn);
             return mdiv(c0 - c1 * cn, c2 - c3 * cn);
         }
         return NAN;
@@ -442,9 +454,156 @@ struct GeodTrack {
         double T = (sdm > 0.0) ? -(Tpp - Tip) : -(Tip);
         for (int it = 0; it < 4096 && (P > T + Tpp); ++it) { T += Tpp; sdm = -sdm; }
         double sn, cn, dn;
-        ladder_descend<LadderLdsAt<STRIDE>, LADDER_RUNGS_VALID>(lad_m, st_m, mdiv(P - T, mK), sn, cn, dn);
+        ladder_descend<LadderLdsAt<STRIDE>, NST>(lad_m, st_m, mdiv(P - T, mK), sn, cn, dn);
         return -sdm * (sq_m2p * cn);
     }
+
+#if S5_FAST
+    // ---- values along a walk ------------------------------------------------------------------------------
+    // A walk (geodesic_follow, ref :891-925) evaluates r and mu at a sequence P_1, P_2 = P_1 + dP, ... of nearby
+    // points: hundreds of sub-steps of 0.05 sqrt(r) each.  Both arguments of the elliptic functions are linear in P,
+    //     u_r = kr (P - Rpc)   (kr = fac / 2 for RR, -fac for RC),     u_p = (P - T) / mK,
+    // so a sub-step moves them by the small amounts v = kr dP and dP / mK, and the addition theorems
+    //     sn(u+v) = (s c' d' + s' c d) / D,  cn(u+v) = (c c' - s d s' d') / D,  dn(u+v) = (d d' - m s c s' c') / D,
+    //     D = 1 - m s^2 s'^2
+    // give the new triple from the old one and sn, cn, dn of the SMALL argument, for which the Maclaurin series of
+    // sn to v^11 is exact to rounding when max(1, |m|) v^2 <= 5.6e-3 (next term 3.6e-3 v^12) -- about sixty
+    // operations instead of sincos and the descent of the ladder; a longer move is made in 2 or 4 equal parts.  `Along` carries the two triples; for the polar
+    // one it is -sdm sn and -sdm cn that are kept: the half-period shifts of position_pol (T += Tpp, sdm = -sdm)
+    // change the sign of sn, cn and sdm together, so these products are continuous functions of P and the phase
+    // bookkeeping drops out.  The caller re-anchors with the full evaluation (anchor(): the very values of rad(), pol())
+    // every few dozen sub-steps, which bounds the accumulated rounding (a few ulp per sub-step) near 1e-14, and
+    // whenever step_is_small() says the series does not apply.
+#ifndef S5_ALONG_LONG
+#define S5_ALONG_LONG 0
+#endif
+#ifndef S5_ALONG_SPLIT
+#define S5_ALONG_SPLIT 0
+#endif
+    struct Along { double Sr, Cr, Dr, Sp, Mp, Dp; };
+    double kr, inv_mK, m_r, m_p, dP_small;
+    double ser_r[5], ser_p[5];                   // sn(v | m) = v (1 + s0 v^2 + s1 v^4 + s2 v^6 + s3 v^8 + s4 v^10)
+
+    static S5_DEV void sn_series(double m, double s[5])
+    {
+        s[0] = -(1. + m) * (1. / 6.);
+        s[1] = (1. + m * (14. + m)) * (1. / 120.);
+        s[2] = -(1. + m * (135. + m * (135. + m))) * (1. / 5040.);
+        s[3] = (1. + m * (1228. + m * (5478. + m * (1228. + m)))) * (1. / 362880.);
+        s[4] = -(1. + m * (11069. + m * (165826. + m * (165826. + m * (11069. + m))))) * (1. / 39916800.);
+    }
+
+    S5_DEV void build_along(const Geod& g, double m_rad)
+    {
+        kr = (type == T_RR) ? 0.5 * fac : -fac;
+        inv_mK = 1.0 / mK;
+        m_r = m_rad; m_p = g.mm;
+        sn_series(m_r, ser_r); sn_series(m_p, ser_p);
+        const double wr = fabs(kr) * sqrt(fmax(1.0, fabs(m_r))), wp = fabs(inv_mK) * sqrt(fmax(1.0, fabs(m_p)));
+        dP_small = (S5_ALONG_LONG ? 0.075 : 0.04) / fmax(wr, wp);
+        if (!(type == T_RR || type == T_RC) || !escapes_ || !(dP_small > 0.0) || m_r == 1.0 || m_p == 1.0 ||
+            st_r.degenerate || st_m.degenerate) dP_small = 0.0;                   // always anchor
+    }
+
+    S5_DEV bool step_is_small(double dP) const { return fabs(dP) <= (S5_ALONG_SPLIT ? 4. : 1.) * dP_small; }
+
+    // sqrt(1 - x) for |x| <= 1.6e-3 (next term 2e-2 x^6; with S5_ALONG_LONG 5.6e-3 and 1.6e-2 x^7)
+    static S5_DEV double sqrt_one_minus(double x)
+    {
+#if S5_ALONG_LONG
+        double p = fma(x, -0.0205078125, -0.02734375);
+        p = fma(x, p, -0.0390625);
+#else
+        double p = fma(x, -0.02734375, -0.0390625);
+#endif
+        p = fma(x, p, -0.0625);
+        p = fma(x, p, -0.125);
+        p = fma(x, p, -0.5);
+        return fma(x, p, 1.0);
+    }
+
+    // (S, C, D) = (sn, cn, dn)(u)  ->  (sn, cn, dn)(u + v).  Written with explicit fused operations: this unit is
+    // compiled without contraction and the forty operations below are the inner loop of the walk.
+    static S5_DEV void add_small(double m, const double ser[5], double v, double& S, double& C, double& D)
+    {
+        const double v2 = v * v;
+#if S5_ALONG_LONG
+        double p = fma(v2, ser[4], ser[3]);
+        p = fma(v2, p, ser[2]);
+#else
+        double p = fma(v2, ser[3], ser[2]);
+#endif
+        p = fma(v2, p, ser[1]);
+        p = fma(v2, p, ser[0]);
+        const double sv = v * fma(v2, p, 1.0);
+        const double x = sv * sv, mx = m * x;
+        const double cv = sqrt_one_minus(x), dv = sqrt_one_minus(mx);
+        // 1 / (1 - y), y = m s^2 s'^2 <= 1.6e-3 (5.6e-3): the geometric series to y^5 (y^6) instead of a reciprocal
+        const double y = mx * (S * S);
+        double q = y + 1.0;
+#if S5_ALONG_LONG
+        q = fma(y, q, 1.0);
+#endif
+        q = fma(y, q, 1.0);
+        q = fma(y, q, 1.0);
+        q = fma(y, q, 1.0);
+        const double inv = fma(y, q, 1.0);
+        const double svC = sv * C, svS = sv * S;
+        const double Sn = fma(S, cv * dv, svC * D) * inv;
+        const double Cn = fma(C, cv, -(svS * D) * dv) * inv;
+        const double Dn = fma(D, dv, -(m * svS) * (C * cv)) * inv;
+        S = Sn; C = Cn; D = Dn;
+    }
+
+    S5_DEV double rad_from(const Along& t, double P) const          // the exits of rad() in its order, as selects
+    {
+        const bool rr = (type == T_RR);
+        const double z = rr ? t.Sr * t.Sr : t.Cr;
+        double r = mdiv(fma(-c1, z, c0), fma(-c3, z, c2));
+        if (!rr && (P > Rpc)) r = NAN;
+        if (P == Rpc) r = rp;
+        if ((P <= 0.0) || (P >= 2. * Rpc)) r = NAN;
+        return r;
+    }
+
+    // full evaluation at P: r, mu as rad(P), pol(P) return them, and the triples for advance()
+    S5_DEV void anchor(double P, Along& t, double& r, double& mu) const
+    {
+        double sn, cn, dn;
+        const double u = kr * (P - Rpc);
+        ladder_descend<LadderLdsAt<STRIDE>, NST>(lad_r, st_r, fabs(u), sn, cn, dn);
+        t.Sr = (u < 0.0) ? -sn : sn; t.Cr = cn; t.Dr = dn;
+        r = rad_from(t, P);
+        double sdm = (beta >= 0.0) ? +1.0 : -1.0;
+        double T = (sdm > 0.0) ? -(Tpp - Tip) : -(Tip);
+        for (int it = 0; it < 4096 && (P > T + Tpp); ++it) { T += Tpp; sdm = -sdm; }
+        ladder_descend<LadderLdsAt<STRIDE>, NST>(lad_m, st_m, mdiv(P - T, mK), sn, cn, dn);
+        t.Sp = -sdm * sn; t.Mp = -sdm * cn; t.Dp = dn;
+        mu = escapes_ ? sq_m2p * t.Mp : NAN;
+    }
+
+    // the same after a small move dP (step_is_small) that ended at P
+    S5_DEV void advance(double dP, double P, Along& t, double& r, double& mu) const
+    {
+#if S5_ALONG_SPLIT
+        const double adP = fabs(dP);
+        const int parts = (adP <= dP_small) ? 1 : (adP <= 2. * dP_small) ? 2 : 4;
+        const double part = (parts == 1) ? dP : (parts == 2) ? 0.5 * dP : 0.25 * dP;
+        for (int k = 0; k < 4; ++k) {
+            if (!wave_any(k < parts)) break;
+            if (k < parts) {
+                add_small(m_r, ser_r, kr * part, t.Sr, t.Cr, t.Dr);
+                add_small(m_p, ser_p, part * inv_mK, t.Sp, t.Mp, t.Dp);
+            }
+        }
+#else
+        add_small(m_r, ser_r, kr * dP, t.Sr, t.Cr, t.Dr);
+        add_small(m_p, ser_p, dP * inv_mK, t.Sp, t.Mp, t.Dp);
+#endif
+        r = rad_from(t, P);
+        mu = sq_m2p * t.Mp;
+    }
+#endif
 
     // one call of geodesic_follow on the tracked geodesic  (ref :891-925)
     S5_DEV void follow(double a, double step, double& P, double& r, double& m, int& status) const

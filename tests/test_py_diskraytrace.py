@@ -145,6 +145,33 @@ def test_thick_disk_surface_search(golden, capi, strict):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(0.9, 70.0, 20.0), (0.998, 30.0, 12.0), (0.2, 60.0, 40.0)], ids=["a0.9", "a0.998", "a0.2"])
+def test_surface_walk_increments_match_full_evaluation(capi, case):
+    """The fast variant walks with the addition theorems of sn, cn, dn between full evaluations (s5_geod.hpp, GeodTrack::
+    Along); the strict variant evaluates r(P), mu(P) in full, in the reference's operation order, at every sub-step.  The
+    stop point is fixed by the sequence of sub-steps, so identical sequences give the same point to rounding: on a
+    256 x 256 image (near-critical rays, both ladder depths, rays through the hole included) the two must agree to
+    1e-9 except where a height comparison at the accuracy threshold went the other way (a handful of rays)."""
+    a, inc, rmax = case
+    n = 256
+    ax = ((np.arange(n) + .5) / n - .5) * 2 * rmax
+    al, be = np.meshgrid(ax, ax)
+    tR = np.linspace(2.0, 60.0, 256); tH = 0.25 * (tR - 2.0)
+    f = capi.disk_surface_rays(a, math.radians(inc), tR, tH, al.ravel(), be.ravel(), strict=False)
+    s = capi.disk_surface_rays(a, math.radians(inc), tR, tH, al.ravel(), be.ravel(), strict=True)
+    same = (f["status"] == s["status"])
+    assert same.mean() > 0.9995, (1 - same.mean())
+    ok = same & (s["status"] == 1)
+    assert ok.sum() > 0.8 * n * n
+    dr = np.abs(f["r"][ok] / s["r"][ok] - 1); dm = np.abs(f["m"][ok] - s["m"][ok]); dP = np.abs(f["P"][ok] / s["P"][ok] - 1)
+    near = (dr < 1e-9) & (dm < 1e-9) & (dP < 1e-9)
+    assert near.mean() > 0.999, (1 - near.mean(), np.sort(dr)[-5:])
+    # and the others stopped one decision apart, not somewhere else: both lie on the surface to the search accuracy
+    R = f["r"][ok] * np.sqrt(1 - f["m"][ok] ** 2); H = f["r"][ok] * f["m"][ok]
+    assert np.max(np.abs(H - np.interp(R, tR, tH, right=np.nan))[R < tR[-1]]) < 2e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
 def test_surface_table_of_maximum_size_and_bad_tables(golden, capi, strict):
     """The accepted maximum of 4096 table nodes (2 x 32 KB of LDS next to the ladders: more than the 64 KB a kernel
