@@ -199,7 +199,10 @@ S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clam
     }
 }
 
-__global__ __launch_bounds__(SURF_BLOCK)
+#ifndef S5_SETUP_WAVES
+#define S5_SETUP_WAVES 1
+#endif
+__global__ __launch_bounds__(SURF_BLOCK, S5_SETUP_WAVES)
 void surface_setup_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH,
                           const double* __restrict__ alpha, const double* __restrict__ beta)
 {

@@ -240,6 +240,11 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
     if (lane + 64 < POOL_SLOTS) ptag[own + lane + 64] = TAG_EMPTY;
     __syncthreads();                                                 // the only workgroup barrier: all quarters exist
     bool drained = false;                                            // wave-uniform: the cursor ran past the last ray
+#ifdef S5_TORUS_DEBUG
+    // timeline of the wave (100 MHz clock): start, first time the cursor was found exhausted, exit
+    unsigned long long* tl = (unsigned long long*)aux.k_end + 16 + 3 * ((size_t)blockIdx.x * WG_WAVES + wave);
+    if (lane == 0) { tl[0] = wall_clock64(); tl[1] = 0; tl[2] = 0; }
+#endif
 
     RayState s;
     s.opt_gr = !((p.options & 1) == 1);
@@ -269,6 +274,9 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
                 if (want && rank == 0u) base = atomicAdd(cursor, (unsigned long long)cnt);
                 base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader, 64) << 32) |
                        (unsigned long long)(unsigned)__shfl((int)(unsigned)base, leader, 64);
+#ifdef S5_TORUS_DEBUG
+                if (base + cnt >= n && !drained && lane == 0) tl[1] = wall_clock64();
+#endif
                 if (base + cnt >= n) drained = true;
                 const unsigned long long mine = base + rank;
                 if (want && mine < n) {
@@ -423,6 +431,9 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
             ptag[slot] = tag;
         }
     }
+#ifdef S5_TORUS_DEBUG
+    if (lane == 0) tl[2] = wall_clock64();
+#endif
 }
 
 // Workspace of the torus job (start state of every ray, start-up flags, cursor): one grow-only device

@@ -507,45 +507,59 @@ struct GeodTrack {
 
     S5_DEV bool step_is_small(double dP) const { return fabs(dP) <= (S5_ALONG_SPLIT ? 4. : 1.) * dP_small; }
 
-    // sqrt(1 - x) for |x| <= 1.6e-3 (next term 2e-2 x^6; with S5_ALONG_LONG 5.6e-3 and 1.6e-2 x^7)
+    // sqrt(1 - x) for |x| <= 1.6e-3 (next term 2e-2 x^6; with S5_ALONG_LONG 5.6e-3 and 1.6e-2 x^7);
+    // TINY: |x| <= 1.6e-5, three terms (next 4e-2 x^4)
+    template <bool TINY>
     static S5_DEV double sqrt_one_minus(double x)
     {
+        double p;
+        if (TINY) p = fma(x, -0.0625, -0.125);
+        else {
 #if S5_ALONG_LONG
-        double p = fma(x, -0.0205078125, -0.02734375);
-        p = fma(x, p, -0.0390625);
+            p = fma(x, -0.0205078125, -0.02734375);
+            p = fma(x, p, -0.0390625);
 #else
-        double p = fma(x, -0.02734375, -0.0390625);
+            p = fma(x, -0.02734375, -0.0390625);
 #endif
-        p = fma(x, p, -0.0625);
-        p = fma(x, p, -0.125);
+            p = fma(x, p, -0.0625);
+            p = fma(x, p, -0.125);
+        }
         p = fma(x, p, -0.5);
         return fma(x, p, 1.0);
     }
 
     // (S, C, D) = (sn, cn, dn)(u)  ->  (sn, cn, dn)(u + v).  Written with explicit fused operations: this unit is
-    // compiled without contraction and the forty operations below are the inner loop of the walk.
+    // compiled without contraction and the forty operations below are the inner loop of the walk.  TINY: every series
+    // two terms shorter, for max(1, |m|) v^2 <= 1.6e-5 (the far part of a walk: most sub-steps).
+    template <bool TINY>
     static S5_DEV void add_small(double m, const double ser[5], double v, double& S, double& C, double& D)
     {
         const double v2 = v * v;
+        double p;
+        if (TINY) p = fma(v2, ser[1], ser[0]);
+        else {
 #if S5_ALONG_LONG
-        double p = fma(v2, ser[4], ser[3]);
-        p = fma(v2, p, ser[2]);
+            p = fma(v2, ser[4], ser[3]);
+            p = fma(v2, p, ser[2]);
 #else
-        double p = fma(v2, ser[3], ser[2]);
+            p = fma(v2, ser[3], ser[2]);
 #endif
-        p = fma(v2, p, ser[1]);
-        p = fma(v2, p, ser[0]);
+            p = fma(v2, p, ser[1]);
+            p = fma(v2, p, ser[0]);
+        }
         const double sv = v * fma(v2, p, 1.0);
         const double x = sv * sv, mx = m * x;
-        const double cv = sqrt_one_minus(x), dv = sqrt_one_minus(mx);
-        // 1 / (1 - y), y = m s^2 s'^2 <= 1.6e-3 (5.6e-3): the geometric series to y^5 (y^6) instead of a reciprocal
+        const double cv = sqrt_one_minus<TINY>(x), dv = sqrt_one_minus<TINY>(mx);
+        // 1 / (1 - y), y = m s^2 s'^2 <= 1.6e-3 (5.6e-3; 1.6e-5): the geometric series to y^5 (y^6; y^3) instead of a reciprocal
         const double y = mx * (S * S);
         double q = y + 1.0;
+        if (!TINY) {
 #if S5_ALONG_LONG
-        q = fma(y, q, 1.0);
+            q = fma(y, q, 1.0);
 #endif
-        q = fma(y, q, 1.0);
-        q = fma(y, q, 1.0);
+            q = fma(y, q, 1.0);
+            q = fma(y, q, 1.0);
+        }
         q = fma(y, q, 1.0);
         const double inv = fma(y, q, 1.0);
         const double svC = sv * C, svS = sv * S;
@@ -592,13 +606,18 @@ struct GeodTrack {
         for (int k = 0; k < 4; ++k) {
             if (!wave_any(k < parts)) break;
             if (k < parts) {
-                add_small(m_r, ser_r, kr * part, t.Sr, t.Cr, t.Dr);
-                add_small(m_p, ser_p, part * inv_mK, t.Sp, t.Mp, t.Dp);
+                add_small<false>(m_r, ser_r, kr * part, t.Sr, t.Cr, t.Dr);
+                add_small<false>(m_p, ser_p, part * inv_mK, t.Sp, t.Mp, t.Dp);
             }
         }
 #else
-        add_small(m_r, ser_r, kr * dP, t.Sr, t.Cr, t.Dr);
-        add_small(m_p, ser_p, dP * inv_mK, t.Sp, t.Mp, t.Dp);
+        if (!wave_any(fabs(dP) > 0.1 * dP_small)) {               // v^2 a hundred times below the bound: the short series
+            add_small<true>(m_r, ser_r, kr * dP, t.Sr, t.Cr, t.Dr);
+            add_small<true>(m_p, ser_p, dP * inv_mK, t.Sp, t.Mp, t.Dp);
+        } else {
+            add_small<false>(m_r, ser_r, kr * dP, t.Sr, t.Cr, t.Dr);
+            add_small<false>(m_p, ser_p, dP * inv_mK, t.Sp, t.Mp, t.Dp);
+        }
 #endif
         r = rad_from(t, P);
         mu = sq_m2p * t.Mp;
