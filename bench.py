@@ -126,8 +126,7 @@ class ImageJob:
         self.capi, self.n, self.stream = capi, n, stream
         inc = incl_deg / 180.0 * math.pi
         if striped:
-            self.desc = capi.image_desc(n, n, SPIN, inc, y0=rank * sharding.STRIPE, y1=n,
-                                        stripe_rows=sharding.STRIPE, stripe_step=world * sharding.STRIPE)
+            self.desc = capi.image_desc(n, n, SPIN, inc, **sharding.job_rows(n, rank, world))
             assert capi.image_rows(self.desc) == sharding.local_rows(n, rank, world)
         else:
             self.desc = capi.image_desc(n, n, SPIN, inc)

@@ -315,6 +315,15 @@ typedef struct sim5gpu_image_desc {
 
 #define SIM5GPU_IMG_DEFAULT 0   /* tuned FP64 sequences ("fast" variant, sim5_amd/csrc/s5_config.hpp)        */
 #define SIM5GPU_IMG_STRICT  1   /* reference parameters, IEEE sqrt/div, no FMA contraction ("strict")       */
+#define SIM5GPU_IMG_MIRROR  2   /* the call also traces the mirror image ny-1-y of every row y it traces.  The rows
+                                 * named by y0, y1 (and the striping) must lie in the upper half, y1 <= (ny+1)/2; the
+                                 * outputs hold ALL rows of the call in increasing row order (the named rows, then
+                                 * their mirrors); the middle row of an odd ny is its own mirror and appears once.  A ray
+                                 * and its mirror image in beta share the geodesic (same l, q: ref src/sim5kerr-geod.c:
+                                 * 76-77), so the default variant traces such a pair in one lane at about two thirds of
+                                 * the cost of two rays; a multi-GPU split deals mirrored stripe pairs for that reason
+                                 * (sim5_amd/sharding.py).  A plain call whose range is symmetric (y0 + y1 == ny) is paired
+                                 * the same way without asking.  The values are those of the unpaired trace, bit for bit. */
 
 /* optional full-precision outputs (any pointer may be NULL) */
 typedef struct sim5gpu_image_aux {

@@ -245,6 +245,18 @@ int attach_flux_table(DiskConsts& d)
 }
 
 // validate a job description and turn it into the kernel argument block
+// rows named by y0, y1 and the striping
+static int image_rows_top(const sim5gpu_image_desc* desc)
+{
+    if (!desc || desc->y1 <= desc->y0) return 0;
+    if (desc->stripe_rows <= 0) return desc->y1 - desc->y0;
+    if (desc->stripe_step < desc->stripe_rows) return 0;       // overlapping or non-advancing stripes: rejected by the launchers
+    int rows = 0;
+    for (int y = desc->y0; y < desc->y1; y += desc->stripe_step)
+        rows += (y + desc->stripe_rows <= desc->y1) ? desc->stripe_rows : desc->y1 - y;
+    return rows;
+}
+
 int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_disk)
 {
     if (!desc) { snprintf(g_err, sizeof g_err, "image descriptor is NULL"); return SIM5GPU_E_ARG; }
@@ -257,6 +269,10 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_
         snprintf(g_err, sizeof g_err, "bad striping stripe_rows=%d stripe_step=%d", desc->stripe_rows, desc->stripe_step);
         return SIM5GPU_E_ARG;
     }
+    if ((desc->flags & SIM5GPU_IMG_MIRROR) && desc->y1 > (desc->ny + 1) / 2) {
+        snprintf(g_err, sizeof g_err, "SIM5GPU_IMG_MIRROR: rows [%d,%d) must lie in the upper half of ny=%d", desc->y0, desc->y1, desc->ny);
+        return SIM5GPU_E_ARG;
+    }
     if (need_disk && (!(desc->bh_mass > 0.0) || !(desc->mdot > 0.0))) {     // a zero-initialised descriptor would give inf / NaN fluxes
         snprintf(g_err, sizeof g_err, "image descriptor needs bh_mass > 0 and mdot > 0 (got %g, %g)", desc->bh_mass, desc->mdot);
         return SIM5GPU_E_ARG;
@@ -265,6 +281,8 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_
     p.nx = desc->nx; p.ny = desc->ny; p.y0 = desc->y0; p.y1 = desc->y1;
     p.stripe_rows = desc->stripe_rows; p.stripe_step = desc->stripe_step;
     p.nrows = sim5gpu_image_rows(desc);
+    p.mirror = (desc->flags & SIM5GPU_IMG_MIRROR) ? 1 : 0;
+    p.nrows_top = image_rows_top(desc);
     p.inv_nx = 1.0 / (double)desc->nx; p.inv_ny = 1.0 / (double)desc->ny;
     p.ny_over_nx = (double)desc->ny / (double)desc->nx;
     { const double ac = fmax(1e-4, desc->a); p.inv_2a2 = 1.0 / (2.0 * ac * ac); }
@@ -449,13 +467,17 @@ int sim5gpu_disk_nt_r_min(double* r_min)
 // number of (packed) output rows of a job description: y1 - y0, or the total height of its stripes
 int sim5gpu_image_rows(const sim5gpu_image_desc* desc)
 {
-    if (!desc || desc->y1 <= desc->y0) return 0;
-    if (desc->stripe_rows <= 0) return desc->y1 - desc->y0;
-    if (desc->stripe_step < desc->stripe_rows) return 0;       // overlapping or non-advancing stripes: rejected by the launchers
-    int rows = 0;
-    for (int y = desc->y0; y < desc->y1; y += desc->stripe_step)
-        rows += (y + desc->stripe_rows <= desc->y1) ? desc->stripe_rows : desc->y1 - y;
-    return rows;
+    const int top = image_rows_top(desc);
+    if (top <= 0 || !(desc->flags & SIM5GPU_IMG_MIRROR)) return top;
+    if (desc->y1 > (desc->ny + 1) / 2) return 0;               // mirrored rows must be named in the upper half: rejected
+    // the middle row of an odd image is its own mirror: it is the last row named, if it is named at all
+    bool has_middle = false;
+    if (desc->ny % 2 == 1) {
+        const int mid = (desc->ny - 1) / 2;
+        if (desc->stripe_rows <= 0) has_middle = (mid >= desc->y0 && mid < desc->y1);
+        else if (mid >= desc->y0 && mid < desc->y1) has_middle = ((mid - desc->y0) % desc->stripe_step) < desc->stripe_rows;
+    }
+    return 2 * top - (has_middle ? 1 : 0);
 }
 
 // ---- whole-job image entry points --------------------------------------------------------------

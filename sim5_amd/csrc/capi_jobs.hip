@@ -127,7 +127,7 @@ int sim5gpu_disk_spectrum(const sim5gpu_image_desc* desc, int n_energies, const 
         snprintf(g_err, sizeof g_err, "disk_spectrum: need energies, spectrum, workspace, n_energies > 0, hardening > 0");
         return SIM5GPU_E_ARG;
     }
-    if (desc && desc->stripe_rows != 0) { snprintf(g_err, sizeof g_err, "disk_spectrum: striping is not supported"); return SIM5GPU_E_ARG; }
+    if (desc && (desc->stripe_rows != 0 || (desc->flags & SIM5GPU_IMG_MIRROR))) { snprintf(g_err, sizeof g_err, "disk_spectrum: striping / mirrored rows are not supported"); return SIM5GPU_E_ARG; }
     ImageParams p;
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
@@ -163,7 +163,7 @@ int sim5gpu_torus_image(const sim5gpu_torus_desc* desc, sim5gpu_stokes* d_stokes
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
     TorusParams p;
     memset(&p, 0, sizeof p);
-    if (desc->img.stripe_rows != 0) { snprintf(g_err, sizeof g_err, "torus_image: striping is not supported"); return SIM5GPU_E_ARG; }
+    if (desc->img.stripe_rows != 0 || (desc->img.flags & SIM5GPU_IMG_MIRROR)) { snprintf(g_err, sizeof g_err, "torus_image: striping / mirrored rows are not supported"); return SIM5GPU_E_ARG; }
     p.nx = ip.nx; p.ny = ip.ny; p.y0 = ip.y0; p.y1 = ip.y1;
     p.nrays = (size_t)(ip.y1 - ip.y0) * (size_t)ip.nx;
     p.a = ip.a; p.incl = ip.incl; p.sin_i = ip.sin_i; p.cos_i = ip.cos_i; p.rmax = ip.rmax;

@@ -26,10 +26,8 @@ struct RayResult {
     float  image_f, image_g;
 };
 
-S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
+S5_DEV RayResult ray_result(const ThinRay& t)
 {
-    ThinRay t;
-    trace_thin_disk<false>(p, alpha, beta, t);
     RayResult out;
     out.cls = t.cls; out.gtype = t.gtype;
     out.r = t.r; out.g = t.g; out.flux = t.flux;
@@ -38,6 +36,13 @@ S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
     out.image_f = hit ? (float)(t.flux * (g2 * g2)) : 0.0f;
     out.image_g = hit ? (float)t.g : 0.0f;
     return out;
+}
+
+S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
+{
+    ThinRay t;
+    trace_thin_disk<false>(p, alpha, beta, t);
+    return ray_result(t);
 }
 
 S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
@@ -65,6 +70,28 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
 constexpr int TILE_W = S5_TILE_W;        // workgroup tile: TILE_W x (256 / TILE_W) pixels
 constexpr int TILE_H = 256 / TILE_W;
 
+// Image-plane coordinates of a pixel (ref disk-image.c:57-58).  The fast variant multiplies by the reciprocals of the
+// image size instead of dividing, and forms beta from the exact odd integer 2 iy + 1 - ny: rows iy and ny - 1 - iy then get
+// beta values that are each other's negatives bit for bit (alpha, beta move by an ulp or two against the reference's
+// expression).  That is what lets the mirrored kernel below give the very image of the plain one.
+S5_DEV double pixel_alpha(const ImageParams& p, int ix)
+{
+#if S5_FAST
+    return (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;
+#else
+    return (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
+#endif
+}
+
+S5_DEV double pixel_beta(const ImageParams& p, int iy)
+{
+#if S5_FAST
+    return ((double)(2 * iy + 1 - p.ny) * (0.5 * p.inv_ny)) * 2.0 * p.rmax * p.ny_over_nx;
+#else
+    return (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax * ((double)p.ny / (double)p.nx);
+#endif
+}
+
 __global__ __launch_bounds__(256, S5_LB_WAVES)
 void disk_image_grid_kernel(ImageParams p)
 {
@@ -73,23 +100,34 @@ void disk_image_grid_kernel(ImageParams p)
     const int ix = blockIdx.x * TILE_W + lane_x;
     const int lr = blockIdx.y * TILE_H + lane_y;                 // packed (local) row
     if (ix >= p.nx || lr >= p.nrows) return;
-    const int iy = p.stripe_rows > 0 ? p.y0 + (lr / p.stripe_rows) * p.stripe_step + lr % p.stripe_rows
-                                     : p.y0 + lr;
-
-    // ref disk-image.c:57-58 (operation order kept; the fast variant multiplies by the reciprocals of the
-    // image size instead of dividing: alpha, beta move by at most 1 ulp)
-#if S5_FAST
-    const double alpha = (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;
-    const double beta = (((double)(iy) + .5) * p.inv_ny - 0.5) * 2.0 * p.rmax * p.ny_over_nx;
-#else
-    const double alpha = (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
-    const double beta = (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax *
-                        ((double)p.ny / (double)p.nx);
-#endif
-
-    const RayResult res = trace_disk_ray(p, alpha, beta);
+    const int iy = image_row(p, lr);
+    const RayResult res = trace_disk_ray(p, pixel_alpha(p, ix), pixel_beta(p, iy));
     store_ray(p, (size_t)lr * (size_t)p.nx + (size_t)ix, res);
 }
+
+#if S5_FAST
+// A row set that is symmetric about the middle of the image -- a plain range with y0 + y1 == ny (the whole image, a centred
+// band) or a SIM5GPU_IMG_MIRROR job (rows of the upper half, striped or not, plus their mirror images) -- has its packed
+// rows in increasing image-row order, so local rows lr and nrows - 1 - lr are mirror images of each other: a lane
+// takes the pixel (ix, iy) of the upper half AND its mirror image (ix, ny - 1 - iy).  The two rays differ in the sign of
+// beta only and share the geodesic (trace_thin_disk_impl<.., PAIR>) -- about two thirds of a ray's arithmetic.  The image
+// is the plain kernel's bit for bit (pixel_beta above); an odd middle row is its own mirror and is written once.
+__global__ __launch_bounds__(256, S5_LB_WAVES)
+void disk_image_mirror_kernel(ImageParams p)
+{
+    const int lane_x = threadIdx.x % TILE_W;
+    const int lane_y = threadIdx.x / TILE_W;
+    const int ix = blockIdx.x * TILE_W + lane_x;
+    const int lr = blockIdx.y * TILE_H + lane_y;                 // local row in the upper half
+    const int half = (p.nrows + 1) / 2;
+    if (ix >= p.nx || lr >= half) return;
+    const int lr2 = p.nrows - 1 - lr;                            // its mirror row (== lr for an odd middle row)
+    ThinRay t, t2;
+    trace_thin_disk_impl<false, true>(p, pixel_alpha(p, ix), pixel_beta(p, image_row_top(p, lr)), t, t2);
+    store_ray(p, (size_t)lr * (size_t)p.nx + (size_t)ix, ray_result(t));
+    if (lr2 != lr) store_ray(p, (size_t)lr2 * (size_t)p.nx + (size_t)ix, ray_result(t2));
+}
+#endif
 
 __global__ __launch_bounds__(256, 2)
 void disk_image_list_kernel(ImageParams p)
@@ -113,6 +151,13 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
         const unsigned blocks = (unsigned)((p.n + 255) / 256);
         hipLaunchKernelGGL(disk_image_list_kernel, dim3(blocks), dim3(256), 0, stream, p);
     } else {
+#if S5_FAST && !defined(S5_NO_MIRROR)
+        if ((p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny)) && p.nrows >= 2) {
+            const dim3 grid((p.nx + TILE_W - 1) / TILE_W, ((p.nrows + 1) / 2 + TILE_H - 1) / TILE_H);
+            hipLaunchKernelGGL(disk_image_mirror_kernel, grid, dim3(256), 0, stream, p);
+            return (int)hipGetLastError();
+        }
+#endif
         const dim3 grid((p.nx + TILE_W - 1) / TILE_W, (p.nrows + TILE_H - 1) / TILE_H);
         hipLaunchKernelGGL(disk_image_grid_kernel, grid, dim3(256), 0, stream, p);
     }

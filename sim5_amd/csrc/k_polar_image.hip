@@ -28,8 +28,7 @@ void disk_image_polarized_kernel(ImageParams p)
     const int ix = blockIdx.x * 16 + lane_x;
     const int lr = blockIdx.y * 16 + lane_y;                     // packed (local) row
     if (ix >= p.nx || lr >= p.nrows) return;
-    const int iy = p.stripe_rows > 0 ? p.y0 + (lr / p.stripe_rows) * p.stripe_step + lr % p.stripe_rows
-                                     : p.y0 + lr;
+    const int iy = image_row(p, lr);
 
 #if S5_FAST
     const double alpha = (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;       // as the unpolarized kernel

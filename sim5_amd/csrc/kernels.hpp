@@ -40,6 +40,8 @@ struct ImageParams {
     int nx, ny, y0, y1;
     int nrows;                         // rows traced by this launch (packed output rows)
     int stripe_rows, stripe_step;      // 0: rows y0..y1-1; else stripes of stripe_rows rows every stripe_step
+    int mirror;                        // SIM5GPU_IMG_MIRROR: packed rows nrows_top .. nrows-1 are the mirror images of the first ones
+    int nrows_top;                     // rows named by y0, y1 and the striping (== nrows without mirror)
     int max_order;
     double a, incl, sin_i, cos_i;      // sin/cos from the host libm
     double rmax, rms;
@@ -63,6 +65,19 @@ struct ImageParams {
     const double* beta;
     size_t n;
 };
+
+// image row of packed (local) output row lr: the rows named by y0, y1 and the striping first, then -- with mirror -- their
+// mirror images ny - 1 - y, so that the packed rows are in increasing image-row order
+__host__ __device__ inline int image_row_top(const ImageParams& p, int t)
+{
+    return p.stripe_rows > 0 ? p.y0 + (t / p.stripe_rows) * p.stripe_step + t % p.stripe_rows : p.y0 + t;
+}
+
+__host__ __device__ inline int image_row(const ImageParams& p, int lr)
+{
+    if (p.mirror && lr >= p.nrows_top) return p.ny - 1 - image_row_top(p, p.nrows - 1 - lr);
+    return image_row_top(p, lr);
+}
 
 // spectrum job (k_spectrum.hip)
 struct SpectrumParams {

@@ -54,17 +54,26 @@ S5_DEV bool icn_plain(double z, double m)
     return !snap && !(z == 0.0) && !(z == 1.0) && !(m == 0.0) && !(m == 1.0);
 }
 
-template <bool WANT_STATE, int KNOWN>
-S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const double a_in, const double a,
+template <bool WANT_STATE, int KNOWN, bool PAIR>
+S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                              const double l, const double q, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_);
 
-template <bool WANT_STATE>
-S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out)
+// PAIR: the lane traces the ray (alpha, beta) into `out` AND its mirror image (alpha, -beta) into `out2`.  The two
+// have the same constants of motion (l, and q through beta^2: ref :76-77), hence the same roots of R(r) and of the
+// polar potential, the same three R_F integrals and the same Landen ladder; only the sign in front of cn^-1 in the
+// position of the equatorial crossing (ref :868-871) and everything after it -- r(P), g, flux -- differ.  A lane's
+// arithmetic for either ray is the arithmetic of the unpaired routine, value for value.
+template <bool WANT_STATE, bool PAIR>
+S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out, ThinRay& out2)
 {
     using namespace s5abi;
     out.cls = PX_ERROR; out.gtype = -1; out.err = GD_OK;
     out.r = NAN; out.g = 0.0; out.flux = 0.0; out.P = NAN;
+    if (PAIR) {
+        out2.cls = PX_ERROR; out2.gtype = -1; out2.err = GD_OK;
+        out2.r = NAN; out2.g = 0.0; out2.flux = 0.0; out2.P = NAN;
+    }
 
     // ---------------- constants of motion and range checks (ref :59-86) ----------------
     const double a_in = p.a;
@@ -144,9 +153,22 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
 
     // one instantiation per uniform class (78 % of the rays of the headline image are RR, 22 % RC, and image
     // neighbours share the class), the generic one for mixed waves
-    if (!wave_any(type != T_RR)) thin_disk_finish<WANT_STATE, T_RR>(p, out, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
-    else if (!wave_any(type != T_RC)) thin_disk_finish<WANT_STATE, T_RC>(p, out, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
-    else thin_disk_finish<WANT_STATE, -1>(p, out, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
+    if (!wave_any(type != T_RR)) thin_disk_finish<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
+    else if (!wave_any(type != T_RC)) thin_disk_finish<WANT_STATE, T_RC, PAIR>(p, out, out2, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
+    else thin_disk_finish<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
+}
+
+template <bool WANT_STATE>
+S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out)
+{
+    trace_thin_disk_impl<WANT_STATE, false>(p, alpha, beta_in, out, out);
+}
+
+// this lane's column of the workgroup's ladder block (256-thread one-dimensional workgroups: all callers)
+S5_DEV double* thin_disk_ladder_column()
+{
+    __shared__ double s_ladder[2 * LADDER_RUNGS * 256];
+    return &s_ladder[threadIdx.x];
 }
 
 // Everything after the class of the ray is known.  KNOWN >= 0 instantiates the routine for a wave whose lanes
@@ -154,8 +176,8 @@ S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double be
 // formulas of the other classes and their special cases are pruned by the compiler.  The arithmetic a lane
 // performs is the same in every instantiation (same expressions, same order), so its result does not depend on
 // which one its wave took -- images stay identical bit for bit whatever the tile shape.
-template <bool WANT_STATE, int KNOWN>
-S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const double a_in, const double a,
+template <bool WANT_STATE, int KNOWN, bool PAIR>
+S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                              const double l, const double q, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_)
 {
@@ -336,10 +358,16 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
     if (WANT_STATE) {
         out.a = a; out.l = l; out.q = q; out.beta = beta; out.Rpc = Rpc; out.rp = rp;
         out.Tpp = 2. * (mK * K); out.Tip = mK * icn_i;
+        if (PAIR) {
+            out2.a = a; out2.l = l; out2.q = q; out2.beta = -beta; out2.Rpc = Rpc; out2.rp = rp;
+            out2.Tpp = out.Tpp; out2.Tip = out.Tip;
+        }
     }
+    if (PAIR) out2.err = err;
     if (!ok) return;
     out.gtype = type;
     out.cls = PX_MISS;
+    if (PAIR) { out2.gtype = type; out2.cls = PX_MISS; }
 
     // ---------------- equatorial crossings and r(P) (ref :846-885, :291-357) ----------------
     const bool q_pos = (q > 0.0);
@@ -351,77 +379,91 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, const do
     if (wave_any(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
         if (uu != u_i && !u_bad && q_pos) icn_u = inv_cn_cold(uu, mmT);
     }
-    bool done = false;
-#pragma unroll 1
-    for (int order = 0; order < p.max_order; ++order) {
-        if (!wave_any(!done)) break;
-        if (!done) {
-            double P;
-            if (!q_pos || u_bad) P = NAN;
-            else {
-                if (beta > 0.0) P = mK * ((2. * (double)order + 1.) * K + icn_u);
-                else if (beta < 0.0) P = mK * ((2. * (double)order + 1.) * K - icn_u);
-                else P = mK * ((2. * (double)order + 1.) * K);
-                if (P > 2. * Rpc) P = NAN;
-            }
-            if (isnan(P)) { out.cls = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; }
-            else {
-                // r(P): RR through sn, RC through cn, one ladder for both
-                double r;
-                const bool in_range = !((P <= 0.0) || (P >= 2. * Rpc));
-                const bool at_peri = (P == Rpc);
-                const bool rr = (type == T_RR), rcx = (type == T_RC) && !(P > Rpc);
-                const bool use_ladder = in_range && !at_peri && (rr || rcx);
-                double su = 0.0, sm = 0.5;
-                if (rr) su = 0.5 * fabs(P - Rpc) * sqAB;
-                else if (rcx) su = sqAB * (Rpc - P);
-                if (use_ladder) sm = mR;
-                double sn = 0.0, cn = 1.0, dn = 1.0;
-                if (wave_any(use_ladder)) {
-#ifdef S5_KO_RAD
-                    if (use_ladder) { sn = 0.3 + 1e-3 * su; cn = 0.9 - 1e-3 * sm; }
-#else
-                    if (use_ladder) sncndn_lds(su, sm, sn, cn, dn);        // 256-thread workgroups (all callers)
+    // r(P) needs sn (RR) or cn (RC) of modulus mR: the rungs of its Landen ladder are climbed ONCE per ray -- they serve
+    // every crossing order and both rays of a pair -- and kept in LDS; lanes that cannot use them climb a short dummy
+    LadderLds lad{thin_disk_ladder_column()};
+    LadderState lst;
+    const bool ladder_class = (type == T_RR) || (type == T_RC);
+    const bool may_cross = q_pos && !u_bad;
+#ifndef S5_KO_RAD
+    if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
+#pragma unroll 1
+    for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
+        const double beta_m = (member == 0) ? beta : -beta;
+        int cls_m = PX_MISS;
+        double r_m = NAN, P_m = NAN, g_m = 0.0, flux_m = 0.0;
+        bool done = false;
+#pragma unroll 1
+        for (int order = 0; order < p.max_order; ++order) {
+            if (!wave_any(!done)) break;
+            if (!done) {
+                double P;
+                if (!may_cross) P = NAN;
+                else {
+                    if (beta_m > 0.0) P = mK * ((2. * (double)order + 1.) * K + icn_u);
+                    else if (beta_m < 0.0) P = mK * ((2. * (double)order + 1.) * K - icn_u);
+                    else P = mK * ((2. * (double)order + 1.) * K);
+                    if (P > 2. * Rpc) P = NAN;
                 }
-                if (!in_range) r = NAN;
-                else if (at_peri) r = rp;
-                else if (rr) {
-                    const double sn2 = sn * sn;
-                    r = mdiv(ra * (rb - rd_) - rb * (ra - rd_) * sn2, rb - rd_ - (ra - rd_) * sn2);
-                } else if (rcx) {
-                    const double Aq = A;
-                    const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
-                    r = mdiv(rb * Aq - ra * Bq - (rb * Aq + ra * Bq) * cn, (Aq - Bq) - (Aq + Bq) * cn);
-                } else r = NAN;
-                if (r >= p.rms) {
-                    out.cls = (order == 0) ? PX_HIT0 : PX_HIT1;
-                    out.r = r; out.P = P;
-                    done = true;
+                if (isnan(P)) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; }
+                else {
+                    // r(P): RR through sn, RC through cn, one ladder for both
+                    double r;
+                    const bool in_range = !((P <= 0.0) || (P >= 2. * Rpc));
+                    const bool at_peri = (P == Rpc);
+                    const bool rr = (type == T_RR), rcx = (type == T_RC) && !(P > Rpc);
+                    const bool use_ladder = in_range && !at_peri && (rr || rcx);
+                    double su = 0.0;
+                    if (rr) su = 0.5 * fabs(P - Rpc) * sqAB;
+                    else if (rcx) su = sqAB * (Rpc - P);
+                    double sn = 0.0, cn = 1.0, dn = 1.0;
+                    if (wave_any(use_ladder)) {
+#ifdef S5_KO_RAD
+                        if (use_ladder) { sn = 0.3 + 1e-3 * su; cn = 0.9 - 1e-3 * mR; }
+#else
+                        if (use_ladder) ladder_descend(lad, lst, su, sn, cn, dn);
+#endif
+                    }
+                    if (!in_range) r = NAN;
+                    else if (at_peri) r = rp;
+                    else if (rr) {
+                        const double sn2 = sn * sn;
+                        r = mdiv(ra * (rb - rd_) - rb * (ra - rd_) * sn2, rb - rd_ - (ra - rd_) * sn2);
+                    } else if (rcx) {
+                        const double Aq = A;
+                        const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
+                        r = mdiv(rb * Aq - ra * Bq - (rb * Aq + ra * Bq) * cn, (Aq - Bq) - (Aq + Bq) * cn);
+                    } else r = NAN;
+                    if (r >= p.rms) {
+                        cls_m = (order == 0) ? PX_HIT0 : PX_HIT1;
+                        r_m = r; P_m = P;
+                        done = true;
+                    }
                 }
             }
         }
-    }
+        if (cls_m == PX_HIT0 || cls_m == PX_HIT1) {
 #if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX)
-    if (out.cls == PX_HIT0 || out.cls == PX_HIT1) {
-        double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
-        sqrt_rsqrt_pos(out.r, x, rx);                 // r >= rms > 0
-        out.g = gfactor_kepler_x(out.r, x, a_in, l);
-        out.flux = disk_flux_x(p.disk, out.r, x, rx);
-    }
-    return;
-#endif
-    if (out.cls == PX_HIT0 || out.cls == PX_HIT1) {
-#ifdef S5_KO_G
-        out.g = 0.5 + 1e-3 * out.r;
+            double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
+            sqrt_rsqrt_pos(r_m, x, rx);                   // r >= rms > 0
+            g_m = gfactor_kepler_x(r_m, x, a_in, l);
+            flux_m = disk_flux_x(p.disk, r_m, x, rx);
 #else
-        out.g = gfactor_kepler(out.r, a_in, l);
+#ifdef S5_KO_G
+            g_m = 0.5 + 1e-3 * r_m;
+#else
+            g_m = gfactor_kepler(r_m, a_in, l);
 #endif
 #ifdef S5_KO_FLUX
-        out.flux = 1e20 * out.r;
+            flux_m = 1e20 * r_m;
 #else
-        out.flux = disk_flux(p.disk, out.r);
+            flux_m = disk_flux(p.disk, r_m);
 #endif
+#endif
+        }
+        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; }
+        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; }
     }
 }
 

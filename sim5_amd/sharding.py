@@ -5,19 +5,51 @@ one gather of the finished tiles to rank 0.  Rows are dealt in stripes of STRIPE
 over the ranks: the expensive band around the black-hole shadow (second crossings, RC geodesics)
 is then shared by all ranks instead of landing on the one or two ranks that own the middle rows.
 
+Stripes are dealt in MIRRORED PAIRS: the upper half of the image is cut into stripes, stripe s goes to rank
+s mod world, and the rank that owns rows [y0, y1) also owns their mirror images [ny - y1, ny - y0).  A ray and its
+mirror image in beta share the geodesic, and the image kernel traces such a pair in one lane
+(SIM5GPU_IMG_MIRROR, include/sim5gpu.h) -- the split keeps that saving on every rank.  A rank's rows are packed
+in increasing row order: its stripes of the upper half, then their mirrors.
+
 Pure index arithmetic (no GPU, no torch) so that it can be checked on CPU with gloo.
 """
 
 STRIPE = 64
 
 
-def stripes_for_rank(ny, rank, world, stripe=STRIPE):
-    """[(y0, y1), ...] image-row ranges owned by `rank`, in increasing row order."""
+def upper_half(ny):
+    """rows [0, upper_half(ny)) are dealt; the others are their mirrors (the middle row of an odd ny is its own)"""
+    return (ny + 1) // 2
+
+
+def top_stripes_for_rank(ny, rank, world, stripe=STRIPE):
+    """[(y0, y1), ...] row ranges of the upper half owned by `rank`, in increasing row order."""
     out = []
-    nstripes = (ny + stripe - 1) // stripe
+    half = upper_half(ny)
+    nstripes = (half + stripe - 1) // stripe
     for s in range(rank, nstripes, world):
-        out.append((s * stripe, min(ny, (s + 1) * stripe)))
+        out.append((s * stripe, min(half, (s + 1) * stripe)))
     return out
+
+
+def stripes_for_rank(ny, rank, world, stripe=STRIPE):
+    """[(y0, y1), ...] ALL image-row ranges owned by `rank` (upper-half stripes and their mirrors), in increasing
+    row order -- the order of the rows in the rank's packed output."""
+    top = top_stripes_for_rank(ny, rank, world, stripe)
+    mid = (ny - 1) // 2 if ny % 2 == 1 else -1
+    bottom = []
+    for (y0, y1) in reversed(top):
+        lo, hi = ny - y1, ny - y0
+        if y0 <= mid < y1:            # the middle row is its own mirror: it is already in the upper stripe
+            lo += 1
+        if hi > lo:
+            bottom.append((lo, hi))
+    return top + bottom
+
+
+def job_rows(ny, rank, world, stripe=STRIPE):
+    """keyword arguments of capi.image_desc for this rank's share: rows of the upper half + SIM5GPU_IMG_MIRROR"""
+    return dict(y0=rank * stripe, y1=upper_half(ny), stripe_rows=stripe, stripe_step=world * stripe, mirror=True)
 
 
 def local_rows(ny, rank, world, stripe=STRIPE):

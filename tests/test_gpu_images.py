@@ -118,6 +118,30 @@ def test_ragged_and_tile_shapes(capi):
     assert o["cls"].shape == (31, 77) and c_alpha.size == 77
 
 
+def test_mirrored_pairs_give_the_plain_image(capi):
+    """A row range symmetric about the middle of the image is traced by the mirror kernel (a lane takes a pixel and its
+    mirror image in beta, k_disk_image.hip); any other range by the plain kernel.  Every output of the symmetric launch must
+    equal, bit for bit, what plain launches over the two halves give: odd and even heights (an odd middle row is its own
+    mirror), sizes that are not multiples of the tile, a centred band, one and two crossing orders, and an oracle check of
+    both halves on the way."""
+    for (nx, ny, a, inc, order) in [(301, 203, 0.9, 60.0, 2), (200, 128, 0.998, 80.0, 2), (97, 64, 0.5, 30.0, 1), (64, 3, 0.7, 50.0, 2)]:
+        for (y0, y1) in [(0, ny), (ny // 3, ny - ny // 3)]:
+            if y1 - y0 < 2:
+                continue
+            mk = lambda lo, hi: capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), y0=lo, y1=hi, max_order=order), full=True)
+            sym = mk(y0, y1)
+            cut = y0 + (y1 - y0) // 2 + 1                       # asymmetric pieces: the plain kernel
+            top, bot = mk(y0, cut), mk(cut, y1)
+            for k in ("cls", "gtype", "image_f", "image_g", "r", "g", "flux"):
+                both = np.concatenate([top[k], bot[k]], axis=0)
+                assert np.array_equal(sym[k], both, equal_nan=True), (k, nx, ny, y0, y1)
+    c = ol.cpu_disk_image("port", 200, 128, 0.998, 80.0, nthreads=4, full=True)
+    o = capi.disk_image(capi.image_desc(200, 128, 0.998, math.radians(80.0)), full=True)
+    assert np.array_equal(o["cls"], c["cls"])
+    assert_close(o["r"], c["r"], what="r"); assert_close(o["g"], c["g"], what="g")
+    assert_close(o["flux"], c["flux"], floor=flux_floor(c["flux"]), what="flux")
+
+
 def test_fast_and_strict_variants_agree(capi):
     """The tuned arithmetic against the reference-parameter arithmetic on the headline image:
     identical classes, values far inside the 1e-6 bar."""
@@ -219,25 +243,57 @@ def test_headline_flux_error_distribution(capi, strict):
     assert rep["max_abs_err_over_peak"] < 1e-9
 
 
-def test_striped_launch_equals_separate_stripes(capi):
-    """One launch over a rank's stripes (what bench.py --gpus N does) == the stripes traced one by one."""
+@VARIANTS
+def test_striped_launch_equals_separate_stripes(capi, strict):
+    """One launch over a rank's share (what bench.py --gpus N does: stripes of the upper half + their mirror images,
+    SIM5GPU_IMG_MIRROR) == those rows of the whole image, bit for bit, and the shares assemble to the whole image: even
+    and odd heights (ragged last stripe; an odd middle row is its own mirror), both variants -- the default one pairs
+    the mirrored rays in a lane, the strict one traces every row by itself."""
     from sim5_amd import sharding
-    n, a, inc, world = 1000, 0.998, 70.0, 3             # 1000 rows: the last stripe is ragged
+    a, inc = 0.998, 70.0
+    for n, world in [(1000, 3), (1001, 3), (130, 2), (257, 8)]:
+        whole = run(capi, n, a, inc, full=True, strict=strict)
+        tiles = []
+        for rank in range(world):
+            kw = sharding.job_rows(n, rank, world)
+            if kw["y0"] >= kw["y1"]:                      # more ranks than stripes: this rank has nothing to trace
+                assert sharding.local_rows(n, rank, world) == 0
+                tiles.append(np.zeros((2, sharding.max_local_rows(n, world), n), np.float32))
+                continue
+            d = capi.image_desc(n, n, a, inc / 180.0 * math.pi, strict=strict, **kw)
+            assert capi.image_rows(d) == sharding.local_rows(n, rank, world)
+            t = capi.disk_image(d, full=True)
+            rows = sharding.stripes_for_rank(n, rank, world)
+            for k in ("image_g", "image_f", "cls", "r", "flux"):
+                ref = np.concatenate([whole[k][y0:y1] for (y0, y1) in rows])
+                assert np.array_equal(t[k], ref, equal_nan=True), (k, n, world, rank)
+            rmax = sharding.max_local_rows(n, world)
+            pad = np.zeros((2, rmax, n), np.float32)
+            pad[0, :t["image_f"].shape[0]] = t["image_f"]; pad[1, :t["image_g"].shape[0]] = t["image_g"]
+            tiles.append(pad)
+        img = sharding.assemble(tiles, n, world)
+        assert np.array_equal(img[0], whole["image_f"]) and np.array_equal(img[1], whole["image_g"])
+
+
+def test_plain_striping_and_mirror_flag_arguments(capi):
+    """Striping without the mirror flag (rows y0 + j * step ... of the whole image) still traces exactly those rows; a
+    mirrored job must name rows of the upper half; the spectrum and torus jobs refuse the flag."""
+    n, a, inc = 500, 0.9, 60.0
     whole = run(capi, n, a, inc, full=True)
-    tiles = []
-    for rank in range(world):
-        d = capi.image_desc(n, n, a, inc / 180.0 * math.pi, y0=rank * sharding.STRIPE, y1=n,
-                            stripe_rows=sharding.STRIPE, stripe_step=world * sharding.STRIPE)
-        assert capi.image_rows(d) == sharding.local_rows(n, rank, world)
-        t = capi.disk_image(d, full=True)
-        ref = np.concatenate([whole["image_g"][y0:y1] for (y0, y1) in sharding.stripes_for_rank(n, rank, world)])
-        assert np.array_equal(t["image_g"], ref)
-        rmax = sharding.max_local_rows(n, world)
-        pad = np.zeros((2, rmax, n), np.float32)
-        pad[0, :t["image_f"].shape[0]] = t["image_f"]; pad[1, :t["image_g"].shape[0]] = t["image_g"]
-        tiles.append(pad)
-    img = sharding.assemble(tiles, n, world)
-    assert np.array_equal(img[0], whole["image_f"]) and np.array_equal(img[1], whole["image_g"])
+    d = capi.image_desc(n, n, a, math.radians(inc), y0=64, y1=n, stripe_rows=64, stripe_step=192)
+    t = capi.disk_image(d, full=True)
+    rows = [(y, min(n, y + 64)) for y in range(64, n, 192)]
+    assert capi.image_rows(d) == sum(y1 - y0 for y0, y1 in rows)
+    assert np.array_equal(t["image_g"], np.concatenate([whole["image_g"][y0:y1] for y0, y1 in rows]))
+    # mirror without striping: a band of the upper half and its mirror image
+    d = capi.image_desc(n, n, a, math.radians(inc), y0=100, y1=180, mirror=True)
+    t = capi.disk_image(d, full=True)
+    assert capi.image_rows(d) == 160
+    assert np.array_equal(t["flux"], np.concatenate([whole["flux"][100:180], whole["flux"][n - 180:n - 100]]))
+    bad = capi.image_desc(n, n, a, math.radians(inc), y0=100, y1=300, mirror=True)
+    assert capi.image_rows(bad) == 0
+    with pytest.raises(RuntimeError):
+        capi.disk_image(bad)
 
 
 def test_deterministic_and_list_mode(capi):

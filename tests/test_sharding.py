@@ -9,17 +9,38 @@ import pytest
 from sim5_amd import sharding
 
 
-@pytest.mark.parametrize("ny,world", [(4096, 1), (4096, 2), (4096, 8), (100, 3), (64, 8), (65, 2), (1, 4)])
+@pytest.mark.parametrize("ny,world", [(4096, 1), (4096, 2), (4096, 8), (8192, 8), (100, 3), (101, 3), (64, 8), (65, 2),
+                                      (129, 2), (1, 4), (2, 2), (1000, 3), (1001, 3)])
 def test_stripes_partition_the_rows(ny, world):
     seen = np.zeros(ny, int)
     for r in range(world):
-        rows = 0
+        rows, last = 0, 0
+        owned = np.zeros(ny, bool)
         for (y0, y1) in sharding.stripes_for_rank(ny, r, world):
-            assert 0 <= y0 < y1 <= ny
+            assert 0 <= y0 < y1 <= ny and y0 >= last           # increasing row order: the order of the packed output
+            last = y1
             seen[y0:y1] += 1
+            owned[y0:y1] = True
             rows += y1 - y0
         assert rows == sharding.local_rows(ny, r, world) <= sharding.max_local_rows(ny, world)
+        assert np.array_equal(owned, owned[::-1])              # a rank owns the mirror image of every row it owns
+        top = sum(y1 - y0 for (y0, y1) in sharding.top_stripes_for_rank(ny, r, world))
+        assert rows in (2 * top, 2 * top - 1)
     assert (seen == 1).all()
+
+
+def test_library_counts_the_rows_of_a_mirrored_job():
+    """sim5gpu_image_rows (host arithmetic, no GPU needed) agrees with the dealing for the job description bench.py makes"""
+    from sim5_amd import capi
+    for ny, world in [(4096, 8), (1000, 3), (1001, 3), (129, 2), (257, 8), (65, 2)]:
+        for r in range(world):
+            kw = sharding.job_rows(ny, r, world)
+            want = sharding.local_rows(ny, r, world)
+            if kw["y0"] >= kw["y1"]:
+                assert want == 0
+                continue
+            d = capi.image_desc(ny, ny, 0.9, 1.0, **kw)
+            assert capi.image_rows(d) == want, (ny, world, r)
 
 
 def test_assemble_restores_row_order():
