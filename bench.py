@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 SPIN, INCL_DEG = 0.998, 70.0
 W_ELL = 1.3e3                     # algorithmic FP64 ops per elliptic thin-disk ray (an estimate)
+IMAGE_KERNEL = "disk_image_mirror_kernel"   # whole images and mirrored stripe shares (k_disk_image.hip); other row sets: disk_image_grid_kernel
 # the same quantity counted exactly on the reference binary (oracle/opcount.c, profiles/r01_opcount_image.json):
 # 363 add + 207 sub + 419 mul + 165 div + 152 sqrt + 308 compare + 11 x87 + 139 library calls per ray
 W_ELL_MEASURED = 1764.8
@@ -177,7 +178,7 @@ def extra_configs(torch, capi, dev, stream):
     img = torch.zeros((2, n, n), dtype=torch.float32, device=dev)
     d = capi.image_desc(n, n, 0.998, 70.0 * rad)
     ms = timed_kernel(capi, stream, lambda: capi.disk_image_device(d, img[0].data_ptr(), img[1].data_ptr(), stream=stream), 20, 3)
-    out["c2_1024_thin_disk"] = {"kernel": "disk_image_grid_kernel", "kernel_ms": ms, "rays": n * n, "rays_per_s": n * n / ms * 1e3,
+    out["c2_1024_thin_disk"] = {"kernel": IMAGE_KERNEL, "kernel_ms": ms, "rays": n * n, "rays_per_s": n * n / ms * 1e3,
                                 "roofline_frac": n * n * W_ELL / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                 "disk_hits": int((img[1] > 0).sum().item()), "disk_hits_reference": 991579}
     # C3: 2048^2, a = 0.9, i = 70, Stokes I, Q, U in f64
@@ -225,7 +226,7 @@ def c5_on_one_gpu(torch, capi, dev, stream):
         per[str(inc)] = {"kernel_ms": ms, "rays_per_s": n * n / ms * 1e3, "disk_hits": hits, "disk_hits_reference": ref.get(inc)}
         ok = ok and (ref.get(inc) is None or ref[inc] == hits)
         tot += ms
-    return {"kernel": "disk_image_grid_kernel", "images": len(C5_INCLINATIONS), "rays": len(C5_INCLINATIONS) * n * n, "scan_ms": tot,
+    return {"kernel": IMAGE_KERNEL, "images": len(C5_INCLINATIONS), "rays": len(C5_INCLINATIONS) * n * n, "scan_ms": tot,
             "rays_per_s": len(C5_INCLINATIONS) * n * n / tot * 1e3,
             "roofline_frac": len(C5_INCLINATIONS) * n * n * W_ELL / (tot * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
             "per_inclination": per, "hits_ok": ok}
@@ -378,14 +379,18 @@ def main():
     out["roofline"] = {
         "bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-        "kernel": "disk_image_grid_kernel", "kernel_ms_avg": kstep / len(jobs), "algorithmic_flops_per_ray": W_ELL,
+        "kernel": IMAGE_KERNEL, "kernel_ms_avg": kstep / len(jobs), "algorithmic_flops_per_ray": W_ELL,
         "rays_per_launch": rays_launch // len(jobs), "per": "GPU (rank 0)",
         "algorithmic_flops_per_ray_counted_on_reference": W_ELL_MEASURED,
         "achieved_with_counted_flops": achieved * W_ELL_MEASURED / W_ELL,
         "frac_with_counted_flops": achieved * W_ELL_MEASURED / W_ELL / PEAK_FP64_VALU_TFLOPS,
         "hbm_algorithmic_bytes_per_launch": rays_launch // len(jobs) * 8,
         "hbm_achieved_GBps": rays_launch * 8 / (kstep * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
-        "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output",
+        "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output.  achieved = "
+                "algorithmic flops (SURVEY 8(d): 1.3e3 per ray, the reference's per-pixel work) / kernel time; the kernel "
+                "traces a ray and its mirror image in beta in one lane -- they share l, q, the roots and the three R_F "
+                "integrals -- so it EXECUTES fewer FP64 operations per ray than the algorithmic count (DESIGN.md 4: "
+                "measured instructions per ray)",
     }
     if per_rank:
         out["per_rank"] = per_rank

@@ -6,7 +6,7 @@
 TAG=${1:-r01}
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 # the headline launches only (the default bench line also times C2..C5 with the same kernel at other image sizes,
 # which would mix into a per-kernel average); the default command itself is profiled as well, further down
 B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"

@@ -17,7 +17,12 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-KERNEL = "disk_image_grid_kernel"
+# the headline image is traced by the mirror kernel since round 2 (a lane takes a ray and its mirror image in beta);
+# `tag`s collected before that hold the grid kernel
+KERNEL = "disk_image_mirror_kernel"
+for _d in glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")):
+    if "disk_image_mirror_kernel" not in open(_d).read():
+        KERNEL = "disk_image_grid_kernel"
 
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 if stats:
@@ -58,7 +63,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                "note": "2*FETCH_SIZE + WRITE_SIZE, KiB->B, per launch of " + KERNEL},
               open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 # the default bench command (headline + the other configurations): per-kernel statistics as rocprofv3 prints them, and the
-# headline launches picked out of its kernel trace by their grid (256 x 256 workgroups of 256 threads: X = 65536, Y = 256)
+# headline launches picked out of its kernel trace by their grid (256 x 256 workgroups of 256 threads: X = 65536, Y = 256;
+# the mirror kernel covers the upper half: Y = 128)
 dstats = glob.glob(os.path.join(src, "stats_default_cmd", "*", "*kernel_stats.csv"))
 if dstats:
     rows = list(csv.reader(open(dstats[0])))
@@ -69,7 +75,8 @@ if dstats:
 dtrace = glob.glob(os.path.join(src, "stats_default_cmd", "*", "*kernel_trace.csv"))
 if dtrace:
     hd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(dtrace[0]))
-          if KERNEL in r["Kernel_Name"] and r.get("Grid_Size_X") == "65536" and r.get("Grid_Size_Y") == "256"]
+          if KERNEL in r["Kernel_Name"] and r.get("Grid_Size_X") == "65536" and
+          r.get("Grid_Size_Y") == ("128" if "mirror" in KERNEL else "256")]
     out["default_cmd_headline_launches"] = {"launches": len(hd), "kernel_ns_avg": sum(hd) / len(hd) if hd else None}
 dl = os.path.join(src, "stats_default_cmd.log")
 if os.path.exists(dl):

@@ -389,7 +389,10 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
 #pragma unroll 1
-    for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
+#ifndef S5_PAIR_MEMBERS
+#define S5_PAIR_MEMBERS 2
+#endif
+    for (int member = 0; member < (PAIR ? S5_PAIR_MEMBERS : 1); ++member) {
         const double beta_m = (member == 0) ? beta : -beta;
         int cls_m = PX_MISS;
         double r_m = NAN, P_m = NAN, g_m = 0.0, flux_m = 0.0;
