@@ -20,6 +20,64 @@ namespace S5NS {
 
 using namespace s5abi;
 
+// the polarization chain of one traced ray (header comment): Stokes I, Q, U and the angle
+S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const ThinRay& t, double& I, double& Q, double& U,
+                         double& chi)
+{
+    I = 0.0; Q = 0.0; U = 0.0; chi = NAN;
+    if (!(t.cls == PX_HIT0 || t.cls == PX_HIT1)) return;
+    const double g2 = t.g * t.g;
+    I = t.flux * (g2 * g2);
+    // geodesic_momentum(gd, P, r, m = 0): sign of dm/dP from the polar phase, radial sign from P vs Rpc
+    double sdm = (t.beta >= 0.0) ? +1.0 : -1.0;
+    double T = (sdm > 0.0) ? -(t.Tpp - t.Tip) : -(t.Tip);
+    for (int it = 0; it < 4096 && (t.P > T + t.Tpp); ++it) { T += t.Tpp; sdm = -sdm; }
+    double k[4], n[4], floc[4], fv[4], wp[2];
+    photon_momentum(t.a, t.r, 0.0, t.l, t.q, (t.P < t.Rpc ? -1. : +1.), sdm, k);
+    Metric mt;
+    kerr_metric(p.a, t.r, 0.0, mt);
+    Tetrad tt;
+    tetrad_azimuthal(mt, omega_kepler(t.r, p.a), tt);
+    bl2on(k, n, tt);
+    floc[0] = 0.0; floc[1] = n[3]; floc[2] = 0.0; floc[3] = -n[1];
+    on2bl(floc, fv, tt);
+    normalize_to(fv, 1.0, mt);
+    polarization_constant(k, fv, mt, wp);
+#if S5_FAST
+    // chi = atan2(Y, X) with X, Y sharing the positive denominator S^2 + T^2 (ref src/sim5polarization.c:279-283):
+    // the angle needs neither division, cos 2chi = (X^2 - Y^2)/(X^2 + Y^2) and sin 2chi = 2XY/(X^2 + Y^2) need no
+    // angle at all; atan2 is evaluated only when the caller asked for the chi plane.
+    {
+        const double S = -alpha - p.a * p.sin_i, Tb = +beta;
+        const double Xn = -S * wp[1] - Tb * wp[0], Yn = -S * wp[0] + Tb * wp[1];
+        const double rn = mrcp(Xn * Xn + Yn * Yn);
+        Q = p.pol_degree * I * ((Xn - Yn) * (Xn + Yn) * rn);
+        U = p.pol_degree * I * (2.0 * Xn * Yn * rn);
+        if (p.chi) chi = matan2(Yn, Xn);
+    }
+#else
+    chi = polarization_angle_rotation(p.a, p.sin_i, alpha, beta, wp);
+    double s2c, c2c;
+    msincos(2.0 * chi, s2c, c2c);
+    Q = p.pol_degree * I * c2c;
+    U = p.pol_degree * I * s2c;
+#endif
+}
+
+S5_DEV void store_polarized(const ImageParams& p, size_t o, const ThinRay& t, double I, double Q, double U, double chi)
+{
+    const size_t npix = (size_t)p.nrows * (size_t)p.nx;
+    p.stokes[o] = I;
+    p.stokes[npix + o] = Q;
+    p.stokes[2 * npix + o] = U;
+    if (p.chi) p.chi[o] = chi;
+    if (p.cls) p.cls[o] = (uint8_t)t.cls;
+    if (p.gtype) p.gtype[o] = (int8_t)t.gtype;
+    if (p.r) p.r[o] = t.r;
+    if (p.g) p.g[o] = t.g;
+    if (p.flux) p.flux[o] = t.flux;
+}
+
 __global__ __launch_bounds__(256, 2)
 void disk_image_polarized_kernel(ImageParams p)
 {
@@ -28,72 +86,47 @@ void disk_image_polarized_kernel(ImageParams p)
     const int ix = blockIdx.x * 16 + lane_x;
     const int lr = blockIdx.y * 16 + lane_y;                     // packed (local) row
     if (ix >= p.nx || lr >= p.nrows) return;
-    const int iy = image_row(p, lr);
-
-#if S5_FAST
-    const double alpha = (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;       // as the unpolarized kernel
-    const double beta = (((double)(iy) + .5) * p.inv_ny - 0.5) * 2.0 * p.rmax * p.ny_over_nx;
-#else
-    const double alpha = (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
-    const double beta = (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax *
-                        ((double)p.ny / (double)p.nx);
-#endif
-    const size_t npix = (size_t)p.nrows * (size_t)p.nx;
-    const size_t o = (size_t)lr * (size_t)p.nx + (size_t)ix;
-
-    double I = 0.0, Q = 0.0, U = 0.0, chi = NAN;
+    const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, image_row(p, lr));       // as the unpolarized kernel
     ThinRay t;
     trace_thin_disk<true>(p, alpha, beta, t);
-    const int cls = t.cls, gtype = t.gtype;
-    const double r_hit = t.r, g_hit = t.g, f_hit = t.flux;
-    if (cls == PX_HIT0 || cls == PX_HIT1) {
-        const double g2 = t.g * t.g;
-        I = t.flux * (g2 * g2);
-        // geodesic_momentum(gd, P, r, m = 0): sign of dm/dP from the polar phase, radial sign from P vs Rpc
-        double sdm = (t.beta >= 0.0) ? +1.0 : -1.0;
-        double T = (sdm > 0.0) ? -(t.Tpp - t.Tip) : -(t.Tip);
-        for (int it = 0; it < 4096 && (t.P > T + t.Tpp); ++it) { T += t.Tpp; sdm = -sdm; }
-        double k[4], n[4], floc[4], fv[4], wp[2];
-        photon_momentum(t.a, t.r, 0.0, t.l, t.q, (t.P < t.Rpc ? -1. : +1.), sdm, k);
-        Metric mt;
-        kerr_metric(p.a, t.r, 0.0, mt);
-        Tetrad tt;
-        tetrad_azimuthal(mt, omega_kepler(t.r, p.a), tt);
-        bl2on(k, n, tt);
-        floc[0] = 0.0; floc[1] = n[3]; floc[2] = 0.0; floc[3] = -n[1];
-        on2bl(floc, fv, tt);
-        normalize_to(fv, 1.0, mt);
-        polarization_constant(k, fv, mt, wp);
-#if S5_FAST
-        // chi = atan2(Y, X) with X, Y sharing the positive denominator S^2 + T^2 (ref src/sim5polarization.c:279-283):
-        // the angle needs neither division, cos 2chi = (X^2 - Y^2)/(X^2 + Y^2) and sin 2chi = 2XY/(X^2 + Y^2) need no
-        // angle at all; atan2 is evaluated only when the caller asked for the chi plane.
-        {
-            const double S = -alpha - p.a * p.sin_i, T = +beta;
-            const double Xn = -S * wp[1] - T * wp[0], Yn = -S * wp[0] + T * wp[1];
-            const double rn = mrcp(Xn * Xn + Yn * Yn);
-            Q = p.pol_degree * I * ((Xn - Yn) * (Xn + Yn) * rn);
-            U = p.pol_degree * I * (2.0 * Xn * Yn * rn);
-            if (p.chi) chi = matan2(Yn, Xn);
-        }
-#else
-        chi = polarization_angle_rotation(p.a, p.sin_i, alpha, beta, wp);
-        double s2c, c2c;
-        msincos(2.0 * chi, s2c, c2c);
-        Q = p.pol_degree * I * c2c;
-        U = p.pol_degree * I * s2c;
-#endif
-    }
-    p.stokes[o] = I;
-    p.stokes[npix + o] = Q;
-    p.stokes[2 * npix + o] = U;
-    if (p.chi) p.chi[o] = chi;
-    if (p.cls) p.cls[o] = (uint8_t)cls;
-    if (p.gtype) p.gtype[o] = (int8_t)gtype;
-    if (p.r) p.r[o] = r_hit;
-    if (p.g) p.g[o] = g_hit;
-    if (p.flux) p.flux[o] = f_hit;
+    double I, Q, U, chi;
+    polarize_ray(p, alpha, beta, t, I, Q, U, chi);
+    store_polarized(p, (size_t)lr * (size_t)p.nx + (size_t)ix, t, I, Q, U, chi);
 }
+
+#if S5_FAST
+// symmetric row sets (k_disk_image.hip: disk_image_mirror_kernel): the pixel and its mirror image in beta share the geodesic;
+// the polarization chain runs for each of the two, as a loop of two passes over ONE inlined copy
+#ifndef S5_LB_POLAR_MIRROR
+#define S5_LB_POLAR_MIRROR 2
+#endif
+__global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)
+void disk_image_polarized_mirror_kernel(ImageParams p)
+{
+    const int lane_x = threadIdx.x & 15;
+    const int lane_y = threadIdx.x >> 4;
+    const int ix = blockIdx.x * 16 + lane_x;
+    const int lr = blockIdx.y * 16 + lane_y;                     // local row in the upper half
+    const int half = (p.nrows + 1) / 2;
+    if (ix >= p.nx || lr >= half) return;
+    const int lr2 = p.nrows - 1 - lr;
+    const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, image_row_top(p, lr));
+    ThinRay t, t2;
+    trace_thin_disk_impl<true, true>(p, alpha, beta, t, t2);
+#pragma unroll 1
+    for (int member = 0; member < 2; ++member) {
+        if (member == 1 && !wave_any(lr2 != lr)) break;
+        // a copy of the member's record: the chain is instantiated once
+        ThinRay m = t;
+        if (member == 1) m = t2;
+        const double b = (member == 0) ? beta : -beta;
+        double I, Q, U, chi;
+        polarize_ray(p, alpha, b, m, I, Q, U, chi);
+        if (member == 0 || lr2 != lr)
+            store_polarized(p, (size_t)(member == 0 ? lr : lr2) * (size_t)p.nx + (size_t)ix, m, I, Q, U, chi);
+    }
+}
+#endif
 
 } // namespace S5NS
 
@@ -104,6 +137,13 @@ int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream
 #endif
 {
     using namespace S5NS;
+#if S5_FAST && !defined(S5_NO_MIRROR)
+    if ((p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny)) && p.nrows >= 2) {
+        const dim3 grid((p.nx + 15) / 16, ((p.nrows + 1) / 2 + 15) / 16);
+        hipLaunchKernelGGL(disk_image_polarized_mirror_kernel, grid, dim3(256), 0, stream, p);
+        return (int)hipGetLastError();
+    }
+#endif
     const dim3 grid((p.nx + 15) / 16, (p.nrows + 15) / 16);
     hipLaunchKernelGGL(disk_image_polarized_kernel, grid, dim3(256), 0, stream, p);
     return (int)hipGetLastError();

@@ -470,4 +470,26 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     }
 }
 
+// Image-plane coordinates of a pixel (ref disk-image.c:57-58).  The fast variant multiplies by the reciprocals of the
+// image size instead of dividing, and forms beta from the exact odd integer 2 iy + 1 - ny: rows iy and ny - 1 - iy then get
+// beta values that are each other's negatives bit for bit (alpha, beta move by an ulp or two against the reference's
+// expression).  That is what lets the mirrored kernel below give the very image of the plain one.
+S5_DEV double pixel_alpha(const s5abi::ImageParams& p, int ix)
+{
+#if S5_FAST
+    return (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;
+#else
+    return (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
+#endif
+}
+
+S5_DEV double pixel_beta(const s5abi::ImageParams& p, int iy)
+{
+#if S5_FAST
+    return ((double)(2 * iy + 1 - p.ny) * (0.5 * p.inv_ny)) * 2.0 * p.rmax * p.ny_over_nx;
+#else
+    return (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax * ((double)p.ny / (double)p.nx);
+#endif
+}
+
 } // namespace S5NS

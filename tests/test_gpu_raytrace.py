@@ -87,6 +87,29 @@ def test_polarized_image(capi, golden):
     assert np.array_equal(cls.to_numpy(np.uint8, (n, n)), o["cls"])
 
 
+def test_polarized_mirrored_pairs_give_the_plain_image(capi):
+    """A symmetric row range is traced by the pairing kernel (pixel + its mirror image in beta per lane), any other by the
+    plain one: Stokes I, Q, U, the angle and the aux planes must agree bit for bit; odd height included."""
+    def pol(nx, ny, y0, y1, a, inc):
+        d = capi.image_desc(nx, ny, a, math.radians(inc), y0=y0, y1=y1, pol_degree=0.1)
+        rows = y1 - y0
+        N = rows * nx
+        st = capi.DeviceBuffer(3 * N * 8); chi = capi.DeviceBuffer(N * 8); gg = capi.DeviceBuffer(N * 8); cls = capi.DeviceBuffer(N)
+        capi.disk_image_polarized_device(d, st.ptr, chi.ptr, aux={"g": gg.ptr, "cls": cls.ptr})
+        capi.synchronize()
+        return (st.to_numpy(np.float64, (3, rows, nx)), chi.to_numpy(np.float64, (rows, nx)),
+                gg.to_numpy(np.float64, (rows, nx)), cls.to_numpy(np.uint8, (rows, nx)))
+    for (nx, ny, a, inc) in [(200, 128, 0.9, 60.0), (131, 77, 0.998, 75.0)]:
+        S, CH, G, CL = pol(nx, ny, 0, ny, a, inc)
+        cut = ny // 2 + 3
+        S1, CH1, G1, CL1 = pol(nx, ny, 0, cut, a, inc)
+        S2, CH2, G2, CL2 = pol(nx, ny, cut, ny, a, inc)
+        assert np.array_equal(S, np.concatenate([S1, S2], axis=1), equal_nan=True)
+        assert np.array_equal(CH, np.concatenate([CH1, CH2]), equal_nan=True)
+        assert np.array_equal(G, np.concatenate([G1, G2])) and np.array_equal(CL, np.concatenate([CL1, CL2]))
+        assert (S[0] > 0).sum() > 0.3 * nx * ny
+
+
 def torus_desc(capi, n, a, inc_deg, **kw):
     img = capi.image_desc(n, n, a, inc_deg / 180.0 * math.pi)
     d = capi.TorusDesc(img=img, r0=kw.get("r0", 100.0), dl_max=kw.get("dl_max", 1e9),
