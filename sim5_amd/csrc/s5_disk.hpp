@@ -56,6 +56,21 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
 }
 
 #if S5_FAST
+// out of line: taken by a fraction of a per cent of the waves, and inlined it costs the callers' hot loops registers (measured
+// on the image kernel: 7 % of its VALU instructions were moves and re-materialisations around this cold body)
+// (arguments by value: a reference to the constants, which live in SGPRs, would force the whole block into scratch)
+static __device__ __noinline__ double disk_flux_closed_form_cold(double r, double x, double a, double x0, double x1, double x2,
+                                                                 double x3, double p1, double p2, double p3, double inv_x0,
+                                                                 double inv_d1, double inv_d2, double inv_d3, double scale)
+{
+    const double f0 = x - x0 - 1.5 * a * mlog(x * inv_x0);
+    const double f1 = p1 * mlog((x - x1) * inv_d1);
+    const double f2 = p2 * mlog((x - x2) * inv_d2);
+    const double f3 = p3 * mlog((x - x3) * inv_d3);
+    const double F = mdiv(1.5, (4. * M_PI * r) * (x * x * (x * x * x - 3. * x + 2. * a))) * (f0 - f1 - f2 - f3);
+    return scale * F;
+}
+
 // the same with x = sqrt(r) and 1/x supplied by the caller (the g-factor of the same point needs sqrt(r) too)
 S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
 {
@@ -81,9 +96,12 @@ S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
         for (int k = FT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
         F = d.scale * (t * acc);
     }
+#ifndef S5_KO_FLUXCF
     if (wave_any(!tab)) {
-        if (!tab) F = disk_flux_closed_form(d, r, x);
+        if (!tab) F = disk_flux_closed_form_cold(r, x, d.a, d.x0, d.x1, d.x2, d.x3, d.p1, d.p2, d.p3, d.inv_x0, d.inv_d1, d.inv_d2,
+                                                 d.inv_d3, d.scale);
     }
+#endif
     return F;
     }
 }
