@@ -8,11 +8,16 @@ include/sim5gpu.h.
 
 N = 1: a step is one complete image.
 N > 1 (launched by torch.distributed.run, one rank per GPU), default `--mode stripes`, the split BASELINE.json's
-north_star names: ONE image per step, its rows dealt to the ranks in 64-row stripes round-robin
-(sim5_amd/sharding.py; one kernel launch per rank and image) and assembled on rank 0 by ONE RCCL gather per image
-INSIDE the timed region (both planes of a rank's stripes are one contiguous payload; double-buffered, so the
-gather of image i overlaps the tracing of image i+1; every gather has completed before the clock stops).  Total
-work is fixed: "scaling": "strong", `value` = rays of one image * K / max-over-ranks time.
+north_star names: ONE image per step, its rows dealt to the ranks in 64-row stripes round-robin -- in mirrored pairs,
+so that every rank runs the pairing kernel (sim5_amd/sharding.py; one kernel launch per rank and image) -- and
+assembled on rank 0 by ONE RCCL gather per image INSIDE the timed region (both planes of a rank's stripes are one
+contiguous payload; double-buffered, so the gather of image i overlaps the tracing of image i+1; every gather has
+completed before the clock stops).  A GPU writes image rows several times faster than one xGMI link carries them and
+rank 0's own rows need no link, so the split is weighted (`--root-band auto`, sharding.plan_dealt_rows): only the
+outer rows are dealt and gathered, a centred band stays with rank 0, which traces it straight into the assembled image
+while the gather is in flight; the band's size balances a kernel time and a gather time measured before the timed
+region (recorded in per_rank.root_band_plan; `--root-band off` deals everything).  Total work is fixed: "scaling":
+"strong", `value` = rays of one image * K / max-over-ranks time.
 `--mode images` (opt-in) is the other way to use N GPUs: N independent images, one per GPU, no collective
 ("scaling": "weak").
 `--workload c5` is BASELINE.json configs[4]: a step is the inclination scan 10..80 deg of 8192 x 8192 images
@@ -121,40 +126,108 @@ def cpu_baseline(nx, ny, budget_s=12.0):
 
 
 class ImageJob:
-    """One thin-disk image (or this rank's stripes of it) per call of trace(): descriptor + launch."""
+    """One thin-disk image per step: this rank's launches (descriptor + launch each).  N = 1 or --mode images: the whole
+    image.  Striped: the rank's mirrored stripe pairs (sharding.job_rows), and on rank 0 -- when the plan keeps a band
+    of the middle rows with it (sharding.root_band) -- that band as a second launch into the assembled image."""
 
-    def __init__(self, capi, sharding, n, incl_deg, rank, world, striped, stream):
+    def __init__(self, capi, sharding, n, incl_deg, rank, world, striped, stream, dealt=None):
         self.capi, self.n, self.stream = capi, n, stream
         inc = incl_deg / 180.0 * math.pi
+        self.desc = self.band_desc = None
         if striped:
-            self.desc = capi.image_desc(n, n, SPIN, inc, **sharding.job_rows(n, rank, world))
-            assert capi.image_rows(self.desc) == sharding.local_rows(n, rank, world)
+            kw = sharding.job_rows(n, rank, world, dealt=dealt)
+            if kw["y0"] < kw["y1"]:
+                self.desc = capi.image_desc(n, n, SPIN, inc, **kw)
+                assert capi.image_rows(self.desc) == sharding.local_rows(n, rank, world, dealt=dealt)
+            band = sharding.root_band(n, dealt) if rank == 0 else None
+            if band:
+                self.band_desc = capi.image_desc(n, n, SPIN, inc, y0=band[0], y1=band[1])
+            self.rays = sharding.rank_rows(n, rank, world, dealt=dealt) * n      # rays this rank traces per image
         else:
             self.desc = capi.image_desc(n, n, SPIN, inc)
-        self.rays = capi.image_rows(self.desc) * n          # rays of one launch of this rank
+            self.rays = capi.image_rows(self.desc) * n
         self.events = None
         self.used = 0
+        self.band_events = None
+        self.band_used = 0
+
+    def _launch(self, desc, buf):
+        self.capi.disk_image_device(desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=self.stream)
 
     def trace(self, buf):
+        if self.desc is None:
+            return
         if self.events is not None and self.used < len(self.events):
             a, b = self.events[self.used]
             self.used += 1
             a.record(self.stream)
-            self.capi.disk_image_device(self.desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=self.stream)
+            self._launch(self.desc, buf)
             b.record(self.stream)
         else:
-            self.capi.disk_image_device(self.desc, buf[0].data_ptr(), buf[1].data_ptr(), stream=self.stream)
+            self._launch(self.desc, buf)
+
+    def trace_band(self, view):
+        if self.band_events is not None and self.band_used < len(self.band_events):
+            a, b = self.band_events[self.band_used]
+            self.band_used += 1
+            a.record(self.stream)
+            self._launch(self.band_desc, view)
+            b.record(self.stream)
+        else:
+            self._launch(self.band_desc, view)
 
     def start_timing(self, launches):
         """HIP events (created here, outside the timed region) around the next `launches` launches"""
         self.events = [(self.capi.Event(), self.capi.Event()) for _ in range(launches)]
         self.used = 0
+        if self.band_desc is not None:
+            self.band_events = [(self.capi.Event(), self.capi.Event()) for _ in range(launches)]
+            self.band_used = 0
 
     def collect(self):
-        """mean kernel ms over the launches recorded since start_timing() (waits for them)"""
+        """mean kernel ms per image over the launches recorded since start_timing() (waits for them)"""
         kms = [a.elapsed_ms(b) for (a, b) in (self.events or [])[:self.used]]
-        self.events = None
-        return sum(kms) / len(kms) if kms else float("nan")
+        bms = [a.elapsed_ms(b) for (a, b) in (self.band_events or [])[:self.band_used]]
+        self.events = self.band_events = None
+        if not kms and not bms:
+            return 0.0 if self.desc is None and self.band_desc is None else float("nan")
+        return (sum(kms) / len(kms) if kms else 0.0) + (sum(bms) / len(bms) if bms else 0.0)
+
+
+def plan_root_band(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, one_gpu_test, setting):
+    """Rows of the upper half to deal over the ranks (sharding.plan_dealt_rows); the band left in the middle stays with
+    rank 0.  `setting`: "auto" measures one full-image kernel on rank 0 and one gather of an equal split (before the timed
+    region) and balances the two; "off" deals the whole upper half; a number fixes the dealt rows (tests).  Every rank
+    gets rank 0's answer.  Returns (dealt, record)."""
+    half = sharding.upper_half(n)
+    rec = {"setting": setting}
+    if setting == "off":
+        dealt = half
+    elif setting != "auto":
+        dealt = max(1, min(half, int(setting)))
+    else:
+        job = ImageJob(capi, sharding, n, INCL_DEG, rank, 1, False, stream)
+        img = torch.zeros((2, n, n), dtype=torch.float32, device=dev)
+        kms = timed_kernel(capi, stream, lambda: job.trace(img), 5, 2)
+        torch.cuda.synchronize()
+        del img
+        pipe = sharding.TilePipeline(torch, dist, rank, world, n, n, dev, host_staged=one_gpu_test)
+        gms = []
+        for _ in range(3):
+            torch.cuda.synchronize(); dist.barrier()
+            g0 = time.perf_counter()
+            pipe.gather(0, async_op=False)
+            torch.cuda.synchronize()
+            gms.append(1e3 * (time.perf_counter() - g0))
+        del pipe
+        dealt = sharding.plan_dealt_rows(n, world, kms, min(gms))
+        rec.update({"kernel_ms_full_image": kms, "gather_ms_equal_split": min(gms)})
+    t = torch.tensor([float(dealt)], dtype=torch.float64, device=cdev)
+    dist.broadcast(t, src=0)                 # rank 0's measurement decides for everybody
+    dealt = int(t.item())
+    rec["dealt_rows_of_upper_half"] = dealt
+    rec["root_band_rows"] = list(sharding.root_band(n, dealt) or ())
+    return dealt, rec
 
 
 def timed_kernel(capi, stream, launch, reps, warm=1):
@@ -240,6 +313,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2/C3/C4/C5 timings after the headline region")
     ap.add_argument("--workload", choices=["headline", "c5"], default="headline")
+    ap.add_argument("--root-band", default="auto",
+                    help="N > 1, stripes: rows of the upper half dealt over the ranks; the band left in the middle stays with rank 0, "
+                         "which needs no link for it (auto: balanced from a measured kernel and gather | off: deal everything | <rows>)")
     ap.add_argument("--mode", choices=["stripes", "images"], default="stripes",
                     help="N > 1: one image in row stripes + one RCCL gather per image (default) | one complete image per GPU, no collective")
     args = ap.parse_args()
@@ -285,12 +361,15 @@ def main():
     c5 = args.workload == "c5"
     n = 8192 if c5 else 4096
     inclinations = C5_INCLINATIONS if c5 else (INCL_DEG,)
-    jobs = [ImageJob(capi, sharding, n, inc, rank, world, striped, stream) for inc in inclinations]
-    pipe = sharding.TilePipeline(torch, dist, rank, world if striped else 1, n, n, dev, host_staged=one_gpu_test)
+    dealt, plan = None, None
+    if striped:
+        dealt, plan = plan_root_band(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, one_gpu_test, args.root_band)
+    jobs = [ImageJob(capi, sharding, n, inc, rank, world, striped, stream, dealt=dealt) for inc in inclinations]
+    pipe = sharding.TilePipeline(torch, dist, rank, world if striped else 1, n, n, dev, host_staged=one_gpu_test, dealt=dealt)
 
     def step(i):
-        for job in jobs:                    # one image per inclination: trace my stripes, gather (overlapped)
-            pipe.step(job.trace)
+        for job in jobs:                    # one image per inclination: trace my share, gather (overlapped), rank 0: its band
+            pipe.step(job.trace, job.trace_band)
 
     def fence():
         pipe.drain()
@@ -317,7 +396,7 @@ def main():
         dist.all_gather(allv, t)
         dt = max(float(v[0].item()) for v in allv)
         per_rank = {"kernel_ms_per_step": [float(v[1].item()) for v in allv],
-                    "rays_per_launch": [sharding.local_rows(n, r, world) * n if striped else n * n for r in range(world)]}
+                    "rays_per_launch": [sharding.rank_rows(n, r, world, dealt=dealt) * n if striped else n * n for r in range(world)]}
     # one gather on its own (not overlapped), after the timed region: the exchange time next to the compute time
     if striped:
         gms = []
@@ -328,11 +407,12 @@ def main():
             torch.cuda.synchronize()
             gms.append(1e3 * (time.perf_counter() - g0))
         per_rank["gather_ms_alone"] = min(gms)          # meaningful on rank 0 (the receiver); rank 0 reports its own
-        per_rank["gather_payload_bytes_per_rank"] = 2 * sharding.max_local_rows(n, world) * n * 4
+        per_rank["gather_payload_bytes_per_rank"] = 2 * sharding.max_local_rows(n, world, dealt=dealt) * n * 4
+        per_rank["root_band_plan"] = plan
     if rank != 0:
         extra = None
         if world > 1 and not args.no_extra and not c5 and striped:
-            run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test)
+            run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, dealt_4096=dealt)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -360,8 +440,9 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ok": ok,
         "config": {"workload": workload, "rays_per_step": rays,
                    "parallelism": ("1 GPU" if world == 1 else
-                                   "64-row stripes round-robin over %d GPUs + 1 RCCL gather per image (%d per step), overlapped "
-                                   "with the next image" % (world, len(inclinations)) if striped else
+                                   "mirrored pairs of 64-row stripes (rows < %d of the upper half) round-robin over %d GPUs + 1 RCCL gather "
+                                   "per image (%d per step), overlapped with the next image; the centred band of %d rows stays on rank 0"
+                                   % (dealt, world, len(inclinations), n - 2 * dealt) if striped else
                                    "%d independent images, one per GPU, no collective" % world),
                    "disk_hits": hits, "disk_hits_reference": hits_ref},
     }
@@ -401,7 +482,8 @@ def main():
                 extra["c5_8192_x8_inclinations"] = c5_on_one_gpu(torch, capi, dev, stream)
                 ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
             elif striped:
-                extra = {"c5_8192_x8_inclinations": run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test)}
+                extra = {"c5_8192_x8_inclinations": run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test,
+                                                                dealt_4096=dealt)}
                 ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
             else:
                 extra = None
@@ -422,21 +504,25 @@ def main():
         sys.exit(1)
 
 
-def run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, reps=2):
+def run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, reps=2, dealt_4096=None):
     """BASELINE.json configs[4] on all ranks: 8192^2 x 8 inclinations, each image in 64-row stripes over the ranks
     and gathered to rank 0 with one collective per image, overlapped with the tracing of the next image.  Called by
     every rank (collective); rank 0 returns the record."""
     n = 8192
-    jobs = [ImageJob(capi, sharding, n, inc, rank, world, True, stream) for inc in C5_INCLINATIONS]
-    pipe = sharding.TilePipeline(torch, dist, rank, world, n, n, dev, host_staged=one_gpu_test)
+    # the plan of the 4096^2 image carries over: kernel and gather times per row both double with the row length, so the
+    # balance point is the same fraction of the image
+    dealt = None if dealt_4096 is None or dealt_4096 >= sharding.upper_half(4096) else 2 * dealt_4096
+    jobs = [ImageJob(capi, sharding, n, inc, rank, world, True, stream, dealt=dealt) for inc in C5_INCLINATIONS]
+    pipe = sharding.TilePipeline(torch, dist, rank, world, n, n, dev, host_staged=one_gpu_test, dealt=dealt)
     ref = reference_hits_c5()
     hits = {}
 
     def scan(check):
         for job, inc in zip(jobs, C5_INCLINATIONS):
-            pipe.step(job.trace)
+            pipe.step(job.trace, job.trace_band)
             if check and rank == 0:
                 pipe.drain()
+                torch.cuda.synchronize()         # the band is traced by this rank, after the gather was issued
                 hits[inc] = int((pipe.last_image()[1] > 0).sum().item())
         pipe.drain()
         dist.barrier()
@@ -459,7 +545,8 @@ def run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one
     rays = len(C5_INCLINATIONS) * n * n
     return {"images": len(C5_INCLINATIONS), "rays": rays, "scan_ms": 1e3 * dt / reps, "rays_per_s": rays * reps / dt,
             "n_gpus": world, "gathers_per_scan": len(C5_INCLINATIONS),
-            "gather_payload_bytes_per_rank": 2 * sharding.max_local_rows(n, world) * n * 4,
+            "gather_payload_bytes_per_rank": 2 * sharding.max_local_rows(n, world, dealt=dealt) * n * 4,
+            "dealt_rows_of_upper_half": dealt if dealt is not None else sharding.upper_half(n),
             "kernel_ms_per_scan_per_rank": [float(v[1].item()) for v in allv],
             "disk_hits": {str(k_): v for k_, v in hits.items()},
             "hits_ok": all(ref.get(i) is None or ref[i] == h for i, h in hits.items())}

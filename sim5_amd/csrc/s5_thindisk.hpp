@@ -338,9 +338,11 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
             for (int k = KT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
             res1 = acc;
         }
+#ifndef S5_KO_KAGM
         if (wave_any(!tab)) {
             if (!tab) res1 = ell_K(mmT);
         }
+#endif
     }
 #endif
     double K = res1;

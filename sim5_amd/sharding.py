@@ -22,20 +22,25 @@ def upper_half(ny):
     return (ny + 1) // 2
 
 
-def top_stripes_for_rank(ny, rank, world, stripe=STRIPE):
-    """[(y0, y1), ...] row ranges of the upper half owned by `rank`, in increasing row order."""
+def _dealt(ny, dealt):
+    return upper_half(ny) if dealt is None else dealt
+
+
+def top_stripes_for_rank(ny, rank, world, stripe=STRIPE, dealt=None):
+    """[(y0, y1), ...] row ranges of the upper half owned by `rank`, in increasing row order.  Only the rows
+    [0, dealt) are dealt (default: the whole upper half); see root_band()."""
     out = []
-    half = upper_half(ny)
+    half = _dealt(ny, dealt)
     nstripes = (half + stripe - 1) // stripe
     for s in range(rank, nstripes, world):
         out.append((s * stripe, min(half, (s + 1) * stripe)))
     return out
 
 
-def stripes_for_rank(ny, rank, world, stripe=STRIPE):
-    """[(y0, y1), ...] ALL image-row ranges owned by `rank` (upper-half stripes and their mirrors), in increasing
+def stripes_for_rank(ny, rank, world, stripe=STRIPE, dealt=None):
+    """[(y0, y1), ...] ALL dealt image-row ranges owned by `rank` (upper-half stripes and their mirrors), in increasing
     row order -- the order of the rows in the rank's packed output."""
-    top = top_stripes_for_rank(ny, rank, world, stripe)
+    top = top_stripes_for_rank(ny, rank, world, stripe, dealt)
     mid = (ny - 1) // 2 if ny % 2 == 1 else -1
     bottom = []
     for (y0, y1) in reversed(top):
@@ -47,60 +52,117 @@ def stripes_for_rank(ny, rank, world, stripe=STRIPE):
     return top + bottom
 
 
-def job_rows(ny, rank, world, stripe=STRIPE):
+def job_rows(ny, rank, world, stripe=STRIPE, dealt=None):
     """keyword arguments of capi.image_desc for this rank's share: rows of the upper half + SIM5GPU_IMG_MIRROR"""
-    return dict(y0=rank * stripe, y1=upper_half(ny), stripe_rows=stripe, stripe_step=world * stripe, mirror=True)
+    return dict(y0=rank * stripe, y1=_dealt(ny, dealt), stripe_rows=stripe, stripe_step=world * stripe, mirror=True)
 
 
-def local_rows(ny, rank, world, stripe=STRIPE):
-    return sum(y1 - y0 for (y0, y1) in stripes_for_rank(ny, rank, world, stripe))
+def root_band(ny, dealt=None):
+    """(y0, y1) of the centred band of rows that is NOT dealt and stays with rank 0, or None.
+
+    A gather to rank 0 moves every row but rank 0's own over the links, and a GPU writes image rows several times
+    faster than one xGMI link carries them, so an equal split leaves rank 0 waiting for the gather.  With dealt <
+    upper_half(ny) only the rows [0, dealt) and their mirrors are dealt round-robin (and gathered); the band
+    [dealt, ny - dealt) in the middle is traced by rank 0 straight into the assembled image while the gather of the dealt
+    rows is in flight (plan_dealt_rows() balances the two).  A centred band is a symmetric row range, so it takes the
+    pairing kernel without a flag."""
+    d = _dealt(ny, dealt)
+    return (d, ny - d) if ny - d > d else None
 
 
-def max_local_rows(ny, world, stripe=STRIPE):
-    return max(local_rows(ny, r, world, stripe) for r in range(world))
+def plan_dealt_rows(ny, world, kernel_ms_full_image, gather_ms_equal_split, stripe=STRIPE):
+    """Rows of the upper half to deal so that rank 0's tracing (its share + the band) takes as long as the gather of the
+    other ranks' shares.  Inputs: the time of ONE full-image kernel on one GPU and of ONE gather of an equal split
+    (payload ny / world rows per rank), both measured by the caller.  Per row: c_k = kernel / ny on a GPU, c_g =
+    gather / (ny / world) over a link (the links of rank 0 work in parallel: the time is set by one rank's payload).
+    Rank 0 traces ny - 2 d (1 - 1/world) rows, a peer sends 2 d / world rows:
+        (ny - 2 d (1 - 1/world)) c_k = (2 d / world) c_g   ->   d = ny c_k / (2 ((1 - 1/world) c_k + c_g / world)).
+    Taken at the whole number of rounds of stripes (every rank the same number of stripes) next to that point which
+    gives the shorter step, at least one round; no band at all if the links keep up."""
+    half = upper_half(ny)
+    unit = stripe * world
+    if world <= 1 or half < unit or not (kernel_ms_full_image > 0) or not (gather_ms_equal_split >= 0):
+        return half
+    c_k = kernel_ms_full_image / ny
+    c_g = gather_ms_equal_split / (ny / world)
+    d = ny * c_k / (2.0 * ((1.0 - 1.0 / world) * c_k + c_g / world))
+    top = (half // unit) * unit
+    lo = int(d // unit) * unit
+    best, best_t = half, None
+    for cand in (lo, lo + unit, half):              # whole rounds of stripes next to the balance point, or no band at all
+        if cand != half and not (unit <= cand <= top and cand < half):
+            continue
+        root_rows = ny - 2 * cand * (1.0 - 1.0 / world) if cand != half else ny / world
+        peer_rows = 2.0 * cand / world if cand != half else ny / world
+        t = max(root_rows * c_k, peer_rows * c_g)
+        if best_t is None or t < best_t:
+            best, best_t = cand, t
+    return best
 
 
-def assemble(tiles, ny, world, stripe=STRIPE):
+def local_rows(ny, rank, world, stripe=STRIPE, dealt=None):
+    return sum(y1 - y0 for (y0, y1) in stripes_for_rank(ny, rank, world, stripe, dealt))
+
+
+def max_local_rows(ny, world, stripe=STRIPE, dealt=None):
+    return max(local_rows(ny, r, world, stripe, dealt) for r in range(world))
+
+
+def rank_rows(ny, rank, world, stripe=STRIPE, dealt=None):
+    """rows a rank traces per image: its dealt share, plus the band on rank 0"""
+    band = root_band(ny, dealt) if rank == 0 else None
+    return local_rows(ny, rank, world, stripe, dealt) + ((band[1] - band[0]) if band else 0)
+
+
+def assemble(tiles, ny, world, stripe=STRIPE, dealt=None, out=None):
     """Rank-0 side: put the gathered per-rank tile buffers back into image row order.
 
-    tiles[r] has shape [..., >= local_rows(r), nx] (rows of rank r's stripes, concatenated).
+    tiles[r] has shape [..., >= local_rows(r), nx] (rows of rank r's stripes, concatenated).  `out`, if given, is the
+    [..., ny, nx] image that already holds rank 0's band (root_band()); the dealt rows are written into it.
     Works for numpy arrays and torch tensors alike (slicing + assignment only).
     """
     first = tiles[0]
-    out = first.new_zeros(first.shape[:-2] + (ny, first.shape[-1])) if hasattr(first, "new_zeros") \
-        else __import__("numpy").zeros(first.shape[:-2] + (ny, first.shape[-1]), dtype=first.dtype)
+    if out is None:
+        out = first.new_zeros(first.shape[:-2] + (ny, first.shape[-1])) if hasattr(first, "new_zeros") \
+            else __import__("numpy").zeros(first.shape[:-2] + (ny, first.shape[-1]), dtype=first.dtype)
     for r in range(world):
         off = 0
-        for (y0, y1) in stripes_for_rank(ny, r, world, stripe):
+        for (y0, y1) in stripes_for_rank(ny, r, world, stripe, dealt):
             out[..., y0:y1, :] = tiles[r][..., off:off + (y1 - y0), :]
             off += y1 - y0
     return out
 
 
 class TilePipeline:
-    """Double-buffered "trace my stripes, gather them to rank 0" loop shared by bench.py and the CPU
+    """Double-buffered "trace my share, gather the shares to rank 0" loop shared by bench.py and the CPU
     (gloo) test.  `trace(buffer)` must enqueue the work that fills `buffer` ([2, rows_max, nx] tensor);
     the gather of image i is issued asynchronously and overlaps the tracing of image i+1; `drain()`
     waits for every outstanding gather.  With world == 1 there is no gather and a single buffer.
 
+    dealt < upper_half(ny): rank 0 additionally traces the centred band root_band(ny, dealt) into its own [2, ny, nx]
+    image with `trace_band(view)`, AFTER the gather of its share has been issued, so that the two overlap.
+
     host_staged=True is the one-GPU test hook of bench.py: the tile is copied to the host and gathered
     synchronously over gloo (RCCL refuses two ranks on one device); same control flow, same buffers."""
 
-    def __init__(self, torch, dist, rank, world, ny, nx, device, dtype=None, host_staged=False):
+    def __init__(self, torch, dist, rank, world, ny, nx, device, dtype=None, host_staged=False, dealt=None):
         self.dist, self.rank, self.world, self.ny = dist, rank, world, ny
         self.host_staged = host_staged and world > 1
+        self.dealt = dealt if world > 1 else None
         dtype = dtype or torch.float32
-        rows_max = max_local_rows(ny, world)
+        rows_max = max(1, max_local_rows(ny, world, dealt=self.dealt))
         self.nbuf = 2 if world > 1 else 1
         self.tiles = [torch.zeros((2, rows_max, nx), dtype=dtype, device=device) for _ in range(self.nbuf)]
         gdev = "cpu" if self.host_staged else device
         self.gathered = [[torch.zeros((2, rows_max, nx), dtype=dtype, device=gdev) for _ in range(world)]
                          for _ in range(self.nbuf)] if (world > 1 and rank == 0) else [None] * self.nbuf
+        self.band = root_band(ny, self.dealt) if (world > 1 and rank == 0) else None
+        self.full = [torch.zeros((2, ny, nx), dtype=dtype, device=device) for _ in range(self.nbuf)] if self.band else None
         self.pending = [None] * self.nbuf
         self.count = 0
         self.gathers = 0
 
-    def step(self, trace):
+    def step(self, trace, trace_band=None):
         b = self.count % self.nbuf
         if self.pending[b] is not None:
             self.pending[b].wait()              # the gather that last read this buffer has finished
@@ -108,6 +170,8 @@ class TilePipeline:
         trace(self.tiles[b])
         if self.world > 1:
             self.gather(b)
+        if self.band:                           # rank 0 only: its band, while the gather is in flight
+            trace_band(self.full[b][:, self.band[0]:self.band[1]])
         self.count += 1
 
     def gather(self, b, async_op=True):
@@ -127,8 +191,11 @@ class TilePipeline:
                 self.pending[b] = None
 
     def last_image(self):
-        """Rank 0: the most recent complete image, [2, ny, nx] (call after drain())."""
+        """Rank 0: the most recent complete image, [2, ny, nx] (call after drain() and a device synchronisation)."""
         b = (self.count - 1) % self.nbuf
         if self.world == 1:
             return self.tiles[b][:, :self.ny]
-        return assemble(self.gathered[b], self.ny, self.world)
+        if self.band:
+            tiles = [t.to(self.full[b].device) for t in self.gathered[b]] if self.host_staged else self.gathered[b]
+            return assemble(tiles, self.ny, self.world, dealt=self.dealt, out=self.full[b])
+        return assemble(self.gathered[b], self.ny, self.world, dealt=self.dealt)

@@ -41,11 +41,12 @@ def test_single_gpu_line_carries_every_config():
     assert all(v["disk_hits"] == v["disk_hits_reference"] for v in c5["per_inclination"].values())
 
 
-@pytest.mark.parametrize("mode", ["stripes", "images"])
-def test_two_ranks_on_one_gpu(mode):
+@pytest.mark.parametrize("mode,band", [("stripes", "auto"), ("stripes", "off"), ("stripes", "512"), ("images", "auto")])
+def test_two_ranks_on_one_gpu(mode, band):
     env = dict(os.environ, SIM5_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode]
+           "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode,
+           "--root-band", band] + (["--no-extra"] if band == "512" else [])
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     o = _line(r.stdout)
@@ -55,8 +56,18 @@ def test_two_ranks_on_one_gpu(mode):
         pr = o["per_rank"]
         assert len(pr["kernel_ms_per_step"]) == 2 and sum(pr["rays_per_launch"]) == 4096 * 4096
         assert pr["gather_ms_alone"] > 0
-        c5 = o["extra"]["c5_8192_x8_inclinations"]
-        assert c5["hits_ok"] and c5["n_gpus"] == 2 and len(c5["disk_hits"]) == 8 and c5["gathers_per_scan"] == 8
+        plan = pr["root_band_plan"]
+        dealt = plan["dealt_rows_of_upper_half"]
+        assert pr["rays_per_launch"][0] == (4096 - dealt) * 4096 and pr["rays_per_launch"][1] == dealt * 4096
+        if band == "off":
+            assert dealt == 2048 and plan["root_band_rows"] == []
+        elif band == "512":
+            assert dealt == 512 and plan["root_band_rows"] == [512, 3584]
+        else:
+            assert dealt % 128 == 0 and plan["kernel_ms_full_image"] > 0 and plan["gather_ms_equal_split"] > 0
+        if band != "512":
+            c5 = o["extra"]["c5_8192_x8_inclinations"]
+            assert c5["hits_ok"] and c5["n_gpus"] == 2 and len(c5["disk_hits"]) == 8 and c5["gathers_per_scan"] == 8
     else:
         assert o["scaling"] == "weak" and o["config"]["rays_per_step"] == 2 * 4096 * 4096
 

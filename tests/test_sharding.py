@@ -29,6 +29,38 @@ def test_stripes_partition_the_rows(ny, world):
     assert (seen == 1).all()
 
 
+@pytest.mark.parametrize("ny,world,dealt", [(4096, 8, 1536), (4096, 2, 640), (4096, 4, 1024), (1001, 3, 192), (200, 2, 128 - 64),
+                                            (8192, 8, 2560), (4096, 8, 2048)])
+def test_root_band_plus_dealt_rows_partition_the_image(ny, world, dealt):
+    """weighted split: rows [0, dealt) of the upper half and their mirrors are dealt, the band in the middle is rank 0's"""
+    seen = np.zeros(ny, int)
+    for r in range(world):
+        for (y0, y1) in sharding.stripes_for_rank(ny, r, world, dealt=dealt):
+            seen[y0:y1] += 1
+        assert sharding.rank_rows(ny, r, world, dealt=dealt) == sharding.local_rows(ny, r, world, dealt=dealt) + (
+            (ny - 2 * dealt) if (r == 0 and sharding.root_band(ny, dealt)) else 0)
+    band = sharding.root_band(ny, dealt)
+    if band:
+        assert band == (dealt, ny - dealt)
+        seen[band[0]:band[1]] += 1
+    assert (seen == 1).all()
+    assert sum(sharding.rank_rows(ny, r, world, dealt=dealt) for r in range(world)) == ny
+
+
+def test_plan_balances_root_tracing_and_gather():
+    # links much slower than the kernel: most of the image stays on rank 0; fast links: equal split, no band
+    for world in (2, 4, 8):
+        d = sharding.plan_dealt_rows(4096, world, 0.48, 1.1 * 2 / world)
+        assert d % (64 * world) == 0 and 64 * world <= d < 2048
+        root = sharding.rank_rows(4096, 0, world, dealt=d) * 0.48 / 4096
+        peer = sharding.rank_rows(4096, 1, world, dealt=d) * (1.1 * 2 / world) / (4096 / world)
+        assert 0.5 < root / peer < 2.0, (world, d, root, peer)
+        assert sharding.plan_dealt_rows(4096, world, 0.48, 1e-4) == 2048 and sharding.root_band(4096, 2048) is None
+    assert sharding.plan_dealt_rows(4096, 1, 0.5, 0.5) == 2048
+    assert sharding.plan_dealt_rows(100, 3, 1.0, 5.0) == 50            # fewer rows than one round of stripes: plain split
+    assert sharding.plan_dealt_rows(4096, 8, float("nan"), 1.0) == 2048
+
+
 def test_library_counts_the_rows_of_a_mirrored_job():
     """sim5gpu_image_rows (host arithmetic, no GPU needed) agrees with the dealing for the job description bench.py makes"""
     from sim5_amd import capi
@@ -85,18 +117,24 @@ def _worker(rank, world, port, ny, nx, q):
     dist.destroy_process_group()
 
 
-def _pipeline_worker(rank, world, port, ny, nx, nimages, q, host_staged=False):
+def _pipeline_worker(rank, world, port, ny, nx, nimages, q, host_staged=False, dealt=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    pipe = sharding.TilePipeline(torch, dist, rank, world, ny, nx, torch.device("cpu"), host_staged=host_staged)
+    pipe = sharding.TilePipeline(torch, dist, rank, world, ny, nx, torch.device("cpu"), host_staged=host_staged, dealt=dealt)
     state = {"img": 0}
+
+    def trace_band(view):                         # rank 0 only: the band [dealt, ny - dealt) of the image being made
+        y0, y1 = sharding.root_band(ny, dealt)
+        rows = torch.arange(y0, y1, dtype=torch.float32)[:, None] * nx + torch.arange(nx, dtype=torch.float32)[None, :]
+        view[0] = rows + 1e6 * (state["img"] - 1)
+        view[1] = -rows
 
     def trace(buf):                               # stand-in kernel: value = image number * 1e6 + row * nx + col
         off = 0
-        for (y0, y1) in sharding.stripes_for_rank(ny, rank, world):
+        for (y0, y1) in sharding.stripes_for_rank(ny, rank, world, dealt=dealt):
             rows = torch.arange(y0, y1, dtype=torch.float32)[:, None] * nx + torch.arange(nx, dtype=torch.float32)[None, :]
             buf[0, off:off + y1 - y0] = rows + 1e6 * state["img"]
             buf[1, off:off + y1 - y0] = -rows
@@ -104,7 +142,7 @@ def _pipeline_worker(rank, world, port, ny, nx, nimages, q, host_staged=False):
         state["img"] += 1
 
     for _ in range(nimages):
-        pipe.step(trace)
+        pipe.step(trace, trace_band)
     pipe.drain()
     dist.barrier()
     if rank == 0:
@@ -114,15 +152,16 @@ def _pipeline_worker(rank, world, port, ny, nx, nimages, q, host_staged=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nimages,host_staged", [(1, False), (4, False), (5, False), (3, True)])
-def test_overlapped_gather_pipeline_gloo(nimages, host_staged):
+@pytest.mark.parametrize("nimages,host_staged,dealt", [(1, False, None), (4, False, None), (5, False, None), (3, True, None),
+                                                       (4, False, 64), (3, True, 64), (2, False, 100)])
+def test_overlapped_gather_pipeline_gloo(nimages, host_staged, dealt):
     """The bench's double-buffered trace/gather loop with world size 2 on CPU (host_staged: the synchronous,
     host-staged gather of bench.py's one-GPU test hook)."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 200, 16, nimages, q, host_staged)) for r in range(2)]
+    ps = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 200, 16, nimages, q, host_staged, dealt)) for r in range(2)]
     for p in ps:
         p.start()
     ok = q.get(timeout=120)
