@@ -42,7 +42,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.c
             e.setdefault("pmc_mean_per_launch", {})[c] = sum(v) / len(v)
 out = {}
 for k, e in kern.items():
-    if not any(s in k for s in ("disk_", "torus_", "spectrum", "map_rays")):
+    if not any(s in k for s in ("disk_", "torus_", "spectrum", "map_rays", "surface_")):
         continue
     ns = e.pop("ns")
     e["kernel_ns_avg"] = sum(ns) / len(ns) if ns else None

@@ -91,8 +91,8 @@ void disk_image_grid_kernel(ImageParams p)
 // beta only and share the geodesic (trace_thin_disk_impl<.., PAIR>) -- about two thirds of a ray's arithmetic.  The image
 // is the plain kernel's bit for bit (pixel_beta above); an odd middle row is its own mirror and is written once.
 #ifndef S5_LB_WAVES_MIRROR
-#define S5_LB_WAVES_MIRROR 4             // the pair needs 132 VGPRs by itself; capped at 128 for the fourth wave per SIMD
-                                         // (no scratch).  Measured, 4096^2, same call: 0.527 -> 0.478 ms
+#define S5_LB_WAVES_MIRROR 4             // four waves per SIMD (the kernel needs 112 VGPRs, no scratch).  Measured, 4096^2, same
+                                         // call: 0.527 ms at three -> 0.478 ms
 #endif
 __global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
 void disk_image_mirror_kernel(ImageParams p)

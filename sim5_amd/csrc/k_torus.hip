@@ -379,13 +379,22 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
                     double dl;
                     bool advanced;
                     Metric g;                                      // metric at the end point of the step
+#ifdef S5_KO_RK4                 // diagnostic builds only (register budget of the two bodies)
+                    if (false) {
+                        dl = 0.0;
+#else
                     if (run == 0 && do_rk4) {
                         dl = next_step_size(k, p.dl_max, s);      // the value the rejected attempt used
                         rk4_step(x, k, dl, s, g);
+#endif
                         if (!s.opt_gr) flat_metric(x[1], x[2], g); // RK4 leaves the Kerr metric (ref :305); the fluid lives in the flat one
                         advanced = true;
                     } else {
+#ifdef S5_KO_VERLET
+                        advanced = false; dl = 0.0;
+#else
                         advanced = verlet_attempt(x, k, p.dl_max, dl, s, g);
+#endif
                     }
 #ifdef S5_TORUS_DEBUG
                     {
@@ -402,12 +411,16 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
                     } else {
                         tag = TAG_V;
                         worst = fmaxf(worst, s.error);
+#ifndef S5_KO_TRANSFER
                         accumulate_transfer(p, s, g, x, k, dl, I, tau);
+#endif
                         const bool done = !(x[1] > r_in) || !(x[1] < r_out) || ((double)s.error > p.max_error) ||
                                           (s.pass >= p.max_steps);
                         if (done) {
                             s.Q = sc[COL_Q * scap + ray];
+#ifndef S5_KO_END
                             write_ray_end(aux, out, ray, x, k, s, I, tau, worst);
+#endif
                             tag = TAG_EMPTY; on = false;
                         }
                     }

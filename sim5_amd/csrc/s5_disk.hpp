@@ -56,34 +56,19 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
 }
 
 #if S5_FAST
-// out of line: taken by a fraction of a per cent of the waves, and inlined it costs the callers' hot loops registers (measured
-// on the image kernel: 7 % of its VALU instructions were moves and re-materialisations around this cold body)
-// (arguments by value: a reference to the constants, which live in SGPRs, would force the whole block into scratch)
-static __device__ __noinline__ double disk_flux_closed_form_cold(double r, double x, double a, double x0, double x1, double x2,
-                                                                 double x3, double p1, double p2, double p3, double inv_x0,
-                                                                 double inv_d1, double inv_d2, double inv_d3, double scale)
+// The radial profile from the host's table (kernels.hpp, capi_core.hip: F / (scale (x - x0)) as polynomials of
+// degree FT_DEG on FT_N equal intervals of w = x0 / x): one reciprocal square root, eight loads of one 64-byte
+// row, seven FMAs -- instead of four logarithms and a division.  Lanes the table must not serve -- within 2e-4
+// of the inner edge in x, where the reference's own double evaluation is rounding noise that parity reproduces,
+// and beyond x = 16 -- are reported through `closed_form` and take disk_flux_closed_form(d, r, x).
+S5_DEV double disk_flux_table(const DiskConsts& d, double r, double x, double rx, bool& closed_form)
 {
-    const double f0 = x - x0 - 1.5 * a * mlog(x * inv_x0);
-    const double f1 = p1 * mlog((x - x1) * inv_d1);
-    const double f2 = p2 * mlog((x - x2) * inv_d2);
-    const double f3 = p3 * mlog((x - x3) * inv_d3);
-    const double F = mdiv(1.5, (4. * M_PI * r) * (x * x * (x * x * x - 3. * x + 2. * a))) * (f0 - f1 - f2 - f3);
-    return scale * F;
-}
-
-// the same with x = sqrt(r) and 1/x supplied by the caller (the g-factor of the same point needs sqrt(r) too)
-S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
-{
+    closed_form = false;
     if (r <= d.rms) return 0.0;
-    {
-    // The radial profile from the host's table (kernels.hpp, capi_core.hip: F / (scale (x - x0)) as polynomials of
-    // degree FT_DEG on FT_N equal intervals of w = x0 / x): one reciprocal square root, eight loads of one 64-byte
-    // row, seven FMAs -- instead of four logarithms and a division.  Lanes the table must not serve -- within 2e-4
-    // of the inner edge in x, where the reference's own double evaluation is rounding noise that parity reproduces,
-    // and beyond x = 16 -- take the closed form, their wave with them.
     const double t = x - d.x0;
     const double w = d.x0 * rx;
     const bool tab = (d.ftab != nullptr) && (t > 2e-4) && (w > d.ft_wmin);
+    closed_form = !tab;
     double F = 0.0;
     if (tab) {
         const double u = (w - d.ft_wmin) * d.ft_inv_dw;
@@ -96,14 +81,23 @@ S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
         for (int k = FT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
         F = d.scale * (t * acc);
     }
+    return F;
+}
+
+// the same with x = sqrt(r) and 1/x supplied by the caller (the g-factor of the same point needs sqrt(r) too); the lanes the
+// table does not serve take the closed form here, their wave with them.  (The image kernels call disk_flux_table and
+// do that AFTER their per-ray loop: inlined into the loop, the cold closed form cost its hot path 7 % of its VALU
+// instructions in moves around a body that 0.09 % of the waves run -- measured; out of line as a function it needs a stack.)
+S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
+{
+    bool cf;
+    double F = disk_flux_table(d, r, x, rx, cf);
 #ifndef S5_KO_FLUXCF
-    if (wave_any(!tab)) {
-        if (!tab) F = disk_flux_closed_form_cold(r, x, d.a, d.x0, d.x1, d.x2, d.x3, d.p1, d.p2, d.p3, d.inv_x0, d.inv_d1, d.inv_d2,
-                                                 d.inv_d3, d.scale);
+    if (wave_any(cf)) {
+        if (cf) F = disk_flux_closed_form(d, r, x);
     }
 #endif
     return F;
-    }
 }
 #endif
 

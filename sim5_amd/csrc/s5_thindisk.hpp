@@ -390,14 +390,16 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #ifndef S5_KO_RAD
     if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
-#pragma unroll 1
 #ifndef S5_PAIR_MEMBERS
-#define S5_PAIR_MEMBERS 2
+#define S5_PAIR_MEMBERS 2                    // 1: timing experiments only (the mirror image is not traced)
 #endif
+    bool cf0 = false, cf1 = false;
+#pragma unroll 1
     for (int member = 0; member < (PAIR ? S5_PAIR_MEMBERS : 1); ++member) {
         const double beta_m = (member == 0) ? beta : -beta;
         int cls_m = PX_MISS;
         double r_m = NAN, P_m = NAN, g_m = 0.0, flux_m = 0.0;
+        bool cf_m = false;                      // fast variant: the flux of this ray is owed by the closed form (below)
         bool done = false;
 #pragma unroll 1
         for (int order = 0; order < p.max_order; ++order) {
@@ -453,7 +455,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
             double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
             sqrt_rsqrt_pos(r_m, x, rx);                   // r >= rms > 0
             g_m = gfactor_kepler_x(r_m, x, a_in, l);
-            flux_m = disk_flux_x(p.disk, r_m, x, rx);
+            flux_m = disk_flux_table(p.disk, r_m, x, rx, cf_m);
 #else
 #ifdef S5_KO_G
             g_m = 0.5 + 1e-3 * r_m;
@@ -467,9 +469,16 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #endif
 #endif
         }
-        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; }
-        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; }
+        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; cf0 = cf_m; }
+        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; cf1 = cf_m; }
     }
+#if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
+    // the closed form of the flux for the few rays the table does not serve (s5_disk.hpp), outside the loop above
+    if (wave_any(cf0 || cf1)) {
+        if (cf0) { double x, rx; sqrt_rsqrt_pos(out.r, x, rx); out.flux = disk_flux_closed_form(p.disk, out.r, x); }
+        if (PAIR && cf1) { double x, rx; sqrt_rsqrt_pos(out2.r, x, rx); out2.flux = disk_flux_closed_form(p.disk, out2.r, x); }
+    }
+#endif
 }
 
 // Image-plane coordinates of a pixel (ref disk-image.c:57-58).  The fast variant multiplies by the reciprocals of the
