@@ -261,7 +261,7 @@ def extra_configs(torch, capi, dev, stream):
     d = capi.image_desc(n, n, 0.9, 70.0 * rad, pol_degree=0.1)
     ms = timed_kernel(capi, stream, lambda: capi.disk_image_polarized_device(d, st.data_ptr(), None, aux={"g": gpl.data_ptr()},
                                                                              stream=stream), 10, 2)
-    out["c3_2048_polarized"] = {"kernel": "disk_image_polarized_kernel", "kernel_ms": ms, "rays": n * n, "rays_per_s": n * n / ms * 1e3,
+    out["c3_2048_polarized"] = {"kernel": "disk_image_polarized_mirror_kernel", "kernel_ms": ms, "rays": n * n, "rays_per_s": n * n / ms * 1e3,
                                 "roofline_frac": n * n * (W_ELL + W_POL) / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                 "disk_hits": int((gpl > 0).sum().item()), "disk_hits_reference": 3871553 + 5993}
     del st, gpl

@@ -4,11 +4,14 @@
 //   geodesic_init_inf -> geodesic_find_midplane_crossing -> geodesic_position_rad ->
 //   gfactorK / disk_nt_flux
 // i.e. the body of the caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105,
-// for up to max_order crossings, and writes (float)(F g^4) and (float)g.
+// for up to max_order crossings, and writes (float)(F g^4) and (float)g.  Where the row set is symmetric about the
+// middle of the image (whole images, centred bands, SIM5GPU_IMG_MIRROR jobs) the fast variant gives a lane the ray AND its
+// mirror image in beta: they share the geodesic (disk_image_mirror_kernel below, s5_thindisk.hpp).
 //
 // Launch geometry: a 256-thread workgroup covers a 16 x 16 pixel tile, each wave64 a 16 x 4
 // patch of it.  Rays of a wave are image-plane neighbours, so they share the geodesic class and
-// the Carlson trip counts almost always (measured lane utilisation 98 %); each wave row stores 16
+// the Carlson trip counts almost always (measured lane utilisation 97 % in the plain kernel, 87 % in the mirrored one,
+// where the per-ray part -- whose lanes differ in the rungs of their ladders -- weighs more); each wave row stores 16
 // consecutive f32 = half a 128-B line per plane, the workgroup whole lines.  No input is read in grid mode
 // (alpha, beta follow from the pixel index, ref disk-image.c:57-58); in list mode alpha[]/beta[] are read
 // coalesced, 8 B per lane.
@@ -63,7 +66,7 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
                                          // 64x1 0.909
 #endif
 #ifndef S5_LB_WAVES
-#define S5_LB_WAVES 2                    // a floor only: the kernel needs 111 VGPRs and 40 KB of LDS per workgroup
+#define S5_LB_WAVES 2                    // a floor only: the kernel needs 105 VGPRs and 32 KB of LDS per workgroup
                                          // (ladder rungs), so 4 waves/SIMD are resident.  Occupancy is not a lever:
                                          // 4 -> 6 waves/SIMD (shorter ladder) 0.922 -> 0.915 ms; forcing 8 spills.
 #endif

@@ -21,7 +21,8 @@
 //
 //  * a wave whose lanes all have the same class (the usual case: image neighbours) takes an instantiation of
 //    the second half of the routine with the class as a compile-time constant (thin_disk_finish<.., KNOWN>);
-//  * the Landen ladder keeps its rungs in LDS (sncndn_lds): 256-thread one-dimensional workgroups only.
+//  * the Landen ladder keeps its rungs in LDS (thin_disk_ladder_column): 256-thread one-dimensional workgroups only;
+//    it is climbed once per ray and descended once per crossing tried (and per ray of a mirrored pair, below).
 //
 // The per-ray state that callers need afterwards (polarization, tests) is returned in ThinRay.
 #pragma once
