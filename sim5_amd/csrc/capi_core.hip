@@ -79,7 +79,7 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot, double alpha)
     d.scale = 9.1721376255e+28 * d.mdot / d.mass;
     d.alpha = f_alpha;
     d.a2f = (double)(f_spin * f_spin);
-    d.ftab = nullptr; d.ft_wmin = 0.0; d.ft_inv_dw = 0.0;
+    d.ftab = nullptr; d.cold = nullptr; d.ft_wmin = 0.0; d.ft_inv_dw = 0.0;
     d.ready = 1;
     return d;
 }
@@ -95,9 +95,13 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot, double alpha)
 // the table must not be used: within 2e-4 of x0, where the reference's own double evaluation is a rounding-noise
 // pattern that parity has to reproduce, and beyond x = 16.  8 KB per spin, kept per device for the last few spins.
 namespace {
-struct FluxTable { int dev; double a; double* ptr; };
-FluxTable g_ftab[16];
-int g_ftab_n = 0, g_ftab_next = 0;
+// One device block per (device, disk model): the COLD_N constants of the closed form (read from memory by the image
+// kernels' rare closed-form lanes, so that they do not occupy ~30 SGPRs of every wave for the whole kernel), then the
+// table.  FT_SLOTS models per device, replaced round robin.
+constexpr int FT_SLOTS = 8, FT_DEVICES = 64;
+struct FluxTable { bool used; double a, scale; double* ptr; bool usable; };
+FluxTable g_ftab[FT_DEVICES][FT_SLOTS];
+int g_ftab_next[FT_DEVICES];
 std::mutex g_ftab_lock;
 
 // f on [lo, hi] as N polynomials of degree DEG in the local coordinate tau in [-1, 1] of N equal intervals: Chebyshev
@@ -209,38 +213,44 @@ int attach_flux_table(DiskConsts& d)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return SIM5GPU_E_HIP;
+    if (dev < 0 || dev >= FT_DEVICES) { snprintf(g_err, sizeof g_err, "device %d: more than %d devices", dev, FT_DEVICES); return SIM5GPU_E_ARG; }
     std::lock_guard<std::mutex> hold(g_ftab_lock);
     const double wmin = d.x0 / 16.0;
     d.ft_wmin = wmin;
     d.ft_inv_dw = (double)s5abi::FT_N / (1.0 - wmin);
-    for (int i = 0; i < g_ftab_n; i++)
-        if (g_ftab[i].dev == dev && g_ftab[i].a == d.a) { d.ftab = g_ftab[i].ptr; return SIM5GPU_OK; }
+    FluxTable* T = g_ftab[dev];
+    for (int i = 0; i < FT_SLOTS; i++)
+        if (T[i].used && T[i].a == d.a && T[i].scale == d.scale) {
+            d.cold = T[i].ptr;
+            d.ftab = T[i].usable ? T[i].ptr + s5abi::COLD_N : nullptr;
+            return SIM5GPU_OK;
+        }
     std::vector<double> tab;
     const double fit_error = build_flux_table(d, wmin, tab);
-    double* ptr = nullptr;
     // towards a = 1 the inner edge approaches the logarithmic singularity at x1 and the uniform grid stops resolving
-    // the profile (1e-10 at a = 0.998, 1e-8 at 0.9995): such spins keep the closed form (remembered as a NULL table)
+    // the profile (1e-10 at a = 0.998, 1e-8 at 0.9995): such spins keep the closed form (remembered as a block without table)
     const bool usable = (fit_error <= 2e-9);
-    hipError_t e = hipSuccess;
-    if (usable) {
-        e = hipMalloc((void**)&ptr, tab.size() * sizeof(double));
-        if (e == hipSuccess) e = hipMemcpy(ptr, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
-    }
+    std::vector<double> block(s5abi::COLD_N, 0.0);
+    const double cold[] = { d.a, d.x0, d.x1, d.x2, d.x3, d.p1, d.p2, d.p3, d.inv_x0, d.inv_d1, d.inv_d2, d.inv_d3, d.scale };
+    static_assert(sizeof cold / sizeof cold[0] <= s5abi::COLD_N, "cold block");
+    for (size_t i = 0; i < sizeof cold / sizeof cold[0]; i++) block[i] = cold[i];
+    if (usable) block.insert(block.end(), tab.begin(), tab.end());
+    double* ptr = nullptr;
+    hipError_t e = hipMalloc((void**)&ptr, block.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(ptr, block.data(), block.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) { if (ptr) (void)hipFree(ptr); set_error("flux table", e); return SIM5GPU_E_HIP; }
     int slot = -1;
-    if (g_ftab_n < 16) slot = g_ftab_n++;
-    else {
-        // a table of THIS device goes (round robin); a kernel still reading it was queued before this call: wait for the device
-        for (int k = 0; k < 16 && slot < 0; k++) {
-            const int c = (g_ftab_next + k) % 16;
-            if (g_ftab[c].dev == dev) { slot = c; g_ftab_next = (c + 1) % 16; }
-        }
-        if (slot < 0) { if (ptr) (void)hipFree(ptr); d.ftab = nullptr; return SIM5GPU_OK; }     // cache full of other devices' tables: closed form
+    for (int i = 0; i < FT_SLOTS && slot < 0; i++) if (!T[i].used) slot = i;
+    if (slot < 0) {
+        // the oldest block of THIS device goes; a kernel still reading it was queued before this call: wait for the device
+        slot = g_ftab_next[dev];
+        g_ftab_next[dev] = (slot + 1) % FT_SLOTS;
         (void)hipDeviceSynchronize();
-        if (g_ftab[slot].ptr) (void)hipFree(g_ftab[slot].ptr);
+        if (T[slot].ptr) (void)hipFree(T[slot].ptr);
     }
-    g_ftab[slot].dev = dev; g_ftab[slot].a = d.a; g_ftab[slot].ptr = ptr;
-    d.ftab = ptr;
+    T[slot].used = true; T[slot].a = d.a; T[slot].scale = d.scale; T[slot].ptr = ptr; T[slot].usable = usable;
+    d.cold = ptr;
+    d.ftab = usable ? ptr + s5abi::COLD_N : nullptr;
     return SIM5GPU_OK;
 }
 

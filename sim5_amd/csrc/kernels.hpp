@@ -11,6 +11,7 @@ namespace s5abi {
 enum : int { PX_ERROR = 0, PX_NAN0 = 1, PX_HIT0 = 2, PX_NAN1 = 3, PX_HIT1 = 4, PX_MISS = 5 };
 
 // Novikov-Thorne disk folded to constants on the host (see s5_disk.hpp); wave-uniform (SGPRs)
+constexpr int COLD_N = 16;            // doubles at the head of a disk model's device block (DiskConsts::cold)
 constexpr int FT_N = 128, FT_DEG = 7;
 constexpr int KT_N = 128, KT_DEG = 7;          // K(m) table: [0, KT_MMAX] in KT_N intervals, degree KT_DEG
 constexpr double KT_MMAX = 0.9;
@@ -32,6 +33,10 @@ struct DiskConsts {
     // covering x0 <= x <= 16; NULL = evaluate the closed form
     const double* ftab;
     double ft_wmin, ft_inv_dw;
+    // the constants of the closed form once more, in DEVICE memory (a, x0, x1, x2, x3, p1, p2, p3, inv_x0, inv_d1, inv_d2,
+    // inv_d3, scale): the image kernels' fast variant reads them from here in the rare lanes that need the closed form,
+    // instead of holding them in SGPRs through the whole kernel.  Set by attach_flux_table (capi_core.hip)
+    const double* cold;
     int    ready;
 };
 

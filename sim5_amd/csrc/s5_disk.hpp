@@ -84,6 +84,19 @@ S5_DEV double disk_flux_table(const DiskConsts& d, double r, double x, double rx
     return F;
 }
 
+// the closed form (fast expression above) with its constants read from the disk model's device block
+// (DiskConsts::cold: a, x0, x1, x2, x3, p1, p2, p3, inv_x0, inv_d1, inv_d2, inv_d3, scale) -- same operations, same values
+S5_DEV double disk_flux_closed_form_mem(const double* __restrict__ c, double r, double x)
+{
+    const double a = c[0], x0 = c[1];
+    const double f0 = x - x0 - 1.5 * a * mlog(x * c[8]);
+    const double f1 = c[5] * mlog((x - c[2]) * c[9]);
+    const double f2 = c[6] * mlog((x - c[3]) * c[10]);
+    const double f3 = c[7] * mlog((x - c[4]) * c[11]);
+    const double F = mdiv(1.5, (4. * M_PI * r) * (x * x * (x * x * x - 3. * x + 2. * a))) * (f0 - f1 - f2 - f3);
+    return c[12] * F;
+}
+
 // the same with x = sqrt(r) and 1/x supplied by the caller (the g-factor of the same point needs sqrt(r) too); the lanes the
 // table does not serve take the closed form here, their wave with them.  (The image kernels call disk_flux_table and
 // do that AFTER their per-ray loop: inlined into the loop, the cold closed form cost its hot path 7 % of its VALU

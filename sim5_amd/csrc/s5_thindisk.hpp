@@ -476,8 +476,11 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
     // the closed form of the flux for the few rays the table does not serve (s5_disk.hpp), outside the loop above
     if (wave_any(cf0 || cf1)) {
-        if (cf0) { double x, rx; sqrt_rsqrt_pos(out.r, x, rx); out.flux = disk_flux_closed_form(p.disk, out.r, x); }
-        if (PAIR && cf1) { double x, rx; sqrt_rsqrt_pos(out2.r, x, rx); out2.flux = disk_flux_closed_form(p.disk, out2.r, x); }
+        // constants from the disk model's device block, not from the kernel arguments: referenced here they would sit in
+        // ~30 SGPRs of every wave from the first instruction (the launchers always attach the block: capi_core.hip)
+        const double* cold = p.disk.cold;
+        if (cf0) { double x, rx; sqrt_rsqrt_pos(out.r, x, rx); out.flux = cold ? disk_flux_closed_form_mem(cold, out.r, x) : NAN; }
+        if (PAIR && cf1) { double x, rx; sqrt_rsqrt_pos(out2.r, x, rx); out2.flux = cold ? disk_flux_closed_form_mem(cold, out2.r, x) : NAN; }
     }
 #endif
 }
