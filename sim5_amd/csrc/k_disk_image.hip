@@ -10,8 +10,7 @@
 //
 // Launch geometry: a 256-thread workgroup covers a 16 x 16 pixel tile, each wave64 a 16 x 4
 // patch of it.  Rays of a wave are image-plane neighbours, so they share the geodesic class and
-// the Carlson trip counts almost always (measured lane utilisation 97 % in the plain kernel, 87 % in the mirrored one,
-// where the per-ray part -- whose lanes differ in the rungs of their ladders -- weighs more); each wave row stores 16
+// the Carlson trip counts almost always (measured lane utilisation 97 % in both kernels); each wave row stores 16
 // consecutive f32 = half a 128-B line per plane, the workgroup whole lines.  No input is read in grid mode
 // (alpha, beta follow from the pixel index, ref disk-image.c:57-58); in list mode alpha[]/beta[] are read
 // coalesced, 8 B per lane.

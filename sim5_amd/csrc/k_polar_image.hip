@@ -98,7 +98,7 @@ void disk_image_polarized_kernel(ImageParams p)
 // symmetric row sets (k_disk_image.hip: disk_image_mirror_kernel): the pixel and its mirror image in beta share the geodesic;
 // the polarization chain runs for each of the two, as a loop of two passes over ONE inlined copy
 #ifndef S5_LB_POLAR_MIRROR
-#define S5_LB_POLAR_MIRROR 2
+#define S5_LB_POLAR_MIRROR 4                // 131 VGPRs by itself; capped at 128 for the fourth wave per SIMD (no scratch): -3 %
 #endif
 __global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)
 void disk_image_polarized_mirror_kernel(ImageParams p)
@@ -113,7 +113,11 @@ void disk_image_polarized_mirror_kernel(ImageParams p)
     const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, image_row_top(p, lr));
     ThinRay t, t2;
     trace_thin_disk_impl<true, true>(p, alpha, beta, t, t2);
+#ifdef S5_POLAR_ROLLED
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
     for (int member = 0; member < 2; ++member) {
         if (member == 1 && !wave_any(lr2 != lr)) break;
         // a copy of the member's record: the chain is instantiated once
