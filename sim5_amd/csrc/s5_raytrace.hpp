@@ -89,7 +89,11 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
 #endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ki[i] = 0.0; di[i] = 0.0; sx[i] = 0.0; sk[i] = 0.0; }
+#ifdef S5_RK4_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int stage = 0; stage < 4; ++stage) {
         const double off = (stage == 0) ? 0.0 : (stage == 3) ? dl : h;
         const double wgt = (stage == 1 || stage == 2) ? 2.0 : 1.0;

@@ -290,7 +290,13 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     const bool plain2 = icn_plain(u_i, mmT);
     const bool need3 = ok && (type == T_RC) && plain0 && !(zR > 0.0);
     double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
+    // unrolled: three inlined R_F bodies (slot 1 is the table, slot 3 rare).  Rolled into one body it once saved the kernel
+    // from 256 VGPRs and spills; at today's 108 VGPRs the copies cost nothing and the rolled loop costs 4 % (measured)
+#ifdef S5_SLOT_ROLLED
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
     for (int slot = 0; slot < 4; ++slot) {
 #if S5_F_AGMK
         if (slot == 1) continue;                         // K(mmT) comes from the AGM below
