@@ -287,6 +287,39 @@ def kat_kerr(ref, rng):
 
 
 # ------------------------------------------------------------------------------------------
+def kat_vectors(ref):
+    """dotprod (Kerr and flat metric, ref src/sim5kerr.c:506-524), vector_norm_to (:553-573: time-like, null and
+    space-like targets) and Omega_from_ell (:1062-1067) of the reference on 800 random metrics and vectors"""
+    rng = np.random.default_rng(20261004)
+    n = 800
+    a = rng.choice([0.0, 0.3, 0.9, 0.998], n)
+    r = (1.0 + np.sqrt(1 - a * a)) * (1.02 + 40.0 * rng.random(n) ** 2)
+    m = rng.uniform(-0.99, 0.99, n)
+    met = np.zeros((n, 8))
+    v1 = rng.normal(size=(n, 4)); v2 = rng.normal(size=(n, 4))
+    dot = np.zeros(n); dot_flat = np.zeros(n)
+    norm = rng.choice([-1.0, 0.0, 1.0, 2.5], n)
+    vn = np.zeros((n, 4)); vn_flat = np.zeros((n, 4))
+    ell = rng.uniform(-3.0, 5.0, n); Om = np.zeros(n)
+    for i in range(n):
+        g = ol.Metric()
+        ref.kerr_metric(a[i], r[i], m[i], C.byref(g))
+        met[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        # vector_norm_to needs a vector of the target's character: force the sign of V.V of v1
+        w = v1[i].copy()
+        if norm[i] < 0: w[0] = 5.0 + abs(w[0]); w[1:] *= 0.05 / (1.0 + r[i])     # time-like (a few stay space-like in the ergosphere: NaN, kept)
+        elif norm[i] > 0: w[0] = 0.0                            # space-like: no t part
+        v1[i] = w
+        dot[i] = ref.dotprod(ol.D4(*v1[i]), ol.D4(*v2[i]), C.byref(g))
+        dot_flat[i] = ref.dotprod(ol.D4(*v1[i]), ol.D4(*v2[i]), None)
+        vv = ol.D4(*w); ref.vector_norm_to(vv, norm[i], C.byref(g)); vn[i] = list(vv)
+        vf = ol.D4(*w); ref.vector_norm_to(vf, norm[i], None); vn_flat[i] = list(vf)
+        Om[i] = ref.Omega_from_ell(ell[i], C.byref(g))
+    save("kat_vectors.npz", a=a, r=r, m=m, metric=met, v1=v1, v2=v2, dot=dot, dot_flat=dot_flat, norm=norm,
+         vn=vn, vn_flat=vn_flat, ell=ell, Omega=Om)
+
+
+# ------------------------------------------------------------------------------------------
 def kat_disk(ref, rng):
     out = {}
     spins = [0.0, 0.5, 0.9, 0.998]
@@ -658,6 +691,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "torus":
             torus_c4()
             return
+        if len(sys.argv) > 1 and sys.argv[1] == "vectors":
+            kat_vectors(ref)
+            return
         kat_elliptic(ref, rng)
         kat_geodesic(ref, rng)
         kat_kerr(ref, rng)
@@ -670,6 +706,7 @@ def main():
         kat_init_src()
         torus_c4()
         kat_disk_model()
+        kat_vectors(ref)
     finally:
         os.dup2(saved, 2)
 

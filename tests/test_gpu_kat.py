@@ -156,6 +156,24 @@ def test_position_azm_timedelay_random_vs_oracle(capi, oracle):
     assert_close(dt, ref_dt, floor=1e-6, what="timedelay vs oracle")
 
 
+def test_vectors(capi, golden):
+    """sim5gpu_dotprod (Kerr and NULL = flat metric), sim5gpu_vector_norm_to and sim5gpu_Omega_from_ell against the
+    reference's values on 800 random metrics and vectors (tests/golden/kat_vectors.npz); NaN where the reference has NaN"""
+    g = golden("kat_vectors.npz")
+    met = np.frombuffer(np.ascontiguousarray(g["metric"]).tobytes(), dtype=capi.METRIC_DTYPE)
+    assert_close(capi.dotprod(g["v1"], g["v2"], met), g["dot"], floor=1e-12, what="dotprod")
+    assert_close(capi.dotprod(g["v1"], g["v2"], None), g["dot_flat"], floor=1e-12, what="dotprod flat")
+    vn = capi.vector_norm_to(g["v1"], g["norm"], met)
+    bad = np.isnan(g["vn"]).any(axis=1)
+    assert np.array_equal(np.isnan(vn).any(axis=1), bad) and bad.sum() < 40
+    assert_close(vn[~bad], g["vn"][~bad], floor=1e-12, what="vector_norm_to")
+    # the scaled vectors do have the norm asked for
+    chk = capi.dotprod(vn[~bad], vn[~bad], met[~bad])
+    assert np.max(np.abs(chk - g["norm"][~bad])) < 1e-9
+    assert_close(capi.vector_norm_to(g["v1"], g["norm"], None), g["vn_flat"], floor=1e-12, what="vector_norm_to flat")
+    assert_close(capi.Omega_from_ell(g["ell"], met), g["Omega"], floor=1e-12, what="Omega_from_ell")
+
+
 def test_kerr(capi, golden):
     g = golden("kat_kerr.npz")
     a, r, m = g["a"], g["r"], g["m"]

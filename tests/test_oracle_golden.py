@@ -150,6 +150,26 @@ def test_azimuth_and_timedelay(oracle, golden):
     assert np.isfinite(g["phi"]).sum() > 2000 and np.isfinite(g["dt_auto"]).sum() > 2000
 
 
+def test_vectors(oracle, golden):
+    """dotprod (Kerr / flat), vector_norm_to (time-like, null, space-like targets; NaN where the reference gives NaN) and
+    Omega_from_ell of the CPU restatement against the reference's values, 800 random metrics"""
+    g = golden("kat_vectors.npz")
+    for i in range(len(g["a"])):
+        mt = ol.Metric()
+        oracle.kerr_metric(g["a"][i], g["r"][i], g["m"][i], C.byref(mt))
+        close(np.frombuffer(ol.struct_bytes(mt), np.float64), g["metric"][i], what="metric")
+        v1, v2 = ol.D4(*g["v1"][i]), ol.D4(*g["v2"][i])
+        close(oracle.dotprod(v1, v2, C.byref(mt)), g["dot"][i], what="dotprod")
+        close(oracle.dotprod(v1, v2, None), g["dot_flat"][i], what="dotprod flat")
+        w = ol.D4(*g["v1"][i]); oracle.vector_norm_to(w, g["norm"][i], C.byref(mt))
+        assert np.array_equal(np.isnan(list(w)), np.isnan(g["vn"][i]))
+        if not np.isnan(g["vn"][i]).any():
+            close(list(w), g["vn"][i], what="vector_norm_to")
+        w = ol.D4(*g["v1"][i]); oracle.vector_norm_to(w, g["norm"][i], None)
+        close(list(w), g["vn_flat"][i], what="vector_norm_to flat")
+        close(oracle.Omega_from_ell(g["ell"][i], C.byref(mt)), g["Omega"][i], what="Omega_from_ell")
+
+
 def test_kerr(oracle, golden):
     g = golden("kat_kerr.npz")
     n = len(g["a"])
