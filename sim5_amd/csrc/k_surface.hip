@@ -17,7 +17,7 @@
 // (GeodTrack, s5_geod.hpp): a sub-step costs two ladder descents instead of two full sncndn evaluations
 // (ref src/sim5kerr-geod.c:891-960, geodesic_follow only changes P).  In the fast variant most sub-steps do not even
 // descend: consecutive points are close, so the two triples (sn, cn, dn) are advanced by the addition theorems
-// (GeodTrack::Along) and the full evaluation re-anchors them every 24 sub-steps.
+// (GeodTrack::Along) and the full evaluation re-anchors them every 48 sub-steps.
 //
 // FOUR kernels per job, the per-ray state between them in a workspace in HBM (the geodesic record and ~100 B of walk
 // state per ray): a register allocation is the maximum over everything a kernel inlines, and the set-up (closed-form
@@ -131,7 +131,7 @@ S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clam
     // ANCHOR_EVERY sub-steps of the WAVE (a wave-uniform count, so that the lanes take the expensive branch together)
     // and whenever a lane's sub-step is too long for the series
 #ifndef S5_ANCHOR_EVERY
-#define S5_ANCHOR_EVERY 24
+#define S5_ANCHOR_EVERY 48
 #endif
     constexpr int ANCHOR_EVERY = S5_ANCHOR_EVERY;
     typename Eval::Along along;

@@ -472,7 +472,7 @@ struct GeodTrack {
     // one it is -sdm sn and -sdm cn that are kept: the half-period shifts of position_pol (T += Tpp, sdm = -sdm)
     // change the sign of sn, cn and sdm together, so these products are continuous functions of P and the phase
     // bookkeeping drops out.  The caller re-anchors with the full evaluation (anchor(): the very values of rad(), pol())
-    // every few dozen sub-steps, which bounds the accumulated rounding (a few ulp per sub-step) near 1e-14, and
+    // every few dozen sub-steps, which bounds the accumulated rounding (a few ulp per sub-step) near 2e-14, and
     // whenever step_is_small() says the series does not apply.
 #ifndef S5_ALONG_LONG
 #define S5_ALONG_LONG 0
