@@ -217,6 +217,44 @@ def test_torus_kernel_matches_cpu_integration(capi, strict, absorb0):
         assert S[:, 4].max() > 1.0            # optically thick lines of sight are in the sample
 
 
+def test_random_torus_jobs(capi):
+    """25 random step-wise jobs (spin 0.01 ... 0.998, inclination 10 ... 85 deg, r0 40 ... 200, precision 1 ... 0.03, images of 6^2
+    ... 27^2 rays, torus size, with and without absorption; tests/tools/fuzz_torus.py runs the open-ended version: 100 jobs,
+    28 760 rays, no finding): the step count of EVERY ray equals the CPU checker's raytrace() loop in both variants; end
+    radius within 1e-6 (strict) / 1e-5 (fast), Stokes I within 1e-5 of the image's peak.  Left out and counted: rays with
+    alpha = 0 exactly (central column of an odd-sized image), whose start-up is degenerate in the reference itself (l = 0:
+    it returns garbage states or rejects the ray, depending on rounding)."""
+    rng = np.random.default_rng(2027)
+    left_out = 0
+    for case in range(25):
+        a = float(rng.choice([0.1, 0.3, 0.9, 0.998, rng.uniform(0.01, 0.99)]))
+        inc = float(rng.uniform(10.0, 85.0))
+        n = int(rng.integers(6, 28))
+        r0 = float(rng.uniform(40.0, 200.0))
+        prec = float(rng.choice([1.0, 1.0, 0.3, 0.1, 0.03]))
+        absorb0 = float(rng.choice([0.0, 0.3]))
+        tr, tw = float(rng.uniform(5.0, 12.0)), float(rng.uniform(1.0, 3.0))
+        what = (case, a, inc, n, r0, prec, absorb0, tr, tw)
+        rmax = ol.Oracle().r_ms(a) + 8.0
+        c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+        al, be = np.tile(c, n), np.repeat(c, n)
+        ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, r0=r0, precision=prec, absorb0=absorb0,
+                             torus_r=tr, torus_w=tw)
+        regular = al != 0.0
+        for strict in (True, False):
+            d = torus_desc(capi, n, a, inc, r0=r0, precision=prec, absorb0=absorb0, torus_r=tr, torus_w=tw)
+            if strict:
+                d.img.flags = 1
+            S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
+            left_out += int(((steps != ref["steps"]) & ~regular).sum())
+            assert np.array_equal(steps[regular], ref["steps"][regular]), what + (strict,)
+            m = regular & (steps > 0)
+            if m.any():
+                assert np.abs(xe[m, 1] / ref["x_end"][m, 1] - 1).max() < (1e-6 if strict else 1e-5), what + (strict,)
+                assert (np.abs(S[m, 0] - ref["I"][m]) / max(float(ref["I"].max()), 1e-300)).max() < 1e-5, what + (strict,)
+    print("alpha = 0 rays with another step count than the CPU loop (left out): %d" % left_out)
+
+
 @pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
 def test_c4_full_size(capi, golden, strict):
     """BASELINE.json configs[3] at its full size: 1024 x 1024 rays through the torus (the real job: 2 048 persistent

@@ -1,0 +1,62 @@
+"""Randomised parity campaign for the step-wise job (run on the GPU box; not part of the suite): random spin, inclination,
+start radius, precision, image size, torus and absorption; per case the GPU job (strict and fast variants) against the CPU
+checker's raytrace() loop on the same rays (oracle/cpu_driver.c:cpu_torus_rays): step counts ray by ray, end point and Stokes I
+of the rays with equal counts.
+usage: python tests/tools/fuzz_torus.py [n_cases] [seed]"""
+import sys, math, time, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sim5_amd.capi as capi
+import oraclelib as ol
+import gen_golden_access as gga
+import test_gpu_raytrace as T
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+bad = 0
+tot_rays = {"strict": 0, "fast": 0}; tot_diff = {"strict": 0, "fast": 0}; degenerate_diff = {"strict": 0, "fast": 0}
+t0 = time.time()
+for case in range(ncases):
+    a = float(rng.choice([0.1, 0.3, 0.9, 0.998, rng.uniform(0.01, 0.99)]))
+    inc = float(rng.uniform(10.0, 85.0))
+    n = int(rng.integers(6, 28))
+    r0 = float(rng.uniform(40.0, 200.0))
+    prec = float(rng.choice([1.0, 1.0, 0.3, 0.1, 0.03]))
+    absorb0 = float(rng.choice([0.0, 0.3]))
+    tr, tw = float(rng.uniform(5.0, 12.0)), float(rng.uniform(1.0, 3.0))
+    rmax = ol.Oracle().r_ms(a) + 8.0
+    c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+    al, be = np.tile(c, n), np.repeat(c, n)
+    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, r0=r0, precision=prec,
+                         absorb0=absorb0, torus_r=tr, torus_w=tw)
+    # alpha = 0 (central column of an odd-sized image): l = 0, the start-up of the ray is degenerate in the reference itself
+    # (it returns garbage states or rejects the ray depending on rounding) -- left out, counted
+    regular = (al != 0.0)
+    msg = []
+    for strict in (True, False):
+        d = T.torus_desc(capi, n, a, inc, r0=r0, precision=prec, absorb0=absorb0, torus_r=tr, torus_w=tw)
+        if strict:
+            d.img.flags = 1
+        S, steps, xe, ce, me, ke = T.run_torus(capi, d, full=True)
+        tag = "strict" if strict else "fast"
+        same = (steps == ref["steps"]) | ~regular
+        degenerate_diff[tag] += int(((steps != ref["steps"]) & ~regular).sum())
+        if not same.all():
+            med = max(1.0, float(np.median(ref["steps"][ref["steps"] > 0]))) if (ref["steps"] > 0).any() else 1.0
+            msg.append("%s: %d of %d step counts differ (by %s; their counts are %.1f-%.1f x the median)" % (
+                tag, int((~same).sum()), same.size, sorted(set((steps - ref["steps"])[~same].tolist()))[:5],
+                float(np.minimum(steps, ref["steps"])[~same].min() / med), float(np.maximum(steps, ref["steps"])[~same].max() / med)))
+        tot_rays[tag] += same.size; tot_diff[tag] += int((~same).sum())
+        m = same & (steps > 0) & regular
+        if m.any():
+            er = np.abs(xe[m, 1] / ref["x_end"][m, 1] - 1).max()
+            eI = (np.abs(S[m, 0] - ref["I"][m]) / max(float(ref["I"].max()), 1e-300)).max()
+            if er > (1e-6 if strict else 1e-5) or eI > 1e-5:
+                w = np.nonzero(m)[0][np.argmax(np.abs(xe[m, 1] / ref["x_end"][m, 1] - 1))]
+                msg.append("%s: r_end %.1e I %.1e (ray alpha %.3f beta %.3f: %d steps, median %d)" % (
+                    tag, er, eI, al[w], be[w], steps[w], int(np.median(ref["steps"]))))
+    print("case %3d a=%.4g inc=%.1f n=%d r0=%.0f prec=%g absorb=%g torus(%.1f,%.1f) mean steps %.0f : %s" % (
+        case, a, inc, n, r0, prec, absorb0, tr, tw, ref["steps"].mean(), "ok" if not msg else "; ".join(msg)), flush=True)
+    bad += bool(msg)
+print("%d cases, %d with findings, %.0f s; rays with another step count than the CPU loop: strict %d of %d, fast %d of %d" % (
+    ncases, bad, time.time() - t0, tot_diff["strict"], tot_rays["strict"], tot_diff["fast"], tot_rays["fast"]))
+print("alpha = 0 rays with another count (left out above): strict %d, fast %d" % (degenerate_diff["strict"], degenerate_diff["fast"]))
