@@ -351,12 +351,22 @@ int cpu_verlet_trace(const char *libpath, const char *prefix, double a, double i
  * Outputs per ray (any may be NULL): steps (0 = the ray could not be started), x_end[4], k_end[4], I, tau,
  * raytrace_error() at the end, largest rtd.error seen.
  */
-int cpu_torus_rays(const char *libpath, const char *prefix, double a, double inc_rad, int n,
+static double shift_ulps(double v, int ulps)
+{
+    for (; ulps > 0; ulps--) v = nextafter(v, INFINITY);
+    for (; ulps < 0; ulps++) v = nextafter(v, -INFINITY);
+    return v;
+}
+
+/* `ulps` (NULL or 8 ints): the start state (x[0..3], k[0..3]) is moved by that many units in the last place before
+ * raytrace_prepare() -- the conditioning probe of the parity tests: how far does the checker's OWN end state move when
+ * its start state changes in the last bit? */
+static int torus_rays_impl(const char *libpath, const char *prefix, double a, double inc_rad, int n,
                    const double *alpha, const double *beta, double r0, double precision, int options,
                    double dl_max, double r_in, double r_out, double max_error, int max_steps,
                    int shape, double torus_r, double torus_w, double torus_l, double emis0, double absorb0,
                    int *steps, double *x_end, double *k_end, double *I_out, double *tau_out,
-                   double *carter, float *max_step_error)
+                   double *carter, float *max_step_error, const int *ulps)
 {
     api_t A; void *h;
     int rc = load_api(libpath, prefix, &A, &h);
@@ -375,6 +385,7 @@ int cpu_torus_rays(const char *libpath, const char *prefix, double a, double inc
             if (!isnan(k[0]) && !isnan(x[2])) {
                 rtd_t rtd;
                 memset(&rtd, 0, sizeof rtd);
+                if (ulps) for (int c = 0; c < 4; c++) { x[c] = shift_ulps(x[c], ulps[c]); k[c] = shift_ulps(k[c], ulps[4 + c]); }
                 A.rt_prepare(a, x, k, precision, options, &rtd);
                 while (made < max_steps) {
                     double dl = dl_max;
@@ -418,4 +429,28 @@ int cpu_torus_rays(const char *libpath, const char *prefix, double a, double inc
         if (max_step_error) max_step_error[i] = worst;
     }
     return 0;
+}
+
+int cpu_torus_rays(const char *libpath, const char *prefix, double a, double inc_rad, int n,
+                   const double *alpha, const double *beta, double r0, double precision, int options,
+                   double dl_max, double r_in, double r_out, double max_error, int max_steps,
+                   int shape, double torus_r, double torus_w, double torus_l, double emis0, double absorb0,
+                   int *steps, double *x_end, double *k_end, double *I_out, double *tau_out,
+                   double *carter, float *max_step_error)
+{
+    return torus_rays_impl(libpath, prefix, a, inc_rad, n, alpha, beta, r0, precision, options, dl_max, r_in, r_out,
+                           max_error, max_steps, shape, torus_r, torus_w, torus_l, emis0, absorb0, steps, x_end, k_end,
+                           I_out, tau_out, carter, max_step_error, 0);
+}
+
+int cpu_torus_rays_perturbed(const char *libpath, const char *prefix, double a, double inc_rad, int n,
+                   const double *alpha, const double *beta, double r0, double precision, int options,
+                   double dl_max, double r_in, double r_out, double max_error, int max_steps,
+                   int shape, double torus_r, double torus_w, double torus_l, double emis0, double absorb0,
+                   int *steps, double *x_end, double *k_end, double *I_out, double *tau_out,
+                   double *carter, float *max_step_error, const int *ulps)
+{
+    return torus_rays_impl(libpath, prefix, a, inc_rad, n, alpha, beta, r0, precision, options, dl_max, r_in, r_out,
+                           max_error, max_steps, shape, torus_r, torus_w, torus_l, emis0, absorb0, steps, x_end, k_end,
+                           I_out, tau_out, carter, max_step_error, ulps);
 }

@@ -8,9 +8,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_build")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libsim5gpu.so")
+# S5_VARIANT=<name> (tests/tools/ab_build.sh): an experiment build goes to lib/ab_<name>.so with its own objects and
+# stamp; the library the product loads is never replaced by an experiment
+_VAR = os.environ.get("S5_VARIANT", "")
+OBJ = os.path.join(CSRC, "_build", "ab_" + _VAR) if _VAR else os.path.join(CSRC, "_build")
+LIB = os.path.join(LIBDIR, ("ab_%s.so" % _VAR) if _VAR else "libsim5gpu.so")
 
 # (source, object, variant): the image kernels are built in both arithmetic variants
 SOURCES = [("capi_core.hip", "capi_core.o", "strict"), ("capi_batch.hip", "capi_batch.o", "strict"),
@@ -58,7 +61,7 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "sim5gpu.h"))
     sources = sorted(set(os.path.join(CSRC, src) for (src, _, _) in SOURCES))
-    stamp = os.path.join(LIBDIR, "build.stamp")
+    stamp = os.path.join(LIBDIR, ("ab_%s.stamp" % _VAR) if _VAR else "build.stamp")
     fp = _fingerprint(headers + sources + [os.path.abspath(__file__)],
                       (FLAGS, VARIANT, os.environ.get("S5_FAST_EXTRA", ""), os.environ.get("S5_TORUS_EXTRA", ""),
                        os.environ.get("S5_TORUS_FAST_EXTRA", ""), os.environ.get("S5_SURF_FAST_EXTRA", "")))

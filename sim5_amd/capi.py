@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsim5gpu.so")
+# SIM5GPU_LIB (the variable the C host shim reads too) selects another build of the library, e.g. an experiment
+# variant sim5_amd/lib/ab_<name>.so of tests/tools/ab_build.sh: the in-tree library is never overwritten
+LIB_PATH = os.environ.get("SIM5GPU_LIB") or os.path.join(_HERE, "lib", "libsim5gpu.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sim5gpu.h")
 
 if not os.path.exists(LIB_PATH):

@@ -188,7 +188,7 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
     const double half_dl2 = 0.5 * dl * dl;
     xp[0] = x[0] + k[0] * dl + dk[0] * half_dl2;
     xp[1] = x[1] + k[1] * dl + dk[1] * half_dl2;
-#if S5_FAST
+#if S5_FAST && !defined(S5_T_POLAR_REF)
     {   // cos(acos(m) + d) = m cos d - sqrt(1 - m^2) sin d: one bounded sincos and a square root instead of acos
         // and cos (the reference's form, ref :177, stays in the strict variant); same step counts on the C4 job
         const double d = k[2] * dl + dk[2] * half_dl2;

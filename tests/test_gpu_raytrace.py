@@ -10,10 +10,10 @@ from gpuutil import REL, assert_close
 
 pytestmark = pytest.mark.gpu
 
-# share of rays whose raytrace() call count must equal the CPU loop's.  Step counts are integer work decided by
-# float thresholds (ref src/sim5raytrace.c:213,220); the strict variant reproduces the reference's arithmetic.
+# Step counts are integer work decided by float thresholds (ref src/sim5raytrace.c:213,220): every ray's raytrace() call
+# count must equal the CPU loop's, in BOTH arithmetic variants.
 STEP_MATCH_STRICT = 1.0
-STEP_MATCH_FAST = 0.98
+STEP_MATCH_FAST = 1.0
 
 
 def test_prepare_and_single_step(capi, golden):
@@ -134,43 +134,68 @@ def run_torus(capi, d, full=False):
     return out + (ke.to_numpy(np.float64, (n, 4)),) if full else out
 
 
-def compare_rays(tag, S, steps, xe, ke, ref, need_same):
+FIELDS = (("t_end", "x_end", 0, 1.0), ("r_end", "x_end", 1, 0.0), ("cos(theta)_end", "x_end", 2, 1e-2), ("phi_end", "x_end", 3, 1.0),
+          ("k_end[0]", "k_end", 0, 0.0), ("k_end[1]", "k_end", 1, 1e-2), ("k_end[2]", "k_end", 2, 1e-4), ("k_end[3]", "k_end", 3, 1e-4))
+
+
+def ray_errors(got, ref):
+    """Per-ray relative differences of two results of the same rays (dicts with x_end, k_end, I, tau): t and phi are sums
+    over the whole ray (|t| ~ 200, |phi| up to a few turns: floor 1), r and k^t are O(1..100) (no floor), cos(theta), k^r,
+    k^theta, k^phi pass through zero (floors 1e-2, 1e-2, 1e-4, 1e-4: k^theta, k^phi ~ 1e-2 at r ~ 100); I and tau against
+    1e-6 of the set's peak.  Returns {field: array}."""
+    out = {}
+    for name, key, c, floor in FIELDS:
+        out[name] = np.abs(got[key][:, c] - ref[key][:, c]) / np.maximum(np.abs(ref[key][:, c]), floor)
+    out["Stokes I"] = np.abs(got["I"] - ref["I"]) / np.maximum(np.abs(ref["I"]), 1e-6 * float(np.abs(ref["I"]).max()))
+    out["tau"] = np.abs(got["tau"] - ref["tau"]) / np.maximum(np.abs(ref["tau"]), 1e-6 * max(float(np.abs(ref["tau"]).max()), 1e-300))
+    return out
+
+
+def oracle_sensitivity(lib, prefix, a, inc_rad, alpha, beta, base, **job):
+    """Conditioning probe: how far does the CHECKER's own result of these rays move when its start state changes in the
+    last bit?  Each of cos(theta), k^r, k^theta, k^phi at the start by +-1 ulp before raytrace_prepare()
+    (oracle/cpu_driver.c:cpu_torus_rays_perturbed), the largest move per ray in the metric of ray_errors(); a ray whose
+    step count changes under such a perturbation sits on a threshold of the step control (infinite sensitivity)."""
+    kap = np.zeros(len(alpha))
+    for comp in (2, 5, 6, 7):
+        for sgn in (1, -1):
+            u = [0] * 8
+            u[comp] = sgn
+            o = gga.torus_rays(lib, prefix, a, inc_rad, alpha, beta, ulps=u, **job)
+            e = np.max(np.stack(list(ray_errors(o, base).values())), axis=0)
+            e[o["steps"] != base["steps"]] = np.inf
+            kap = np.maximum(kap, e)
+    return kap
+
+
+def compare_rays(tag, S, steps, xe, ke, ref, need_same, probe=None):
     """GPU rays against the CPU integration of the same rays (dict of oracle/cpu_driver.c:cpu_torus_rays arrays):
     step counts, and for rays with identical counts the end point (all four coordinates), the end momentum and
-    the transfer integrals I and tau within 1e-6."""
+    the transfer integrals I and tau within 1e-6 -- in BOTH arithmetic variants, every ray.
+
+    The one admissible exception is a ray that is ill-conditioned in the REFERENCE itself: a photon that winds around
+    the photon orbit amplifies a last-bit difference exponentially, for any two implementations.  It is not excused by
+    a looser bar but by a measurement: `probe(indices)` reruns the CHECKER on those rays with its start state moved by
+    +-1 ulp (oracle_sensitivity) and the ray passes only if the checker's own result moves by at least as much as the
+    GPU's differs.  Such rays are counted and printed; more than 0.1 % of a set fails."""
     same = steps == ref["steps"]
     print("%s: %d of %d rays with identical step counts (the others differ by %s steps)" % (
         tag, int(same.sum()), same.size, sorted(set((steps - ref["steps"])[~same].tolist()))[:8]))
     assert same.sum() >= need_same * same.size, (tag, int(same.sum()), same.size)
     assert np.array_equal(steps == 0, ref["steps"] == 0)
     m = same & (steps > 0)
-    strict = " strict" in tag
-    worst = {}
-
-    def check(name, got, want, floor=0.0):
-        # Bar 1e-6 (north_star) for every ray in the strict variant.  The fast variant evaluates the polar update in
-        # another (algebraically equal) form: its rounding differs from the reference's in the last bit of every step,
-        # and a ray that winds around the photon orbit (1 000+ steps instead of ~520) amplifies that exponentially --
-        # such rays are ill-conditioned for any two implementations.  Fast: 99.9 % of the rays within 1e-6, all within
-        # 1e-5; the worst value is printed.
-        e = np.abs(got - want) / np.maximum(np.abs(want), floor)
-        worst[name] = float(e.max()) if e.size else 0.0
-        if strict:
-            assert e.max() <= REL, "%s %s: max rel err %.3e" % (tag, name, e.max())
-        else:
-            assert (e <= REL).mean() >= 0.999 and e.max() <= 1e-5, "%s %s: %d of %d rays above 1e-6, max %.3e" % (
-                tag, name, int((e > REL).sum()), e.size, e.max())
-
-    # t and phi are sums over the whole ray (|t| ~ 200, |phi| up to a few turns), r and cos(theta) are O(1..100)
-    check("t_end", xe[m, 0], ref["x_end"][m, 0], 1.0)
-    check("r_end", xe[m, 1], ref["x_end"][m, 1])
-    check("cos(theta)_end", xe[m, 2], ref["x_end"][m, 2], 1e-2)
-    check("phi_end", xe[m, 3], ref["x_end"][m, 3], 1.0)
-    for c, floor in ((0, 0.0), (1, 1e-2), (2, 1e-4), (3, 1e-4)):          # k^t ~ 1, k^r ~ 1, k^theta, k^phi ~ 1e-2 at r ~ 100
-        check("k_end[%d]" % c, ke[m, c], ref["k_end"][m, c], floor)
-    check("Stokes I", S[m, 0], ref["I"][m], 1e-6 * float(ref["I"].max()))
-    check("tau", S[m, 4], ref["tau"][m], 1e-6 * max(float(ref["tau"].max()), 1e-300))
-    print("   worst relative differences:", {k: "%.1e" % v for k, v in worst.items()})
+    errs = ray_errors({"x_end": xe, "k_end": ke, "I": S[:, 0], "tau": S[:, 4]}, ref)
+    print("   worst relative differences:", {k: "%.1e" % (float(v[m].max()) if m.any() else 0.0) for k, v in errs.items()})
+    tot = np.max(np.stack(list(errs.values())), axis=0)
+    over = np.nonzero(m & (tot > REL))[0]
+    if over.size:
+        assert probe is not None, "%s: %d rays above 1e-6 (worst %.3e) and no conditioning probe" % (tag, over.size, tot[over].max())
+        assert over.size <= 1e-3 * max(int(m.sum()), 1000), "%s: %d of %d rays above 1e-6" % (tag, over.size, int(m.sum()))
+        kap = probe(over)
+        print("   %d ray(s) above 1e-6: difference %s, the checker's own +-1 ulp sensitivity %s" % (
+            over.size, ["%.1e" % v for v in tot[over][:8]], ["%.1e" % v for v in kap[:8]]))
+        assert (tot[over] <= kap).all(), "%s: rays above 1e-6 that are well-conditioned in the checker: %s" % (
+            tag, [(int(i), float(t), float(k)) for i, t, k in zip(over, tot[over], kap) if t > k][:8])
     assert (S[:, 1:4] == 0).all()
     return same
 
@@ -209,9 +234,14 @@ def test_torus_kernel_matches_cpu_integration(capi, strict, absorb0):
     S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
     rmax = ol.Oracle().r_ms(a) + 8.0
     c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
-    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), np.tile(c, n), np.repeat(c, n), r0=r0, absorb0=absorb0)
+    al, be = np.tile(c, n), np.repeat(c, n)
+    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, r0=r0, absorb0=absorb0)
+
+    def probe(idx):
+        sub = {k: v[idx] for k, v in ref.items()}
+        return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al[idx], be[idx], sub, r0=r0, absorb0=absorb0)
     compare_rays("24x24 %s absorb0=%g" % ("strict" if strict else "fast", absorb0), S, steps, xe, ke, ref,
-                 STEP_MATCH_STRICT if strict else STEP_MATCH_FAST)
+                 STEP_MATCH_STRICT if strict else STEP_MATCH_FAST, probe)
     assert (S[:, 0] >= 0).all() and S[:, 0].max() > 1.0
     if absorb0 > 0:
         assert S[:, 4].max() > 1.0            # optically thick lines of sight are in the sample
@@ -219,11 +249,12 @@ def test_torus_kernel_matches_cpu_integration(capi, strict, absorb0):
 
 def test_random_torus_jobs(capi):
     """25 random step-wise jobs (spin 0.01 ... 0.998, inclination 10 ... 85 deg, r0 40 ... 200, precision 1 ... 0.03, images of 6^2
-    ... 27^2 rays, torus size, with and without absorption; tests/tools/fuzz_torus.py runs the open-ended version: 100 jobs,
-    28 760 rays, no finding): the step count of EVERY ray equals the CPU checker's raytrace() loop in both variants; end
-    radius within 1e-6 (strict) / 1e-5 (fast), Stokes I within 1e-5 of the image's peak.  Left out and counted: rays with
-    alpha = 0 exactly (central column of an odd-sized image), whose start-up is degenerate in the reference itself (l = 0:
-    it returns garbage states or rejects the ray, depending on rounding)."""
+    ... 27^2 rays, torus size, with and without absorption; tests/tools/fuzz_torus.py runs the open-ended version): the step
+    count of EVERY ray equals the CPU checker's raytrace() loop in both variants; end point, end momentum, Stokes I and tau
+    within 1e-6 in both variants (compare_rays: a ray may exceed it only if the checker's own result moves as much under a
+    +-1 ulp change of its start state).  Left out and counted: rays with alpha = 0 exactly (central column of an odd-sized
+    image), whose start-up is degenerate in the reference itself (l = 0: it returns garbage states or rejects the ray,
+    depending on rounding)."""
     rng = np.random.default_rng(2027)
     left_out = 0
     for case in range(25):
@@ -238,20 +269,23 @@ def test_random_torus_jobs(capi):
         rmax = ol.Oracle().r_ms(a) + 8.0
         c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
         al, be = np.tile(c, n), np.repeat(c, n)
-        ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, r0=r0, precision=prec, absorb0=absorb0,
-                             torus_r=tr, torus_w=tw)
-        regular = al != 0.0
+        job = dict(r0=r0, precision=prec, absorb0=absorb0, torus_r=tr, torus_w=tw)
+        ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, **job)
+        regular = np.nonzero(al != 0.0)[0]
+        sub = {k: v[regular] for k, v in ref.items()}
+
+        def probe(idx):
+            return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al[regular][idx], be[regular][idx],
+                                      {k: v[idx] for k, v in sub.items()}, **job)
         for strict in (True, False):
-            d = torus_desc(capi, n, a, inc, r0=r0, precision=prec, absorb0=absorb0, torus_r=tr, torus_w=tw)
+            d = torus_desc(capi, n, a, inc, **job)
             if strict:
                 d.img.flags = 1
             S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
-            left_out += int(((steps != ref["steps"]) & ~regular).sum())
+            left_out += int((steps != ref["steps"]).sum() - (steps[regular] != ref["steps"][regular]).sum())
             assert np.array_equal(steps[regular], ref["steps"][regular]), what + (strict,)
-            m = regular & (steps > 0)
-            if m.any():
-                assert np.abs(xe[m, 1] / ref["x_end"][m, 1] - 1).max() < (1e-6 if strict else 1e-5), what + (strict,)
-                assert (np.abs(S[m, 0] - ref["I"][m]) / max(float(ref["I"].max()), 1e-300)).max() < 1e-5, what + (strict,)
+            compare_rays("random job %d %s" % (case, "strict" if strict else "fast"), S[regular], steps[regular], xe[regular],
+                         ke[regular], sub, 1.0, probe)
     print("alpha = 0 rays with another step count than the CPU loop (left out): %d" % left_out)
 
 
@@ -295,7 +329,16 @@ def test_c4_full_size(capi, golden, strict):
         ref = {k: g["thin_" + k] for k in ("steps", "x_end", "k_end", "carter", "max_step_error")}
         ref["I"] = g[tag + "_I"]; ref["tau"] = g[tag + "_tau"]
         name = "C4 1024^2 %s %s" % ("strict" if strict else "fast", tag)
-        same = compare_rays(name, S[sel], steps[sel], xe[sel], ke[sel], ref, STEP_MATCH_STRICT if strict else STEP_MATCH_FAST)
+        rmax = ol.Oracle().r_ms(a) + 8.0
+        cc = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+
+        def probe(idx, absorb0=absorb0, ref=ref):
+            # the restatement is bit-identical to the reference on these rays (tests/test_oracle_golden.py), so its
+            # sensitivity is the reference's
+            al, be = cc[g["thin_ix"][idx]], cc[g["thin_iy"][idx]]
+            return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, {k: v[idx] for k, v in ref.items()},
+                                      r0=r0, absorb0=absorb0)
+        same = compare_rays(name, S[sel], steps[sel], xe[sel], ke[sel], ref, STEP_MATCH_STRICT if strict else STEP_MATCH_FAST, probe)
         # conservation: the Carter-constant error of the GPU rays is the reference's on the same rays
         assert_close(ce[sel][same], ref["carter"][same], floor=1e-3, rtol=1e-3, what=name + " raytrace_error")
         print("%s: %.1f steps/ray, %.3g raytrace() calls, I max %.4g, |dQ/Q| median %.2e, 99.9%% %.2e, max %.2e; rays stopped by "

@@ -336,6 +336,33 @@ def test_torus_c4_port_equals_reference(golden):
     assert g["absorb_tau"].max() > 5 and g["thin_I"].max() > 20
 
 
+def test_torus_conditioning_probe(golden):
+    """The conditioning probe of the GPU parity tests (cpu_torus_rays_perturbed): no shift = the plain loop bit for bit,
+    restatement and reference move alike under the same +-1 ulp shift of the start state, and on the C4 sample the
+    reference's own end states move by up to ~1e-8 for one unit in the last place -- the amplification of rays that
+    wind around the photon orbit, which any two implementations see."""
+    import gen_golden_access as gga
+    g = golden("torus_c4.npz")
+    n, a, inc = int(g["n"][0]), float(g["a"][0]), math.radians(float(g["inc_deg"][0]))
+    rmax = ol.Oracle().r_ms(a) + 8.0
+    c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
+    order = np.arange(2, g["thin_steps"].size, 8)                      # 512 rays of the sample
+    al, be = c[g["thin_ix"]][order], c[g["thin_iy"]][order]
+    base = gga.torus_rays(ol.ORACLE_SO, "orc_", a, inc, al, be)
+    zero = gga.torus_rays(ol.ORACLE_SO, "orc_", a, inc, al, be, ulps=[0] * 8)
+    for k in base:
+        assert np.array_equal(base[k], zero[k], equal_nan=True) and np.array_equal(base[k][:, ...], g["thin_" + k][order], equal_nan=True), k
+    u = [0, 0, 0, 0, 0, 1, 0, 0]                                       # k^r one unit in the last place up
+    port = gga.torus_rays(ol.ORACLE_SO, "orc_", a, inc, al, be, ulps=u)
+    if ol.have_reference():
+        refp = gga.torus_rays(ol.REF_SO, "", a, inc, al, be, ulps=u)
+        for k in port:
+            assert np.array_equal(port[k], refp[k], equal_nan=True), k
+    assert np.array_equal(port["steps"], base["steps"])
+    move = np.abs(port["x_end"][:, 1] / base["x_end"][:, 1] - 1)
+    assert 1e-10 < move.max() < 1e-6 and (move > 0).mean() > 0.5, (move.max(), (move > 0).mean())   # worst ray: ~1e7 x the shift
+
+
 def test_disk_model_rest(oracle, golden):
     """disk_nt_mdot / disk_nt_lumi / disk_nt_sigma incl. the luminosity-parametrised set-up (bisection over the Simpson
     integral of the flux), and r_ph / r_mb: bit for bit against the reference."""

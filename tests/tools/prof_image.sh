@@ -3,7 +3,7 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B="python3 tests/tools/bench_image.py"
 for name in "$@"; do
-  cp sim5_amd/lib/ab_$name.so sim5_amd/lib/libsim5gpu.so
+  export SIM5GPU_LIB=$GRAFT_REPO_ROOT/sim5_amd/lib/ab_$name.so      # the in-tree library stays as it is
   OUT=gpurun_out/prof_img_$name; rm -rf $OUT; mkdir -p $OUT
   rocprofv3 --kernel-trace --output-format csv -d $OUT/p1 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVES -- $B > $OUT/p1.log 2>&1 &&
   rocprofv3 --kernel-trace --output-format csv -d $OUT/p2 --pmc GRBM_GUI_ACTIVE VALUBusy VALUUtilization -- $B > $OUT/p2.log 2>&1

@@ -1,7 +1,7 @@
 # ON THE GPU BOX: per-kernel time and counters of the surface search job (tests/tools/bench_surface.py).
 #   gpurun -- bash tests/tools/prof_surface.sh [variant]
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-[ -n "$1" ] && cp sim5_amd/lib/ab_$1.so sim5_amd/lib/libsim5gpu.so
+[ -n "$1" ] && export SIM5GPU_LIB=$GRAFT_REPO_ROOT/sim5_amd/lib/ab_$1.so      # the in-tree library stays as it is
 OUT=gpurun_out/prof_surf; rm -rf $OUT; mkdir -p $OUT
 B="python3 tests/tools/bench_surface.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B > $OUT/kt.log 2>&1 &&
