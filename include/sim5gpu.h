@@ -274,6 +274,62 @@ int sim5gpu_polarization_angle_rotation(size_t n, const double *a, const double 
 int sim5gpu_blackbody_Iv(size_t n, const double *T, const double *hardf, const double *cos_mu,
                          const double *E, double *Iv);
 
+/* ---- (1b) the remaining public prototypes of the SIM5 headers a caller of this path may link
+ * (ref src/sim5kerr.h:36-175, src/sim5kerr-geod.h:77, src/sim5elliptic.h:25-33, src/sim5radiation.h:33-35).
+ * Vectors are n x 4, a connection is n x 64 (G[i][j][k] row-major, the reference's double[4][4][4]). ---- */
+
+/* flat_metric / flat_metric_contravariant / kerr_metric_contravariant / flat_connection
+ * (ref src/sim5kerr.c:31-50, 54-71, 105-132, 199-229) */
+int sim5gpu_flat_metric(size_t n, const double *r, const double *m, sim5gpu_metric *metric);
+int sim5gpu_flat_metric_contravariant(size_t n, const double *r, const double *m, sim5gpu_metric *metric);
+int sim5gpu_kerr_metric_contravariant(size_t n, const double *a, const double *r, const double *m,
+                                      sim5gpu_metric *metric);
+int sim5gpu_flat_connection(size_t n, const double *r, const double *m, double *G);
+
+/* Gamma: -G^i_(jk) U^j V^k for a connection handed in by the caller (ref src/sim5kerr.c:422-440) */
+int sim5gpu_Gamma(size_t n, const double *G, const double *U, const double *V, double *result);
+
+/* vector_covariant / vector_norm / vector_3norm / vector_norm_to_null (ref src/sim5kerr.c:477-532, 577-605);
+ * metric == NULL: Minkowski, as in the reference; vector_norm_to_null scales v in place */
+int sim5gpu_vector_covariant(size_t n, const double *v1, double *v2, const sim5gpu_metric *metric);
+int sim5gpu_vector_norm(size_t n, const double *v, const sim5gpu_metric *metric, double *out);
+int sim5gpu_vector_3norm(size_t n, const double *v, double *out);
+int sim5gpu_vector_norm_to_null(size_t n, double *v, const double *V0, const sim5gpu_metric *metric);
+
+/* tetrad_general / tetrad_radial (ref src/sim5kerr.c:630-674, 715-762) */
+int sim5gpu_tetrad_general(size_t n, const sim5gpu_metric *metric, const double *U, sim5gpu_tetrad *t);
+int sim5gpu_tetrad_radial(size_t n, const sim5gpu_metric *metric, const double *v_r, sim5gpu_tetrad *t);
+
+/* omega_r / omega_z: epicyclic frequencies; ell_from_Omega (ref src/sim5kerr.c:1076-1098, 1114-1124) */
+int sim5gpu_omega_r(size_t n, const double *r, const double *a, double *out);
+int sim5gpu_omega_z(size_t n, const double *r, const double *a, double *out);
+int sim5gpu_ell_from_Omega(size_t n, const double *Omega, const sim5gpu_metric *metric, double *ell);
+
+/* fourvelocity_zamo / _azimuthal / _radial / _norm / fourvelocity (ref src/sim5kerr.c:1278-1353) */
+int sim5gpu_fourvelocity_zamo(size_t n, const sim5gpu_metric *metric, double *U);
+int sim5gpu_fourvelocity_azimuthal(size_t n, const double *Omega, const sim5gpu_metric *metric, double *U);
+int sim5gpu_fourvelocity_radial(size_t n, const double *vr, const sim5gpu_metric *metric, double *U);
+int sim5gpu_fourvelocity_norm(size_t n, const double *U1, const double *U2, const double *U3,
+                              const sim5gpu_metric *metric, double *out);
+int sim5gpu_fourvelocity(size_t n, const double *U1, const double *U2, const double *U3,
+                         const sim5gpu_metric *metric, double *U);
+
+/* geodesic_position_pol_sign_k_theta (ref src/sim5kerr-geod.c:413-457): +1 / -1, NaN for RR_DBL / RR_BH */
+int sim5gpu_geodesic_position_pol_sign_k_theta(size_t n, const sim5gpu_geodesic *g, const double *P, double *sign);
+
+/* Legendre integrals by angle / by sine (ref src/sim5elliptic.c:235-252, 339-357, 453-474, 382-423).  which:
+ * 0 = elliptic_f(phi = x, m), 1 = elliptic_e_sin(sin_phi = x, m), 2 = elliptic_pi_sin(sin_phi = x, nn, m),
+ * 3 = elliptic_pi(phi = x, nn, m): complex, out is n x 2 {re, im} (the imaginary part is non-zero for nn > 1) */
+int sim5gpu_legendre(int which, size_t n, const double *x, const double *nn, const double *m, double *out);
+
+/* blackbody: the spectrum form of blackbody_Iv, Iv[i] for n_energies energies of ONE black body (ref
+ * src/sim5radiation.c:53-78; T <= 0 leaves Iv untouched, as there); blackbody_photons / blackbody_photons_total
+ * (ref :83-114) */
+int sim5gpu_blackbody(double T, double hardf, double cos_mu, size_t n_energies, const double *E, double *Iv);
+int sim5gpu_blackbody_photons(size_t n, const double *T, const double *hardf, const double *cos_mu,
+                              const double *E, double *out);
+int sim5gpu_blackbody_photons_total(size_t n, const double *T, const double *hardf, double *out);
+
 /* ==================================================================================== */
 /* (2) whole-job kernels (DEVICE buffers, asynchronous on `stream`)                     */
 /* ==================================================================================== */

@@ -669,6 +669,178 @@ def torus_c4():
     save("torus_c4.npz", **out)
 
 
+def kat_boundary():
+    """The public prototypes of the cited reference headers that are not on the inner path: metric
+    helpers, Gamma, vector helpers, tetrad_general / tetrad_radial, epicyclic frequencies, four-velocities, Legendre
+    integrals by angle / sine, black-body spectrum and photon counts, sign of k^theta, ensure_range, sort_roots -- inputs
+    next to the unmodified reference's outputs (ref src/sim5kerr.h:36-175, src/sim5elliptic.h:25-33,
+    src/sim5radiation.h:33-35, src/sim5kerr-geod.h:77, src/sim5math.h:76, src/sim5polyroots.h:26)."""
+    L = C.CDLL(ol.REF_SO)
+    D, I, D4, PM, PT, PG, PD, G444 = ol.D, ol.I, ol.D4, ol.PM, ol.PT, ol.PG, ol.PD, ol.G444
+    sig = {"flat_metric": (None, [D, D, PM]), "flat_metric_contravariant": (None, [D, D, PM]),
+           "kerr_metric": (None, [D, D, D, PM]), "kerr_metric_contravariant": (None, [D, D, D, PM]),
+           "flat_connection": (None, [D, D, G444]), "kerr_connection": (None, [D, D, D, G444]),
+           "Gamma": (None, [G444, D4, D4, D4]),
+           "vector_covariant": (None, [D4, D4, PM]), "vector_norm": (D, [D4, PM]), "vector_3norm": (D, [D4]),
+           "vector_norm_to_null": (None, [D4, D, PM]), "vector_multiply": (None, [D4, D]),
+           "tetrad_general": (None, [PM, D4, PT]), "tetrad_radial": (None, [PM, D, PT]),
+           "omega_r": (D, [D, D]), "omega_z": (D, [D, D]), "OmegaK": (D, [D, D]), "r_ms": (D, [D]),
+           "ell_from_Omega": (D, [D, PM]),
+           "fourvelocity_zamo": (None, [PM, D4]), "fourvelocity_azimuthal": (None, [D, PM, D4]),
+           "fourvelocity_radial": (None, [D, PM, D4]), "fourvelocity_norm": (D, [D, D, D, PM]),
+           "fourvelocity": (None, [D, D, D, PM, D4]),
+           "photon_momentum": (None, [D, D, D, D, D, D, D, D4]),
+           "geodesic_init_inf": (I, [D, D, D, D, PG, ol.PI]), "geodesic_position_pol_sign_k_theta": (D, [PG, D]),
+           "geodesic_dm_sign": (D, [PG, D]),
+           "elliptic_f": (D, [D, D]), "elliptic_e_sin": (D, [D, D]), "elliptic_pi_sin": (D, [D, D, D]),
+           "elliptic_pi": (ol.Cplx, [D, D, D]),
+           "blackbody": (None, [D, D, D, PD, PD, I]), "blackbody_photons": (D, [D, D, D, D]),
+           "blackbody_photons_total": (D, [D, D]), "blackbody_Iv": (D, [D, D, D, D]),
+           "ensure_range": (I, [PD, D, D, D]),
+           "sort_roots": (None, [ol.PI, C.POINTER(ol.Cplx), C.POINTER(ol.Cplx), C.POINTER(ol.Cplx), C.POINTER(ol.Cplx)]),
+           "sim5round": (C.c_long, [D]), "factorial": (C.c_long, [C.c_long]),
+           "reduce_angle_pi": (D, [D]), "reduce_angle_2pi": (D, [D])}
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name); fn.restype = res; fn.argtypes = args
+    rng = np.random.default_rng(20261101)
+    n = 500
+    out = {}
+    a = rng.choice([0.0, 0.1, 0.5, 0.9, 0.998], n)
+    r = (1.0 + np.sqrt(1 - a * a)) * (1.05 + 30.0 * rng.random(n) ** 2)
+    m = rng.uniform(-0.97, 0.97, n)
+    m[:30] = 0.0
+    fm = np.zeros((n, 8)); fmc = np.zeros((n, 8)); kmc = np.zeros((n, 8)); km = np.zeros((n, 8)); fc = np.zeros((n, 64))
+    Gd = np.zeros((n, 64)); U = rng.normal(size=(n, 4)); V = rng.normal(size=(n, 4)); gam = np.zeros((n, 4)); Vsp = np.zeros((n, 4))
+    vcov = np.zeros((n, 4)); vcov_flat = np.zeros((n, 4)); vnorm = np.zeros(n); vnorm_flat = np.zeros(n); v3 = np.zeros(n)
+    knull = np.zeros((n, 4)); V0 = rng.uniform(0.5, 3.0, n) * np.where(rng.random(n) < 0.2, -1, 1)
+    vnull = np.zeros((n, 4)); vnull_flat_in = np.zeros((n, 4)); vnull_flat = np.zeros((n, 4))
+    Om = np.zeros(n); Ufluid = np.zeros((n, 4)); tgen = np.zeros((n, 24)); trad = np.zeros((n, 24))
+    v_r = rng.uniform(-0.4, 0.4, n); v_r[:25] = 0.0
+    rorb = np.zeros(n); om_r = np.zeros(n); om_z = np.zeros(n); ellO = np.zeros(n)
+    uz = np.zeros((n, 4)); ua = np.zeros((n, 4)); ur = np.zeros((n, 4)); un = np.zeros(n); uf = np.zeros((n, 4))
+    U123 = rng.uniform(-0.2, 0.2, (n, 3))
+    l = rng.uniform(-3, 3, n); q = rng.uniform(0.5, 25, n)
+    for i in range(n):
+        g = ol.Metric(); gc = ol.Metric(); t = ol.Tetrad(); G = G444()
+        L.flat_metric(r[i], m[i], C.byref(g)); fm[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        L.flat_metric_contravariant(r[i], m[i], C.byref(g)); fmc[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        L.kerr_metric_contravariant(a[i], r[i], m[i], C.byref(gc)); kmc[i] = np.frombuffer(ol.struct_bytes(gc), np.float64)
+        L.flat_connection(r[i], m[i], G); fc[i] = np.frombuffer(bytes(memoryview(G)), np.float64)
+        L.kerr_metric(a[i], r[i], m[i], C.byref(g)); km[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        # Gamma: the Kerr connection of the point for half of the cases, an arbitrary dense array for the others
+        if i % 2 == 0:
+            L.kerr_connection(a[i], r[i], m[i], G)
+            Gd[i] = np.frombuffer(bytes(memoryview(G)), np.float64)
+        else:
+            Gd[i] = rng.normal(size=64)
+            C.memmove(G, Gd[i].ctypes.data, 512)
+        res = D4(); L.Gamma(G, D4(*U[i]), D4(*V[i]), res); gam[i] = list(res)
+        w = D4(); L.vector_covariant(D4(*U[i]), w, C.byref(g)); vcov[i] = list(w)
+        w = D4(); L.vector_covariant(D4(*U[i]), w, None); vcov_flat[i] = list(w)
+        sp = V[i].copy(); sp[0] = 0.0                       # space-like: vector_norm is sqrt(V.V)
+        Vsp[i] = sp
+        vnorm[i] = L.vector_norm(D4(*sp), C.byref(g)); vnorm_flat[i] = L.vector_norm(D4(*sp), None)
+        v3[i] = L.vector_3norm(D4(*U[i]))
+        kk = D4(); L.photon_momentum(a[i], r[i], m[i], l[i], q[i], 1.0 if i % 3 else -1.0, 1.0 if i % 5 else -1.0, kk)
+        knull[i] = list(kk)
+        if not math.isnan(knull[i, 0]):
+            w = D4(*knull[i]); L.vector_norm_to_null(w, V0[i], C.byref(g)); vnull[i] = list(w)
+        else:
+            vnull[i] = np.nan
+        fl = rng.normal(size=4); fl[0] = math.sqrt(fl[1] ** 2 + fl[2] ** 2 + fl[3] ** 2); vnull_flat_in[i] = fl
+        w = D4(*fl); L.vector_norm_to_null(w, V0[i], None); vnull_flat[i] = list(w)
+        # an orbiting observer with small radial / polar velocity components for tetrad_general
+        Om[i] = L.OmegaK(r[i], a[i]) * rng.uniform(0.3, 1.0)
+        uu = D4(); L.fourvelocity(U123[i, 0] * 0.3, U123[i, 1] * 0.01, Om[i], C.byref(g), uu); Ufluid[i] = list(uu)
+        L.tetrad_general(C.byref(g), uu, C.byref(t)); tgen[i] = np.frombuffer(ol.struct_bytes(t), np.float64)
+        L.tetrad_radial(C.byref(g), v_r[i], C.byref(t)); trad[i] = np.frombuffer(ol.struct_bytes(t), np.float64)
+        rorb[i] = L.r_ms(a[i]) * (1.0 + 20.0 * rng.random() ** 2)
+        om_r[i] = L.omega_r(rorb[i], a[i]); om_z[i] = L.omega_z(rorb[i], a[i])
+        ellO[i] = L.ell_from_Omega(Om[i], C.byref(g))
+        w = D4(); L.fourvelocity_zamo(C.byref(g), w); uz[i] = list(w)
+        w = D4(); L.fourvelocity_azimuthal(Om[i], C.byref(g), w); ua[i] = list(w)
+        w = D4(); L.fourvelocity_radial(v_r[i], C.byref(g), w); ur[i] = list(w)
+        un[i] = L.fourvelocity_norm(U123[i, 0], U123[i, 1], U123[i, 2] * 0.1, C.byref(g))
+        w = D4(); L.fourvelocity(U123[i, 0], U123[i, 1], U123[i, 2] * 0.1, C.byref(g), w); uf[i] = list(w)
+    out.update(a=a, r=r, m=m, flat_metric=fm, flat_metric_contra=fmc, kerr_metric=km, kerr_metric_contra=kmc, flat_connection=fc,
+               G=Gd, U=U, V=V, Vsp=Vsp, Gamma=gam, vcov=vcov, vcov_flat=vcov_flat, vnorm=vnorm, vnorm_flat=vnorm_flat, v3norm=v3,
+               knull=knull, V0=V0, vnull=vnull, vnull_flat_in=vnull_flat_in, vnull_flat=vnull_flat, Omega=Om, Ufluid=Ufluid,
+               tetrad_general=tgen, v_r=v_r, tetrad_radial=trad, r_orbit=rorb, omega_r=om_r, omega_z=om_z, ell_from_Omega=ellO,
+               u_zamo=uz, u_azimuthal=ua, u_radial=ur, U123=np.column_stack([U123[:, 0], U123[:, 1], U123[:, 2] * 0.1]),
+               u_norm=un, u_general=uf)
+    # sign of k^theta along geodesics from infinity (all classes the grid of a small image offers)
+    rows = []
+    for aa, inc in ((0.0, 60.0), (0.9, 70.0), (0.998, 85.0), (0.5, 20.0)):
+        rmax = L.r_ms(aa) + 8.0
+        for al in np.linspace(-rmax, rmax, 11):
+            for be in np.linspace(-rmax, rmax, 11):
+                rows.append((deg(inc), aa, al + 0.013, be + 0.007))
+    rows = np.array(rows)
+    ng = len(rows)
+    dump = np.zeros((ng, 240), np.uint8); okg = np.zeros(ng, np.int32); Pq = np.zeros((ng, 3)); sg = np.full((ng, 3), np.nan)
+    dms = np.full((ng, 3), np.nan)
+    for i in range(ng):
+        gd = ol.Geodesic(); err = C.c_int(0)
+        okg[i] = L.geodesic_init_inf(rows[i, 0], rows[i, 1], rows[i, 2], rows[i, 3], C.byref(gd), C.byref(err))
+        dump[i] = np.frombuffer(ol.struct_bytes(gd), np.uint8)
+        if okg[i]:
+            Pq[i] = gd.Rpc * np.array([0.3, 1.0, 1.9]) * rng.uniform(0.8, 1.0, 3)
+            for j in range(3):
+                sg[i, j] = L.geodesic_position_pol_sign_k_theta(C.byref(gd), Pq[i, j])
+                dms[i, j] = L.geodesic_dm_sign(C.byref(gd), Pq[i, j])
+    out.update(geod_in=rows, geod=dump, geod_ok=okg, geod_P=Pq, sign_k_theta=sg, dm_sign=dms)
+    # Legendre integrals by angle / sine
+    ne = 600
+    mm = rng.uniform(0, 1, ne); mm[:10] = 0.0; mm[10:20] = 1.0
+    phi = rng.uniform(-9.0, 9.0, ne); phi[20:30] = 0.0
+    sp = rng.uniform(0, 1, ne); sp[30:40] = 0.0; sp[40:50] = 1.0
+    nn = np.where(rng.random(ne) < 0.7, rng.uniform(-3, 0.95, ne), rng.uniform(1.05, 4.0, ne))
+    nn_sin = rng.uniform(-3, 0.95, ne)
+    ef = np.array([L.elliptic_f(p_, m_) for p_, m_ in zip(phi, mm)])
+    ee = np.array([L.elliptic_e_sin(s_, m_) for s_, m_ in zip(sp, mm)])
+    eps = np.array([L.elliptic_pi_sin(s_, n_, m_) for s_, n_, m_ in zip(sp, nn_sin, mm)])
+    epi = np.zeros((ne, 2))
+    for i in range(ne):
+        z = L.elliptic_pi(phi[i], nn[i], mm[i]); epi[i] = (z.re, z.im)
+    out.update(leg_m=mm, leg_phi=phi, leg_sin=sp, leg_n=nn, leg_n_sin=nn_sin, elliptic_f=ef, elliptic_e_sin=ee,
+               elliptic_pi_sin=eps, elliptic_pi=epi)
+    # black body: spectra of a few temperatures, photon counts
+    E = 10.0 ** np.linspace(-2, 1.5, 64)
+    spec = []
+    bb_par = [(1e6, 1.7, 0.5), (3e6, 1.0, -1.0), (1e7, 1.7, 1.0), (2e5, 2.0, 0.0), (0.0, 1.7, 0.3)]
+    for (T, hf, cm) in bb_par:
+        Iv = np.full(64, -7.0)                              # T <= 0 leaves the array untouched
+        L.blackbody(T, hf, cm, E.ctypes.data_as(PD), Iv.ctypes.data_as(PD), 64)
+        spec.append(Iv)
+    Tn = 10.0 ** rng.uniform(5, 7.5, 200); hn = rng.uniform(1.0, 2.0, 200); cn_ = rng.uniform(-1, 1, 200); En = 10.0 ** rng.uniform(-2, 1, 200)
+    out.update(bb_E=E, bb_par=np.array(bb_par), bb_spectra=np.array(spec), bbp_T=Tn, bbp_hardf=hn, bbp_cos=cn_, bbp_E=En,
+               blackbody_photons=np.array([L.blackbody_photons(*x) for x in zip(Tn, hn, cn_, En)]),
+               blackbody_photons_total=np.array([L.blackbody_photons_total(t_, h_) for t_, h_ in zip(Tn, hn)]))
+    # host-side helpers: ensure_range, sort_roots, rounding / angle reductions
+    val = rng.uniform(-1.5, 1.5, 200); acc = rng.choice([1e-4, 0.1, 0.6], 200)
+    er_ok = np.zeros(200, np.int32); er_val = np.zeros(200)
+    for i in range(200):
+        v = C.c_double(val[i]); er_ok[i] = L.ensure_range(C.byref(v), -1.0, 1.0, acc[i]); er_val[i] = v.value
+    zs = rng.normal(size=(300, 4, 2)); kind = rng.integers(0, 4, 300)
+    for i in range(300):                                   # 4, 2 or 0 real roots; complex ones in conjugate pairs
+        if kind[i] == 0: zs[i, :, 1] = 0.0
+        elif kind[i] == 1: zs[i, :2, 1] = 0.0; zs[i, 3] = (zs[i, 2, 0], -zs[i, 2, 1])
+        elif kind[i] == 2: zs[i, 1] = (zs[i, 0, 0], -zs[i, 0, 1]); zs[i, 3] = (zs[i, 2, 0], -zs[i, 2, 1])
+        else: zs[i, 0, 1] = 0.0; zs[i, 2, 1] = 0.0; zs[i, 3] = (zs[i, 1, 0], -zs[i, 1, 1])
+    srt = np.zeros((300, 4, 2)); nre = np.zeros(300, np.int32)
+    for i in range(300):
+        z = [ol.Cplx(zs[i, j, 0], zs[i, j, 1]) for j in range(4)]; s_ = C.c_int(0)
+        L.sort_roots(C.byref(s_), C.byref(z[0]), C.byref(z[1]), C.byref(z[2]), C.byref(z[3]))
+        nre[i] = s_.value; srt[i] = [(zz.re, zz.im) for zz in z]
+    ang = rng.uniform(-20, 20, 100)
+    out.update(er_val=val, er_acc=acc, er_ok=er_ok, er_out=er_val, roots_in=zs, roots_sorted=srt, roots_nreal=nre,
+               angles=ang, reduce_pi=np.array([L.reduce_angle_pi(x) for x in ang]),
+               reduce_2pi=np.array([L.reduce_angle_2pi(x) for x in ang]),
+               round_in=ang, round_out=np.array([L.sim5round(x) for x in ang], dtype=np.int64),
+               factorial=np.array([L.factorial(k) for k in range(0, 15)], dtype=np.int64))
+    save("kat_boundary.npz", **out)
+
+
 def main():
     if not ol.have_reference():
         sys.exit("oracle/_ref/libsim5ref.so missing: run `make -C oracle` in the build container")
@@ -694,6 +866,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "vectors":
             kat_vectors(ref)
             return
+        if len(sys.argv) > 1 and sys.argv[1] == "boundary":
+            kat_boundary()
+            return
         kat_elliptic(ref, rng)
         kat_geodesic(ref, rng)
         kat_kerr(ref, rng)
@@ -707,6 +882,7 @@ def main():
         torus_c4()
         kat_disk_model()
         kat_vectors(ref)
+        kat_boundary()
     finally:
         os.dup2(saved, 2)
 

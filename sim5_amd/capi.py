@@ -637,6 +637,218 @@ def blackbody_Iv(T, hardf, cos_mu, E):
     return out
 
 
+# ---- (1b) the remaining public SIM5 prototypes (include/sim5gpu.h group (1b)) -------------------
+def _metric_or_none(metric):
+    if metric is None:
+        return None, None
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    return metric, _p(metric)
+
+
+def flat_metric(r, m, contravariant=False):
+    r = _f64(r).ravel()
+    n = r.size
+    m = _f64(m, n)
+    out = np.zeros(n, dtype=METRIC_DTYPE)
+    fn = _lib.sim5gpu_flat_metric_contravariant if contravariant else _lib.sim5gpu_flat_metric
+    _check(fn(SZ(n), _p(r), _p(m), _p(out)), "sim5gpu_flat_metric")
+    return out
+
+
+def flat_metric_contravariant(r, m):
+    return flat_metric(r, m, contravariant=True)
+
+
+def kerr_metric_contravariant(a, r, m):
+    r = _f64(r).ravel()
+    n = r.size
+    a, m = _f64(a, n), _f64(m, n)
+    out = np.zeros(n, dtype=METRIC_DTYPE)
+    _check(_lib.sim5gpu_kerr_metric_contravariant(SZ(n), _p(a), _p(r), _p(m), _p(out)), "sim5gpu_kerr_metric_contravariant")
+    return out
+
+
+def flat_connection(r, m):
+    r = _f64(r).ravel()
+    n = r.size
+    m = _f64(m, n)
+    G = np.zeros((n, 4, 4, 4))
+    _check(_lib.sim5gpu_flat_connection(SZ(n), _p(r), _p(m), _p(G)), "sim5gpu_flat_connection")
+    return G
+
+
+def Gamma(G, U, V):
+    G = _f64(G).reshape(-1, 4, 4, 4)
+    n = G.shape[0]
+    U, V = _f64(U, n, 4), _f64(V, n, 4)
+    out = np.zeros((n, 4))
+    _check(_lib.sim5gpu_Gamma(SZ(n), _p(G), _p(U), _p(V), _p(out)), "sim5gpu_Gamma")
+    return out
+
+
+def vector_covariant(v, metric=None):
+    v = _f64(v).reshape(-1, 4)
+    n = v.shape[0]
+    metric, mp = _metric_or_none(metric)
+    out = np.zeros((n, 4))
+    _check(_lib.sim5gpu_vector_covariant(SZ(n), _p(v), _p(out), mp), "sim5gpu_vector_covariant")
+    return out
+
+
+def vector_norm(v, metric=None):
+    v = _f64(v).reshape(-1, 4)
+    n = v.shape[0]
+    metric, mp = _metric_or_none(metric)
+    out = np.empty(n)
+    _check(_lib.sim5gpu_vector_norm(SZ(n), _p(v), mp, _p(out)), "sim5gpu_vector_norm")
+    return out
+
+
+def vector_3norm(v):
+    v = _f64(v).reshape(-1, 4)
+    out = np.empty(v.shape[0])
+    _check(_lib.sim5gpu_vector_3norm(SZ(v.shape[0]), _p(v), _p(out)), "sim5gpu_vector_3norm")
+    return out
+
+
+def vector_norm_to_null(v, V0, metric=None):
+    v = np.array(_f64(v).reshape(-1, 4))
+    n = v.shape[0]
+    V0 = _f64(V0, n)
+    metric, mp = _metric_or_none(metric)
+    _check(_lib.sim5gpu_vector_norm_to_null(SZ(n), _p(v), _p(V0), mp), "sim5gpu_vector_norm_to_null")
+    return v
+
+
+def tetrad_general(metric, U):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    n = metric.size
+    U = _f64(U, n, 4)
+    t = np.zeros(n, dtype=TETRAD_DTYPE)
+    _check(_lib.sim5gpu_tetrad_general(SZ(n), _p(metric), _p(U), _p(t)), "sim5gpu_tetrad_general")
+    return t
+
+
+def tetrad_radial(metric, v_r):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    n = metric.size
+    v_r = _f64(v_r, n)
+    t = np.zeros(n, dtype=TETRAD_DTYPE)
+    _check(_lib.sim5gpu_tetrad_radial(SZ(n), _p(metric), _p(v_r), _p(t)), "sim5gpu_tetrad_radial")
+    return t
+
+
+def _ra(fn, name, r, a):
+    r = _f64(r).ravel()
+    a = _f64(a, r.size)
+    out = np.empty(r.size)
+    _check(fn(SZ(r.size), _p(r), _p(a), _p(out)), name)
+    return out
+
+
+def omega_r(r, a):
+    return _ra(_lib.sim5gpu_omega_r, "sim5gpu_omega_r", r, a)
+
+
+def omega_z(r, a):
+    return _ra(_lib.sim5gpu_omega_z, "sim5gpu_omega_z", r, a)
+
+
+def ell_from_Omega(Omega, metric):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    Omega = _f64(Omega, metric.size)
+    out = np.empty(metric.size)
+    _check(_lib.sim5gpu_ell_from_Omega(SZ(metric.size), _p(Omega), _p(metric), _p(out)), "sim5gpu_ell_from_Omega")
+    return out
+
+
+def fourvelocity_zamo(metric):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    U = np.zeros((metric.size, 4))
+    _check(_lib.sim5gpu_fourvelocity_zamo(SZ(metric.size), _p(metric), _p(U)), "sim5gpu_fourvelocity_zamo")
+    return U
+
+
+def _fourvel1(fn, name, x, metric):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    x = _f64(x, metric.size)
+    U = np.zeros((metric.size, 4))
+    _check(fn(SZ(metric.size), _p(x), _p(metric), _p(U)), name)
+    return U
+
+
+def fourvelocity_azimuthal(Omega, metric):
+    return _fourvel1(_lib.sim5gpu_fourvelocity_azimuthal, "sim5gpu_fourvelocity_azimuthal", Omega, metric)
+
+
+def fourvelocity_radial(vr, metric):
+    return _fourvel1(_lib.sim5gpu_fourvelocity_radial, "sim5gpu_fourvelocity_radial", vr, metric)
+
+
+def fourvelocity_norm(U1, U2, U3, metric):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    n = metric.size
+    U1, U2, U3 = _f64(U1, n), _f64(U2, n), _f64(U3, n)
+    out = np.empty(n)
+    _check(_lib.sim5gpu_fourvelocity_norm(SZ(n), _p(U1), _p(U2), _p(U3), _p(metric), _p(out)), "sim5gpu_fourvelocity_norm")
+    return out
+
+
+def fourvelocity(U1, U2, U3, metric):
+    metric = np.ascontiguousarray(metric, dtype=METRIC_DTYPE).ravel()
+    n = metric.size
+    U1, U2, U3 = _f64(U1, n), _f64(U2, n), _f64(U3, n)
+    U = np.zeros((n, 4))
+    _check(_lib.sim5gpu_fourvelocity(SZ(n), _p(U1), _p(U2), _p(U3), _p(metric), _p(U)), "sim5gpu_fourvelocity")
+    return U
+
+
+def geodesic_position_pol_sign_k_theta(g, P):
+    return _geod_P(_lib.sim5gpu_geodesic_position_pol_sign_k_theta, "sim5gpu_geodesic_position_pol_sign_k_theta", g, P)
+
+
+LEGENDRE = {"elliptic_f": 0, "elliptic_e_sin": 1, "elliptic_pi_sin": 2, "elliptic_pi": 3}
+
+
+def legendre(name, x, m, nn=None):
+    """elliptic_f(phi, m), elliptic_e_sin(s, m), elliptic_pi_sin(s, nn, m) -> float64[n]; elliptic_pi(phi, nn, m) ->
+    complex128[n]"""
+    which = LEGENDRE[name]
+    x = _f64(x).ravel()
+    n = x.size
+    m = _f64(m, n)
+    nn = _f64(nn, n) if nn is not None else None
+    out = np.empty(2 * n if which == 3 else n)
+    _check(_lib.sim5gpu_legendre(I(which), SZ(n), _p(x), _p(nn) if nn is not None else None, _p(m), _p(out)),
+           "sim5gpu_legendre(%s)" % name)
+    return out.view(np.complex128) if which == 3 else out
+
+
+def blackbody(T, hardf, cos_mu, E):
+    """spectrum of ONE black body over the energies E [keV] (the reference's array form)"""
+    E = _f64(E).ravel()
+    out = np.zeros(E.size)
+    _check(_lib.sim5gpu_blackbody(D(T), D(hardf), D(cos_mu), SZ(E.size), _p(E), _p(out)), "sim5gpu_blackbody")
+    return out
+
+
+def blackbody_photons(T, hardf, cos_mu, E):
+    E = _f64(E).ravel()
+    n = E.size
+    T, hardf, cos_mu = _f64(T, n), _f64(hardf, n), _f64(cos_mu, n)
+    out = np.empty(n)
+    _check(_lib.sim5gpu_blackbody_photons(SZ(n), _p(T), _p(hardf), _p(cos_mu), _p(E), _p(out)), "sim5gpu_blackbody_photons")
+    return out
+
+
+def blackbody_photons_total(T, hardf):
+    T = _f64(T).ravel()
+    hardf = _f64(hardf, T.size)
+    out = np.empty(T.size)
+    _check(_lib.sim5gpu_blackbody_photons_total(SZ(T.size), _p(T), _p(hardf), _p(out)), "sim5gpu_blackbody_photons_total")
+    return out
+
+
 # ---- whole-job kernels --------------------------------------------------------------------------
 IMG_DEFAULT, IMG_STRICT, IMG_MIRROR = 0, 1, 2
 

@@ -489,3 +489,277 @@ void jacobi_sncndn(double u, double m, double *sn, double *cn, double *dn)
 {
     *sn = jacobi_sn(u, m); *cn = jacobi_cn(u, m); *dn = jacobi_dn(u, m);
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * The rest of the public prototypes of the reference headers this path cites (ref src/sim5kerr.h:36-175,
+ * src/sim5kerr-geod.h:74,77, src/sim5elliptic.h:25-33, src/sim5radiation.h:33-35, src/sim5math.h:69-91,
+ * src/sim5polyroots.h:26).  Everything that computes goes to the library (group (1b) of include/sim5gpu.h, n = 1);
+ * what only moves, compares or reorders values (vector_set/copy/multiply, the complex accessors, ensure_range,
+ * sort_roots, the angle reductions) is done here, as it involves no ray arithmetic.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef int (*fn_rm_metric)(size_t, const double *, const double *, sim5metric *);
+typedef int (*fn_arm_metric)(size_t, const double *, const double *, const double *, sim5metric *);
+
+void flat_metric(double r, double m, sim5metric *metric)
+{
+    S5_FN(fn_rm_metric, f, "sim5gpu_flat_metric");
+    s5_check(f(1, &r, &m, metric), "flat_metric");
+}
+
+void flat_metric_contravariant(double r, double m, sim5metric *metric)
+{
+    S5_FN(fn_rm_metric, f, "sim5gpu_flat_metric_contravariant");
+    s5_check(f(1, &r, &m, metric), "flat_metric_contravariant");
+}
+
+void kerr_metric_contravariant(double a, double r, double m, sim5metric *metric)
+{
+    S5_FN(fn_arm_metric, f, "sim5gpu_kerr_metric_contravariant");
+    s5_check(f(1, &a, &r, &m, metric), "kerr_metric_contravariant");
+}
+
+void flat_connection(double r, double m, double G[4][4][4])
+{
+    typedef int (*fn)(size_t, const double *, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_flat_connection");
+    s5_check(f(1, &r, &m, &G[0][0][0]), "flat_connection");
+}
+
+void Gamma(double G[4][4][4], double U[4], double V[4], double result[4])
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_Gamma");
+    s5_check(f(1, &G[0][0][0], U, V, result), "Gamma");
+}
+
+void vector_set(double x[4], double x0, double x1, double x2, double x3) { x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3; }
+void vector_copy(double src[4], double dst[4]) { dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; }
+
+void vector_multiply(double V[4], double factor)
+{
+    /* one rounding per component, the same on any IEEE machine (ref src/sim5kerr.c:536-549) */
+    V[0] *= factor; V[1] *= factor; V[2] *= factor; V[3] *= factor;
+}
+
+void vector_covariant(double V1[4], double V2[4], sim5metric *m)
+{
+    typedef int (*fn)(size_t, const double *, double *, const sim5metric *);
+    S5_FN(fn, f, "sim5gpu_vector_covariant");
+    s5_check(f(1, V1, V2, m), "vector_covariant");
+}
+
+double vector_norm(double V[4], sim5metric *m)
+{
+    typedef int (*fn)(size_t, const double *, const sim5metric *, double *);
+    S5_FN(fn, f, "sim5gpu_vector_norm");
+    double out = NAN;
+    s5_check(f(1, V, m, &out), "vector_norm");
+    return out;
+}
+
+double vector_3norm(double V[4])
+{
+    typedef int (*fn)(size_t, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_vector_3norm");
+    double out = NAN;
+    s5_check(f(1, V, &out), "vector_3norm");
+    return out;
+}
+
+void vector_norm_to_null(double V[4], double V0, sim5metric *m)
+{
+    typedef int (*fn)(size_t, double *, const double *, const sim5metric *);
+    S5_FN(fn, f, "sim5gpu_vector_norm_to_null");
+    s5_check(f(1, V, &V0, m), "vector_norm_to_null");
+}
+
+void tetrad_general(sim5metric *m, double U[], sim5tetrad *t)
+{
+    typedef int (*fn)(size_t, const sim5metric *, const double *, sim5tetrad *);
+    S5_FN(fn, f, "sim5gpu_tetrad_general");
+    s5_check(f(1, m, U, t), "tetrad_general");
+}
+
+void tetrad_radial(sim5metric *m, double v_r, sim5tetrad *t)
+{
+    typedef int (*fn)(size_t, const sim5metric *, const double *, sim5tetrad *);
+    S5_FN(fn, f, "sim5gpu_tetrad_radial");
+    s5_check(f(1, m, &v_r, t), "tetrad_radial");
+}
+
+double omega_r(double r, double a)
+{
+    S5_FN(fn_d2, f, "sim5gpu_omega_r");
+    double out = NAN;
+    s5_check(f(1, &r, &a, &out), "omega_r");
+    return out;
+}
+
+double omega_z(double r, double a)
+{
+    S5_FN(fn_d2, f, "sim5gpu_omega_z");
+    double out = NAN;
+    s5_check(f(1, &r, &a, &out), "omega_z");
+    return out;
+}
+
+double ell_from_Omega(double Omega, sim5metric *m)
+{
+    typedef int (*fn)(size_t, const double *, const sim5metric *, double *);
+    S5_FN(fn, f, "sim5gpu_ell_from_Omega");
+    double out = NAN;
+    s5_check(f(1, &Omega, m, &out), "ell_from_Omega");
+    return out;
+}
+
+void fourvelocity_zamo(sim5metric *m, double U[4])
+{
+    typedef int (*fn)(size_t, const sim5metric *, double *);
+    S5_FN(fn, f, "sim5gpu_fourvelocity_zamo");
+    s5_check(f(1, m, U), "fourvelocity_zamo");
+}
+
+typedef int (*fn_fourvel1)(size_t, const double *, const sim5metric *, double *);
+void fourvelocity_azimuthal(double Omega, sim5metric *m, double U[4])
+{
+    S5_FN(fn_fourvel1, f, "sim5gpu_fourvelocity_azimuthal");
+    s5_check(f(1, &Omega, m, U), "fourvelocity_azimuthal");
+}
+
+void fourvelocity_radial(double vr, sim5metric *m, double U[4])
+{
+    S5_FN(fn_fourvel1, f, "sim5gpu_fourvelocity_radial");
+    s5_check(f(1, &vr, m, U), "fourvelocity_radial");
+}
+
+typedef int (*fn_fourvel3)(size_t, const double *, const double *, const double *, const sim5metric *, double *);
+double fourvelocity_norm(double U1, double U2, double U3, sim5metric *m)
+{
+    S5_FN(fn_fourvel3, f, "sim5gpu_fourvelocity_norm");
+    double out = NAN;
+    s5_check(f(1, &U1, &U2, &U3, m, &out), "fourvelocity_norm");
+    return out;
+}
+
+void fourvelocity(double U1, double U2, double U3, sim5metric *m, double U[])
+{
+    S5_FN(fn_fourvel3, f, "sim5gpu_fourvelocity");
+    s5_check(f(1, &U1, &U2, &U3, m, U), "fourvelocity");
+}
+
+/* an empty stub in the reference (ref src/sim5kerr-geod.c:266-283): x is left untouched */
+void geodesic_position(geodesic *g, double P, double x[4]) { (void)g; (void)P; (void)x; }
+
+double geodesic_position_pol_sign_k_theta(geodesic *g, double P)
+{
+    S5_FN(fn_geod_P, f, "sim5gpu_geodesic_position_pol_sign_k_theta");
+    double s = NAN;
+    s5_check(f(1, g, &P, &s), "geodesic_position_pol_sign_k_theta");
+    return s;
+}
+
+/* Legendre integrals by angle / by sine: selector numbering of sim5gpu_legendre (include/sim5gpu.h) */
+typedef int (*fn_legendre)(int, size_t, const double *, const double *, const double *, double *);
+double elliptic_f(double phi, double m)
+{
+    S5_FN(fn_legendre, f, "sim5gpu_legendre");
+    double out = NAN;
+    s5_check(f(0, 1, &phi, NULL, &m, &out), "elliptic_f");
+    return out;
+}
+
+double elliptic_e_sin(double sin_phi, double m)
+{
+    S5_FN(fn_legendre, f, "sim5gpu_legendre");
+    double out = NAN;
+    s5_check(f(1, 1, &sin_phi, NULL, &m, &out), "elliptic_e_sin");
+    return out;
+}
+
+double elliptic_pi_sin(double sin_phi, double n, double m)
+{
+    S5_FN(fn_legendre, f, "sim5gpu_legendre");
+    double out = NAN;
+    s5_check(f(2, 1, &sin_phi, &n, &m, &out), "elliptic_pi_sin");
+    return out;
+}
+
+sim5complex elliptic_pi(double phi, double n, double m)
+{
+    S5_FN(fn_legendre, f, "sim5gpu_legendre");
+    double out[2] = { NAN, NAN };
+    s5_check(f(3, 1, &phi, &n, &m, out), "elliptic_pi");
+    return out[0] + out[1] * _Complex_I;
+}
+
+void blackbody(double T, double hardf, double cos_mu, double E[], double Iv[], int en_bins)
+{
+    typedef int (*fn)(double, double, double, size_t, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_blackbody");
+    if (en_bins <= 0) return;
+    s5_check(f(T, hardf, cos_mu, (size_t)en_bins, E, Iv), "blackbody");
+}
+
+double blackbody_photons(double T, double hardf, double cos_mu, double E)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_blackbody_photons");
+    double out = NAN;
+    s5_check(f(1, &T, &hardf, &cos_mu, &E, &out), "blackbody_photons");
+    return out;
+}
+
+double blackbody_photons_total(double T, double hardf)
+{
+    S5_FN(fn_d2, f, "sim5gpu_blackbody_photons_total");
+    double out = NAN;
+    s5_check(f(1, &T, &hardf, &out), "blackbody_photons_total");
+    return out;
+}
+
+/* ---- values moved, compared or reordered (ref src/sim5math.c:16-58, 188-223, src/sim5polyroots.c:278-325) ---- */
+long sim5round(double num) { return (long)(num + 0.5); }
+
+long int factorial(long int n) { return (n <= 1) ? 1 : n * factorial(n - 1); }
+
+double reduce_angle_pi(double phi)
+{
+    while (phi < 0.0) phi += 2. * PI;
+    while (phi > PI) phi -= PI;
+    return phi;
+}
+
+double reduce_angle_2pi(double phi)
+{
+    while (phi >= +PI2) phi -= PI2;
+    while (phi < 0.0) phi += PI2;
+    return phi;
+}
+
+int ensure_range(double *val, double min, double max, double acc)
+{
+    if (*val < min - acc) return 0;
+    if (*val > max + acc) return 0;
+    if (*val < min) *val = min;
+    if (*val > max) *val = max;
+    return 1;
+}
+
+sim5complex makeComplex(double r, double i) { return r + _Complex_I * i; }
+sim5complex nullComplex(void) { return 0.0; }
+double sim5creal(sim5complex a) { return creal(a); }
+double sim5cimag(sim5complex a) { return cimag(a); }
+
+void sort_roots(int *s, sim5complex *z1, sim5complex *z2, sim5complex *z3, sim5complex *z4)
+{
+    sim5complex in[4] = { *z1, *z2, *z3, *z4 }, out[4];
+    int nreal = 0, k;
+    for (int i = 0; i < 4; i++) if (cimag(in[i]) == 0.) out[nreal++] = in[i];          /* real roots first */
+    k = nreal;
+    for (int i = 0; i < 4; i++) if (cimag(in[i]) != 0.) out[k++] = in[i];              /* complex ones after, in their order */
+    for (int i = 0; i < nreal; i++)                                                     /* the real ones descending */
+        for (int j = 0; j < nreal - i; j++)
+            if (creal(out[i + j]) > creal(out[i])) { sim5complex t = out[i + j]; out[i + j] = out[i]; out[i] = t; }
+    *s = nreal;
+    *z1 = out[0]; *z2 = out[1]; *z3 = out[2]; *z4 = out[3];
+}

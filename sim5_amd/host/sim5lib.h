@@ -54,7 +54,27 @@ extern "C" {
 #define sqrt4(a) pow(a,0.25)
 #define deg2rad(a) ((a)/180.0*M_PI)
 #define rad2deg(a) ((a)*180.0/M_PI)
+#define odd(a) ((a%2==1)?1:0)
+#define sign(a) ((a) >= 0.0 ? (+1.0) : (-1.0))
+#define EE(a) pow(10.0,a)
+#define ave(a, b, w) ((1.0-(w))*(a) + (w)*(b))
+#define logave(a, b, w) (exp((1.0-(w))*log(a) + (w)*log(b)))
+#define inrange(a, min, max) (((a)>=(min))&&((a)<=(max)))
+#define ComplexI _Complex_I
 typedef double _Complex sim5complex;
+
+/* helpers of sim5math.h that move or compare values (ref src/sim5math.c:16-58, 188-223); no ray arithmetic */
+long        sim5round(double num);
+long int    factorial(long int n);
+double      reduce_angle_pi(double phi);
+double      reduce_angle_2pi(double phi);
+int         ensure_range(double *val, double min, double max, double acc);
+sim5complex makeComplex(double r, double i);
+sim5complex nullComplex(void);
+double      sim5creal(sim5complex a);
+double      sim5cimag(sim5complex a);
+/* ref src/sim5polyroots.h:26: real roots first (descending), complex after; *s = number of real roots */
+void        sort_roots(int *s, sim5complex *z1, sim5complex *z2, sim5complex *z3, sim5complex *z4);
 
 /* ---- physical constants used by the callers on this path (CGS) ---- */
 #define grav_radius         1.476716e+05
@@ -108,8 +128,10 @@ typedef struct geodesic {
 int    geodesic_init_inf(double i, double a, double alpha, double beta, geodesic *g, int *error);
 int    geodesic_init_src(double a, double r, double m, double k[4], int ppc, geodesic *g, int *error);
 double geodesic_P_int(geodesic *g, double r, int ppc);
+void   geodesic_position(geodesic *g, double P, double x[4]);      /* an empty stub in the reference too (ref src/sim5kerr-geod.c:266-283) */
 double geodesic_position_rad(geodesic *g, double P);
 double geodesic_position_pol(geodesic *g, double P);
+double geodesic_position_pol_sign_k_theta(geodesic *g, double P);
 double geodesic_dm_sign(geodesic *g, double P);
 void   geodesic_momentum(geodesic *g, double P, double r, double m, double k[]);
 double geodesic_position_azm(geodesic *g, double r, double m, double P);
@@ -123,10 +145,24 @@ typedef struct sim5metric sim5metric;
 struct sim5tetrad { double e[4][4]; sim5metric metric; };
 typedef struct sim5tetrad sim5tetrad;
 
+void   flat_metric(double r, double m, sim5metric *metric);
+void   flat_metric_contravariant(double r, double m, sim5metric *metric);
 void   kerr_metric(double a, double r, double m, sim5metric *metric);
+void   kerr_metric_contravariant(double a, double r, double m, sim5metric *metric);
+void   flat_connection(double r, double m, double G[4][4][4]);
 void   kerr_connection(double a, double r, double m, double G[4][4][4]);
+void   Gamma(double G[4][4][4], double U[4], double V[4], double result[4]);
+void   vector_set(double x[4], double x0, double x1, double x2, double x3);
+void   vector_copy(double src[4], double dst[4]);
+void   vector_covariant(double V1[4], double V2[4], sim5metric *m);
+double vector_norm(double V[4], sim5metric *m);
+double vector_3norm(double V[4]);
+void   vector_multiply(double V[4], double factor);
 double dotprod(double V1[4], double V2[4], sim5metric *m);
 void   vector_norm_to(double V[4], double norm, sim5metric *m);
+void   vector_norm_to_null(double V[4], double V0, sim5metric *m);
+void   tetrad_general(sim5metric *m, double U[], sim5tetrad *t);
+void   tetrad_radial(sim5metric *m, double v_r, sim5tetrad *t);
 void   tetrad_zamo(sim5metric *m, sim5tetrad *t);
 void   tetrad_azimuthal(sim5metric *m, double Omega, sim5tetrad *t);
 void   tetrad_surface(sim5metric *m, double Omega, double V, double dhdr, sim5tetrad *t);
@@ -138,11 +174,19 @@ double r_mb(double a);
 double r_ph(double a);
 double OmegaK(double r, double a);
 double ellK(double r, double a);
+double omega_r(double r, double a);
+double omega_z(double r, double a);
 double Omega_from_ell(double ell, sim5metric *m);
+double ell_from_Omega(double Omega, sim5metric *m);
 double gfactorK(double r, double a, double l);
 void   photon_momentum(double a, double r, double m, double l, double q, double r_sign, double m_sign, double k[4]);
 void   photon_motion_constants(double a, double r, double m, double k[4], double *L, double *Q);
 double photon_carter_const(double k[4], sim5metric *metric);
+void   fourvelocity_zamo(sim5metric *m, double U[4]);
+void   fourvelocity_azimuthal(double Omega, sim5metric *m, double U[4]);
+void   fourvelocity_radial(double vr, sim5metric *m, double U[4]);
+double fourvelocity_norm(double U1, double U2, double U3, sim5metric *m);
+void   fourvelocity(double U1, double U2, double U3, sim5metric *m, double U[]);
 
 /* ---- step-wise integrator ---- */
 #define RTOPT_NONE              0
@@ -188,6 +232,9 @@ void        polarization_vector(double k[4], sim5complex wp, sim5metric *metric,
 sim5complex polarization_constant_infinity(double a, double alpha, double beta, double incl);
 double      polarization_angle_rotation(double a, double inc, double alpha, double beta, sim5complex kappa);
 double      blackbody_Iv(double T, double hardf, double cos_mu, double E);
+void        blackbody(double T, double hardf, double cos_mu, double E[], double Iv[], int en_bins);
+double      blackbody_photons(double T, double hardf, double cos_mu, double E);
+double      blackbody_photons_total(double T, double hardf);
 
 /* ---- elliptic functions ---- */
 double rf(double x, double y, double z);
@@ -204,11 +251,15 @@ double jacobi_dn(double u, double m);
 void   jacobi_sncndn(double u, double m, double *sn, double *cn, double *dn);
 /* Legendre integrals of the 1st-3rd kind and the radial / polar integrals built on them
    (ref: src/sim5elliptic.h:25-56); a `sim5complex c` is the complex root u + i v */
+double elliptic_f(double phi, double m);
 double elliptic_f_sin(double sin_phi, double m);
 double elliptic_f_cos(double cos_phi, double m);
+double elliptic_e_sin(double sin_phi, double m);
 double elliptic_e_cos(double cos_phi, double m);
 double elliptic_pi_complete(double n, double m);
 double elliptic_pi_cos(double cos_phi, double n, double m);
+double elliptic_pi_sin(double sin_phi, double n, double m);
+sim5complex elliptic_pi(double phi, double n, double m);
 double integral_R_r0_re(double a, double b, double c, double d, double X);
 double integral_R_r0_cc(double a, double b, sim5complex c, double X);
 double integral_R_r0_re_inf(double a, double b, double c, double d);

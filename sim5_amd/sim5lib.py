@@ -386,3 +386,139 @@ def jacobi_sn(u, m):
 
 def jacobi_cn(u, m):
     return float(_c.elliptic("jacobi_cn", [u], m)[0])
+
+
+# ---- the rest of the headers the SWIG interface exports (ref src/sim5lib.swig:33-39: sim5elliptic.h, sim5kerr.h,
+#      sim5kerr-geod.h, ...) ------------------------------------------------------------------------------------
+def flat_metric(r, m, metric):
+    metric._rec[:] = _c.flat_metric([r], m)
+
+
+def flat_metric_contravariant(r, m, metric):
+    metric._rec[:] = _c.flat_metric_contravariant([r], m)
+
+
+def kerr_metric_contravariant(a, r, m, metric):
+    metric._rec[:] = _c.kerr_metric_contravariant(a, [r], m)
+
+
+def flat_connection(r, m, G=None):
+    return _c.flat_connection([r], m)[0]
+
+
+def Gamma(G, U, V, result):
+    _arr(result)[:] = _c.Gamma(np.asarray(G, dtype=np.float64), _arr(U), _arr(V))[0]
+
+
+def vector_set(x, x0, x1, x2, x3):
+    _arr(x)[:] = (x0, x1, x2, x3)
+
+
+def vector_copy(src, dst):
+    _arr(dst)[:] = _arr(src)
+
+
+def vector_multiply(v, factor):
+    _arr(v)[:] = _arr(v) * factor
+
+
+def vector_covariant(v1, v2, metric):
+    _arr(v2)[:] = _c.vector_covariant(_arr(v1), None if metric is None else _met(metric))[0]
+
+
+def vector_norm(v, metric):
+    return float(_c.vector_norm(_arr(v), None if metric is None else _met(metric))[0])
+
+
+def vector_3norm(v):
+    return float(_c.vector_3norm(_arr(v))[0])
+
+
+def vector_norm_to(v, norm, metric):
+    _arr(v)[:] = _c.vector_norm_to(_arr(v), norm, None if metric is None else _met(metric))[0]
+
+
+def vector_norm_to_null(v, V0, metric):
+    _arr(v)[:] = _c.vector_norm_to_null(_arr(v), V0, None if metric is None else _met(metric))[0]
+
+
+def tetrad_general(metric, U, tetrad):
+    tetrad._rec[:] = _c.tetrad_general(_met(metric), _arr(U))
+
+
+def tetrad_radial(metric, v_r, tetrad):
+    tetrad._rec[:] = _c.tetrad_radial(_met(metric), v_r)
+
+
+def omega_r(r, a):
+    return float(_c.omega_r([r], a)[0])
+
+
+def omega_z(r, a):
+    return float(_c.omega_z([r], a)[0])
+
+
+def ell_from_Omega(Omega, metric):
+    return float(_c.ell_from_Omega(Omega, _met(metric))[0])
+
+
+def fourvelocity_zamo(metric, U):
+    _arr(U)[:] = _c.fourvelocity_zamo(_met(metric))[0]
+
+
+def fourvelocity_azimuthal(Omega, metric, U):
+    _arr(U)[:] = _c.fourvelocity_azimuthal(Omega, _met(metric))[0]
+
+
+def fourvelocity_radial(vr, metric, U):
+    _arr(U)[:] = _c.fourvelocity_radial(vr, _met(metric))[0]
+
+
+def fourvelocity_norm(U1, U2, U3, metric):
+    return float(_c.fourvelocity_norm(U1, U2, U3, _met(metric))[0])
+
+
+def fourvelocity(U1, U2, U3, metric, U):
+    _arr(U)[:] = _c.fourvelocity(U1, U2, U3, _met(metric))[0]
+
+
+def photon_motion_constants(a, r, m, k, L, Q):
+    l_, q_ = _c.photon_motion_constants(a, [r], m, _arr(k))
+    L.assign(l_[0]); Q.assign(q_[0])
+
+
+def geodesic_position(g, P, x):
+    pass                                       # an empty stub in the reference too (ref src/sim5kerr-geod.c:266-283)
+
+
+def geodesic_position_pol_sign_k_theta(g, P):
+    return float(_c.geodesic_position_pol_sign_k_theta(g._rec, P)[0])
+
+
+def elliptic_f(phi, m):
+    return float(_c.legendre("elliptic_f", [phi], m)[0])
+
+
+def elliptic_e_sin(sin_phi, m):
+    return float(_c.legendre("elliptic_e_sin", [sin_phi], m)[0])
+
+
+def elliptic_pi_sin(sin_phi, n, m):
+    return float(_c.legendre("elliptic_pi_sin", [sin_phi], m, nn=n)[0])
+
+
+def elliptic_pi(phi, n, m):
+    return complex(_c.legendre("elliptic_pi", [phi], m, nn=n)[0])
+
+
+def blackbody(T, hardf, cos_mu, E, Iv, en_bins):
+    if T > 0.0 and en_bins > 0:
+        _arr(Iv)[:en_bins] = _c.blackbody(T, hardf, cos_mu, _arr(E)[:en_bins])
+
+
+def blackbody_photons(T, hardf, cos_mu, E):
+    return float(_c.blackbody_photons(T, hardf, cos_mu, [E])[0])
+
+
+def blackbody_photons_total(T, hardf):
+    return float(_c.blackbody_photons_total([T], hardf)[0])

@@ -87,3 +87,121 @@ def test_product_does_not_reach_into_oracle():
                     if re.search(r"oracle[/.]|oraclelib|liboracle|sim5ref", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+# ---- the SIM5 scalar boundary against the inventory of the reference's headers ------------------------------------------
+# Prototypes of the cited headers that are NOT served, each with the reason (explicit list).
+OUT_OF_SCOPE = {
+    "kerr_newman_metric": "Kerr-Newman spacetime: not on the Kerr null-geodesic path (SURVEY.md 2 row 3)",
+    "kerr_newman_metric_contravariant": "Kerr-Newman spacetime",
+    "kerr_newman_connection": "Kerr-Newman spacetime",
+    "blackbody_photon_energy_random": "Monte-Carlo sampler on the RNG (SURVEY.md 2 row 15: RNG out of scope)",
+    "sim5seed": "RNG", "sim5rand": "RNG", "sim5urand": "RNG",
+    "cartesian2spherical1": "cartesian helper, no caller on the path", "cartesian2spherical2": "cartesian helper, no caller on the path",
+    "quadratic_eq": "dead code in the reference: the quartic is solved in closed form inside geodesic_priv_R_roots (SURVEY.md 2 row 4)",
+    "cubic_eq": "dead code (as quadratic_eq)", "quartic_eq": "dead code: zero callers", "quartic_eq_c": "dead code",
+    "sort_roots_re": "helper of the dead quartic_eq", "sort_mix": "helper of the dead quartic_eq", "sort_mix2": "helper of the dead quartic_eq",
+}
+
+
+def _inventory():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_prototypes.json")))["prototypes"]
+
+
+def _list_prototypes_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("list_prototypes", os.path.join(ROOT, "oracle", "list_prototypes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def host_shim_so(tmp_path_factory):
+    """sim5_amd/host/sim5lib.c as a shared object (plain C, the reference's example flags): resolvable symbols"""
+    import subprocess
+    so = str(tmp_path_factory.mktemp("shim") / "libsim5shim.so")
+    host = os.path.join(ROOT, "sim5_amd", "host")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O2", "-w", "-fgnu89-inline", "-I", host, os.path.join(host, "sim5lib.c"),
+                    "-o", so, "-lm"], check=True)
+    return so
+
+
+def test_host_shim_serves_every_prototype_of_the_cited_headers(host_shim_so):
+    """Every public prototype of the nine reference headers the boundary cites (inventory: oracle/list_prototypes.py ->
+    tests/golden/reference_prototypes.json, 140 names with their type signatures) is declared by sim5_amd/host/sim5lib.h
+    with the same types and defined by sim5lib.c, except the names of OUT_OF_SCOPE."""
+    lp = _list_prototypes_module()
+    inv = _inventory()
+    assert len(inv) >= 138
+    ours = {p["name"]: p for p in lp.prototypes(os.path.join(ROOT, "sim5_amd", "host", "sim5lib.h"), marked=False)}
+    lib = C.CDLL(host_shim_so)
+    missing, differ, unresolved = [], [], []
+    for p in inv:
+        if p["name"] in OUT_OF_SCOPE:
+            assert p["name"] not in ours, "%s is served: take it off the out-of-scope list" % p["name"]
+            continue
+        if p["name"] not in ours:
+            missing.append("%s (%s:%d)" % (p["name"], p["header"], p["line"]))
+        elif ours[p["name"]]["signature"] != p["signature"]:
+            differ.append((p["name"], p["signature"], ours[p["name"]]["signature"]))
+        if not hasattr(lib, p["name"]):
+            unresolved.append(p["name"])
+    assert not missing, missing
+    assert not differ, differ
+    assert not unresolved, unresolved
+    assert set(OUT_OF_SCOPE) <= {p["name"] for p in inv}
+    # in the build container the committed inventory is re-derived from the reference's headers
+    if os.path.exists(os.path.join(lp.REF, "src", "sim5kerr.h")):
+        fresh = []
+        for h in lp.HEADERS:
+            for p in lp.prototypes(os.path.join(lp.REF, "src", h)):
+                if not any(q["name"] == p["name"] for q in fresh):
+                    fresh.append(dict(p, header="src/" + h))
+        key = lambda ps: [(p["name"], p["signature"], p["header"], p["line"]) for p in ps]
+        assert key(fresh) == key(inv)
+
+
+def test_host_side_helpers_match_the_reference(host_shim_so, golden):
+    """The helpers the shim answers itself -- they move, compare or reorder values, no ray arithmetic: ensure_range,
+    sort_roots, the angle reductions, sim5round, factorial, the complex accessors, vector_set/copy/multiply -- against
+    the reference's outputs (kat_boundary.npz); none of them needs the GPU library."""
+    g = golden("kat_boundary.npz")
+    L = C.CDLL(host_shim_so)
+    D, PD = C.c_double, C.POINTER(C.c_double)
+
+    class Cx(C.Structure):
+        _fields_ = [("re", D), ("im", D)]
+    L.ensure_range.argtypes = [PD, D, D, D]; L.ensure_range.restype = C.c_int
+    for v, acc, ok, out in zip(g["er_val"], g["er_acc"], g["er_ok"], g["er_out"]):
+        x = D(v)
+        assert L.ensure_range(C.byref(x), -1.0, 1.0, acc) == ok and x.value == out
+    PC = C.POINTER(Cx)
+    L.sort_roots.argtypes = [C.POINTER(C.c_int), PC, PC, PC, PC]; L.sort_roots.restype = None
+    for zin, zout, nre in zip(g["roots_in"], g["roots_sorted"], g["roots_nreal"]):
+        z = [Cx(*zin[j]) for j in range(4)]; s = C.c_int(-1)
+        L.sort_roots(C.byref(s), C.byref(z[0]), C.byref(z[1]), C.byref(z[2]), C.byref(z[3]))
+        assert s.value == nre and np.array_equal(np.array([(q.re, q.im) for q in z]), zout)
+    for name, key in (("reduce_angle_pi", "reduce_pi"), ("reduce_angle_2pi", "reduce_2pi")):
+        fn = getattr(L, name); fn.argtypes = [D]; fn.restype = D
+        assert np.array_equal(np.array([fn(x) for x in g["angles"]]), g[key])
+    L.sim5round.argtypes = [D]; L.sim5round.restype = C.c_long
+    assert np.array_equal(np.array([L.sim5round(x) for x in g["round_in"]]), g["round_out"])
+    L.factorial.argtypes = [C.c_long]; L.factorial.restype = C.c_long
+    assert np.array_equal(np.array([L.factorial(k) for k in range(15)]), g["factorial"])
+    L.makeComplex.argtypes = [D, D]; L.makeComplex.restype = Cx
+    L.nullComplex.restype = Cx
+    L.sim5creal.argtypes = [Cx]; L.sim5creal.restype = D
+    L.sim5cimag.argtypes = [Cx]; L.sim5cimag.restype = D
+    z = L.makeComplex(1.5, -2.25)
+    assert (z.re, z.im) == (1.5, -2.25) and L.sim5creal(z) == 1.5 and L.sim5cimag(z) == -2.25
+    z0 = L.nullComplex(); assert (z0.re, z0.im) == (0.0, 0.0)
+    D4 = D * 4
+    L.vector_set.argtypes = [D4, D, D, D, D]; L.vector_copy.argtypes = [D4, D4]; L.vector_multiply.argtypes = [D4, D]
+    v = D4(); w = D4()
+    L.vector_set(v, 1.0, 2.0, 3.0, 4.5); L.vector_copy(v, w); L.vector_multiply(w, 0.1)
+    assert list(v) == [1.0, 2.0, 3.0, 4.5] and list(w) == [1.0 * 0.1, 2.0 * 0.1, 3.0 * 0.1, 4.5 * 0.1]
+    L.geodesic_position.argtypes = [C.c_void_p, D, D4]; L.geodesic_position.restype = None
+    L.geodesic_position(None, 1.0, v)                       # the reference's empty stub: nothing is touched
+    assert list(v) == [1.0, 2.0, 3.0, 4.5]

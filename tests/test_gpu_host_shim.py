@@ -56,6 +56,83 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     assert abs(float(tail[4]) / orc.geodesic_timedelay(C.byref(gd), P1, 0.0, 0.0, P2, 0.0, 0.0) - 1) < 1e-9
 
 
+def test_boundary_prototypes_program(tmp_path, capi):
+    """tests/c/boundary_probe.c: the public prototypes that are not on the inner path, called from C through
+    sim5_amd/host/sim5lib.c (n = 1 batch calls on the GPU), every printed number against the UNMODIFIED reference
+    (oracle/_ref/libsim5ref.so, compiled from the reference's sources in the build container; it travels to the GPU
+    box) called with the same arguments."""
+    if not ol.have_reference():
+        pytest.skip("oracle/_ref/libsim5ref.so not present")
+    exe = str(tmp_path / "bprobe")
+    subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", "boundary_probe.c"), os.path.join(HOST, "sim5lib.c"),
+                    "-I", HOST, "-o", exe, "-lm", "-O3", "-w", "-fgnu89-inline"], check=True)
+    env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+    L = C.CDLL(ol.REF_SO)
+    D, D4, PM, PT = ol.D, ol.D4, ol.PM, ol.PT
+
+    def fn(name, res, *args):
+        f = getattr(L, name); f.restype = res; f.argtypes = list(args); return f
+    for (a, r, m) in ((0.9, 6.0, 0.3), (0.0, 9.0, -0.5), (0.998, 2.5, 0.0)):
+        p = subprocess.run([exe, str(a), str(r), str(m)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got = {ln.split()[0]: np.array([float(v) for v in ln.split()[1:]]) for ln in p.stdout.splitlines()}
+        want = {}
+        g, gc, gf, gfc, t = ol.Metric(), ol.Metric(), ol.Metric(), ol.Metric(), ol.Tetrad()
+        fn("kerr_metric", None, D, D, D, PM)(a, r, m, C.byref(g))
+        fn("kerr_metric_contravariant", None, D, D, D, PM)(a, r, m, C.byref(gc))
+        fn("flat_metric", None, D, D, PM)(r, m, C.byref(gf))
+        fn("flat_metric_contravariant", None, D, D, PM)(r, m, C.byref(gfc))
+        mt = lambda x: np.frombuffer(ol.struct_bytes(x), np.float64)[3:8].copy()
+        want["kerr_metric_contravariant"], want["flat_metric"], want["flat_metric_contravariant"] = mt(gc), mt(gf), mt(gfc)
+        G = ol.G444(); k = D4(1.0, -0.6, 0.02, 0.01); dk = D4()
+        fn("flat_connection", None, D, D, ol.G444)(r, m, G)
+        null = fn("vector_norm_to_null", None, D4, D, PM); gam = fn("Gamma", None, ol.G444, D4, D4, D4)
+        dot = fn("dotprod", D, D4, D4, PM); cov = fn("vector_covariant", None, D4, D4, PM)
+        null(k, 1.0, C.byref(gf)); gam(G, k, k, dk)
+        want["flat_null_k"], want["flat_Gamma"], want["flat_kk"] = np.array(list(k)), np.array(list(dk)), np.array([dot(k, k, C.byref(gf))])
+        fn("kerr_connection", None, D, D, D, ol.G444)(a, r, m, G)
+        kc = D4(*list(k)); null(kc, 2.0, C.byref(g)); gam(G, kc, kc, dk)
+        want["kerr_null_k"], want["kerr_Gamma"] = np.array(list(kc)), np.array(list(dk))
+        cov(kc, dk, C.byref(g)); want["kerr_k_cov"] = np.array(list(dk))
+        cov(kc, dk, None); want["flat_k_cov"] = np.array(list(dk))
+        sp = D4(0.0, 0.3, -0.2, 0.05)
+        want["norms"] = np.array([fn("vector_norm", D, D4, PM)(sp, C.byref(g)), L.vector_norm(sp, None), fn("vector_3norm", D, D4)(sp)])
+        fn("vector_multiply", None, D4, D)(sp, 2.5); want["multiplied"] = np.array(list(sp))
+        Om = 0.7 * fn("OmegaK", D, D, D)(r, a)
+        U = D4()
+        fn("fourvelocity_zamo", None, PM, D4)(C.byref(g), U); want["fourvelocity_zamo"] = np.array(list(U))
+        fn("fourvelocity_azimuthal", None, D, PM, D4)(Om, C.byref(g), U); want["fourvelocity_azimuthal"] = np.array(list(U))
+        fn("fourvelocity_radial", None, D, PM, D4)(-0.2, C.byref(g), U); want["fourvelocity_radial"] = np.array(list(U))
+        want["fourvelocity_norm"] = np.array([fn("fourvelocity_norm", D, D, D, D, PM)(0.05, 0.01, 0.5 * Om, C.byref(g))])
+        fn("fourvelocity", None, D, D, D, PM, D4)(0.05, 0.01, 0.5 * Om, C.byref(g), U); want["fourvelocity"] = np.array(list(U))
+        te = lambda x: np.frombuffer(ol.struct_bytes(x), np.float64)[:16].copy()
+        fn("tetrad_general", None, PM, D4, PT)(C.byref(g), U, C.byref(t)); want["tetrad_general"] = te(t)
+        trad = fn("tetrad_radial", None, PM, D, PT)
+        trad(C.byref(g), -0.2, C.byref(t)); want["tetrad_radial"] = te(t)
+        trad(C.byref(g), 0.0, C.byref(t)); want["tetrad_radial0"] = te(t)
+        want["frequencies"] = np.array([fn("omega_r", D, D, D)(r + 6.0, a), fn("omega_z", D, D, D)(r + 6.0, a),
+                                        fn("ell_from_Omega", D, D, PM)(Om, C.byref(g))])
+        gd = ol.Geodesic(); e = C.c_int(0)
+        v = [float("nan")] * 3
+        if fn("geodesic_init_inf", ol.I, D, D, D, D, ol.PG, ol.PI)(math.radians(65.0), a, 4.0, -3.0, C.byref(gd), C.byref(e)):
+            sk = fn("geodesic_position_pol_sign_k_theta", D, ol.PG, D); dms = fn("geodesic_dm_sign", D, ol.PG, D)
+            v = [sk(C.byref(gd), 0.4 * gd.Rpc), dms(C.byref(gd), 0.4 * gd.Rpc), sk(C.byref(gd), 1.7 * gd.Rpc)]
+        want["sign_k_theta"] = np.array(v)
+        epi = fn("elliptic_pi", ol.Cplx, D, D, D)
+        z, w = epi(-2.2, 1.8, 0.45), epi(4.0, -0.6, 0.45)
+        want["legendre"] = np.array([fn("elliptic_f", D, D, D)(-2.2, 0.45), fn("elliptic_e_sin", D, D, D)(0.8, 0.45),
+                                     fn("elliptic_pi_sin", D, D, D, D)(0.8, -0.6, 0.45), z.re, z.im, w.re, w.im])
+        E = np.array([0.1, 0.5, 1.0, 3.0, 9.0]); Iv = np.full(5, -1.0)
+        bb = fn("blackbody", None, D, D, D, ol.PD, ol.PD, ol.I)
+        bb(2.5e6, 1.7, 0.4, E.ctypes.data_as(ol.PD), Iv.ctypes.data_as(ol.PD), 5); want["blackbody"] = Iv.copy()
+        bb(0.0, 1.7, 0.4, E.ctypes.data_as(ol.PD), Iv.ctypes.data_as(ol.PD), 5); want["blackbody_T0"] = Iv.copy()
+        want["photons"] = np.array([fn("blackbody_photons", D, D, D, D, D)(2.5e6, 1.7, 0.4, 1.0), fn("blackbody_photons_total", D, D, D)(2.5e6, 1.7)])
+        want["helpers"] = np.array([1.0, 1.0, 2.0, 0.5])
+        assert set(got) == set(want), set(got) ^ set(want)
+        for name in want:
+            assert_close(got[name], want[name], rtol=1e-9, floor=1e-9, what="%s (a=%g r=%g m=%g)" % (name, a, r, m))
+
+
 def test_radii_and_disk_report_program(tmp_path, capi, golden):
     """tests/c/disk_dump.c through the scalar API: the radii of example 01, the disk report incl. a set-up by
     luminosity, and disk_nt_dump's table (ref src/sim5disk-nt.c:310-360) against the reference's numbers."""

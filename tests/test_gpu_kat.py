@@ -255,3 +255,75 @@ def test_empty_batches_and_null_pointers(capi):
     assert capi.elliptic("rf", np.zeros(0), np.zeros(0), np.zeros(0)).size == 0
     rc = capi._lib.sim5gpu_gfactorK(C.c_size_t(4), None, None, None, None)
     assert rc == -3
+
+
+def test_boundary_prototypes(capi, golden):
+    """The remaining public prototypes of the cited reference headers (C-ABI group (1b), sim5_amd/csrc/capi_boundary.hip)
+    against the unmodified reference's outputs (oracle/gen_golden.py:kat_boundary): metric helpers, Gamma on Kerr and on
+    arbitrary dense connections, the vector helpers (Kerr metric and NULL = Minkowski), tetrad_general / tetrad_radial,
+    epicyclic frequencies, ell_from_Omega, the five four-velocity routines, sign of k^theta, Legendre integrals by angle
+    and by sine (incl. the complex hyperbolic case of elliptic_pi), black-body spectrum and photon counts.  NaN patterns
+    (space-like "four-velocities" inside the ergosphere, the reference's 0/0 in kerr_connection at a = 0) must coincide."""
+    g = golden("kat_boundary.npz")
+    a, r, m = g["a"], g["r"], g["m"]
+    MD = capi.METRIC_DTYPE
+
+    def rows(rec):
+        return np.frombuffer(np.ascontiguousarray(rec).tobytes(), np.float64).reshape(len(rec), -1)
+    km = np.frombuffer(g["kerr_metric"].tobytes(), dtype=MD)
+    assert_close(rows(capi.flat_metric(r, m)), g["flat_metric"], rtol=1e-15, what="flat_metric")
+    assert_close(rows(capi.flat_metric_contravariant(r, m)), g["flat_metric_contra"], rtol=1e-14, what="flat_metric_contravariant")
+    assert_close(rows(capi.kerr_metric_contravariant(a, r, m)), g["kerr_metric_contra"], rtol=1e-12, what="kerr_metric_contravariant")
+    assert_close(capi.flat_connection(r, m).reshape(-1, 64), g["flat_connection"], rtol=1e-14, what="flat_connection")
+    assert_close(capi.Gamma(g["G"], g["U"], g["V"]), g["Gamma"], rtol=1e-9, floor=1e-9, what="Gamma")
+    assert_close(capi.vector_covariant(g["U"], km), g["vcov"], rtol=1e-12, floor=1e-12, what="vector_covariant")
+    assert_close(capi.vector_covariant(g["U"]), g["vcov_flat"], rtol=0.0, what="vector_covariant flat")
+    assert_close(capi.vector_norm(g["Vsp"], km), g["vnorm"], rtol=1e-13, what="vector_norm")
+    assert_close(capi.vector_norm(g["Vsp"]), g["vnorm_flat"], rtol=1e-15, what="vector_norm flat")
+    assert_close(capi.vector_3norm(g["U"]), g["v3norm"], rtol=1e-15, what="vector_3norm")
+    ok = ~np.isnan(g["knull"][:, 0])
+    assert_close(capi.vector_norm_to_null(g["knull"][ok], g["V0"][ok], km[ok]), g["vnull"][ok], floor=1e-9, what="vector_norm_to_null")
+    assert_close(capi.vector_norm_to_null(g["vnull_flat_in"], g["V0"]), g["vnull_flat"], rtol=1e-14, what="vector_norm_to_null flat")
+    tg = rows(capi.tetrad_general(km, g["Ufluid"]))
+    assert_close(tg, g["tetrad_general"], floor=1e-9, what="tetrad_general")
+    assert (~np.isnan(g["tetrad_general"][:, :16]).any(axis=1)).sum() > 400
+    assert_close(rows(capi.tetrad_radial(km, g["v_r"])), g["tetrad_radial"], floor=1e-12, what="tetrad_radial")
+    assert_close(capi.omega_r(g["r_orbit"], a), g["omega_r"], floor=1e-9, what="omega_r")     # -> 0 at the marginally stable orbit
+    assert_close(capi.omega_z(g["r_orbit"], a), g["omega_z"], what="omega_z")
+    assert_close(capi.ell_from_Omega(g["Omega"], km), g["ell_from_Omega"], rtol=1e-12, what="ell_from_Omega")
+    assert_close(capi.fourvelocity_zamo(km), g["u_zamo"], rtol=1e-12, floor=1e-12, what="fourvelocity_zamo")
+    assert_close(capi.fourvelocity_azimuthal(g["Omega"], km), g["u_azimuthal"], rtol=1e-10, floor=1e-12, what="fourvelocity_azimuthal")
+    assert_close(capi.fourvelocity_radial(g["v_r"], km), g["u_radial"], rtol=1e-12, floor=1e-12, what="fourvelocity_radial")
+    U1, U2, U3 = g["U123"].T
+    assert_close(capi.fourvelocity_norm(U1, U2, U3, km), g["u_norm"], rtol=1e-10, what="fourvelocity_norm")
+    assert_close(capi.fourvelocity(U1, U2, U3, km), g["u_general"], rtol=1e-10, floor=1e-12, what="fourvelocity")
+    # sign of k^theta: integers, exact; fed with the reference's records
+    ref = np.frombuffer(g["geod"].tobytes(), dtype=capi.GEODESIC_DTYPE)
+    okg = g["geod_ok"] == 1
+    for j in range(3):
+        s = capi.geodesic_position_pol_sign_k_theta(ref[okg], g["geod_P"][okg, j])
+        assert np.array_equal(s, g["sign_k_theta"][okg, j], equal_nan=True)
+        assert np.array_equal(s, -g["dm_sign"][okg, j], equal_nan=True)
+    assert okg.sum() > 300
+    # Legendre integrals
+    assert_close(capi.legendre("elliptic_f", g["leg_phi"], g["leg_m"]), g["elliptic_f"], floor=1e-9, what="elliptic_f")
+    assert_close(capi.legendre("elliptic_e_sin", g["leg_sin"], g["leg_m"]), g["elliptic_e_sin"], what="elliptic_e_sin")
+    assert_close(capi.legendre("elliptic_pi_sin", g["leg_sin"], g["leg_m"], nn=g["leg_n_sin"]), g["elliptic_pi_sin"], what="elliptic_pi_sin")
+    z = capi.legendre("elliptic_pi", g["leg_phi"], g["leg_m"], nn=g["leg_n"])
+    assert_close(z.real, g["elliptic_pi"][:, 0], floor=1e-6, what="Re elliptic_pi")
+    assert_close(z.imag, g["elliptic_pi"][:, 1], floor=1e-9, what="Im elliptic_pi")
+    assert (g["elliptic_pi"][:, 1] != 0).sum() > 20                                   # hyperbolic cases with la < 0 are in the sample
+    # black body
+    for (T, hf, cm), want in zip(g["bb_par"], g["bb_spectra"]):
+        got = capi.blackbody(T, hf, cm, g["bb_E"]) if T > 0 else np.full(64, -7.0)
+        if T <= 0:                                           # the reference leaves Iv untouched for T <= 0: so does the entry point
+            import ctypes as C
+            buf = np.full(64, -7.0)
+            assert capi._lib.sim5gpu_blackbody(C.c_double(T), C.c_double(hf), C.c_double(cm), C.c_size_t(64),
+                                               g["bb_E"].ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p)) == 0
+            got = buf
+        assert_close(got, want, rtol=1e-12, floor=1e-300, what="blackbody T=%g" % T)
+    assert_close(capi.blackbody_photons(g["bbp_T"], g["bbp_hardf"], g["bbp_cos"], g["bbp_E"]), g["blackbody_photons"],
+                 rtol=1e-12, floor=1e-300, what="blackbody_photons")
+    assert_close(capi.blackbody_photons_total(g["bbp_T"], g["bbp_hardf"]), g["blackbody_photons_total"], rtol=1e-14,
+                 what="blackbody_photons_total")
