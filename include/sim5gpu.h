@@ -381,6 +381,11 @@ typedef struct sim5gpu_image_desc {
                                  * (sim5_amd/sharding.py).  A plain call whose range is symmetric (y0 + y1 == ny) is paired
                                  * the same way without asking.  The values are those of the unpaired trace, bit for bit. */
 
+#define SIM5GPU_IMG_INPLACE 4   /* sim5gpu_disk_image only: the output pointers are WHOLE-image planes (ny x nx) and every traced row
+                                 * is written at its image row instead of packed -- a rank that assembles the image (the root of
+                                 * a gather) traces its own stripes and its band straight into the final image.  The aux planes,
+                                 * if given, are whole-image planes too. */
+
 /* optional full-precision outputs (any pointer may be NULL) */
 typedef struct sim5gpu_image_aux {
     uint8_t *cls;           /* SIM5GPU_PX_*                         */
@@ -392,6 +397,17 @@ typedef struct sim5gpu_image_aux {
 
 /* rows of output a job description produces (y1 - y0, or the total height of its stripes) */
 int sim5gpu_image_rows(const sim5gpu_image_desc *desc);
+
+/* image row of every packed output row of a job description: rows[i], i < min(sim5gpu_image_rows(desc), capacity).
+ * Host arithmetic (no GPU needed): the rule by which a share's rows go back into the image. */
+int sim5gpu_image_row_map(const sim5gpu_image_desc *desc, int *rows, int capacity);
+
+/* Put the packed rows of up to 16 shares of ONE image (e.g. the per-rank payloads a gather delivered to the root)
+ * at their image rows, in one launch.  descs[i] is the job description share i was traced with; d_shares holds the
+ * shares as consecutive blocks of [2 planes][share_rows][nx] floats (share_rows >= rows of the largest share: the
+ * layout of gathered fixed-size payloads); d_image_f / d_image_g are the ny x nx planes of the whole image. */
+int sim5gpu_image_place_shares(int n_shares, const sim5gpu_image_desc *descs, const float *d_shares, size_t share_rows,
+                               float *d_image_f, float *d_image_g, void *stream);
 
 /* The caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105 as one kernel:
  * image_f = (float)(F g^4), image_g = (float)g, zero where the ray does not hit the disk. */

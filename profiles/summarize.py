@@ -59,9 +59,19 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024.0
     out["hbm"] = {"fetch_bytes_raw": fetch, "fetch_bytes_x2_gfx950": 2 * fetch, "write_bytes": write,
                   "algorithmic_bytes": rays * 8}
-    json.dump({"hbm_bytes_per_launch": 2 * fetch + write, "source": "profiles/%s_pmc.json" % tag,
-               "note": "2*FETCH_SIZE + WRITE_SIZE, KiB->B, per launch of " + KERNEL},
-              open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+    tj = {"hbm_bytes_per_launch": 2 * fetch + write, "source": "profiles/%s_pmc.json" % tag,
+          "note": "2*FETCH_SIZE + WRITE_SIZE, KiB->B, per launch of " + KERNEL}
+    # FP64 operations the kernel EXECUTES (wave instructions x 64 lanes; an FMA counts 2; the quarter-rate seeds rcp / rsq /
+    # sqrt are listed separately): what roofline.executed_frac in bench.py is computed from
+    if all(k in pmc for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64")):
+        add, mul, fma = (pmc[k]["mean_per_launch"] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+        tj["executed_fp64_flops_per_launch"] = 64.0 * (add + mul + 2.0 * fma)
+        tj["executed_fp64_flops_per_ray"] = 64.0 * (add + mul + 2.0 * fma) / rays
+        tj["executed_fp64_wave_instructions_per_64_rays"] = {"add": add / (rays / 64), "mul": mul / (rays / 64), "fma": fma / (rays / 64),
+                                                            "trans": pmc.get("SQ_INSTS_VALU_TRANS_F64", {}).get("mean_per_launch", 0.0) / (rays / 64)}
+        tj["valu_wave_instructions_per_64_rays"] = pmc["SQ_INSTS_VALU"]["mean_per_launch"] / (rays / 64) if "SQ_INSTS_VALU" in pmc else None
+        tj["kernel"] = KERNEL
+    json.dump(tj, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 # the default bench command (headline + the other configurations): per-kernel statistics as rocprofv3 prints them, and the
 # headline launches picked out of its kernel trace by their grid (256 x 256 workgroups of 256 threads: X = 65536, Y = 256;
 # the mirror kernel covers the upper half: Y = 128)

@@ -18,6 +18,7 @@ LIB = os.path.join(LIBDIR, ("ab_%s.so" % _VAR) if _VAR else "libsim5gpu.so")
 # (source, object, variant): the image kernels are built in both arithmetic variants
 SOURCES = [("capi_core.hip", "capi_core.o", "strict"), ("capi_batch.hip", "capi_batch.o", "strict"),
            ("capi_jobs.hip", "capi_jobs.o", "strict"), ("capi_boundary.hip", "capi_boundary.o", "strict"),
+           ("k_assemble.hip", "k_assemble.o", "strict"),
            ("k_torus.hip", "k_torus_strict.o", "strict"), ("k_torus.hip", "k_torus_fast.o", "fast"),
            ("k_disk_image.hip", "k_disk_image_strict.o", "strict"), ("k_disk_image.hip", "k_disk_image_fast.o", "fast"),
            ("k_polar_image.hip", "k_polar_image_strict.o", "strict"), ("k_polar_image.hip", "k_polar_image_fast.o", "fast"),

@@ -850,24 +850,41 @@ def blackbody_photons_total(T, hardf):
 
 
 # ---- whole-job kernels --------------------------------------------------------------------------
-IMG_DEFAULT, IMG_STRICT, IMG_MIRROR = 0, 1, 2
+IMG_DEFAULT, IMG_STRICT, IMG_MIRROR, IMG_INPLACE = 0, 1, 2, 4
 
 
 def image_desc(nx, ny, a, incl_rad, y0=0, y1=None, rmax=0.0, rms=0.0, bh_mass=10.0, mdot=0.1,
                alpha_visc=0.1, max_order=2, pol_degree=0.0, strict=False, stripe_rows=0, stripe_step=0,
-               disk_spin=-1.0, mirror=False):
+               disk_spin=-1.0, mirror=False, inplace=False):
     """Job description; defaults are those of the reference example (disk-image.c:41-45).
     strict=True selects the reference-parameter arithmetic variant (SIM5GPU_IMG_STRICT); mirror=True adds the mirror
-    images ny-1-y of the named rows, which must lie in the upper half (SIM5GPU_IMG_MIRROR)."""
+    images ny-1-y of the named rows, which must lie in the upper half (SIM5GPU_IMG_MIRROR); inplace=True: the outputs are
+    whole-image planes and every traced row is written at its image row (SIM5GPU_IMG_INPLACE)."""
     return ImageDesc(nx=nx, ny=ny, y0=y0, y1=ny if y1 is None else y1, a=a, incl=incl_rad,
                      rmax=rmax, rms=rms, bh_mass=bh_mass, mdot=mdot, alpha_visc=alpha_visc,
-                     max_order=max_order, flags=(IMG_STRICT if strict else IMG_DEFAULT) | (IMG_MIRROR if mirror else 0), pol_degree=pol_degree,
+                     max_order=max_order, flags=(IMG_STRICT if strict else IMG_DEFAULT) | (IMG_MIRROR if mirror else 0) | (IMG_INPLACE if inplace else 0),
+                     pol_degree=pol_degree,
                      stripe_rows=stripe_rows, stripe_step=stripe_step, disk_spin=disk_spin)
 
 
 def image_rows(desc):
     _lib.sim5gpu_image_rows.restype = I
     return _lib.sim5gpu_image_rows(C.byref(desc))
+
+
+def image_row_map(desc):
+    """image row of every packed output row of the job (host arithmetic of the library, no GPU)"""
+    n = image_rows(desc)
+    rows = np.zeros(max(n, 1), dtype=np.int32)
+    _check(_lib.sim5gpu_image_row_map(C.byref(desc), _p(rows), I(n)), "sim5gpu_image_row_map")
+    return rows[:n]
+
+
+def image_place_shares(descs, d_shares, share_rows, d_image_f, d_image_g, stream=None):
+    """rows of len(descs) shares (consecutive [2][share_rows][nx] float blocks at d_shares) to their image rows, one launch"""
+    arr = (ImageDesc * len(descs))(*descs)
+    _check(_lib.sim5gpu_image_place_shares(I(len(descs)), arr, VP(d_shares), SZ(share_rows), VP(d_image_f), VP(d_image_g),
+                                           VP(stream or 0)), "sim5gpu_image_place_shares")
 
 
 def disk_image_device(desc, d_image_f, d_image_g, aux=None, stream=None):

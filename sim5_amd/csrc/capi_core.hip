@@ -292,6 +292,7 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_
     p.stripe_rows = desc->stripe_rows; p.stripe_step = desc->stripe_step;
     p.nrows = sim5gpu_image_rows(desc);
     p.mirror = (desc->flags & SIM5GPU_IMG_MIRROR) ? 1 : 0;
+    p.inplace = (desc->flags & SIM5GPU_IMG_INPLACE) ? 1 : 0;
     p.nrows_top = image_rows_top(desc);
     p.inv_nx = 1.0 / (double)desc->nx; p.inv_ny = 1.0 / (double)desc->ny;
     p.ny_over_nx = (double)desc->ny / (double)desc->nx;
@@ -530,6 +531,7 @@ int sim5gpu_disk_rays(const sim5gpu_image_desc* desc, size_t n, const double* d_
     int rc = fill_image_params(&dd, p);
     if (rc) return rc;
     if (n == 0) return SIM5GPU_OK;
+    if (desc->flags & SIM5GPU_IMG_INPLACE) { snprintf(g_err, sizeof g_err, "disk_rays: SIM5GPU_IMG_INPLACE needs the pixel grid"); return SIM5GPU_E_ARG; }
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
     if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.img_f = d_image_f; p.img_g = d_image_g;
@@ -548,6 +550,7 @@ int sim5gpu_disk_image_host(const sim5gpu_image_desc* desc, float* h_image_f, fl
     ImageParams chk;
     int rc = fill_image_params(desc, chk);
     if (rc) return rc;
+    if (desc->flags & SIM5GPU_IMG_INPLACE) { snprintf(g_err, sizeof g_err, "disk_image_host: SIM5GPU_IMG_INPLACE is for device buffers"); return SIM5GPU_E_ARG; }
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
     const size_t n = (size_t)sim5gpu_image_rows(desc) * (size_t)desc->nx;
     DevBuf<float> f(n), g(n);
@@ -571,6 +574,42 @@ int sim5gpu_disk_image_host(const sim5gpu_image_desc* desc, float* h_image_f, fl
         if (h_aux->g) S5_HIP(gg.to_host(h_aux->g));
         if (h_aux->flux) S5_HIP(fl.to_host(h_aux->flux));
     }
+    return SIM5GPU_OK;
+}
+
+/* image row of every packed output row of a job description (host arithmetic, no GPU): rows[i] for i < min(count, capacity) */
+int sim5gpu_image_row_map(const sim5gpu_image_desc* desc, int* rows, int capacity)
+{
+    ImageParams p;
+    const int rc = fill_image_params(desc, p, false);
+    if (rc) return rc;
+    if (!rows && capacity > 0) return SIM5GPU_E_ARG;
+    for (int lr = 0; lr < p.nrows && lr < capacity; ++lr) rows[lr] = image_row(p, lr);
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_image_place_shares(int n_shares, const sim5gpu_image_desc* descs, const float* d_shares, size_t share_rows,
+                               float* d_image_f, float* d_image_g, void* stream)
+{
+    if (n_shares == 0) return SIM5GPU_OK;
+    if (n_shares < 0 || n_shares > 16 || !descs || !d_shares || !d_image_f || !d_image_g) {
+        snprintf(g_err, sizeof g_err, "image_place_shares: bad arguments (1..16 shares, non-NULL pointers)");
+        return SIM5GPU_E_ARG;
+    }
+    RowMap maps[16];
+    for (int i = 0; i < n_shares; ++i) {
+        ImageParams p;
+        const int rc = fill_image_params(&descs[i], p, false);
+        if (rc) return rc;
+        if (p.nx != descs[0].nx || p.ny != descs[0].ny || (size_t)p.nrows > share_rows) {
+            snprintf(g_err, sizeof g_err, "image_place_shares: share %d does not fit (nx=%d ny=%d rows=%d, block rows=%zu)", i, p.nx, p.ny, p.nrows, share_rows);
+            return SIM5GPU_E_ARG;
+        }
+        maps[i] = RowMap{ p.ny, p.y0, p.nrows, p.nrows_top, p.stripe_rows, p.stripe_step, p.mirror };
+    }
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    hipError_t e = (hipError_t)s5_launch_place_shares(n_shares, maps, d_shares, share_rows, descs[0].nx, d_image_f, d_image_g, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("image_place_shares launch", e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;
 }
 

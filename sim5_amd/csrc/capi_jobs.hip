@@ -16,6 +16,7 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     ImageParams p;
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
+    if (desc->flags & SIM5GPU_IMG_INPLACE) { snprintf(g_err, sizeof g_err, "disk_image_polarized: SIM5GPU_IMG_INPLACE is not supported"); return SIM5GPU_E_ARG; }
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
     if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.stokes = d_stokes;
@@ -127,7 +128,7 @@ int sim5gpu_disk_spectrum(const sim5gpu_image_desc* desc, int n_energies, const 
         snprintf(g_err, sizeof g_err, "disk_spectrum: need energies, spectrum, workspace, n_energies > 0, hardening > 0");
         return SIM5GPU_E_ARG;
     }
-    if (desc && (desc->stripe_rows != 0 || (desc->flags & SIM5GPU_IMG_MIRROR))) { snprintf(g_err, sizeof g_err, "disk_spectrum: striping / mirrored rows are not supported"); return SIM5GPU_E_ARG; }
+    if (desc && (desc->stripe_rows != 0 || (desc->flags & (SIM5GPU_IMG_MIRROR | SIM5GPU_IMG_INPLACE)))) { snprintf(g_err, sizeof g_err, "disk_spectrum: striping / mirrored / in-place rows are not supported"); return SIM5GPU_E_ARG; }
     ImageParams p;
     int rc = fill_image_params(desc, p);
     if (rc) return rc;

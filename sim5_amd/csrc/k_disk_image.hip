@@ -82,7 +82,7 @@ void disk_image_grid_kernel(ImageParams p)
     if (ix >= p.nx || lr >= p.nrows) return;
     const int iy = image_row(p, lr);
     const RayResult res = trace_disk_ray(p, pixel_alpha(p, ix), pixel_beta(p, iy));
-    store_ray(p, (size_t)lr * (size_t)p.nx + (size_t)ix, res);
+    store_ray(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, res);     // packed rows, or in place in the whole image
 }
 
 #if S5_FAST
@@ -107,9 +107,10 @@ void disk_image_mirror_kernel(ImageParams p)
     if (ix >= p.nx || lr >= half) return;
     const int lr2 = p.nrows - 1 - lr;                            // its mirror row (== lr for an odd middle row)
     ThinRay t, t2;
-    trace_thin_disk_impl<false, true>(p, pixel_alpha(p, ix), pixel_beta(p, image_row_top(p, lr)), t, t2);
-    store_ray(p, (size_t)lr * (size_t)p.nx + (size_t)ix, ray_result(t));
-    if (lr2 != lr) store_ray(p, (size_t)lr2 * (size_t)p.nx + (size_t)ix, ray_result(t2));
+    const int iy = image_row_top(p, lr);
+    trace_thin_disk_impl<false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);
+    store_ray(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, ray_result(t));
+    if (lr2 != lr) store_ray(p, (size_t)(p.inplace ? p.ny - 1 - iy : lr2) * (size_t)p.nx + (size_t)ix, ray_result(t2));
 }
 #endif
 

@@ -48,6 +48,7 @@ struct ImageParams {
     int mirror;                        // SIM5GPU_IMG_MIRROR: packed rows nrows_top .. nrows-1 are the mirror images of the first ones
     int nrows_top;                     // rows named by y0, y1 and the striping (== nrows without mirror)
     int max_order;
+    int inplace;                       // SIM5GPU_IMG_INPLACE: the outputs are whole-image planes, a traced row is written at its image row
     double a, incl, sin_i, cos_i;      // sin/cos from the host libm
     double rmax, rms;
     double inv_nx, inv_ny, ny_over_nx; // 1/nx, 1/ny, ny/nx (host doubles; used by the fast variant)
@@ -84,6 +85,17 @@ __host__ __device__ inline int image_row(const ImageParams& p, int lr)
     return image_row_top(p, lr);
 }
 
+// the rows a job description traces, without the rest of the job: what placing a share into the whole image needs
+// (k_assemble.hip); same rule as image_row()
+struct RowMap { int ny, y0, nrows, nrows_top, stripe_rows, stripe_step, mirror; };
+
+__host__ __device__ inline int image_row(const RowMap& p, int lr)
+{
+    const int t = (p.mirror && lr >= p.nrows_top) ? p.nrows - 1 - lr : lr;
+    const int y = p.stripe_rows > 0 ? p.y0 + (t / p.stripe_rows) * p.stripe_step + t % p.stripe_rows : p.y0 + t;
+    return (p.mirror && lr >= p.nrows_top) ? p.ny - 1 - y : y;
+}
+
 // spectrum job (k_spectrum.hip)
 struct SpectrumParams {
     int n_energies;
@@ -110,6 +122,9 @@ struct SurfaceParams {
 // fast = tuned FP64 sequences (default); strict = reference parameters, IEEE sqrt/div, no contraction
 int s5_launch_disk_image_fast(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream);
+// k_assemble.hip: rows of n shares ([2][share_rows][nx] floats each, share i at shares + i * 2 * share_rows * nx) to their image rows
+int s5_launch_place_shares(int n_shares, const s5abi::RowMap* maps, const float* shares, size_t share_rows, int nx,
+                           float* image_f, float* image_g, hipStream_t stream);
 int s5_launch_disk_image_polarized_fast(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_spectrum_fast(const s5abi::ImageParams& p, const s5abi::SpectrumParams& sp,

@@ -133,69 +133,111 @@ def assemble(tiles, ny, world, stripe=STRIPE, dealt=None, out=None):
     return out
 
 
+def place_shares(tiles, ny, world, out, stripe=STRIPE, dealt=None, first=1):
+    """Reference form of the root's assembly: rows of the gathered per-rank blocks tiles[first:] to their image rows in
+    `out` ([..., ny, nx]); rank 0's own rows are already there (it traces in place).  Slicing + assignment only (numpy or
+    torch); bench.py does the same on the GPU with ONE kernel (sim5gpu_image_place_shares)."""
+    for r in range(first, world):
+        off = 0
+        for (y0, y1) in stripes_for_rank(ny, r, world, stripe, dealt):
+            out[..., y0:y1, :] = tiles[r][..., off:off + (y1 - y0), :]
+            off += y1 - y0
+    return out
+
+
 class TilePipeline:
-    """Double-buffered "trace my share, gather the shares to rank 0" loop shared by bench.py and the CPU
-    (gloo) test.  `trace(buffer)` must enqueue the work that fills `buffer` ([2, rows_max, nx] tensor);
-    the gather of image i is issued asynchronously and overlaps the tracing of image i+1; `drain()`
-    waits for every outstanding gather.  With world == 1 there is no gather and a single buffer.
+    """Double-buffered "trace my share, gather the shares to rank 0, put them in row order" loop shared by bench.py and
+    the CPU (gloo) test.  One step = one image:
 
-    dealt < upper_half(ny): rank 0 additionally traces the centred band root_band(ny, dealt) into its own [2, ny, nx]
-    image with `trace_band(view)`, AFTER the gather of its share has been issued, so that the two overlap.
+      every rank   trace(buffer, inplace) enqueues the work that fills its share.  Peers: `buffer` is the [2, rows_max, nx]
+                   payload of the gather, rows packed (inplace False).  Rank 0: `buffer` is its [2, ny, nx] IMAGE and the
+                   share is written at its image rows (inplace True: SIM5GPU_IMG_INPLACE) -- rank 0's rows never move.
+      every rank   ONE gather per image (both planes of a rank's stripes are one contiguous payload), asynchronous.
+      rank 0       trace_band(view) traces the centred band root_band(ny, dealt) into the same image while the gather is
+                   in flight (dealt < upper_half(ny) only).
+      rank 0       when the gather of an image has completed, place(shares, image) copies the peers' rows to their image
+                   rows -- so every step ends with a complete row-major [2, ny, nx] image on rank 0.  The placement of
+                   image i is issued after the tracing of image i+1 has been enqueued, so gather i overlaps tracing i+1;
+                   drain() completes everything outstanding.
 
-    host_staged=True is the one-GPU test hook of bench.py: the tile is copied to the host and gathered
-    synchronously over gloo (RCCL refuses two ranks on one device); same control flow, same buffers."""
+    `place(gathered, image)`: gathered is the [world, 2, rows_max, nx] tensor the gather filled (block 0, rank 0's own
+    contribution, is not used); default: place_shares() above.  host_staged=True is the one-GPU test hook of bench.py:
+    the tile is copied to the host and gathered synchronously over gloo (RCCL refuses two ranks on one device); same
+    control flow, same buffers."""
 
-    def __init__(self, torch, dist, rank, world, ny, nx, device, dtype=None, host_staged=False, dealt=None):
+    def __init__(self, torch, dist, rank, world, ny, nx, device, dtype=None, host_staged=False, dealt=None, place=None):
         self.dist, self.rank, self.world, self.ny = dist, rank, world, ny
         self.host_staged = host_staged and world > 1
         self.dealt = dealt if world > 1 else None
         dtype = dtype or torch.float32
         rows_max = max(1, max_local_rows(ny, world, dealt=self.dealt))
+        self.rows_max = rows_max
         self.nbuf = 2 if world > 1 else 1
-        self.tiles = [torch.zeros((2, rows_max, nx), dtype=dtype, device=device) for _ in range(self.nbuf)]
+        root = world > 1 and rank == 0
+        # the payload of the gather (rank 0 contributes a block nobody reads: its rows are traced in place)
+        self.tiles = [torch.zeros((2, rows_max, nx), dtype=dtype, device=device) for _ in range(self.nbuf if not root else 1)]
         gdev = "cpu" if self.host_staged else device
-        self.gathered = [[torch.zeros((2, rows_max, nx), dtype=dtype, device=gdev) for _ in range(world)]
-                         for _ in range(self.nbuf)] if (world > 1 and rank == 0) else [None] * self.nbuf
-        self.band = root_band(ny, self.dealt) if (world > 1 and rank == 0) else None
-        self.full = [torch.zeros((2, ny, nx), dtype=dtype, device=device) for _ in range(self.nbuf)] if self.band else None
-        self.pending = [None] * self.nbuf
+        self.gathered = [torch.zeros((world, 2, rows_max, nx), dtype=dtype, device=gdev) for _ in range(self.nbuf)] if root else [None] * self.nbuf
+        self.staged = torch.zeros((world, 2, rows_max, nx), dtype=dtype, device=device) if (root and self.host_staged) else None
+        self.band = root_band(ny, self.dealt) if root else None
+        self.full = [torch.zeros((2, ny, nx), dtype=dtype, device=device) for _ in range(self.nbuf)] if (root or world == 1) else None
+        self.pending = [None] * self.nbuf       # gather in flight on this buffer
+        self.unplaced = [False] * self.nbuf     # rank 0: gathered[b] holds rows that are not in full[b] yet
+        self._place = place or (lambda gathered, image: place_shares(gathered, ny, world, image, dealt=self.dealt))
         self.count = 0
         self.gathers = 0
+        self.placed = 0
 
     def step(self, trace, trace_band=None):
+        if self.band and trace_band is None:
+            raise ValueError("TilePipeline.step: rank 0 keeps the band %r of the image: trace_band is required" % (self.band,))
         b = self.count % self.nbuf
-        if self.pending[b] is not None:
-            self.pending[b].wait()              # the gather that last read this buffer has finished
-            self.pending[b] = None
-        trace(self.tiles[b])
-        if self.world > 1:
+        self.finish(b)                          # buffer b is free: its gather has completed and its rows are placed
+        if self.world == 1:
+            trace(self.full[b], True)
+        elif self.rank == 0:
+            trace(self.full[b], True)           # in place: rank 0's rows are final
             self.gather(b)
-        if self.band:                           # rank 0 only: its band, while the gather is in flight
-            trace_band(self.full[b][:, self.band[0]:self.band[1]])
+            if self.band:                       # its band, while the gather is in flight
+                trace_band(self.full[b][:, self.band[0]:self.band[1]])
+            if self.count > 0:
+                self.finish((self.count - 1) % self.nbuf)      # the previous image is complete from here on
+        else:
+            trace(self.tiles[b], False)
+            self.gather(b)
         self.count += 1
 
     def gather(self, b, async_op=True):
         """ONE collective per image: both planes of this rank's stripes in a single contiguous payload."""
+        mine = self.tiles[0] if self.rank == 0 else self.tiles[b]
+        glist = list(self.gathered[b].unbind(0)) if self.rank == 0 else None
         if self.host_staged:
-            self.dist.gather(self.tiles[b].cpu(), self.gathered[b], dst=0)
+            self.dist.gather(mine.cpu(), glist, dst=0)
         else:
-            w = self.dist.gather(self.tiles[b], self.gathered[b], dst=0, async_op=async_op)
+            w = self.dist.gather(mine, glist, dst=0, async_op=async_op)
             if async_op:
                 self.pending[b] = w
+        self.unplaced[b] = self.rank == 0
         self.gathers += 1
+
+    def finish(self, b):
+        """the gather that last used buffer b has completed; rank 0: the peers' rows are in the image"""
+        if self.pending[b] is not None:
+            self.pending[b].wait()              # the current stream waits for the collective (no host block on RCCL)
+            self.pending[b] = None
+        if self.unplaced[b]:
+            src = self.gathered[b]
+            if self.host_staged:
+                self.staged.copy_(src)
+                src = self.staged
+            self._place(src, self.full[b])
+            self.unplaced[b] = False
+            self.placed += 1
 
     def drain(self):
         for b in range(self.nbuf):
-            if self.pending[b] is not None:
-                self.pending[b].wait()
-                self.pending[b] = None
+            self.finish(b)
 
     def last_image(self):
         """Rank 0: the most recent complete image, [2, ny, nx] (call after drain() and a device synchronisation)."""
-        b = (self.count - 1) % self.nbuf
-        if self.world == 1:
-            return self.tiles[b][:, :self.ny]
-        if self.band:
-            tiles = [t.to(self.full[b].device) for t in self.gathered[b]] if self.host_staged else self.gathered[b]
-            return assemble(tiles, self.ny, self.world, dealt=self.dealt, out=self.full[b])
-        return assemble(self.gathered[b], self.ny, self.world, dealt=self.dealt)
+        return self.full[(self.count - 1) % self.nbuf]

@@ -32,6 +32,8 @@ def test_single_gpu_line_carries_every_config():
     o = _line(r.stdout)
     assert o["ok"] is True and o["n_gpus"] == 1 and o["config"]["disk_hits"] == 15865362
     assert o["roofline"]["frac"] > 0.2 and o["roofline"]["rays_per_launch"] == 4096 * 4096
+    assert 0.1 < o["roofline"]["executed_frac"] < o["roofline"]["frac"] and "frac_with_counted_flops" not in o["roofline"]
+    assert o["cold_clock"]["kernel_ms"] > 0 and "variant" in o["extra"]["c4_1024_torus_verlet"]
     x = o["extra"]
     assert x["c2_1024_thin_disk"]["disk_hits"] == x["c2_1024_thin_disk"]["disk_hits_reference"]
     assert x["c3_2048_polarized"]["disk_hits"] == x["c3_2048_polarized"]["disk_hits_reference"]
@@ -43,7 +45,7 @@ def test_single_gpu_line_carries_every_config():
 
 @pytest.mark.parametrize("mode,band", [("stripes", "auto"), ("stripes", "off"), ("stripes", "512"), ("images", "auto")])
 def test_two_ranks_on_one_gpu(mode, band):
-    env = dict(os.environ, SIM5_BENCH_ONE_GPU="1")
+    env = dict(os.environ, SIM5_BENCH_ONE_GPU="1", SIM5_BENCH_CHECK_EVERY_STEP="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode,
            "--root-band", band] + (["--no-extra"] if band == "512" else [])
@@ -55,7 +57,13 @@ def test_two_ranks_on_one_gpu(mode, band):
         assert o["scaling"] == "strong" and o["config"]["rays_per_step"] == 4096 * 4096
         pr = o["per_rank"]
         assert len(pr["kernel_ms_per_step"]) == 2 and sum(pr["rays_per_launch"]) == 4096 * 4096
-        assert pr["gather_ms_alone"] > 0
+        assert pr["gather_ms_alone"] > 0 and pr["place_ms_alone"] > 0
+        # every step of the timed region ended with a complete row-major image on rank 0: its hit count, step by step
+        # (spin-up + warm-up + timed steps, each checked one step later without draining the pipeline)
+        assert pr["assemblies_in_timed_region"] == 3
+        hs = o["hits_of_every_assembled_image"]
+        assert len(hs) >= 3 and all(h == 15865362 for h in hs), hs
+        assert o["value_kernel_only"] > o["value"] > 0 and o["kernel_ms_per_step_max_over_ranks"] == max(pr["kernel_ms_per_step"])
         plan = pr["root_band_plan"]
         dealt = plan["dealt_rows_of_upper_half"]
         assert pr["rays_per_launch"][0] == (4096 - dealt) * 4096 and pr["rays_per_launch"][1] == dealt * 4096
@@ -65,6 +73,8 @@ def test_two_ranks_on_one_gpu(mode, band):
             assert dealt == 512 and plan["root_band_rows"] == [512, 3584]
         else:
             assert dealt % 128 == 0 and plan["kernel_ms_full_image"] > 0 and plan["gather_ms_equal_split"] > 0
+            assert len(plan["kernel_ms_samples"]) >= 10 and str(dealt) in plan["candidates_dealt_rows"]
+            assert all(c["predicted_step_ms"] > 0 for c in plan["candidates_dealt_rows"].values())
         if band != "512":
             c5 = o["extra"]["c5_8192_x8_inclinations"]
             assert c5["hits_ok"] and c5["n_gpus"] == 2 and len(c5["disk_hits"]) == 8 and c5["gathers_per_scan"] == 8

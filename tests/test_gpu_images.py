@@ -388,3 +388,53 @@ def test_rejects_bad_arguments(capi):
     # out-of-range physics is a per-ray status, not an API failure: spin > 1-1e-6 rejects every ray
     o = capi.disk_image(capi.image_desc(16, 16, 0.9999999, 1.0), full=True)
     assert (o["cls"] == 0).all() and (o["image_f"] == 0).all()
+
+
+def test_in_place_rows_and_share_placement(capi):
+    """The multi-GPU assembly on one GPU: (i) SIM5GPU_IMG_INPLACE writes every traced row of a striped, mirrored share
+    at its image row of a whole-image buffer and leaves the other rows untouched; (ii) sim5gpu_image_place_shares puts
+    the packed shares of the other ranks (the blocks a gather delivers) at their image rows with one kernel; together
+    with the centred band of rank 0 the result is the single-launch image bit for bit.  Odd sizes and a dealt-rows plan
+    included."""
+    from sim5_amd import sharding
+    for (nx, ny, world, dealt) in [(256, 512, 4, None), (200, 301, 3, None), (320, 512, 2, 128), (192, 1001, 8, None)]:
+        a, inc = 0.9, math.radians(65.0)
+        whole = capi.disk_image(capi.image_desc(nx, ny, a, inc))
+        want = np.stack([whole["image_f"], whole["image_g"]])
+        full = capi.DeviceBuffer(2 * ny * nx * 4); full.fill(0xff)              # NaN pattern: rows nobody wrote stay NaN
+        rows_max = max(1, sharding.max_local_rows(ny, world, dealt=dealt))
+        shares = capi.DeviceBuffer(world * 2 * rows_max * nx * 4); shares.zero()
+        plane = ny * nx * 4
+        # rank 0: its share in place, then its band (a plain contiguous range into the view of the image)
+        kw = sharding.job_rows(ny, 0, world, dealt=dealt)
+        d0 = capi.image_desc(nx, ny, a, inc, inplace=True, **kw)
+        capi.disk_image_device(d0, full.ptr, full.ptr + plane)
+        capi.synchronize()
+        got = full.to_numpy(np.float32, (2, ny, nx))
+        own = np.zeros(ny, bool)
+        for (y0, y1) in sharding.stripes_for_rank(ny, 0, world, dealt=dealt):
+            own[y0:y1] = True
+        assert np.array_equal(got[:, own], want[:, own]) and np.isnan(got[:, ~own]).all()
+        assert np.array_equal(capi.image_row_map(d0), np.nonzero(own)[0])
+        band = sharding.root_band(ny, dealt)
+        if band:
+            db = capi.image_desc(nx, ny, a, inc, y0=band[0], y1=band[1])
+            capi.disk_image_device(db, full.ptr + band[0] * nx * 4, full.ptr + plane + band[0] * nx * 4)
+        # the peers: packed shares, as the gather lays them out ([rank][plane][rows_max][nx]; block 0 unused)
+        descs = []
+        for r in range(1, world):
+            kw = sharding.job_rows(ny, r, world, dealt=dealt)
+            d = capi.image_desc(nx, ny, a, inc, **kw)
+            descs.append(d)
+            base = shares.ptr + r * 2 * rows_max * nx * 4
+            tmp_f = capi.DeviceBuffer(capi.image_rows(d) * nx * 4); tmp_g = capi.DeviceBuffer(capi.image_rows(d) * nx * 4)
+            capi.disk_image_device(d, tmp_f.ptr, tmp_g.ptr)
+            capi.synchronize()
+            blk = np.zeros((2, rows_max, nx), np.float32)
+            blk[0, :capi.image_rows(d)] = tmp_f.to_numpy(np.float32, (capi.image_rows(d), nx))
+            blk[1, :capi.image_rows(d)] = tmp_g.to_numpy(np.float32, (capi.image_rows(d), nx))
+            capi._lib.sim5gpu_memcpy_h2d(capi.VP(base), blk.ctypes.data_as(capi.VP), capi.SZ(blk.nbytes))
+        capi.image_place_shares(descs, shares.ptr + 2 * rows_max * nx * 4, rows_max, full.ptr, full.ptr + plane)
+        capi.synchronize()
+        got = full.to_numpy(np.float32, (2, ny, nx))
+        assert np.array_equal(got, want), (nx, ny, world, dealt, int((got != want).sum()))

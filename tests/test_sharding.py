@@ -132,23 +132,29 @@ def _pipeline_worker(rank, world, port, ny, nx, nimages, q, host_staged=False, d
         view[0] = rows + 1e6 * (state["img"] - 1)
         view[1] = -rows
 
-    def trace(buf):                               # stand-in kernel: value = image number * 1e6 + row * nx + col
+    def trace(buf, inplace):                      # stand-in kernel: value = image number * 1e6 + row * nx + col
         off = 0
         for (y0, y1) in sharding.stripes_for_rank(ny, rank, world, dealt=dealt):
             rows = torch.arange(y0, y1, dtype=torch.float32)[:, None] * nx + torch.arange(nx, dtype=torch.float32)[None, :]
-            buf[0, off:off + y1 - y0] = rows + 1e6 * state["img"]
-            buf[1, off:off + y1 - y0] = -rows
+            lo = y0 if inplace else off             # rank 0 writes its rows where they belong in the image
+            buf[0, lo:lo + y1 - y0] = rows + 1e6 * state["img"]
+            buf[1, lo:lo + y1 - y0] = -rows
             off += y1 - y0
+        assert inplace == (rank == 0) and buf.shape[1] == (ny if inplace else sharding.max_local_rows(ny, world, dealt=dealt))
         state["img"] += 1
 
-    for _ in range(nimages):
-        pipe.step(trace, trace_band)
+    expect = torch.arange(ny * nx, dtype=torch.float32).reshape(ny, nx)
+    good = True
+    for i in range(nimages):
+        pipe.step(trace, trace_band if sharding.root_band(ny, dealt) else None)
+        if rank == 0 and i > 0:                   # every step ends with the previous image complete, in row order
+            prev = pipe.full[(pipe.count - 2) % pipe.nbuf]
+            good = good and bool(torch.equal(prev[0], expect + 1e6 * (i - 1)) and torch.equal(prev[1], -expect)) and pipe.placed == i
     pipe.drain()
     dist.barrier()
     if rank == 0:
         img = pipe.last_image()
-        expect = torch.arange(ny * nx, dtype=torch.float32).reshape(ny, nx)
-        q.put(bool(torch.equal(img[0], expect + 1e6 * (nimages - 1)) and torch.equal(img[1], -expect)))
+        q.put(good and pipe.placed == nimages and bool(torch.equal(img[0], expect + 1e6 * (nimages - 1)) and torch.equal(img[1], -expect)))
     dist.destroy_process_group()
 
 
@@ -169,6 +175,52 @@ def test_overlapped_gather_pipeline_gloo(nimages, host_staged, dealt):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_pipeline_refuses_a_missing_band_tracer():
+    """rank 0 keeps a band but the caller passes no trace_band: an error before any collective is issued"""
+    import torch
+
+    class NoDist:
+        def gather(self, *a, **k):
+            raise AssertionError("a collective was issued")
+    pipe = sharding.TilePipeline(torch, NoDist(), 0, 2, 200, 16, torch.device("cpu"), dealt=64)
+    with pytest.raises(ValueError, match="trace_band"):
+        pipe.step(lambda buf, inplace: None)
+
+
+def test_place_shares_restores_row_order():
+    ny, nx, world = 201, 5, 3
+    full = np.arange(2 * ny * nx, dtype=np.float32).reshape(2, ny, nx)
+    for dealt in (None, 64):
+        rmax = sharding.max_local_rows(ny, world, dealt=dealt)
+        tiles = np.zeros((world, 2, rmax, nx), np.float32)
+        out = np.zeros_like(full)
+        for r in range(world):
+            off = 0
+            for (y0, y1) in sharding.stripes_for_rank(ny, r, world, dealt=dealt):
+                if r == 0:
+                    out[:, y0:y1] = full[:, y0:y1]                     # rank 0 traced in place
+                tiles[r][:, off:off + y1 - y0] = full[:, y0:y1]
+                off += y1 - y0
+        band = sharding.root_band(ny, dealt)
+        if band:
+            out[:, band[0]:band[1]] = full[:, band[0]:band[1]]
+        assert np.array_equal(sharding.place_shares(tiles, ny, world, out, dealt=dealt), full)
+
+
+def test_library_row_map_is_the_dealing_rule():
+    """sim5gpu_image_row_map (host arithmetic of the library: the rule its kernels and sim5gpu_image_place_shares use)
+    gives every packed row of a rank's job the image row sharding.stripes_for_rank says"""
+    from sim5_amd import capi
+    for ny, world, dealt in [(4096, 8, None), (4096, 4, 1024), (1001, 3, 192), (129, 2, None), (257, 8, None), (65, 2, None)]:
+        for r in range(world):
+            kw = sharding.job_rows(ny, r, world, dealt=dealt)
+            if kw["y0"] >= kw["y1"]:
+                continue
+            rows = capi.image_row_map(capi.image_desc(ny, ny, 0.9, 1.0, **kw))
+            want = [y for (y0, y1) in sharding.stripes_for_rank(ny, r, world, dealt=dealt) for y in range(y0, y1)]
+            assert rows.tolist() == want, (ny, world, dealt, r)
 
 
 def test_gather_world_size_2_gloo():
