@@ -14,6 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 _VAR = os.environ.get("S5_VARIANT", "")
 OBJ = os.path.join(CSRC, "_build", "ab_" + _VAR) if _VAR else os.path.join(CSRC, "_build")
 LIB = os.path.join(LIBDIR, ("ab_%s.so" % _VAR) if _VAR else "libsim5gpu.so")
+LIB_RCCL = os.path.join(LIBDIR, ("ab_%s_rccl.so" % _VAR) if _VAR else "libsim5gpu_rccl.so")
 
 # (source, object, variant): the image kernels are built in both arithmetic variants
 SOURCES = [("capi_core.hip", "capi_core.o", "strict"), ("capi_batch.hip", "capi_batch.o", "strict"),
@@ -61,12 +62,13 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "sim5gpu.h"))
-    sources = sorted(set(os.path.join(CSRC, src) for (src, _, _) in SOURCES))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "sim5gpu_rccl.h"))
+    sources = sorted(set(os.path.join(CSRC, src) for (src, _, _) in SOURCES)) + [os.path.join(CSRC, "rccl_shard.hip")]
     stamp = os.path.join(LIBDIR, ("ab_%s.stamp" % _VAR) if _VAR else "build.stamp")
     fp = _fingerprint(headers + sources + [os.path.abspath(__file__)],
                       (FLAGS, VARIANT, os.environ.get("S5_FAST_EXTRA", ""), os.environ.get("S5_TORUS_EXTRA", ""),
                        os.environ.get("S5_TORUS_FAST_EXTRA", ""), os.environ.get("S5_SURF_FAST_EXTRA", "")))
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_RCCL) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
         return LIB
     if os.path.exists(stamp):
         os.remove(stamp)
@@ -127,9 +129,26 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    build_rccl(hipcc, force=force or bool(cmds), verbose=verbose)
     with open(stamp, "w") as fh:
         fh.write(fp + "\n")
     return LIB
+
+
+def build_rccl(hipcc, force=False, verbose=False):
+    """libsim5gpu_rccl.so: the multi-GPU form of the image job (include/sim5gpu_rccl.h) -- host code on top of the base
+    library's C-ABI and librccl, a library of its own so that libsim5gpu.so keeps no RCCL dependency."""
+    src = os.path.join(CSRC, "rccl_shard.hip")
+    deps = [src, os.path.join(os.path.dirname(HERE), "include", "sim5gpu_rccl.h"), os.path.join(os.path.dirname(HERE), "include", "sim5gpu.h"), LIB]
+    if not force and _newer(LIB_RCCL, deps):
+        return LIB_RCCL
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-fPIC", "-std=c++17", "-Wall", "-shared", src, "-o", LIB_RCCL,
+           "-L" + LIBDIR, "-l:" + os.path.basename(LIB), "-L/opt/rocm/lib", "-lrccl",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_RCCL
 
 
 if __name__ == "__main__":

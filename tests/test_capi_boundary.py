@@ -205,3 +205,42 @@ def test_host_side_helpers_match_the_reference(host_shim_so, golden):
     L.geodesic_position.argtypes = [C.c_void_p, D, D4]; L.geodesic_position.restype = None
     L.geodesic_position(None, 1.0, v)                       # the reference's empty stub: nothing is touched
     assert list(v) == [1.0, 2.0, 3.0, 4.5]
+
+
+# ---- the multi-GPU library (include/sim5gpu_rccl.h) ----------------------------------------------------------------------
+def test_rccl_library_exports_every_declared_symbol_and_fails_loudly(capi):
+    src = open(os.path.join(ROOT, "include", "sim5gpu_rccl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(sim5gpu_[a-zA-Z0-9_]+)\s*\(", src)))
+    assert len(names) >= 10
+    from sim5_amd import rccl
+    lib = C.CDLL(rccl.LIB_PATH)
+    assert not [n for n in names if not hasattr(lib, n)]
+    # the base library keeps no RCCL dependency
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+    if capi.device_count() == 0:
+        with pytest.raises(rccl.Sim5GpuRcclError, match="no CPU fallback"):
+            rccl.Shard(None, 0, 1, 64, 64)
+
+
+def test_shard_plan_is_the_python_dealing_rule(capi):
+    """sim5gpu_shard_plan (C, host arithmetic) against sim5_amd/sharding.py, the rule the gloo tests and the randomised
+    campaign (tests/tools/fuzz_stripes.py) check: rows per rank, the band, and the share's job description row by row"""
+    from sim5_amd import rccl, sharding
+    for (ny, world, dealt) in [(4096, 8, 0), (4096, 2, 640), (4096, 4, 1024), (1001, 3, 192), (8192, 8, 2560), (129, 2, 0), (65, 1, 0)]:
+        d = capi.image_desc(ny, ny, 0.9, 1.0)
+        dd = None if dealt == 0 else dealt
+        total = 0
+        for r in range(world):
+            rows, band, share = rccl.shard_plan(d, r, world, dealt)
+            assert rows == sharding.rank_rows(ny, r, world, dealt=dd if world > 1 else None), (ny, world, dealt, r)
+            want_band = (sharding.root_band(ny, dd) if world > 1 else None) or (0, 0)
+            assert band == tuple(want_band)
+            own = [y for (y0, y1) in sharding.stripes_for_rank(ny, r, world, dealt=dd if world > 1 else None) for y in range(y0, y1)]
+            if own:
+                assert capi.image_row_map(share).tolist() == own
+                assert bool(share.flags & capi.IMG_INPLACE) == (r == 0) and (share.flags & capi.IMG_MIRROR)
+            total += rows
+        assert total == ny

@@ -184,3 +184,44 @@ def test_batch_example_program(tmp_path, capi):
     # "%e" keeps 7 significant digits
     assert np.allclose(img_g, c["image_g"], rtol=2e-6, atol=0)
     assert "photons: 921600" in p.stderr
+
+
+def test_sharded_example_program_with_one_rank(tmp_path, capi):
+    """examples/disk_image_sharded.c (include/sim5gpu_rccl.h) with a world of ONE rank on the GPU: the C-level multi-GPU
+    entry points -- plan, in-place tracing of the rank's mirrored stripes, the begin/end pipeline -- produce the
+    reference's image (hit count of BASELINE.md for 1024^2).  More than one rank needs more than one GPU: RCCL refuses
+    two ranks on one device, so the gather itself first runs on the driver's multi-GPU node."""
+    exe = str(tmp_path / "sharded")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "disk_image_sharded.c"),
+                    "-o", exe, "-L", libdir, "-lsim5gpu_rccl", "-lsim5gpu", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"],
+                   check=True)
+    p = subprocess.run([exe, "0", "1", str(tmp_path / "id"), "0.998", "70", "1024", "5"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    assert "disk hits 991579" in p.stdout and "rows on rank 0: 1024" in p.stdout, p.stdout
+
+
+def test_rccl_shard_objects_with_a_world_of_one(capi):
+    """The RCCL side with one rank in this process: unique id, ncclCommInitRank, a Shard with a communicator, images
+    through begin/end with two in flight, bit-identical to sim5gpu_disk_image; argument errors are reported, not crashed on."""
+    from sim5_amd import rccl
+    comm = rccl.comm_create(rccl.unique_id(), 0, 1)
+    n = 512
+    sh = rccl.Shard(comm, 0, 1, n, n)
+    want = capi.disk_image(capi.image_desc(n, n, 0.9, math.radians(60.0)))
+    f = [capi.DeviceBuffer(n * n * 4) for _ in range(2)]; g = [capi.DeviceBuffer(n * n * 4) for _ in range(2)]
+    d = capi.image_desc(n, n, 0.9, math.radians(60.0))
+    sh.begin(d, f[0].ptr, g[0].ptr)
+    sh.begin(d, f[1].ptr, g[1].ptr)
+    with pytest.raises(rccl.Sim5GpuRcclError, match="in flight"):
+        sh.begin(d, f[0].ptr, g[0].ptr)
+    sh.end(); sh.end()
+    with pytest.raises(rccl.Sim5GpuRcclError, match="no image in flight"):
+        sh.end()
+    with pytest.raises(rccl.Sim5GpuRcclError, match="WHOLE-image"):
+        sh.image(capi.image_desc(n, n, 0.9, 1.0, y0=0, y1=64), f[0].ptr, g[0].ptr)
+    capi.synchronize()
+    for b in range(2):
+        assert np.array_equal(f[b].to_numpy(np.float32, (n, n)), want["image_f"]) and np.array_equal(g[b].to_numpy(np.float32, (n, n)), want["image_g"])
+    sh.destroy()
+    rccl.comm_destroy(comm)
