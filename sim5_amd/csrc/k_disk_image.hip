@@ -47,15 +47,20 @@ S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
     return ray_result(t);
 }
 
+// AUX = false: the instantiation for jobs without full-precision planes (every production job: bench, sharded images) --
+// five pointers fewer held in SGPRs through the kernel and no tests around the stores
+template <bool AUX>
 S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
 {
     p.img_f[o] = res.image_f;
     p.img_g[o] = res.image_g;
-    if (p.cls) p.cls[o] = (uint8_t)res.cls;
-    if (p.gtype) p.gtype[o] = (int8_t)res.gtype;
-    if (p.r) p.r[o] = res.r;
-    if (p.g) p.g[o] = res.g;
-    if (p.flux) p.flux[o] = res.flux;
+    if (AUX) {
+        if (p.cls) p.cls[o] = (uint8_t)res.cls;
+        if (p.gtype) p.gtype[o] = (int8_t)res.gtype;
+        if (p.r) p.r[o] = res.r;
+        if (p.g) p.g[o] = res.g;
+        if (p.flux) p.flux[o] = res.flux;
+    }
 }
 
 #ifndef S5_TILE_W
@@ -72,6 +77,7 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
 constexpr int TILE_W = S5_TILE_W;        // workgroup tile: TILE_W x (256 / TILE_W) pixels
 constexpr int TILE_H = 256 / TILE_W;
 
+template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_WAVES)
 void disk_image_grid_kernel(ImageParams p)
 {
@@ -82,7 +88,7 @@ void disk_image_grid_kernel(ImageParams p)
     if (ix >= p.nx || lr >= p.nrows) return;
     const int iy = image_row(p, lr);
     const RayResult res = trace_disk_ray(p, pixel_alpha(p, ix), pixel_beta(p, iy));
-    store_ray(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, res);     // packed rows, or in place in the whole image
+    store_ray<AUX>(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, res);     // packed rows, or in place in the whole image
 }
 
 #if S5_FAST
@@ -96,21 +102,30 @@ void disk_image_grid_kernel(ImageParams p)
 #define S5_LB_WAVES_MIRROR 4             // four waves per SIMD (the kernel needs 112 VGPRs, no scratch).  Measured, 4096^2, same
                                          // call: 0.527 ms at three -> 0.478 ms
 #endif
+template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
 void disk_image_mirror_kernel(ImageParams p)
 {
     const int lane_x = threadIdx.x % TILE_W;
     const int lane_y = threadIdx.x / TILE_W;
     const int ix = blockIdx.x * TILE_W + lane_x;
+#ifdef S5_ROWS_TOP_DOWN
     const int lr = blockIdx.y * TILE_H + lane_y;                 // local row in the upper half
+#else
+    // Row tiles are handed out from the MIDDLE of the image outwards (workgroups are dispatched in blockIdx order): the rays
+    // around the shadow -- second crossings, RC geodesics, deeper Landen ladders -- cost several times the rays of the
+    // outer rows, which mostly miss; started first they are done when the cheap rows fill the end of the launch, instead of
+    // forming its tail.  Matters for small images (1024^2 is two rounds of resident waves); the pixel a lane traces is the same.
+    const int lr = (int)(gridDim.y - 1u - blockIdx.y) * TILE_H + lane_y;      // local row in the upper half
+#endif
     const int half = (p.nrows + 1) / 2;
     if (ix >= p.nx || lr >= half) return;
     const int lr2 = p.nrows - 1 - lr;                            // its mirror row (== lr for an odd middle row)
     ThinRay t, t2;
     const int iy = image_row_top(p, lr);
     trace_thin_disk_impl<false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);
-    store_ray(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, ray_result(t));
-    if (lr2 != lr) store_ray(p, (size_t)(p.inplace ? p.ny - 1 - iy : lr2) * (size_t)p.nx + (size_t)ix, ray_result(t2));
+    store_ray<AUX>(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, ray_result(t));
+    if (lr2 != lr) store_ray<AUX>(p, (size_t)(p.inplace ? p.ny - 1 - iy : lr2) * (size_t)p.nx + (size_t)ix, ray_result(t2));
 }
 #endif
 
@@ -120,7 +135,7 @@ void disk_image_list_kernel(ImageParams p)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const RayResult res = trace_disk_ray(p, p.alpha[i], p.beta[i]);
-    store_ray(p, i, res);
+    store_ray<true>(p, i, res);
 }
 
 } // namespace S5NS
@@ -132,6 +147,7 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
 #endif
 {
     using namespace S5NS;
+    const bool aux = p.cls || p.gtype || p.r || p.g || p.flux;
     if (p.alpha) {
         const unsigned blocks = (unsigned)((p.n + 255) / 256);
         hipLaunchKernelGGL(disk_image_list_kernel, dim3(blocks), dim3(256), 0, stream, p);
@@ -139,12 +155,14 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
 #if S5_FAST && !defined(S5_NO_MIRROR)
         if ((p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny)) && p.nrows >= 2) {
             const dim3 grid((p.nx + TILE_W - 1) / TILE_W, ((p.nrows + 1) / 2 + TILE_H - 1) / TILE_H);
-            hipLaunchKernelGGL(disk_image_mirror_kernel, grid, dim3(256), 0, stream, p);
+            if (aux) hipLaunchKernelGGL(disk_image_mirror_kernel<true>, grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL(disk_image_mirror_kernel<false>, grid, dim3(256), 0, stream, p);
             return (int)hipGetLastError();
         }
 #endif
         const dim3 grid((p.nx + TILE_W - 1) / TILE_W, (p.nrows + TILE_H - 1) / TILE_H);
-        hipLaunchKernelGGL(disk_image_grid_kernel, grid, dim3(256), 0, stream, p);
+        if (aux) hipLaunchKernelGGL(disk_image_grid_kernel<true>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(disk_image_grid_kernel<false>, grid, dim3(256), 0, stream, p);
     }
     return (int)hipGetLastError();
 }

@@ -43,4 +43,55 @@
 #define S5_F_LIBM S5_FAST         // cbrt for x^(1/3), fused sincos, folded constant reciprocals
 #endif
 
+// Selective FMA contraction in the fast variant.  The translation units are compiled with -ffp-contract=off (the
+// reference build has no FMA); a region named below lets the compiler fuse a*b+c when its bit is set in S5_FPC_MASK.
+//   1 quartic (constants of motion, closed-form roots)     2 class set-up, polar roots, crossing logic
+//   4 the quotients of r(P)                                8 Carlson R_F loop and series
+//  16 Landen ladder (climb, descent)                      32 g-factor and flux table
+// Bisected on MI355X against the CPU checker, 4096^2 headline image, one region at a time (round 3): regions
+// 2 .. 32 leave the worst pixel where it was (r 3e-13 .. 7e-13, g 7e-13, flux 6e-8; class map identical), region 1 alone
+// takes it to r 1.4e-7, g 7e-7, flux 2.3e-5 -- the discriminant X = F^2 - 4 E^3 of the resolvent cubic cancels to rounding
+// noise near the double-root locus, and only the reference's own two roundings (F^2 rounded, then the difference) put the
+// same rays on the same side of X = 0.  So everything but the quartic contracts: 0.377 -> 0.366 ms on the headline image.
+#ifndef S5_FPC_MASK
+#define S5_FPC_MASK (S5_FAST ? 62 : 0)
+#endif
+// contract(on), not (fast): a*b+c is fused only inside ONE source expression, decided by the front end (llvm.fmuladd, always
+// v_fma_f64 on gfx950), so a routine rounds the same way in every kernel and template instantiation it is inlined into.
+// With (fast) the back end fuses across statements where it finds it profitable, which differs from one instantiation
+// to the next: the pairing kernel and the plain kernel then disagree in the last bit (caught by
+// tests/test_gpu_images.py::test_mirrored_pairs_give_the_plain_image).
+#define S5_FPC_PRAGMA_ON  _Pragma("clang fp contract(on)")
+#define S5_FPC_PRAGMA_OFF _Pragma("clang fp contract(off)")
+#if S5_FAST && (S5_FPC_MASK & 1)
+#define S5_FPC_QUARTIC S5_FPC_PRAGMA_ON
+#else
+#define S5_FPC_QUARTIC
+#endif
+#if S5_FAST && (S5_FPC_MASK & 2)
+#define S5_FPC_FINISH S5_FPC_PRAGMA_ON
+#else
+#define S5_FPC_FINISH
+#endif
+#if S5_FAST && (S5_FPC_MASK & 4)
+#define S5_FPC_RADIUS S5_FPC_PRAGMA_ON
+#else
+#define S5_FPC_RADIUS S5_FPC_PRAGMA_OFF
+#endif
+#if S5_FAST && (S5_FPC_MASK & 8)
+#define S5_FPC_RF S5_FPC_PRAGMA_ON
+#else
+#define S5_FPC_RF
+#endif
+#if S5_FAST && (S5_FPC_MASK & 16)
+#define S5_FPC_LADDER S5_FPC_PRAGMA_ON
+#else
+#define S5_FPC_LADDER
+#endif
+#if S5_FAST && (S5_FPC_MASK & 32)
+#define S5_FPC_GFLUX S5_FPC_PRAGMA_ON
+#else
+#define S5_FPC_GFLUX
+#endif
+
 #define S5_DEV __device__ __forceinline__

@@ -63,6 +63,7 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
 // and beyond x = 16 -- are reported through `closed_form` and take disk_flux_closed_form(d, r, x).
 S5_DEV double disk_flux_table(const DiskConsts& d, double r, double x, double rx, bool& closed_form)
 {
+    S5_FPC_GFLUX
     closed_form = false;
     if (r <= d.rms) return 0.0;
     const double t = x - d.x0;

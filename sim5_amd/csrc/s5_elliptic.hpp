@@ -36,6 +36,7 @@ namespace S5NS {
 template <bool CHECKED>
 S5_DEV double carlson_rf_impl(double x, double y, double z)
 {
+    S5_FPC_RF
     const double tol = 0.03, third = 1.0 / 3.0;
     bool bad = false;
     if (CHECKED) {
@@ -333,6 +334,7 @@ struct LadderState {
 template <class Ladder, int NR = LADDER_RUNGS>
 S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
 {
+    S5_FPC_LADDER
     if (m == 1.0) m = 0.999999999;
     const double conv = 1.0e-8;
     double emc = 1.0 - m;
@@ -365,6 +367,7 @@ S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
 template <class Ladder, int NR = LADDER_RUNGS>
 S5_DEV void ladder_descend(const Ladder& lad, const LadderState& st, double u, double& sn, double& cn, double& dn)
 {
+    S5_FPC_LADDER
     if (st.degenerate) {
         cn = 1.0 / cosh(u);
         dn = cn;

@@ -408,6 +408,7 @@ S5_DEV double omega_from_ell(double ell, const Metric& g)                       
 // with x = sqrt(r) supplied by the caller
 S5_DEV double gfactor_kepler_x(double r, double x, double a, double l)
 {
+    S5_FPC_GFLUX
     const double den = a + r * x;
     const double t = mrcp(den * r);
     const double Om = r * t;

@@ -68,6 +68,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 template <bool WANT_STATE, bool PAIR>
 S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out, ThinRay& out2)
 {
+    S5_FPC_QUARTIC
     using namespace s5abi;
     out.cls = PX_ERROR; out.gtype = -1; out.err = GD_OK;
     out.r = NAN; out.g = 0.0; out.flux = 0.0; out.P = NAN;
@@ -182,6 +183,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                              const double l, const double q, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_)
 {
+    S5_FPC_FINISH
     using namespace s5abi;
     const int type = (KNOWN >= 0) ? KNOWN : type_in;
     const double a2 = a * a, l2 = l * l;
@@ -452,9 +454,11 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                     if (!in_range) r = NAN;
                     else if (at_peri) r = rp;
                     else if (rr) {
+                        S5_FPC_RADIUS
                         const double sn2 = sn * sn;
                         r = mdiv(ra * (rb - rd_) - rb * (ra - rd_) * sn2, rb - rd_ - (ra - rd_) * sn2);
                     } else if (rcx) {
+                        S5_FPC_RADIUS
                         const double Aq = A;
                         const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
                         r = mdiv(rb * Aq - ra * Bq - (rb * Aq + ra * Bq) * cn, (Aq - Bq) - (Aq + Bq) * cn);

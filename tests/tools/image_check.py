@@ -17,8 +17,8 @@ for k in ("r","g","flux"):
     out.append("%s max %.2e  >1e-10: %d  >1e-12: %d"%(k,e.max(),(e>1e-10).sum(),(e>1e-12).sum()))
 d=capi.image_desc(n,n,0.998,70/180*math.pi)
 bf=capi.DeviceBuffer(n*n*4); bg=capi.DeviceBuffer(n*n*4)
-for _ in range(3): capi.disk_image_device(d,bf.ptr,bg.ptr)
+for _ in range(200 if "--warm" in sys.argv else 3): capi.disk_image_device(d,bf.ptr,bg.ptr)   # --warm: ~80 ms of launches first (working clock)
 capi.synchronize(); e0=capi.Event(); e1=capi.Event(); e0.record()
-for _ in range(10): capi.disk_image_device(d,bf.ptr,bg.ptr)
-e1.record(); ms=e0.elapsed_ms(e1)/10
+for _ in range(50): capi.disk_image_device(d,bf.ptr,bg.ptr)
+e1.record(); ms=e0.elapsed_ms(e1)/50
 print(" | ".join(out), "| %.3f ms  %.3e rays/s"%(ms, n*n/ms*1e3))
