@@ -119,11 +119,29 @@ void disk_image_mirror_kernel(ImageParams p)
     const int lr = (int)(gridDim.y - 1u - blockIdx.y) * TILE_H + lane_y;      // local row in the upper half
 #endif
     const int half = (p.nrows + 1) / 2;
+#ifndef S5_FLUX_TABLE_LDS
     if (ix >= p.nx || lr >= half) return;
+#endif
     const int lr2 = p.nrows - 1 - lr;                            // its mirror row (== lr for an odd middle row)
     ThinRay t, t2;
     const int iy = image_row_top(p, lr);
+#ifdef S5_FLUX_TABLE_LDS
+    // A/B build only (north_star: "LDS staging of the disk_nt radial profile"): the 8 KB flux table copied to LDS by the
+    // workgroup before it traces.  Measured against the table read from global memory (L1/L2-resident): DESIGN.md 4.
+    __shared__ double s_ftab[FT_N * (FT_DEG + 1)];
+    ImageParams pl = p;
+    if (p.disk.ftab) {
+        for (int i = (int)threadIdx.x; i < FT_N * (FT_DEG + 1); i += 256) s_ftab[i] = p.disk.ftab[i];
+        pl.disk.ftab = s_ftab;
+    }
+    __syncthreads();
+    trace_thin_disk_impl<false, true>(pl, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);
+#else
     trace_thin_disk_impl<false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);
+#endif
+#ifdef S5_FLUX_TABLE_LDS
+    if (ix >= p.nx || lr >= half) return;                        // after the barrier of the table copy (tiles of the bench sizes are full)
+#endif
     store_ray<AUX>(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, ray_result(t));
     if (lr2 != lr) store_ray<AUX>(p, (size_t)(p.inplace ? p.ny - 1 - iy : lr2) * (size_t)p.nx + (size_t)ix, ray_result(t2));
 }
