@@ -438,7 +438,11 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc *desc, double *d_stoke
  * points, DEVICE memory), interpolated linearly, H = H[0] below the first point and a constant opening angle
  * beyond the last.  Outputs (DEVICE, n each; k is n x 4 and may be NULL): position integral P, radius r,
  * cos(theta) m, photon momentum k (pointing away from the disk, as :250) and status 1 = found / 0 = none.
- * strict != 0 selects the reference-parameter arithmetic. */
+ * strict: bit 0 selects the reference-parameter arithmetic; SIM5GPU_SURFACE_TABLE_CHECKED: the caller vouches that d_R
+ * is strictly ascending and NaN-free.  Without it the entry point reads the table back and checks it -- a bad table is
+ * an argument error of the call -- which waits for everything enqueued on `stream` before; with it the job is purely
+ * asynchronous (an unchecked bad table gives status 0 / NaN rays, never a fault: every table access is bounded). */
+#define SIM5GPU_SURFACE_TABLE_CHECKED 2
 int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double *d_R, const double *d_H,
                               size_t n, const double *d_alpha, const double *d_beta,
                               double *d_P, double *d_r, double *d_m, double *d_k, int *d_status,

@@ -942,7 +942,18 @@ def disk_spectrum(desc, energies, hardening=1.7, limb_darkening=1):
     return dS.to_numpy(np.float64, (E.size,))
 
 
-def disk_surface_rays(a, incl_rad, table_R, table_H, alpha, beta, strict=False):
+SURFACE_TABLE_CHECKED = 2
+
+
+def _surface_flags(tR, strict, checked):
+    """bit 0: strict arithmetic; SURFACE_TABLE_CHECKED when the caller vouches for the table (checked=True) -- the library
+    then skips its blocking read-back of the table.  checked=None: vouch for it if this host copy passes the same test."""
+    if checked is None:
+        checked = bool(tR.size >= 2 and np.all(np.diff(tR) > 0) and not np.isnan(tR[0]))
+    return (1 if strict else 0) | (SURFACE_TABLE_CHECKED if checked else 0)
+
+
+def disk_surface_rays(a, incl_rad, table_R, table_H, alpha, beta, strict=False, checked=False):
     """Surface search for a thick disk H(R) (host arrays in and out): dict(P, r, m, k[n,4], status)."""
     tR = np.ascontiguousarray(table_R, dtype=np.float64).ravel()
     tH = np.ascontiguousarray(table_H, dtype=np.float64).ravel()
@@ -956,7 +967,7 @@ def disk_surface_rays(a, incl_rad, table_R, table_H, alpha, beta, strict=False):
     _check(_lib.sim5gpu_disk_surface_rays(D(a), D(incl_rad), I(tR.size), VP(bufs["tR"].ptr), VP(bufs["tH"].ptr),
                                           SZ(n), VP(bufs["al"].ptr), VP(bufs["be"].ptr), VP(out["P"].ptr),
                                           VP(out["r"].ptr), VP(out["m"].ptr), VP(out["k"].ptr), VP(out["st"].ptr),
-                                          I(1 if strict else 0), VP(0)), "sim5gpu_disk_surface_rays")
+                                          I(_surface_flags(tR, strict, checked)), VP(0)), "sim5gpu_disk_surface_rays")
     synchronize()
     return {"P": out["P"].to_numpy(np.float64, (n,)), "r": out["r"].to_numpy(np.float64, (n,)),
             "m": out["m"].to_numpy(np.float64, (n,)), "k": out["k"].to_numpy(np.float64, (n, 4)),
@@ -964,7 +975,7 @@ def disk_surface_rays(a, incl_rad, table_R, table_H, alpha, beta, strict=False):
 
 
 def disk_surface_frame(a, incl_rad, bh_mass, mdot, table_R, table_H, alpha, beta, table_vr=None, disk_spin=-1.0,
-                       strict=False):
+                       strict=False, checked=False):
     """Surface search + local frame in one kernel (host arrays in and out):
     dict(P, r, m, k[n,4], status, g, mue, flux)."""
     tR = np.ascontiguousarray(table_R, dtype=np.float64).ravel()
@@ -988,7 +999,7 @@ def disk_surface_frame(a, incl_rad, bh_mass, mdot, table_R, table_H, alpha, beta
                                            VP(bufs["tV"].ptr if "tV" in bufs else 0), SZ(n),
                                            VP(bufs["al"].ptr), VP(bufs["be"].ptr), VP(out["P"].ptr), VP(out["r"].ptr),
                                            VP(out["m"].ptr), VP(out["k"].ptr), VP(out["st"].ptr), VP(out["g"].ptr),
-                                           VP(out["mue"].ptr), VP(out["flux"].ptr), I(1 if strict else 0), VP(0)),
+                                           VP(out["mue"].ptr), VP(out["flux"].ptr), I(_surface_flags(tR, strict, checked)), VP(0)),
            "sim5gpu_disk_surface_frame")
     synchronize()
     res = {"P": out["P"].to_numpy(np.float64, (n,)), "r": out["r"].to_numpy(np.float64, (n,)),

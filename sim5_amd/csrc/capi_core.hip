@@ -97,11 +97,12 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot, double alpha)
 namespace {
 // One device block per (device, disk model): the COLD_N constants of the closed form (read from memory by the image
 // kernels' rare closed-form lanes, so that they do not occupy ~30 SGPRs of every wave for the whole kernel), then the
-// table.  FT_SLOTS models per device, replaced round robin.
-constexpr int FT_SLOTS = 8, FT_DEVICES = 64;
-struct FluxTable { bool used; double a, scale; double* ptr; bool usable; };
-FluxTable g_ftab[FT_DEVICES][FT_SLOTS];
-int g_ftab_next[FT_DEVICES];
+// table.  One block per (spin, scale) and device, kept for the life of the process (8 KB each: a sweep over a thousand disk
+// models is 8 MB) -- a block is never freed, so a kernel that another thread is about to launch with its pointer cannot
+// lose it, and no entry point ever has to wait for the device to recycle one.
+constexpr int FT_DEVICES = 64;
+struct FluxTable { double a, scale; double* ptr; bool usable; };
+std::vector<FluxTable> g_ftab[FT_DEVICES];
 std::mutex g_ftab_lock;
 
 // f on [lo, hi] as N polynomials of degree DEG in the local coordinate tau in [-1, 1] of N equal intervals: Chebyshev
@@ -218,9 +219,9 @@ int attach_flux_table(DiskConsts& d)
     const double wmin = d.x0 / 16.0;
     d.ft_wmin = wmin;
     d.ft_inv_dw = (double)s5abi::FT_N / (1.0 - wmin);
-    FluxTable* T = g_ftab[dev];
-    for (int i = 0; i < FT_SLOTS; i++)
-        if (T[i].used && T[i].a == d.a && T[i].scale == d.scale) {
+    std::vector<FluxTable>& T = g_ftab[dev];
+    for (size_t i = T.size(); i-- > 0;)                                  // the newest models first
+        if (T[i].a == d.a && T[i].scale == d.scale) {
             d.cold = T[i].ptr;
             d.ftab = T[i].usable ? T[i].ptr + s5abi::COLD_N : nullptr;
             return SIM5GPU_OK;
@@ -239,16 +240,7 @@ int attach_flux_table(DiskConsts& d)
     hipError_t e = hipMalloc((void**)&ptr, block.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(ptr, block.data(), block.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) { if (ptr) (void)hipFree(ptr); set_error("flux table", e); return SIM5GPU_E_HIP; }
-    int slot = -1;
-    for (int i = 0; i < FT_SLOTS && slot < 0; i++) if (!T[i].used) slot = i;
-    if (slot < 0) {
-        // the oldest block of THIS device goes; a kernel still reading it was queued before this call: wait for the device
-        slot = g_ftab_next[dev];
-        g_ftab_next[dev] = (slot + 1) % FT_SLOTS;
-        (void)hipDeviceSynchronize();
-        if (T[slot].ptr) (void)hipFree(T[slot].ptr);
-    }
-    T[slot].used = true; T[slot].a = d.a; T[slot].scale = d.scale; T[slot].ptr = ptr; T[slot].usable = usable;
+    T.push_back(FluxTable{ d.a, d.scale, ptr, usable });
     d.cold = ptr;
     d.ftab = usable ? ptr + s5abi::COLD_N : nullptr;
     return SIM5GPU_OK;

@@ -30,7 +30,9 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
 
 // The surface table must have strictly ascending radii: equal neighbours would divide by zero in the interpolation
 // and a descending pair breaks the bisection.  The table (<= 32 KB) is read back on the job's stream and checked
-// before the launch, so a bad table is an argument error of this call and not NaNs in its output.
+// before the launch, so a bad table is an argument error of this call and not NaNs in its output.  The read-back blocks
+// the host until the stream has drained; a caller that has checked its table (it usually holds the host copy) passes
+// SIM5GPU_SURFACE_TABLE_CHECKED and the job is enqueued without touching the host, overlapping whatever is in flight.
 static int check_surface_table(const char* fn, int n_table, const double* d_R, hipStream_t stream)
 {
     std::vector<double> h((size_t)n_table);
@@ -62,7 +64,8 @@ int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double* 
     }
     if (n == 0) return SIM5GPU_OK;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
-    { int rc = check_surface_table("disk_surface_rays", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
+    if (!(strict & SIM5GPU_SURFACE_TABLE_CHECKED)) { int rc = check_surface_table("disk_surface_rays", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
+    strict &= 1;
     SurfaceParams p;
     p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
     p.tab_vr = nullptr; p.out_g = nullptr; p.out_mue = nullptr; p.out_flux = nullptr;
@@ -94,7 +97,8 @@ int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdo
     }
     if (n == 0) return SIM5GPU_OK;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
-    { int rc = check_surface_table("disk_surface_frame", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
+    if (!(strict & SIM5GPU_SURFACE_TABLE_CHECKED)) { int rc = check_surface_table("disk_surface_frame", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
+    strict &= 1;
     SurfaceParams p;
     p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
     p.disk = make_disk_consts(bh_mass, disk_spin >= 0.0 ? disk_spin : a, mdot);

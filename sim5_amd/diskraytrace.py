@@ -102,7 +102,7 @@ class DiskRaytrace:
             # thick disk: the reference's __find_surface (:257-335) as one kernel; the disk model supplies
             # its photosphere as a table through surface_table() -> (R[], H[])
             tR, tH = self.disk.surface_table()
-            s = _c.disk_surface_rays(self.bh_spin, incl, tR, tH, alpha, beta)
+            s = _c.disk_surface_rays(self.bh_spin, incl, tR, tH, alpha, beta, checked=None)      # the host copy is checked here: no read-back
             good = s["status"] == 1
             return {"ok": good, "r": np.where(good, s["r"], 0.0), "m": np.where(good, s["m"], 0.0),
                     "P": s["P"], "k": s["k"], "gd": None}
@@ -160,7 +160,7 @@ class DiskRaytrace:
         if not flat and getattr(self.disk, "fused", False) and fused:
             # surface search and local frame in one kernel; the selection rules of ref :174-198 on the host
             s = _c.disk_surface_frame(self.bh_spin, incl, self.disk.bh_mass, self.disk.mdot, self.disk.tR, self.disk.tH,
-                                      alpha, beta, table_vr=self.disk.tV, disk_spin=self.disk.bh_spin)
+                                      alpha, beta, table_vr=self.disk.tV, disk_spin=self.disk.bh_spin, checked=None)
             r, m = s["r"], s["m"]
             R = r * np.sqrt(1. - m * m)
             sel = (s["status"] == 1) & (s["flux"] != 0.0) & (s["g"] > 0.0)
