@@ -21,6 +21,9 @@ namespace S5NS {
 using namespace s5abi;
 
 // the polarization chain of one traced ray (header comment): Stokes I, Q, U and the angle
+// AUX = false: the instantiation for jobs that take the Stokes planes only (no chi plane, no full-precision planes): six
+// pointers fewer held in SGPRs through the kernel, no atan2, no tests around the stores (as k_disk_image.hip)
+template <bool AUX>
 S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const ThinRay& t, double& I, double& Q, double& U,
                          double& chi)
 {
@@ -53,7 +56,7 @@ S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const 
         const double rn = mrcp(Xn * Xn + Yn * Yn);
         Q = p.pol_degree * I * ((Xn - Yn) * (Xn + Yn) * rn);
         U = p.pol_degree * I * (2.0 * Xn * Yn * rn);
-        if (p.chi) chi = matan2(Yn, Xn);
+        if (AUX && p.chi) chi = matan2(Yn, Xn);
     }
 #else
     chi = polarization_angle_rotation(p.a, p.sin_i, alpha, beta, wp);
@@ -64,20 +67,24 @@ S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const 
 #endif
 }
 
+template <bool AUX>
 S5_DEV void store_polarized(const ImageParams& p, size_t o, const ThinRay& t, double I, double Q, double U, double chi)
 {
     const size_t npix = (size_t)p.nrows * (size_t)p.nx;
     p.stokes[o] = I;
     p.stokes[npix + o] = Q;
     p.stokes[2 * npix + o] = U;
-    if (p.chi) p.chi[o] = chi;
-    if (p.cls) p.cls[o] = (uint8_t)t.cls;
-    if (p.gtype) p.gtype[o] = (int8_t)t.gtype;
-    if (p.r) p.r[o] = t.r;
-    if (p.g) p.g[o] = t.g;
-    if (p.flux) p.flux[o] = t.flux;
+    if (AUX) {
+        if (p.chi) p.chi[o] = chi;
+        if (p.cls) p.cls[o] = (uint8_t)t.cls;
+        if (p.gtype) p.gtype[o] = (int8_t)t.gtype;
+        if (p.r) p.r[o] = t.r;
+        if (p.g) p.g[o] = t.g;
+        if (p.flux) p.flux[o] = t.flux;
+    }
 }
 
+template <bool AUX>
 __global__ __launch_bounds__(256, 2)
 void disk_image_polarized_kernel(ImageParams p)
 {
@@ -90,8 +97,8 @@ void disk_image_polarized_kernel(ImageParams p)
     ThinRay t;
     trace_thin_disk<true>(p, alpha, beta, t);
     double I, Q, U, chi;
-    polarize_ray(p, alpha, beta, t, I, Q, U, chi);
-    store_polarized(p, (size_t)lr * (size_t)p.nx + (size_t)ix, t, I, Q, U, chi);
+    polarize_ray<AUX>(p, alpha, beta, t, I, Q, U, chi);
+    store_polarized<AUX>(p, (size_t)lr * (size_t)p.nx + (size_t)ix, t, I, Q, U, chi);
 }
 
 #if S5_FAST
@@ -100,13 +107,15 @@ void disk_image_polarized_kernel(ImageParams p)
 #ifndef S5_LB_POLAR_MIRROR
 #define S5_LB_POLAR_MIRROR 4                // 131 VGPRs by itself; capped at 128 for the fourth wave per SIMD (no scratch): -3 %
 #endif
+template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)
 void disk_image_polarized_mirror_kernel(ImageParams p)
 {
     const int lane_x = threadIdx.x & 15;
     const int lane_y = threadIdx.x >> 4;
     const int ix = blockIdx.x * 16 + lane_x;
-    const int lr = blockIdx.y * 16 + lane_y;                     // local row in the upper half
+    const int lr = (int)(gridDim.y - 1u - blockIdx.y) * 16 + lane_y;    // local row in the upper half; row tiles from the middle of the
+                                                                        // image outwards: the expensive rays first (k_disk_image.hip)
     const int half = (p.nrows + 1) / 2;
     if (ix >= p.nx || lr >= half) return;
     const int lr2 = p.nrows - 1 - lr;
@@ -125,9 +134,9 @@ void disk_image_polarized_mirror_kernel(ImageParams p)
         if (member == 1) m = t2;
         const double b = (member == 0) ? beta : -beta;
         double I, Q, U, chi;
-        polarize_ray(p, alpha, b, m, I, Q, U, chi);
+        polarize_ray<AUX>(p, alpha, b, m, I, Q, U, chi);
         if (member == 0 || lr2 != lr)
-            store_polarized(p, (size_t)(member == 0 ? lr : lr2) * (size_t)p.nx + (size_t)ix, m, I, Q, U, chi);
+            store_polarized<AUX>(p, (size_t)(member == 0 ? lr : lr2) * (size_t)p.nx + (size_t)ix, m, I, Q, U, chi);
     }
 }
 #endif
@@ -141,14 +150,17 @@ int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream
 #endif
 {
     using namespace S5NS;
+    const bool aux = p.chi || p.cls || p.gtype || p.r || p.g || p.flux;
 #if S5_FAST && !defined(S5_NO_MIRROR)
     if ((p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny)) && p.nrows >= 2) {
         const dim3 grid((p.nx + 15) / 16, ((p.nrows + 1) / 2 + 15) / 16);
-        hipLaunchKernelGGL(disk_image_polarized_mirror_kernel, grid, dim3(256), 0, stream, p);
+        if (aux) hipLaunchKernelGGL(disk_image_polarized_mirror_kernel<true>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(disk_image_polarized_mirror_kernel<false>, grid, dim3(256), 0, stream, p);
         return (int)hipGetLastError();
     }
 #endif
     const dim3 grid((p.nx + 15) / 16, (p.nrows + 15) / 16);
-    hipLaunchKernelGGL(disk_image_polarized_kernel, grid, dim3(256), 0, stream, p);
+    if (aux) hipLaunchKernelGGL(disk_image_polarized_kernel<true>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(disk_image_polarized_kernel<false>, grid, dim3(256), 0, stream, p);
     return (int)hipGetLastError();
 }
