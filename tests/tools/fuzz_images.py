@@ -48,7 +48,14 @@ for case in range(ncases):
         fl = np.maximum(np.abs(st["flux"][same]), 1e-9 * np.abs(st["flux"]).max() + 1e-300)
         ef = (np.abs(sym["flux"][same] - st["flux"][same]) / fl).max()
         if er > 1e-7 or eg > 1e-7 or ef > 1e-6:
-            msg.append("fast vs strict r %.1e g %.1e flux %.1e" % (er, eg, ef))
+            # where: radius of the worst flux pixel, its distance from the inner edge of the flux (x - x0 in x = sqrt(r)), the two values
+            e_all = np.abs(sym["flux"][same] - st["flux"][same]) / fl
+            j = int(np.argmax(e_all))
+            rw = st["r"][same][j]
+            lit = st["r"][same][st["flux"][same] > 0]
+            msg.append("fast vs strict r %.1e g %.1e flux %.1e [worst flux pixel: r %.9f, sqrt(r) - sqrt(r_in) %.2e, F fast %.6e strict %.6e, F/peak %.1e]" % (
+                er, eg, ef, rw, math.sqrt(rw) - math.sqrt(lit.min()) if lit.size else float("nan"), sym["flux"][same][j], st["flux"][same][j],
+                st["flux"][same][j] / np.abs(st["flux"]).max()))
     if nx * ny <= 40000:
         c = ol.cpu_disk_image("port", nx, ny, a, inc, nthreads=8, full=True) if (order == 2 and rmax == 0.0) else None
         if c is not None:
