@@ -499,6 +499,11 @@ typedef struct sim5gpu_torus_aux {
     double *k_end;           /* n x 4 final momentum                         */
 } sim5gpu_torus_aux;
 
+/* The surface-search and torus jobs keep a per-device workspace that grows to the largest job seen (surface search:
+ * ~0.5 GB per million rays; torus: 120 B per ray).  This gives them back (waits for the devices that own them); the next
+ * job allocates again.  *bytes, if not NULL, receives the number of bytes freed. */
+int sim5gpu_release_workspaces(size_t *bytes);
+
 /* d_stokes: (y1-y0) x nx records of sim5gpu_stokes */
 int sim5gpu_torus_image(const sim5gpu_torus_desc *desc, sim5gpu_stokes *d_stokes,
                         const sim5gpu_torus_aux *d_aux, void *stream);

@@ -1010,6 +1010,13 @@ def disk_surface_frame(a, incl_rad, bh_mass, mdot, table_R, table_H, alpha, beta
     return res
 
 
+def release_workspaces():
+    """give back the grow-only workspaces of the surface-search and torus jobs; returns the bytes freed"""
+    n = SZ(0)
+    _check(_lib.sim5gpu_release_workspaces(C.byref(n)), "sim5gpu_release_workspaces")
+    return int(n.value)
+
+
 def torus_image_device(desc, d_stokes, aux=None, stream=None):
     a = None
     if aux:

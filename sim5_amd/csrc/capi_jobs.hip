@@ -195,4 +195,16 @@ int sim5gpu_torus_image(const sim5gpu_torus_desc* desc, sim5gpu_stokes* d_stokes
     return SIM5GPU_OK;
 }
 
+/* Workspaces of the surface-search and torus jobs grow to the largest job seen on a device and are kept (0.5 GB per
+ * million rays for the surface search, 120 B per ray for the torus job): this gives them back.  Waits for the devices
+ * that own them.  *bytes (may be NULL) receives what was freed. */
+int sim5gpu_release_workspaces(size_t* bytes)
+{
+    if (!have_device()) { if (bytes) *bytes = 0; return SIM5GPU_OK; }
+    const size_t freed = s5_release_surface_workspace_fast() + s5_release_surface_workspace_strict() +
+                         s5f::release_torus_workspace_fast() + s5::release_torus_workspace_strict();
+    if (bytes) *bytes = freed;
+    return SIM5GPU_OK;
+}
+
 } // extern "C"

@@ -390,6 +390,32 @@ struct SurfaceWorkspace {
     hipStream_t side = nullptr;              // the deep-ladder walk runs here, beside the main walk
     hipEvent_t fork = nullptr, join = nullptr;
 };
+SurfaceWorkspace g_surface_ws[64];
+std::mutex g_surface_lock;
+}
+
+// give the grow-only workspaces of every device back (sim5gpu_release_workspaces): waits for the device that owns a block
+#if S5_FAST
+size_t s5_release_surface_workspace_fast()
+#else
+size_t s5_release_surface_workspace_strict()
+#endif
+{
+    std::lock_guard<std::mutex> hold(g_surface_lock);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    size_t freed = 0;
+    for (int d = 0; d < 64; ++d) {
+        SurfaceWorkspace& W = g_surface_ws[d];
+        if (!W.base) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(W.base);
+        freed += W.cap;
+        W.base = nullptr; W.cap = 0; W.used = false; W.last = nullptr;
+    }
+    (void)hipSetDevice(cur);
+    return freed;
 }
 
 #if S5_FAST
@@ -401,9 +427,8 @@ int s5_launch_disk_surface_strict(const s5abi::SurfaceParams& p, const double* t
                                   double* k, int* status, hipStream_t stream)
 {
     using namespace S5NS;
-    static SurfaceWorkspace g_ws[64];
-    static std::mutex g_lock;
-    std::lock_guard<std::mutex> hold(g_lock);
+    SurfaceWorkspace* g_ws = g_surface_ws;
+    std::lock_guard<std::mutex> hold(g_surface_lock);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;

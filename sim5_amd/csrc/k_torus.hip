@@ -522,4 +522,28 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
     return 0;
 }
 
+// give the grow-only workspaces of every device back (sim5gpu_release_workspaces): waits for the device that owns a block
+#if S5_FAST
+size_t release_torus_workspace_fast()
+#else
+size_t release_torus_workspace_strict()
+#endif
+{
+    std::lock_guard<std::mutex> hold(g_ws_lock);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    size_t freed = 0;
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+        TorusWorkspace& w = g_ws_dev[d];
+        if (!w.base) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(w.base);
+        freed += w.cap;
+        w.base = nullptr; w.cap = 0; w.used = false; w.last = nullptr;
+    }
+    (void)hipSetDevice(cur);
+    return freed;
+}
+
 } // namespace S5NS

@@ -27,5 +27,7 @@ struct TorusAux {
 
 } // namespace s5abi
 
-namespace s5 { int launch_torus_strict(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream); }
-namespace s5f { int launch_torus_fast(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream); }
+namespace s5 { int launch_torus_strict(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream);
+               size_t release_torus_workspace_strict(); }
+namespace s5f { int launch_torus_fast(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream);
+                size_t release_torus_workspace_fast(); }

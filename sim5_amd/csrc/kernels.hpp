@@ -137,3 +137,6 @@ int s5_launch_disk_surface_strict(const s5abi::SurfaceParams& p, const double* t
 int s5_launch_disk_surface_fast(const s5abi::SurfaceParams& p, const double* tabR, const double* tabH,
                                 const double* alpha, const double* beta, double* P, double* r, double* m,
                                 double* k, int* status, hipStream_t stream);
+// grow-only per-device workspaces of the surface job given back (bytes freed); k_torus.hpp has the march kernel's
+size_t s5_release_surface_workspace_fast();
+size_t s5_release_surface_workspace_strict();

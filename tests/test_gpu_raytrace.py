@@ -420,3 +420,22 @@ def test_torus_kernel_parameter_sweep(capi, strict):
         print("torus sweep a=%g i=%g precision=%g %s: %d of %d rays with identical step counts" % (a, inc, prec, "strict" if strict else "fast", same, len(res)))
         assert same >= (STEP_MATCH_STRICT if strict else STEP_MATCH_FAST) * len(res), (a, inc, prec, strict, same, len(res))
         assert np.isfinite(S[:, 0]).all()
+
+
+def test_workspaces_can_be_released(capi):
+    """sim5gpu_release_workspaces gives the grow-only workspaces of the torus and surface jobs back; the next job allocates
+    again and produces the same result."""
+    d = torus_desc(capi, 32, 0.9, 70.0)
+    a = run_torus(capi, d)
+    tR = np.linspace(2.0, 40.0, 64); tH = 0.2 * (tR - 2.0)
+    c = ((np.arange(24) + .5) / 24 - 0.5) * 40.0
+    s1 = capi.disk_surface_rays(0.9, math.radians(70.0), tR, tH, np.tile(c, 24), np.repeat(c, 24))
+    freed = capi.release_workspaces()
+    assert freed > 32 * 32 * 100
+    assert capi.release_workspaces() == 0
+    b = run_torus(capi, d)
+    s2 = capi.disk_surface_rays(0.9, math.radians(70.0), tR, tH, np.tile(c, 24), np.repeat(c, 24))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k], equal_nan=True)
