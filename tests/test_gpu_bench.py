@@ -82,6 +82,23 @@ def test_two_ranks_on_one_gpu(mode, band):
         assert o["scaling"] == "weak" and o["config"]["rays_per_step"] == 2 * 4096 * 4096
 
 
+def test_four_ranks_on_one_gpu():
+    """The same with FOUR ranks (three peers in the gather and in the placement launch, a band planned from measurements):
+    every step's image has the reference's hit count and the shares tile the image."""
+    env = dict(os.environ, SIM5_BENCH_ONE_GPU="1", SIM5_BENCH_CHECK_EVERY_STEP="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--no-extra"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    o = _line(r.stdout)
+    assert o["ok"] is True and o["n_gpus"] == 4 and o["config"]["disk_hits"] == 15865362
+    pr = o["per_rank"]
+    assert len(pr["kernel_ms_per_step"]) == 4 and sum(pr["rays_per_launch"]) == 4096 * 4096
+    assert all(h == 15865362 for h in o["hits_of_every_assembled_image"]) and len(o["hits_of_every_assembled_image"]) >= 3
+    dealt = pr["root_band_plan"]["dealt_rows_of_upper_half"]
+    assert dealt % 256 == 0 and pr["rays_per_launch"][1] == pr["rays_per_launch"][2] == pr["rays_per_launch"][3] == dealt // 2 * 4096
+
+
 def test_rccl_collectives_of_the_bench_with_one_rank():
     """The real `nccl` (= RCCL) backend with a world of one rank: async gather of the kernel's output tile issued on
     torch's stream, barrier, all_gather, synchronous gather -- the calls bench.py makes for N > 1 (tests/tools/nccl_world1.py)."""
