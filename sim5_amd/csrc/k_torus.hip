@@ -106,8 +106,8 @@ S5_DEV double torus_density(const TorusParams& p, double r, double m)
 #endif
 // Emission and absorption picked up over one accepted step (see the header comment for the model).  `g` is the
 // metric at the end point of the step, which both halves of raytrace() have just evaluated there.
-S5_DEV void accumulate_transfer(const TorusParams& p, const RayState& s, const Metric& g, const double x[4], const double k[4],
-                                double dl_taken, double& I, double& tau)
+S5_DEV void accumulate_transfer(const TorusParams& p, const bool no_absorption, const RayState& s, const Metric& g, const double x[4],
+                                const double k[4], double dl_taken, double& I, double& tau)
 {
 #if S5_FAST
     // same quantities with the divisions folded: exp(-d2 / 2w^2) with the wave-uniform 1/(2w^2), u^t from one rsqrt,
@@ -129,7 +129,7 @@ S5_DEV void accumulate_transfer(const TorusParams& p, const RayState& s, const M
     const double k_f = k[3] * g.g33 + k[0] * g.g03;
     const double sQ = sqrt_pos(Q);
     const double gfac = mdiv((B >= 0.0 ? s.E : -s.E) * sQ, k_t * B + A * k_f);
-    if (p.absorb0 == 0.0) {
+    if (no_absorption) {
         I += (gfac * gfac * gfac) * (p.emis0 * rho) * dl_taken;
     } else {
         const double ds = mdiv(dl_taken, gfac);
@@ -149,7 +149,7 @@ S5_DEV void accumulate_transfer(const TorusParams& p, const RayState& s, const M
     const double gfac = mdiv(s.E, ut * (k_t + Om * k_f));   // E_inf / E_local
     const double ds = mdiv(dl_taken, gfac);
     const double g2 = gfac * gfac;
-    const double att = (p.absorb0 == 0.0) ? 1.0 : exp(-tau);     // tau stays 0 without absorption (wave-uniform test)
+    const double att = no_absorption ? 1.0 : exp(-tau);          // tau stays 0 without absorption (wave-uniform test)
     I += (g2 * g2) * p.emis0 * rho * att * ds;
     tau += p.absorb0 * rho * ds;
 #endif
@@ -217,7 +217,7 @@ S5_DEV void wave_lds_fence()
 }
 
 __global__ __launch_bounds__(256, S5_MARCH_WAVES)
-void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
+void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__ ok,
                        unsigned long long* __restrict__ cursor, sim5gpu_stokes* __restrict__ out, TorusAux aux)
 {
     extern __shared__ char pool_raw[];
@@ -230,9 +230,30 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
     unsigned short* plist = (unsigned short*)(ptag + WG_SLOTS) + wave * 64;   // [64] slots of this wave's current batch
     const int own = wave * POOL_SLOTS;                               // this wave's quarter: the slots it refills
 
-    const size_t n = p.nrays;
+    const size_t n = p_arg.nrays;
+#if S5_FAST && !defined(S5_TORUS_UNIFORMS_IN_SGPRS)
+    // The wave-uniform doubles the step loop reads every pass -- torus geometry, emissivity, stop radii, step cap -- are
+    // kept in VGPRs (a copy per lane, 2 registers each), not in SGPRs.  The kernel's argument block and pointers alone
+    // are ~70 SGPRs; with the exec masks of the nested per-lane branches the scalar file overflows (110 SGPRs spilled to
+    // VGPR lanes) and every use of a parameter in the loop was a v_readlane pair on the VALU, ~140 per accepted step in
+    // the transfer and stop-test blocks.  The kernel has VGPRs to spare (211 of the 256 its two waves per SIMD allow): 230
+    // now, SGPR spills 110 -> 66, VALU instructions in the code -7 %, the C4 job 31.0 -> 29.4 ms (same call, same results).
+    // Not in the strict variant: its bodies already use 255 registers, and the copies would go to scratch.
+    TorusParams p = p_arg;
+#define S5_TO_VGPR(x) asm volatile("" : "+v"(x))
+    const bool no_absorption = (p_arg.absorb0 == 0.0);             // the wave-uniform branch on it stays scalar
+    S5_TO_VGPR(p.torus_r); S5_TO_VGPR(p.torus_w); S5_TO_VGPR(p.torus_l); S5_TO_VGPR(p.inv_2w2); S5_TO_VGPR(p.cut_d2);
+    S5_TO_VGPR(p.emis0); S5_TO_VGPR(p.absorb0); S5_TO_VGPR(p.max_error); S5_TO_VGPR(p.dl_max);
+    double r_in = p_arg.r_stop_in * r_horizon(p_arg.a);
+    double r_out = p_arg.r_stop_out * p_arg.r0;
+    S5_TO_VGPR(r_in); S5_TO_VGPR(r_out);
+#undef S5_TO_VGPR
+#else
+    const TorusParams& p = p_arg;
+    const bool no_absorption = (p_arg.absorb0 == 0.0);
     const double r_in = p.r_stop_in * r_horizon(p.a);
     const double r_out = p.r_stop_out * p.r0;
+#endif
     const double* __restrict__ sc = start.d;
     const size_t scap = start.cap;
 
@@ -252,6 +273,10 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
     s.step_epsilon = S5_DIVC(msqrt(p.precision), 10.);
     s.bh_spin = p.a;
     s.refines = 0; s.Q = 0.0;
+#if S5_FAST && !defined(S5_TORUS_UNIFORMS_IN_SGPRS)
+    asm volatile("" : "+v"(s.step_epsilon));                    // as above: read every pass, kept in VGPRs
+    asm volatile("" : "+v"(s.bh_spin));
+#endif
 
     // every pass either consumes cursor positions or advances at least one pooled ray by half a raytrace() call
     const unsigned long long guard = 8ull * (unsigned long long)(p.max_steps + 2) * ((n + 63) / 64 + 2);
@@ -412,7 +437,7 @@ void torus_pool_kernel(TorusParams p, RayCols start, const int* __restrict__ ok,
                         tag = TAG_V;
                         worst = fmaxf(worst, s.error);
 #ifndef S5_KO_TRANSFER
-                        accumulate_transfer(p, s, g, x, k, dl, I, tau);
+                        accumulate_transfer(p, no_absorption, s, g, x, k, dl, I, tau);
 #endif
                         const bool done = !(x[1] > r_in) || !(x[1] < r_out) || ((double)s.error > p.max_error) ||
                                           (s.pass >= p.max_steps);
