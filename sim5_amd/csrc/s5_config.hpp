@@ -94,4 +94,12 @@
 #define S5_FPC_GFLUX
 #endif
 
+// fast variant: the image kernels' rays do not evaluate the radial integral Rpc; r(P) comes from the addition theorem
+// (s5_thindisk.hpp).  -DS5_NO_RPC_BY_ADDITION restores the R_F evaluation for A/B measurements.
+#if S5_FAST && !defined(S5_NO_RPC_BY_ADDITION)
+#define S5_RPC_ADD 1
+#else
+#define S5_RPC_ADD 0
+#endif
+
 #define S5_DEV __device__ __forceinline__

@@ -364,6 +364,47 @@ S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
     st.c = c; st.top = top; st.incomplete = climbing;
 }
 
+#if S5_FAST
+// The descent of the regular case (modulus in (0, 1), rungs complete) carried as FRACTIONS, without the final square root
+// and division: with s0 = sin(u c) != 0 and rho^2 = C^2 + ga^2,
+//   sn = sign(s0) |ga| / rho,   cn = sign(s0) sign(ga) C / rho,   dn = N / D   (N and D have the same sign).
+// The recurrence  a <- c a;  c <- dn c;  dn <- (g_i + a)/(b_i + a);  a <- c/b_i  of the reference (ref: src/sim5elliptic.c:
+// 598-606) with a = A/al, c = C/ga, dn = N/D:  dn' = (g_i ga al + C A)/(b_i ga al + C A),  c' = N C/(D ga),  a'' = c'/b_i
+// -- seven multiplications per rung and no division; cot(u c) enters as cos/sin without being divided.  Only the ratios
+// matter and C^2 + ga^2 is roughly cubed by a rung (it starts in [1/4, 1]), so every second rung the pair (C, ga) is
+// rescaled by the exact power of two that brings ga's exponent back to zero.
+template <class Ladder, int NR = LADDER_RUNGS>
+S5_DEV void ladder_descend_fractions(const Ladder& lad, const LadderState& st, const double s0, const double c0,
+                                     double& C, double& ga, double& N, double& D)      // (s0, c0) = sincos(u st.c)
+{
+    S5_FPC_LADDER
+    const int top = st.top;
+    const double c = st.c;
+    double A = c0, al = s0;
+    C = c * c0; ga = s0; N = 1.0; D = 1.0;
+#pragma unroll
+    for (int i = NR - 1; i >= 0; --i) {
+        if (wave_any(i <= top)) {          // rungs no lane of the wave reached are skipped
+            if (i <= top) {
+                const double b = lad.get_a(i), g = lad.get_g(i);
+                const double t1 = C * A, t2 = ga * al;
+                const double Nn = g * t2 + t1, Dn = b * t2 + t1;
+                C = N * C;
+                ga = D * ga;
+                if ((i & 1) == 0) {
+                    const int e = -__builtin_amdgcn_frexp_exp(fabs(C) + fabs(ga));
+                    C = __builtin_amdgcn_ldexp(C, e);
+                    ga = __builtin_amdgcn_ldexp(ga, e);
+                }
+                A = C;
+                al = ga * b;
+                N = Nn; D = Dn;
+            }
+        }
+    }
+}
+#endif
+
 template <class Ladder, int NR = LADDER_RUNGS>
 S5_DEV void ladder_descend(const Ladder& lad, const LadderState& st, double u, double& sn, double& cn, double& dn)
 {
@@ -383,33 +424,9 @@ S5_DEV void ladder_descend(const Ladder& lad, const LadderState& st, double u, d
     sn = s0; cn = c0; dn = 1.0;
     if (s0 != 0.0) {
 #if S5_FAST
-        // The descent a <- c a;  c <- dn c;  dn <- (g_i + a)/(b_i + a);  a <- c/b_i  carried as fractions
-        //   a = A/al, c = C/ga, dn = N/D:   dn' = (g_i ga al + C A)/(b_i ga al + C A),  c' = N C/(D ga),  a'' = c'/b_i
-        // -- seven multiplications per rung and no division; cot(u c) enters as cos/sin without being divided, and
-        // sn = |ga| / sqrt(C^2 + ga^2), cn = C sign(ga) / sqrt(C^2 + ga^2) leave through ONE reciprocal square root.
-        // Only the ratios matter and C^2 + ga^2 is roughly cubed by a rung (it starts in [1/4, 1]), so every second rung
-        // the pair (C, ga) is rescaled by the exact power of two that brings ga's exponent back to zero.
-        double A = c0, al = s0, C = c * c0, ga = s0, N = 1.0, D = 1.0;
-#pragma unroll
-        for (int i = NR - 1; i >= 0; --i) {
-            if (wave_any(i <= top)) {          // rungs no lane of the wave reached are skipped
-                if (i <= top) {
-                    const double b = lad.get_a(i), g = lad.get_g(i);
-                    const double t1 = C * A, t2 = ga * al;
-                    const double Nn = g * t2 + t1, Dn = b * t2 + t1;
-                    C = N * C;
-                    ga = D * ga;
-                    if ((i & 1) == 0) {
-                        const int e = -__builtin_amdgcn_frexp_exp(fabs(C) + fabs(ga));
-                        C = __builtin_amdgcn_ldexp(C, e);
-                        ga = __builtin_amdgcn_ldexp(ga, e);
-                    }
-                    A = C;
-                    al = ga * b;
-                    N = Nn; D = Dn;
-                }
-            }
-        }
+        // the descent carried as fractions (ladder_descend_fractions above), leaving through ONE reciprocal square root
+        double C, ga, N, D;
+        ladder_descend_fractions<Ladder, NR>(lad, st, s0, c0, C, ga, N, D);
         const double rs = rsqrt_pos(C * C + ga * ga);
         a = fabs(ga) * rs;
         sn = (s0 >= 0.0 ? a : -a);

@@ -45,6 +45,17 @@ static __device__ __noinline__ double inv_sn_cold(double z, double m) { return i
 static __device__ __noinline__ double inv_cn_cold(double z, double m) { return inv_cn(z, m); }
 static __device__ __noinline__ double inv_tn_cold(double z, double m) { return inv_tn(z, m); }
 
+// the complete descent (flipped and degenerate moduli included) for the few lanes that cannot take the fraction form
+struct SnCn { double sn, cn; };
+static __device__ __noinline__ SnCn ladder_descend_cold(double* column, LadderState st, double u)
+{
+    LadderLds lad{column};
+    SnCn o;
+    double dn;
+    ladder_descend(lad, st, u, o.sn, o.cn, dn);
+    return o;
+}
+
 // true if inv_sn(z, m) takes the plain z * R_F(1-z^2, 1-m z^2, 1) form
 S5_DEV bool isn_plain(double m) { return !(fabs(m - 0.0) < 1e-8) && !(fabs(m - 1.0) < 1e-8); }
 // true if inv_cn(z, m) takes the plain sqrt(1-z^2) R_F(z^2, 1-m(1-z^2), 1) [+ second term for z < 0] form
@@ -290,7 +301,37 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                       : (type == T_CC) ? (!(mR == 0.0) && !(mR == 1.0) && isn_plain(mR))
                                        : isn_plain(mR);
     const bool plain2 = icn_plain(u_i, mmT);
-    const bool need3 = ok && (type == T_RC) && plain0 && !(zR > 0.0);
+    // what the crossing search below needs to know already here
+    const bool q_pos = (q > 0.0);
+    double uu = u_i;
+    const bool u_bad = (uu < -1.0 - 1e-4) || (uu > +1.0 + 1e-4);
+    if (uu < -1.0) uu = -1.0;
+    if (uu > +1.0) uu = +1.0;
+    const bool ladder_class = (type == T_RR) || (type == T_RC);
+    const bool may_cross = q_pos && !u_bad;
+    // r(P) needs sn (RR) or cn (RC) of modulus mR: the rungs of its Landen ladder are climbed ONCE per ray -- they serve
+    // every crossing order and both rays of a pair -- and kept in LDS; lanes that cannot use them climb a short dummy
+    LadderLds lad{thin_disk_ladder_column()};
+    LadderState lst{};
+#ifndef S5_KO_RAD
+    if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
+#endif
+#if S5_RPC_ADD
+    // THE RADIAL INTEGRAL IS NOT EVALUATED for a ray whose crossing search can do without its value (fast variant, callers
+    // that do not ask for the geodesic's state).  r(P) takes sn or cn of  c (Rpc - P)  = F0 - w,  where w = c P and
+    // F0 = c Rpc is an inverse Jacobi function of an ALGEBRAIC argument: sn(F0) = zR (RR), cn(F0) = zR (RC) -- the very
+    // argument the R_F of slot 0 would be called with.  So sn, cn, dn of w come from the ladder, those of F0 from zR, and
+    // the addition theorem gives sn(w - F0) or cn(F0 - w) -- no inverse function.  The comparisons of P with Rpc and
+    // 2 Rpc (ref :303-309, :336, :881) become sign tests on the same quantities (below); they need w < 2 K(mR) to be
+    // unambiguous, and K(mR) = pi / (2 c_N) is the last mean of the ladder that is climbed anyway.
+    constexpr bool ADD = !WANT_STATE;
+    const bool by_add = ADD && ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
+    const bool need_rf0 = !ADD || (ok && may_cross && !by_add);
+#else
+    constexpr bool ADD = false;
+    const bool by_add = false, need_rf0 = true;
+#endif
+    const bool need3 = ok && (type == T_RC) && plain0 && !(zR > 0.0) && need_rf0;
     double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
     // unrolled: three inlined R_F bodies (slot 1 is the table, slot 3 rare).  Rolled into one body it once saved the kernel
     // from 256 VGPRs and spills; at today's 108 VGPRs the copies cost nothing and the rolled loop costs 4 % (measured)
@@ -304,6 +345,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         if (slot == 1) continue;                         // K(mmT) comes from the AGM below
 #endif
         if (slot == 3 && !wave_any(need3)) break;
+        if (slot == 0 && ADD && !wave_any(need_rf0)) continue;
         double x, y, mult;
         if (slot == 0) {
             const double z2 = zT * zT;
@@ -357,8 +399,8 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     double K = res1;
     double icn_i = res2;
     // special cases, out of line
-    if (wave_any(ok && !plain0)) {
-        if (ok && !plain0)
+    if (wave_any(ok && !plain0 && need_rf0)) {
+        if (ok && !plain0 && need_rf0)
             Rint = (type == T_RC) ? inv_cn_cold(zR, mR) : (type == T_CC) ? inv_tn_cold(zR, mR) : inv_sn_cold(zR, mR);
     }
     if (wave_any(ok && !plain2)) {
@@ -381,23 +423,27 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     if (PAIR) { out2.gtype = type; out2.cls = PX_MISS; }
 
     // ---------------- equatorial crossings and r(P) (ref :846-885, :291-357) ----------------
-    const bool q_pos = (q > 0.0);
-    double uu = u_i;
-    bool u_bad = (uu < -1.0 - 1e-4) || (uu > +1.0 + 1e-4);
-    if (uu < -1.0) uu = -1.0;
-    if (uu > +1.0) uu = +1.0;
     double icn_u = icn_i;
     if (wave_any(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
         if (uu != u_i && !u_bad && q_pos) icn_u = inv_cn_cold(uu, mmT);
     }
-    // r(P) needs sn (RR) or cn (RC) of modulus mR: the rungs of its Landen ladder are climbed ONCE per ray -- they serve
-    // every crossing order and both rays of a pair -- and kept in LDS; lanes that cannot use them climb a short dummy
-    LadderLds lad{thin_disk_ladder_column()};
-    LadderState lst;
-    const bool ladder_class = (type == T_RR) || (type == T_RC);
-    const bool may_cross = q_pos && !u_bad;
-#ifndef S5_KO_RAD
-    if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
+#if S5_RPC_ADD
+    // per-ray constants of the addition theorem (by_add lanes): sn, cn, dn of F0 as products
+    double add_z2 = 0.0, add_cd = 0.0, add_s = 0.0, add_d = 0.0, add_w = 0.0, two_K = 0.0;
+    if (ADD && wave_any(by_add)) {
+        two_K = mdiv(3.14159265358979323846, lst.c);
+        if (type == T_RC) {
+            add_z2 = 1. - zR * zR;                              // sn^2(F0)
+            const double d2 = 1. - mR * add_z2;                 // dn^2(F0)
+            add_s = sqrt_pos(add_z2); add_d = sqrt_pos(d2);
+            add_cd = add_s * add_d;
+            add_w = sqAB;
+        } else {
+            add_z2 = zR * zR;                                   // sn^2(F0)
+            add_cd = sqrt_pos((1. - add_z2) * (1. - mR * add_z2));      // cn(F0) dn(F0)
+            add_w = 0.5 * sqAB;
+        }
+    }
 #endif
 #ifndef S5_PAIR_MEMBERS
 #define S5_PAIR_MEMBERS 2                    // 1: timing experiments only (the mirror image is not traced)
@@ -430,19 +476,84 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                     if (beta_m > 0.0) P = mK * ((2. * (double)order + 1.) * K + icn_u);
                     else if (beta_m < 0.0) P = mK * ((2. * (double)order + 1.) * K - icn_u);
                     else P = mK * ((2. * (double)order + 1.) * K);
+#if S5_RPC_ADD
+                    // beyond 2 Rpc for sure: RR (F0 < K) from w = 2 K(mR), RC (F0 < 2 K) from w = 4 K(mR)
+                    if (by_add) { if (!(add_w * P < ((type == T_RC) ? two_K + two_K : two_K))) P = NAN; }
+                    else
+#endif
                     if (P > 2. * Rpc) P = NAN;
                 }
                 if (isnan(P)) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; }
                 else {
                     // r(P): RR through sn, RC through cn, one ladder for both
                     double r;
-                    const bool in_range = !((P <= 0.0) || (P >= 2. * Rpc));
-                    const bool at_peri = (P == Rpc);
-                    const bool rr = (type == T_RR), rcx = (type == T_RC) && !(P > Rpc);
+                    const bool in_range = by_add || !((P <= 0.0) || (P >= 2. * Rpc));
+                    const bool at_peri = !by_add && (P == Rpc);
+                    const bool rr = (type == T_RR);
+                    bool rcx = (type == T_RC) && (by_add || !(P > Rpc));
                     const bool use_ladder = in_range && !at_peri && (rr || rcx);
                     double su = 0.0;
                     if (rr) su = 0.5 * fabs(P - Rpc) * sqAB;
                     else if (rcx) su = sqAB * (Rpc - P);
+#if S5_RPC_ADD
+                    // sn^2 = Pn / Q (RR), cn = X / Y (RC): by_add lanes from the addition theorem, the others from sn, cn
+                    double Pn = 0.0, Q = 1.0, X = 1.0, Y = 1.0;
+                    bool beyond = false;                         // by_add lanes: P turns out to be >= 2 Rpc
+                    if (ADD) {
+                        if (wave_any(use_ladder && !by_add)) {
+                            if (use_ladder && !by_add) {
+                                const SnCn o = ladder_descend_cold(lad.base, lst, su);
+                                Pn = o.sn * o.sn; X = o.cn;
+                            }
+                        }
+                        if (wave_any(by_add)) {
+                            if (by_add) {
+                                double s0, c0, C, ga, N, D;
+                                const double w = add_w * P;
+                                msincos(w * lst.c, s0, c0);                    // RR: 0 < w c < pi, RC: < 2 pi
+                                ladder_descend_fractions(lad, lst, s0, c0, C, ga, N, D);
+                                // numerators of sn(w) and cn(w) over rho (the signs as ladder_descend assigns them)
+                                const double S = (s0 >= 0.0) ? fabs(ga) : -fabs(ga);
+                                const double Cc = ((ga >= 0.0) == (s0 >= 0.0)) ? C : -C;
+                                const double rho2 = C * C + ga * ga;
+                                if (rr) {
+                                    // sn(w - F0) = rho (S cn dn(F0) D - zR Cc N) / (D (rho^2 - m zR^2 S^2))
+                                    const double num = S * add_cd * D - zR * Cc * N;
+                                    const double den = D * (rho2 - (mR * add_z2) * (S * S));
+                                    Pn = rho2 * (num * num);
+                                    Q = den * den;
+                                } else {
+                                    // cn(F0 - w) = rho (zR Cc D + sn dn(F0) S N) / (D (rho^2 - m sn^2(F0) S^2)).  F0 - w lies in
+                                    // (-4K, 2K): for w < 2K the sign of sn(F0 - w), i.e. of (sn(F0) Cc N - zR S dn(F0) D) D, says
+                                    // whether P <= Rpc (for w >= 2K > F0 it is not); past Rpc the ray is still inside 2 Rpc
+                                    // while cn(F0 - w) > cn(F0) = zR (|F0 - w| < 4K - F0 here)
+                                    const double rho = sqrt_pos(rho2);
+                                    X = rho * (zR * Cc * D + add_cd * S * N);
+                                    Y = D * (rho2 - (mR * add_z2) * (S * S));
+                                    const double sgn = (add_s * Cc * N - zR * S * add_d * D) * D;
+                                    if (!(sgn >= 0.0) || !(w < two_K)) {
+                                        rcx = false;
+                                        beyond = !((X - zR * Y) * Y > 0.0);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (!in_range) r = NAN;
+                    else if (at_peri) r = rp;
+                    else if (rr) {
+                        S5_FPC_RADIUS
+                        const double dnm = (rb - rd_) * Q - (ra - rd_) * Pn;
+                        r = mdiv(ra * (rb - rd_) * Q - rb * (ra - rd_) * Pn, dnm);
+                        if (by_add && !(dnm > 0.0)) beyond = true;             // sn^2(w - F0) >= sn^2(F0): w >= 2 F0
+                    } else if (rcx) {
+                        S5_FPC_RADIUS
+                        const double Aq = A;
+                        const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
+                        r = mdiv((rb * Aq - ra * Bq) * Y - (rb * Aq + ra * Bq) * X, (Aq - Bq) * Y - (Aq + Bq) * X);
+                    } else r = NAN;
+                    if (beyond) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; r = NAN; }
+#else
                     double sn = 0.0, cn = 1.0, dn = 1.0;
                     if (wave_any(use_ladder)) {
 #ifdef S5_KO_RAD
@@ -463,6 +574,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                         const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
                         r = mdiv(rb * Aq - ra * Bq - (rb * Aq + ra * Bq) * cn, (Aq - Bq) - (Aq + Bq) * cn);
                     } else r = NAN;
+#endif
                     if (r >= p.rms) {
                         cls_m = (order == 0) ? PX_HIT0 : PX_HIT1;
                         r_m = r; P_m = P;
