@@ -36,7 +36,7 @@ S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const 
     double T = (sdm > 0.0) ? -(t.Tpp - t.Tip) : -(t.Tip);
     for (int it = 0; it < 4096 && (t.P > T + t.Tpp); ++it) { T += t.Tpp; sdm = -sdm; }
     double k[4], n[4], floc[4], fv[4], wp[2];
-    photon_momentum(t.a, t.r, 0.0, t.l, t.q, (t.P < t.Rpc ? -1. : +1.), sdm, k);
+    photon_momentum(t.a, t.r, 0.0, t.l, t.q, (t.dP > 0.0 ? -1. : +1.), sdm, k);
     Metric mt;
     kerr_metric(p.a, t.r, 0.0, mt);
     Tetrad tt;
@@ -105,7 +105,8 @@ void disk_image_polarized_kernel(ImageParams p)
 // symmetric row sets (k_disk_image.hip: disk_image_mirror_kernel): the pixel and its mirror image in beta share the geodesic;
 // the polarization chain runs for each of the two, as a loop of two passes over ONE inlined copy
 #ifndef S5_LB_POLAR_MIRROR
-#define S5_LB_POLAR_MIRROR 4                // 131 VGPRs by itself; capped at 128 for the fourth wave per SIMD (no scratch): -3 %
+#define S5_LB_POLAR_MIRROR 3                // ~150 VGPRs with the addition-theorem r(P) (s5_thindisk.hpp): three waves per SIMD and
+                                            // no scratch; capped at 128 for a fourth wave it spills 20 registers -- same time (measured)
 #endif
 template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)

@@ -54,7 +54,7 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
         if (t.cls == PX_HIT0 && t.flux != 0.0) {
             double k[4], U[4], N[4];
             const double e0[4] = { 1.0, 0.0, 0.0, 0.0 }, e2[4] = { 0.0, 0.0, 1.0, 0.0 };
-            photon_momentum(p.a, t.r, 0.0, t.l, t.q, t.Rpc - t.P, 1.0, k);           // ref py :250
+            photon_momentum(p.a, t.r, 0.0, t.l, t.q, t.dP, 1.0, k);           // ref py :250
             Metric mt;
             kerr_metric(p.a, t.r, 0.0, mt);
             Tetrad tt;

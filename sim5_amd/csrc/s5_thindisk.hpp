@@ -37,7 +37,9 @@ struct ThinRay {
     double r, g, flux; // accepted crossing (r = NaN if none)
     double P;          // position integral of the accepted crossing
     // geodesic quantities (valid when err == 0)
-    double a, l, q, beta, Rpc, Tpp, Tip, rp;
+    double a, l, q, beta, Tpp, Tip, rp;
+    double dP;         // a number with the sign of Rpc - P at the accepted crossing (the radial direction there, ref :806);
+                       // Rpc - P itself where the radial integral was evaluated
 };
 
 // generic routines out of line: taken only by lanes in a special case of the inverse functions
@@ -317,14 +319,16 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
 #if S5_RPC_ADD
-    // THE RADIAL INTEGRAL IS NOT EVALUATED for a ray whose crossing search can do without its value (fast variant, callers
-    // that do not ask for the geodesic's state).  r(P) takes sn or cn of  c (Rpc - P)  = F0 - w,  where w = c P and
+    // THE RADIAL INTEGRAL IS NOT EVALUATED for a ray whose crossing search can do without its value (fast variant).  r(P) takes sn or cn of  c (Rpc - P)  = F0 - w,  where w = c P and
     // F0 = c Rpc is an inverse Jacobi function of an ALGEBRAIC argument: sn(F0) = zR (RR), cn(F0) = zR (RC) -- the very
     // argument the R_F of slot 0 would be called with.  So sn, cn, dn of w come from the ladder, those of F0 from zR, and
     // the addition theorem gives sn(w - F0) or cn(F0 - w) -- no inverse function.  The comparisons of P with Rpc and
     // 2 Rpc (ref :303-309, :336, :881) become sign tests on the same quantities (below); they need w < 2 K(mR) to be
     // unambiguous, and K(mR) = pi / (2 c_N) is the last mean of the ladder that is climbed anyway.
-    constexpr bool ADD = !WANT_STATE;
+#ifndef S5_RPC_ADD_STATE
+#define S5_RPC_ADD_STATE 1                  // 0: callers that take the ray's state (polarized image, spectrum) keep the R_F
+#endif
+    constexpr bool ADD = !WANT_STATE || (S5_RPC_ADD_STATE != 0);
     const bool by_add = ADD && ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
     const bool need_rf0 = !ADD || (ok && may_cross && !by_add);
 #else
@@ -409,10 +413,10 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     const double Rpc = pre * Rint;
 
     if (WANT_STATE) {
-        out.a = a; out.l = l; out.q = q; out.beta = beta; out.Rpc = Rpc; out.rp = rp;
+        out.a = a; out.l = l; out.q = q; out.beta = beta; out.rp = rp; out.dP = NAN;
         out.Tpp = 2. * (mK * K); out.Tip = mK * icn_i;
         if (PAIR) {
-            out2.a = a; out2.l = l; out2.q = q; out2.beta = -beta; out2.Rpc = Rpc; out2.rp = rp;
+            out2.a = a; out2.l = l; out2.q = q; out2.beta = -beta; out2.rp = rp; out2.dP = NAN;
             out2.Tpp = out.Tpp; out2.Tip = out.Tip;
         }
     }
@@ -463,7 +467,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     for (int member = 0; member < (PAIR ? S5_PAIR_MEMBERS : 1); ++member) {
         const double beta_m = (member == 0) ? beta : -beta;
         int cls_m = PX_MISS;
-        double r_m = NAN, P_m = NAN, g_m = 0.0, flux_m = 0.0;
+        double r_m = NAN, P_m = NAN, g_m = 0.0, flux_m = 0.0, dP_m = NAN;
         bool cf_m = false;                      // fast variant: the flux of this ray is owed by the closed form (below)
         bool done = false;
 #pragma unroll 1
@@ -492,6 +496,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                     const bool rr = (type == T_RR);
                     bool rcx = (type == T_RC) && (by_add || !(P > Rpc));
                     const bool use_ladder = in_range && !at_peri && (rr || rcx);
+                    double dP = Rpc - P;
                     double su = 0.0;
                     if (rr) su = 0.5 * fabs(P - Rpc) * sqAB;
                     else if (rcx) su = sqAB * (Rpc - P);
@@ -499,7 +504,15 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                     // sn^2 = Pn / Q (RR), cn = X / Y (RC): by_add lanes from the addition theorem, the others from sn, cn
                     double Pn = 0.0, Q = 1.0, X = 1.0, Y = 1.0;
                     bool beyond = false;                         // by_add lanes: P turns out to be >= 2 Rpc
-                    if (ADD) {
+                    if (!ADD) {
+                        if (wave_any(use_ladder)) {
+                            if (use_ladder) {
+                                double sn, cn, dn;
+                                ladder_descend(lad, lst, su, sn, cn, dn);
+                                Pn = sn * sn; X = cn;
+                            }
+                        }
+                    } else {
                         if (wave_any(use_ladder && !by_add)) {
                             if (use_ladder && !by_add) {
                                 const SnCn o = ladder_descend_cold(lad.base, lst, su);
@@ -522,6 +535,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                                     const double den = D * (rho2 - (mR * add_z2) * (S * S));
                                     Pn = rho2 * (num * num);
                                     Q = den * den;
+                                    dP = -(num * D);                          // sign of F0 - w (|w - F0| < K in range)
                                 } else {
                                     // cn(F0 - w) = rho (zR Cc D + sn dn(F0) S N) / (D (rho^2 - m sn^2(F0) S^2)).  F0 - w lies in
                                     // (-4K, 2K): for w < 2K the sign of sn(F0 - w), i.e. of (sn(F0) Cc N - zR S dn(F0) D) D, says
@@ -531,6 +545,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                                     X = rho * (zR * Cc * D + add_cd * S * N);
                                     Y = D * (rho2 - (mR * add_z2) * (S * S));
                                     const double sgn = (add_s * Cc * N - zR * S * add_d * D) * D;
+                                    dP = sgn;
                                     if (!(sgn >= 0.0) || !(w < two_K)) {
                                         rcx = false;
                                         beyond = !((X - zR * Y) * Y > 0.0);
@@ -577,7 +592,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #endif
                     if (r >= p.rms) {
                         cls_m = (order == 0) ? PX_HIT0 : PX_HIT1;
-                        r_m = r; P_m = P;
+                        r_m = r; P_m = P; dP_m = dP;
                         done = true;
                     }
                 }
@@ -602,8 +617,8 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #endif
 #endif
         }
-        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; cf0 = cf_m; }
-        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; cf1 = cf_m; }
+        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; cf0 = cf_m; if (WANT_STATE) out.dP = dP_m; }
+        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; cf1 = cf_m; if (WANT_STATE) out2.dP = dP_m; }
     }
 #if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
     // the closed form of the flux for the few rays the table does not serve (s5_disk.hpp), outside the loop above
