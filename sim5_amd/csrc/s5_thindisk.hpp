@@ -519,7 +519,12 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                                 Pn = o.sn * o.sn; X = o.cn;
                             }
                         }
+#ifdef S5_KO_RAD                 // diagnostic knock-out: timing-breakdown builds only, never shipped
+                        if (by_add) { Pn = 0.05 + 1e-4 * P; Q = 1.0; X = 0.9 - 1e-3 * P; Y = 1.0; dP = 1.0; }
+                        if (false) {
+#else
                         if (wave_any(by_add)) {
+#endif
                             if (by_add) {
                                 double s0, c0, C, ga, N, D;
                                 const double w = add_w * P;
