@@ -22,6 +22,10 @@
 #define CHECK(call) do { int rc_ = (call); if (rc_ != 0) { fprintf(stderr, "ERROR: %s -> %d: %s | %s\n", #call, rc_, \
     sim5gpu_rccl_last_error(), sim5gpu_last_error()); return 1; } } while (0)
 
+/* SIM5_EXAMPLE_VERBOSE=1: a line on stderr after every stage, each behind a synchronisation (to place a GPU fault) */
+static int verbose = 0;
+#define STAGE(what) do { if (verbose) { CHECK(sim5gpu_synchronize(NULL)); fprintf(stderr, "[rank %d] %s\n", rank, what); } } while (0)
+
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 int main(int argc, char **argv)
@@ -33,6 +37,7 @@ int main(int argc, char **argv)
     const int n = argc > 6 ? atoi(argv[6]) : 4096, images = argc > 7 ? atoi(argv[7]) : 10;
     char id[SIM5GPU_RCCL_ID_BYTES];
     void *comm = NULL;
+    verbose = getenv("SIM5_EXAMPLE_VERBOSE") != NULL;
 
     if (world > 1) {
         if (rank == 0) {                                  /* the id travels through a file: write, then rename into place */
@@ -69,16 +74,20 @@ int main(int argc, char **argv)
         CHECK(sim5gpu_malloc((void **)&d_g, (size_t)n * n * sizeof(float)));
     }
     /* pipelined: the gather of image i runs while image i+1 is traced */
+    STAGE("buffers allocated");
     CHECK(sim5gpu_disk_image_sharded(sh, &img, d_f, d_g, NULL));       /* warm-up: code, tables, first collective */
     CHECK(sim5gpu_synchronize(NULL));
+    STAGE("warm-up image done");
     const double t0 = now();
     for (int i = 0; i < images; i++) {
         CHECK(sim5gpu_shard_image_begin(sh, &img, d_f, d_g, NULL));
         if (i > 0) CHECK(sim5gpu_shard_image_end(sh, NULL));
+        STAGE("image begun");
     }
     CHECK(sim5gpu_shard_image_end(sh, NULL));
     CHECK(sim5gpu_synchronize(NULL));
     const double dt = now() - t0;
+    STAGE("timed images done");
     if (rank == 0) {
         float *g = (float *)malloc((size_t)n * n * sizeof(float));
         CHECK(sim5gpu_memcpy_d2h(g, d_g, (size_t)n * n * sizeof(float)));
@@ -87,8 +96,10 @@ int main(int argc, char **argv)
         printf("ranks %d  image %d x %d  rows on rank 0: %d  images %d  %.3f ms per image  %.4e rays/s  disk hits %ld\n",
                world, n, n, rows, images, 1e3 * dt / images, (double)n * n * images / dt, hits);
         free(g);
+        fflush(stdout);
         sim5gpu_free(d_f); sim5gpu_free(d_g);
     }
+    STAGE("image planes released");
     CHECK(sim5gpu_shard_destroy(sh));
     if (comm) CHECK(sim5gpu_rccl_comm_destroy(comm));
     return 0;

@@ -105,9 +105,11 @@ void disk_image_polarized_kernel(ImageParams p)
 // symmetric row sets (k_disk_image.hip: disk_image_mirror_kernel): the pixel and its mirror image in beta share the geodesic;
 // the polarization chain runs for each of the two, as a loop of two passes over ONE inlined copy
 #ifndef S5_LB_POLAR_MIRROR
-#define S5_LB_POLAR_MIRROR 4                // ~150 VGPRs by itself with the addition-theorem r(P) (s5_thindisk.hpp); capped at 128 for the
-                                            // fourth wave per SIMD it spills 20 registers (80-96 B of scratch per lane) and is still
-                                            // 5 % faster than three waves without scratch: 0.137 against 0.145 ms at C3 (measured)
+#define S5_LB_POLAR_MIRROR 3                // ~150 VGPRs by itself with the addition-theorem r(P) (s5_thindisk.hpp): three waves per SIMD,
+                                            // NO SCRATCH.  Capped at 128 for a fourth wave it spilled 20-30 registers and measured 5 % faster
+                                            // (0.137 against 0.145 ms at C3) -- not taken: a register spill in the image kernel (same
+                                            // routine, same toolchain) gave wrong pixels and a memory fault; spills are
+                                            // refused in these kernels by tests/test_capi_boundary.py
 #endif
 template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)

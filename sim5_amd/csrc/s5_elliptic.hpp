@@ -33,8 +33,10 @@ namespace S5NS {
 // ---------------------------------------------------------------------------------------
 // CHECKED = false: the caller guarantees x, y, z > 0 for every lane whose result it uses (other lanes may carry
 // anything: NaN stops a lane's loop at once, its result is discarded by the caller)
-template <bool CHECKED>
-S5_DEV double carlson_rf_impl(double x, double y, double z)
+// ROOT_X: the caller knows sqrt(x) exactly (x was formed as its square) and z = 1: the first pass then needs ONE square root
+// instead of three (sqrt_x is ignored otherwise)
+template <bool CHECKED, bool ROOT_X = false>
+S5_DEV double carlson_rf_impl(double x, double y, double z, double sqrt_x = 0.0)
 {
     S5_FPC_RF
     const double tol = 0.03, third = 1.0 / 3.0;
@@ -51,6 +53,20 @@ S5_DEV double carlson_rf_impl(double x, double y, double z)
     // by 1/4 inside the loop, and since powers of two are exact the values are those of the textbook form.
     double A = A0, pw = 1.0;                        // pw = 2^n
     bool live = dev >= tol * A;
+    if (ROOT_X) {
+        if (wave_any(live)) {
+            if (live) {
+                const double sy = sqrt_pos(y);
+                const double lam = sqrt_x * (sy + 1.0) + sy;
+                x += lam;
+                y += lam;
+                z += lam;
+                A += lam;
+                pw += pw;
+                live = dev >= tol * A;
+            }
+        }
+    }
     for (int pass = 0; pass < 32; ++pass) {
         if (!wave_any(live)) break;
         if (live) {                              // a lane's result depends on its own arguments only
@@ -64,7 +80,14 @@ S5_DEV double carlson_rf_impl(double x, double y, double z)
             live = dev >= tol * A;
         }
     }
-    const double rA = mrcp(A);                      // 1 / (4^n A_n)
+    // 1/(4^n A_n) and its square root from one reciprocal square root
+#ifdef S5_RF_TAIL_RCP                               // A/B builds: the reciprocal and its square root separately
+    const double rA = mrcp(A);
+    const double rsA = sqrt_pos(rA);
+#else
+    const double rsA = rsqrt_pos(A);
+    const double rA = rsA * rsA;
+#endif
     const double X = dx0 * rA, Y = dy0 * rA, Z = -(X + Y);
     const double E2 = X * Y - Z * Z, E3 = X * Y * Z;
     // coefficient of E2^j E3^k: (-1)^j (1/2)_(j+k) / (j! k! (2(2j+3k)+1))  (DLMF 19.19.7 with E1 = 0), all terms
@@ -73,9 +96,11 @@ S5_DEV double carlson_rf_impl(double x, double y, double z)
     const double s3 = hfmac(E3, hfma(E3, 5.0 / 304.0, 3.0 / 104.0), 1.0 / 14.0);                            // pure E3
     const double sx = hfma(E2, hfma(E2, -35.0 / 608.0, 1.0 / 16.0), hfma(E3, -15.0 / 272.0, -3.0 / 44.0)); // x E2 E3
     const double ser = hfma(E2, hfma(E3, sx, s2), hfmac(E3, s3, 1.0));
-    const double res = ser * pw * sqrt_pos(rA);     // A_n^-1/2 = 2^n (4^n A_n)^-1/2
+    const double res = ser * pw * rsA;              // A_n^-1/2 = 2^n (4^n A_n)^-1/2
     return (CHECKED && bad) ? NAN : res;
 }
+// R_F(sx^2, y, 1) for 0 < sx, y (callers as carlson_rf_positive)
+S5_DEV double carlson_rf_root_x(double sx, double x, double y) { return carlson_rf_impl<false, true>(x, y, 1.0, sx); }
 S5_DEV double carlson_rf(double x, double y, double z) { return carlson_rf_impl<true>(x, y, z); }
 S5_DEV double carlson_rf_positive(double x, double y, double z) { return carlson_rf_impl<false>(x, y, z); }
 #else

@@ -201,6 +201,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     const int type = (KNOWN >= 0) ? KNOWN : type_in;
     const double a2 = a * a, l2 = l * l;
     double A = 0.0;                  // RC: |r1 - (u + i v)|, kept for r(P)
+    double Bkeep = 0.0;              // RC, fast variant: |r2 - (u + i v)| as well (two registers instead of the complex root's four)
     // ---------------- per-class set-up of the radial integral (ref :1051-1100) ----------------
     // Rpc = pre * inverse-Jacobi(zR | mR); sqAB is reused by r(P)
     double mR, zR, pre, sqAB, rp;
@@ -231,7 +232,8 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         zR = mdiv(Aq - Bq, Aq + Bq);
         rp = ra;
         // keep A, B for r(P): the RC formula needs them again
-        A = Aq;                       // kept for r(P); B is recomputed there from the same expression
+        A = Aq;                       // kept for r(P); the strict variant recomputes B there from the same expression
+        Bkeep = Bq;
     } else {
         const double b1 = ra, a1 = rb, b2 = rc_, a2c = rd_;
         const double Aq = msqrt(sq(b1 - b2) + sq(a1 + a2c));
@@ -325,6 +327,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     // the addition theorem gives sn(w - F0) or cn(F0 - w) -- no inverse function.  The comparisons of P with Rpc and
     // 2 Rpc (ref :303-309, :336, :881) become sign tests on the same quantities (below); they need w < 2 K(mR) to be
     // unambiguous, and K(mR) = pi / (2 c_N) is the last mean of the ladder that is climbed anyway.
+    constexpr double S5_PI = 3.14159265358979323846;
 #ifndef S5_RPC_ADD_STATE
 #define S5_RPC_ADD_STATE 1                  // 0: callers that take the ray's state (polarized image, spectrum) keep the R_F
 #endif
@@ -370,7 +373,12 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         const double v = mult * (1.5 + 0.1 * x + 0.01 * y);
 #else
         // plain lanes have x, y > 0 by construction (z^2 < 1, moduli in [0,1)); the others are redone out of line
+#if S5_FAST && !defined(S5_NO_RF_ROOT_X)
+        // slot 2: x = u_i^2 was formed as a square, its root is |u_i| (first pass of the duplication with one square root)
+        const double v = mult * ((slot == 2) ? carlson_rf_root_x(fabs(u_i), x, y) : carlson_rf_positive(x, y, 1.0));
+#else
         const double v = mult * carlson_rf_positive(x, y, 1.0);
+#endif
 #endif
         if (slot == 0) res0 = v; else if (slot == 1) res1 = v; else if (slot == 2) res2 = v; else res3 = v;
     }
@@ -431,21 +439,24 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     if (wave_any(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
         if (uu != u_i && !u_bad && q_pos) icn_u = inv_cn_cold(uu, mmT);
     }
+#if S5_FAST
+    const double mKK = mK * K, mKi = mK * icn_u;
+#endif
 #if S5_RPC_ADD
-    // per-ray constants of the addition theorem (by_add lanes): sn, cn, dn of F0 as products
-    double add_z2 = 0.0, add_cd = 0.0, add_s = 0.0, add_d = 0.0, add_w = 0.0, two_K = 0.0;
+    // per-ray constants of the addition theorem (by_add lanes): sn, cn, dn of F0 as products.  Few, and the cheap ones are
+    // re-formed where they are used: every double kept across the crossing loop is two of the kernel's 128 registers.
+    double add_cd = 0.0, add_s = 0.0, add_d = 0.0, add_mz2 = 0.0;
     if (ADD && wave_any(by_add)) {
-        two_K = mdiv(3.14159265358979323846, lst.c);
         if (type == T_RC) {
-            add_z2 = 1. - zR * zR;                              // sn^2(F0)
-            const double d2 = 1. - mR * add_z2;                 // dn^2(F0)
-            add_s = sqrt_pos(add_z2); add_d = sqrt_pos(d2);
+            const double s2 = 1. - zR * zR;                     // sn^2(F0)
+            const double d2 = 1. - mR * s2;                     // dn^2(F0)
+            add_s = sqrt_pos(s2); add_d = sqrt_pos(d2);
             add_cd = add_s * add_d;
-            add_w = sqAB;
+            add_mz2 = mR * s2;
         } else {
-            add_z2 = zR * zR;                                   // sn^2(F0)
-            add_cd = sqrt_pos((1. - add_z2) * (1. - mR * add_z2));      // cn(F0) dn(F0)
-            add_w = 0.5 * sqAB;
+            const double z2 = zR * zR;                          // sn^2(F0)
+            add_cd = sqrt_pos((1. - z2) * (1. - mR * z2));      // cn(F0) dn(F0)
+            add_mz2 = mR * z2;
         }
     }
 #endif
@@ -477,12 +488,20 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                 double P;
                 if (!may_cross) P = NAN;
                 else {
+#if S5_FAST
+                    // mK distributed over the sum (two products formed once per ray, not three factors kept per crossing)
+                    if (beta_m > 0.0) P = (2. * (double)order + 1.) * mKK + mKi;
+                    else if (beta_m < 0.0) P = (2. * (double)order + 1.) * mKK - mKi;
+                    else P = (2. * (double)order + 1.) * mKK;
+#else
                     if (beta_m > 0.0) P = mK * ((2. * (double)order + 1.) * K + icn_u);
                     else if (beta_m < 0.0) P = mK * ((2. * (double)order + 1.) * K - icn_u);
                     else P = mK * ((2. * (double)order + 1.) * K);
+#endif
 #if S5_RPC_ADD
-                    // beyond 2 Rpc for sure: RR (F0 < K) from w = 2 K(mR), RC (F0 < 2 K) from w = 4 K(mR)
-                    if (by_add) { if (!(add_w * P < ((type == T_RC) ? two_K + two_K : two_K))) P = NAN; }
+                    // beyond 2 Rpc for sure: RR (F0 < K) from w = 2 K(mR), RC (F0 < 2 K) from w = 4 K(mR); K(mR) = pi / (2 c_N), so in
+                    // terms of the angle w c_N the descent starts from: pi and 2 pi
+                    if (by_add) { if (!((((type == T_RC) ? sqAB : 0.5 * sqAB) * P) * lst.c < ((type == T_RC) ? 2. * S5_PI : S5_PI))) P = NAN; }
                     else
 #endif
                     if (P > 2. * Rpc) P = NAN;
@@ -527,8 +546,8 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #endif
                             if (by_add) {
                                 double s0, c0, C, ga, N, D;
-                                const double w = add_w * P;
-                                msincos(w * lst.c, s0, c0);                    // RR: 0 < w c < pi, RC: < 2 pi
+                                const double wc = (((type == T_RC) ? sqAB : 0.5 * sqAB) * P) * lst.c;     // RR: 0 < w c < pi, RC: < 2 pi
+                                msincos(wc, s0, c0);
                                 ladder_descend_fractions(lad, lst, s0, c0, C, ga, N, D);
                                 // numerators of sn(w) and cn(w) over rho (the signs as ladder_descend assigns them)
                                 const double S = (s0 >= 0.0) ? fabs(ga) : -fabs(ga);
@@ -537,7 +556,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                                 if (rr) {
                                     // sn(w - F0) = rho (S cn dn(F0) D - zR Cc N) / (D (rho^2 - m zR^2 S^2))
                                     const double num = S * add_cd * D - zR * Cc * N;
-                                    const double den = D * (rho2 - (mR * add_z2) * (S * S));
+                                    const double den = D * (rho2 - add_mz2 * (S * S));
                                     Pn = rho2 * (num * num);
                                     Q = den * den;
                                     dP = -(num * D);                          // sign of F0 - w (|w - F0| < K in range)
@@ -548,10 +567,10 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                                     // while cn(F0 - w) > cn(F0) = zR (|F0 - w| < 4K - F0 here)
                                     const double rho = sqrt_pos(rho2);
                                     X = rho * (zR * Cc * D + add_cd * S * N);
-                                    Y = D * (rho2 - (mR * add_z2) * (S * S));
+                                    Y = D * (rho2 - add_mz2 * (S * S));
                                     const double sgn = (add_s * Cc * N - zR * S * add_d * D) * D;
                                     dP = sgn;
-                                    if (!(sgn >= 0.0) || !(w < two_K)) {
+                                    if (!(sgn >= 0.0) || !(wc < S5_PI)) {
                                         rcx = false;
                                         beyond = !((X - zR * Y) * Y > 0.0);
                                     }
@@ -562,14 +581,15 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                     if (!in_range) r = NAN;
                     else if (at_peri) r = rp;
                     else if (rr) {
+                        // ref :320 divided through by r1 - r4: (r2 - r4)/(r1 - r4) is zR^2 = sn^2(F0) (the fourth root is not kept)
                         S5_FPC_RADIUS
-                        const double dnm = (rb - rd_) * Q - (ra - rd_) * Pn;
-                        r = mdiv(ra * (rb - rd_) * Q - rb * (ra - rd_) * Pn, dnm);
+                        const double z2q = (zR * zR) * Q;
+                        const double dnm = z2q - Pn;
+                        r = mdiv(ra * z2q - rb * Pn, dnm);
                         if (by_add && !(dnm > 0.0)) beyond = true;             // sn^2(w - F0) >= sn^2(F0): w >= 2 F0
                     } else if (rcx) {
                         S5_FPC_RADIUS
-                        const double Aq = A;
-                        const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
+                        const double Aq = A, Bq = Bkeep;
                         r = mdiv((rb * Aq - ra * Bq) * Y - (rb * Aq + ra * Bq) * X, (Aq - Bq) * Y - (Aq + Bq) * X);
                     } else r = NAN;
                     if (beyond) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; r = NAN; }

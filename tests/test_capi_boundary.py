@@ -244,3 +244,22 @@ def test_shard_plan_is_the_python_dealing_rule(capi):
                 assert bool(share.flags & capi.IMG_INPLACE) == (r == 0) and (share.flags & capi.IMG_MIRROR)
             total += rows
         assert total == ny
+
+
+def test_no_register_spills_in_the_image_kernels():
+    """The whole-image kernels of the fast variant run without scratch memory: no spilled VGPR, no private segment.  (A build
+    of disk_image_mirror_kernel that spilled ONE double under its 128-register cap produced wrong pixels in some launches
+    and a memory fault in others -- DESIGN.md 4, round 3 -- so a spill there is a build error, not a tuning matter.)"""
+    from sim5_amd import capi
+    from sim5_amd.codeobj import kernel_metadata
+    meta = kernel_metadata(capi.LIB_PATH)
+    image = {k: v for k, v in meta.items() if "s5f" in k and "disk_image" in k}
+    assert len(image) >= 9, sorted(meta)
+    for k, v in image.items():
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+    march = [v for k, v in meta.items() if "s5f" in k and "torus_pool_kernel" in k]
+    assert march and all(v["vgpr_spill_count"] == 0 for v in march), march
+    # the occupancy the launchers count on: four waves per SIMD for the unpolarized kernels, three for the polarized pairs
+    for k, v in image.items():
+        cap = 168 if "polarized" in k else 128
+        assert v["vgpr_count"] <= cap, (k, v)
