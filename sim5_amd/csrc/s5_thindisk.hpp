@@ -47,17 +47,6 @@ static __device__ __noinline__ double inv_sn_cold(double z, double m) { return i
 static __device__ __noinline__ double inv_cn_cold(double z, double m) { return inv_cn(z, m); }
 static __device__ __noinline__ double inv_tn_cold(double z, double m) { return inv_tn(z, m); }
 
-// the complete descent (flipped and degenerate moduli included) for the few lanes that cannot take the fraction form
-struct SnCn { double sn, cn; };
-static __device__ __noinline__ SnCn ladder_descend_cold(double* column, LadderState st, double u)
-{
-    LadderLds lad{column};
-    SnCn o;
-    double dn;
-    ladder_descend(lad, st, u, o.sn, o.cn, dn);
-    return o;
-}
-
 // true if inv_sn(z, m) takes the plain z * R_F(1-z^2, 1-m z^2, 1) form
 S5_DEV bool isn_plain(double m) { return !(fabs(m - 0.0) < 1e-8) && !(fabs(m - 1.0) < 1e-8); }
 // true if inv_cn(z, m) takes the plain sqrt(1-z^2) R_F(z^2, 1-m(1-z^2), 1) [+ second term for z < 0] form
@@ -70,15 +59,21 @@ S5_DEV bool icn_plain(double z, double m)
 
 template <bool WANT_STATE, int KNOWN, bool PAIR>
 S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
-                             const double l, const double q, const double beta, int err, const int type_in,
+                             const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_);
+template <bool WANT_STATE, int KNOWN, bool PAIR>
+S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+                                    const double l, const double q, const double alpha, const double beta, int err, const int type_in,
+                                    const double ra, const double rb, const double rc_, const double rd_);
+// internal class value: the fast routine leaves this ray to the direct one (never stored)
+constexpr int PX_COLD_MARK = 100;
 
 // PAIR: the lane traces the ray (alpha, beta) into `out` AND its mirror image (alpha, -beta) into `out2`.  The two
 // have the same constants of motion (l, and q through beta^2: ref :76-77), hence the same roots of R(r) and of the
 // polar potential, the same three R_F integrals and the same Landen ladder; only the sign in front of cn^-1 in the
 // position of the equatorial crossing (ref :868-871) and everything after it -- r(P), g, flux -- differ.  A lane's
 // arithmetic for either ray is the arithmetic of the unpaired routine, value for value.
-template <bool WANT_STATE, bool PAIR>
+template <bool WANT_STATE, bool PAIR, bool DIRECT = false>
 S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out, ThinRay& out2)
 {
     S5_FPC_QUARTIC
@@ -166,11 +161,36 @@ S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, doub
         ra = c_hi; rb = h_hi; rc_ = c_lo; rd_ = h_lo; type = T_CC;      // (b1, a1, b2, a2)
     }
 
-    // one instantiation per uniform class (78 % of the rays of the headline image are RR, 22 % RC, and image
-    // neighbours share the class), the generic one for mixed waves
-    if (!wave_any(type != T_RR)) thin_disk_finish<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
-    else if (!wave_any(type != T_RC)) thin_disk_finish<WANT_STATE, T_RC, PAIR>(p, out, out2, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
-    else thin_disk_finish<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, beta, err, type, ra, rb, rc_, rd_);
+    // DIRECT: the reference's sequence for every lane (radial integral by R_F, comparisons with Rpc, special cases): the
+    // strict variant's only path; in the fast variant the path of the few rays its own routine hands back
+    if constexpr (DIRECT || !S5_RPC_ADD) {
+        // one instantiation per uniform class (78 % of the rays of the headline image are RR, 22 % RC, and image
+        // neighbours share the class), the generic one for mixed waves
+        if constexpr (DIRECT) thin_disk_finish_direct<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+        else if (!wave_any(type != T_RR)) thin_disk_finish_direct<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+        else if (!wave_any(type != T_RC)) thin_disk_finish_direct<WANT_STATE, T_RC, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+        else thin_disk_finish_direct<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+        return;
+    } else {
+#if S5_RPC_ADD
+    if (!wave_any(type != T_RR)) thin_disk_finish<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+    else if (!wave_any(type != T_RC)) thin_disk_finish<WANT_STATE, T_RC, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+    else thin_disk_finish<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+    // The rays the fast routine left to the direct one: run HERE, inlined, from the pixel's coordinates -- the fast path's state
+    // is dead by now, so the copy costs the hot path neither registers nor a call (an out-of-line copy called from inside the
+    // routine cost the kernel 8 %: SGPRs saved and restored around the call sites, a stack reserved for every wave; inlined at
+    // the routine's end with the roots kept alive for it: 6 %).  It redoes both rays of the lane's pair; the wave waits.
+    const bool c0 = (out.cls == PX_COLD_MARK), c1 = PAIR && (out2.cls == PX_COLD_MARK);
+    if (wave_any(c0 || c1)) {
+        if (c0 || c1) {
+            ThinRay d0, d1;
+            trace_thin_disk_impl<WANT_STATE, PAIR, true>(p, alpha, beta_in, d0, PAIR ? d1 : d0);
+            if (c0) out = d0;
+            if (c1) out2 = d1;
+        }
+    }
+#endif
+    }
 }
 
 template <bool WANT_STATE>
@@ -192,8 +212,8 @@ S5_DEV double* thin_disk_ladder_column()
 // performs is the same in every instantiation (same expressions, same order), so its result does not depend on
 // which one its wave took -- images stay identical bit for bit whatever the tile shape.
 template <bool WANT_STATE, int KNOWN, bool PAIR>
-S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
-                             const double l, const double q, const double beta, int err, const int type_in,
+S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+                             const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_)
 {
     S5_FPC_FINISH
@@ -201,10 +221,9 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     const int type = (KNOWN >= 0) ? KNOWN : type_in;
     const double a2 = a * a, l2 = l * l;
     double A = 0.0;                  // RC: |r1 - (u + i v)|, kept for r(P)
-    double Bkeep = 0.0;              // RC, fast variant: |r2 - (u + i v)| as well (two registers instead of the complex root's four)
     // ---------------- per-class set-up of the radial integral (ref :1051-1100) ----------------
     // Rpc = pre * inverse-Jacobi(zR | mR); sqAB is reused by r(P)
-    double mR, zR, pre, sqAB, rp;
+    double mR, zR, pre = 0.0, sqAB, rp;
     if (type == T_RR || type == T_RR_DBL) {
 #if S5_FAST
         // 1/sqAB also gives the denominator of the modulus: 1/((ra-rc)(rb-rd)) = (1/sqAB)^2
@@ -222,6 +241,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         const double Aq = msqrt(sq(ra - rc_) + sq(rd_));
         const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
 #if S5_FAST
+        double pre;
         sqrt_rsqrt_pos(Aq * Bq, sqAB, pre);
         mR = (sq(Aq + Bq) - sq(ra - rb)) * (0.25 * (pre * pre));       // 1/(A B) = (1/sqrt(A B))^2
 #else
@@ -232,8 +252,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         zR = mdiv(Aq - Bq, Aq + Bq);
         rp = ra;
         // keep A, B for r(P): the RC formula needs them again
-        A = Aq;                       // kept for r(P); the strict variant recomputes B there from the same expression
-        Bkeep = Bq;
+        A = Aq;                       // kept for r(P); B is recomputed there from the same expression
     } else {
         const double b1 = ra, a1 = rb, b2 = rc_, a2c = rd_;
         const double Aq = msqrt(sq(b1 - b2) + sq(a1 + a2c));
@@ -305,40 +324,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                       : (type == T_CC) ? (!(mR == 0.0) && !(mR == 1.0) && isn_plain(mR))
                                        : isn_plain(mR);
     const bool plain2 = icn_plain(u_i, mmT);
-    // what the crossing search below needs to know already here
-    const bool q_pos = (q > 0.0);
-    double uu = u_i;
-    const bool u_bad = (uu < -1.0 - 1e-4) || (uu > +1.0 + 1e-4);
-    if (uu < -1.0) uu = -1.0;
-    if (uu > +1.0) uu = +1.0;
-    const bool ladder_class = (type == T_RR) || (type == T_RC);
-    const bool may_cross = q_pos && !u_bad;
-    // r(P) needs sn (RR) or cn (RC) of modulus mR: the rungs of its Landen ladder are climbed ONCE per ray -- they serve
-    // every crossing order and both rays of a pair -- and kept in LDS; lanes that cannot use them climb a short dummy
-    LadderLds lad{thin_disk_ladder_column()};
-    LadderState lst{};
-#ifndef S5_KO_RAD
-    if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
-#endif
-#if S5_RPC_ADD
-    // THE RADIAL INTEGRAL IS NOT EVALUATED for a ray whose crossing search can do without its value (fast variant).  r(P) takes sn or cn of  c (Rpc - P)  = F0 - w,  where w = c P and
-    // F0 = c Rpc is an inverse Jacobi function of an ALGEBRAIC argument: sn(F0) = zR (RR), cn(F0) = zR (RC) -- the very
-    // argument the R_F of slot 0 would be called with.  So sn, cn, dn of w come from the ladder, those of F0 from zR, and
-    // the addition theorem gives sn(w - F0) or cn(F0 - w) -- no inverse function.  The comparisons of P with Rpc and
-    // 2 Rpc (ref :303-309, :336, :881) become sign tests on the same quantities (below); they need w < 2 K(mR) to be
-    // unambiguous, and K(mR) = pi / (2 c_N) is the last mean of the ladder that is climbed anyway.
-    constexpr double S5_PI = 3.14159265358979323846;
-#ifndef S5_RPC_ADD_STATE
-#define S5_RPC_ADD_STATE 1                  // 0: callers that take the ray's state (polarized image, spectrum) keep the R_F
-#endif
-    constexpr bool ADD = !WANT_STATE || (S5_RPC_ADD_STATE != 0);
-    const bool by_add = ADD && ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
-    const bool need_rf0 = !ADD || (ok && may_cross && !by_add);
-#else
-    constexpr bool ADD = false;
-    const bool by_add = false, need_rf0 = true;
-#endif
-    const bool need3 = ok && (type == T_RC) && plain0 && !(zR > 0.0) && need_rf0;
+    const bool need3 = ok && (type == T_RC) && plain0 && !(zR > 0.0);
     double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
     // unrolled: three inlined R_F bodies (slot 1 is the table, slot 3 rare).  Rolled into one body it once saved the kernel
     // from 256 VGPRs and spills; at today's 108 VGPRs the copies cost nothing and the rolled loop costs 4 % (measured)
@@ -352,7 +338,6 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         if (slot == 1) continue;                         // K(mmT) comes from the AGM below
 #endif
         if (slot == 3 && !wave_any(need3)) break;
-        if (slot == 0 && ADD && !wave_any(need_rf0)) continue;
         double x, y, mult;
         if (slot == 0) {
             const double z2 = zT * zT;
@@ -373,12 +358,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         const double v = mult * (1.5 + 0.1 * x + 0.01 * y);
 #else
         // plain lanes have x, y > 0 by construction (z^2 < 1, moduli in [0,1)); the others are redone out of line
-#if S5_FAST && !defined(S5_NO_RF_ROOT_X)
-        // slot 2: x = u_i^2 was formed as a square, its root is |u_i| (first pass of the duplication with one square root)
-        const double v = mult * ((slot == 2) ? carlson_rf_root_x(fabs(u_i), x, y) : carlson_rf_positive(x, y, 1.0));
-#else
         const double v = mult * carlson_rf_positive(x, y, 1.0);
-#endif
 #endif
         if (slot == 0) res0 = v; else if (slot == 1) res1 = v; else if (slot == 2) res2 = v; else res3 = v;
     }
@@ -411,8 +391,8 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     double K = res1;
     double icn_i = res2;
     // special cases, out of line
-    if (wave_any(ok && !plain0 && need_rf0)) {
-        if (ok && !plain0 && need_rf0)
+    if (wave_any(ok && !plain0)) {
+        if (ok && !plain0)
             Rint = (type == T_RC) ? inv_cn_cold(zR, mR) : (type == T_CC) ? inv_tn_cold(zR, mR) : inv_sn_cold(zR, mR);
     }
     if (wave_any(ok && !plain2)) {
@@ -435,30 +415,23 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     if (PAIR) { out2.gtype = type; out2.cls = PX_MISS; }
 
     // ---------------- equatorial crossings and r(P) (ref :846-885, :291-357) ----------------
+    const bool q_pos = (q > 0.0);
+    double uu = u_i;
+    bool u_bad = (uu < -1.0 - 1e-4) || (uu > +1.0 + 1e-4);
+    if (uu < -1.0) uu = -1.0;
+    if (uu > +1.0) uu = +1.0;
     double icn_u = icn_i;
     if (wave_any(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
         if (uu != u_i && !u_bad && q_pos) icn_u = inv_cn_cold(uu, mmT);
     }
-#if S5_FAST
-    const double mKK = mK * K, mKi = mK * icn_u;
-#endif
-#if S5_RPC_ADD
-    // per-ray constants of the addition theorem (by_add lanes): sn, cn, dn of F0 as products.  Few, and the cheap ones are
-    // re-formed where they are used: every double kept across the crossing loop is two of the kernel's 128 registers.
-    double add_cd = 0.0, add_s = 0.0, add_d = 0.0, add_mz2 = 0.0;
-    if (ADD && wave_any(by_add)) {
-        if (type == T_RC) {
-            const double s2 = 1. - zR * zR;                     // sn^2(F0)
-            const double d2 = 1. - mR * s2;                     // dn^2(F0)
-            add_s = sqrt_pos(s2); add_d = sqrt_pos(d2);
-            add_cd = add_s * add_d;
-            add_mz2 = mR * s2;
-        } else {
-            const double z2 = zR * zR;                          // sn^2(F0)
-            add_cd = sqrt_pos((1. - z2) * (1. - mR * z2));      // cn(F0) dn(F0)
-            add_mz2 = mR * z2;
-        }
-    }
+    // r(P) needs sn (RR) or cn (RC) of modulus mR: the rungs of its Landen ladder are climbed ONCE per ray -- they serve
+    // every crossing order and both rays of a pair -- and kept in LDS; lanes that cannot use them climb a short dummy
+    LadderLds lad{thin_disk_ladder_column()};
+    LadderState lst;
+    const bool ladder_class = (type == T_RR) || (type == T_RC);
+    const bool may_cross = q_pos && !u_bad;
+#ifndef S5_KO_RAD
+    if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
 #ifndef S5_PAIR_MEMBERS
 #define S5_PAIR_MEMBERS 2                    // 1: timing experiments only (the mirror image is not traced)
@@ -488,112 +461,22 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                 double P;
                 if (!may_cross) P = NAN;
                 else {
-#if S5_FAST
-                    // mK distributed over the sum (two products formed once per ray, not three factors kept per crossing)
-                    if (beta_m > 0.0) P = (2. * (double)order + 1.) * mKK + mKi;
-                    else if (beta_m < 0.0) P = (2. * (double)order + 1.) * mKK - mKi;
-                    else P = (2. * (double)order + 1.) * mKK;
-#else
                     if (beta_m > 0.0) P = mK * ((2. * (double)order + 1.) * K + icn_u);
                     else if (beta_m < 0.0) P = mK * ((2. * (double)order + 1.) * K - icn_u);
                     else P = mK * ((2. * (double)order + 1.) * K);
-#endif
-#if S5_RPC_ADD
-                    // beyond 2 Rpc for sure: RR (F0 < K) from w = 2 K(mR), RC (F0 < 2 K) from w = 4 K(mR); K(mR) = pi / (2 c_N), so in
-                    // terms of the angle w c_N the descent starts from: pi and 2 pi
-                    if (by_add) { if (!((((type == T_RC) ? sqAB : 0.5 * sqAB) * P) * lst.c < ((type == T_RC) ? 2. * S5_PI : S5_PI))) P = NAN; }
-                    else
-#endif
                     if (P > 2. * Rpc) P = NAN;
                 }
                 if (isnan(P)) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; }
                 else {
                     // r(P): RR through sn, RC through cn, one ladder for both
                     double r;
-                    const bool in_range = by_add || !((P <= 0.0) || (P >= 2. * Rpc));
-                    const bool at_peri = !by_add && (P == Rpc);
-                    const bool rr = (type == T_RR);
-                    bool rcx = (type == T_RC) && (by_add || !(P > Rpc));
+                    const bool in_range = !((P <= 0.0) || (P >= 2. * Rpc));
+                    const bool at_peri = (P == Rpc);
+                    const bool rr = (type == T_RR), rcx = (type == T_RC) && !(P > Rpc);
                     const bool use_ladder = in_range && !at_peri && (rr || rcx);
-                    double dP = Rpc - P;
                     double su = 0.0;
                     if (rr) su = 0.5 * fabs(P - Rpc) * sqAB;
                     else if (rcx) su = sqAB * (Rpc - P);
-#if S5_RPC_ADD
-                    // sn^2 = Pn / Q (RR), cn = X / Y (RC): by_add lanes from the addition theorem, the others from sn, cn
-                    double Pn = 0.0, Q = 1.0, X = 1.0, Y = 1.0;
-                    bool beyond = false;                         // by_add lanes: P turns out to be >= 2 Rpc
-                    if (!ADD) {
-                        if (wave_any(use_ladder)) {
-                            if (use_ladder) {
-                                double sn, cn, dn;
-                                ladder_descend(lad, lst, su, sn, cn, dn);
-                                Pn = sn * sn; X = cn;
-                            }
-                        }
-                    } else {
-                        if (wave_any(use_ladder && !by_add)) {
-                            if (use_ladder && !by_add) {
-                                const SnCn o = ladder_descend_cold(lad.base, lst, su);
-                                Pn = o.sn * o.sn; X = o.cn;
-                            }
-                        }
-#ifdef S5_KO_RAD                 // diagnostic knock-out: timing-breakdown builds only, never shipped
-                        if (by_add) { Pn = 0.05 + 1e-4 * P; Q = 1.0; X = 0.9 - 1e-3 * P; Y = 1.0; dP = 1.0; }
-                        if (false) {
-#else
-                        if (wave_any(by_add)) {
-#endif
-                            if (by_add) {
-                                double s0, c0, C, ga, N, D;
-                                const double wc = (((type == T_RC) ? sqAB : 0.5 * sqAB) * P) * lst.c;     // RR: 0 < w c < pi, RC: < 2 pi
-                                msincos(wc, s0, c0);
-                                ladder_descend_fractions(lad, lst, s0, c0, C, ga, N, D);
-                                // numerators of sn(w) and cn(w) over rho (the signs as ladder_descend assigns them)
-                                const double S = (s0 >= 0.0) ? fabs(ga) : -fabs(ga);
-                                const double Cc = ((ga >= 0.0) == (s0 >= 0.0)) ? C : -C;
-                                const double rho2 = C * C + ga * ga;
-                                if (rr) {
-                                    // sn(w - F0) = rho (S cn dn(F0) D - zR Cc N) / (D (rho^2 - m zR^2 S^2))
-                                    const double num = S * add_cd * D - zR * Cc * N;
-                                    const double den = D * (rho2 - add_mz2 * (S * S));
-                                    Pn = rho2 * (num * num);
-                                    Q = den * den;
-                                    dP = -(num * D);                          // sign of F0 - w (|w - F0| < K in range)
-                                } else {
-                                    // cn(F0 - w) = rho (zR Cc D + sn dn(F0) S N) / (D (rho^2 - m sn^2(F0) S^2)).  F0 - w lies in
-                                    // (-4K, 2K): for w < 2K the sign of sn(F0 - w), i.e. of (sn(F0) Cc N - zR S dn(F0) D) D, says
-                                    // whether P <= Rpc (for w >= 2K > F0 it is not); past Rpc the ray is still inside 2 Rpc
-                                    // while cn(F0 - w) > cn(F0) = zR (|F0 - w| < 4K - F0 here)
-                                    const double rho = sqrt_pos(rho2);
-                                    X = rho * (zR * Cc * D + add_cd * S * N);
-                                    Y = D * (rho2 - add_mz2 * (S * S));
-                                    const double sgn = (add_s * Cc * N - zR * S * add_d * D) * D;
-                                    dP = sgn;
-                                    if (!(sgn >= 0.0) || !(wc < S5_PI)) {
-                                        rcx = false;
-                                        beyond = !((X - zR * Y) * Y > 0.0);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (!in_range) r = NAN;
-                    else if (at_peri) r = rp;
-                    else if (rr) {
-                        // ref :320 divided through by r1 - r4: (r2 - r4)/(r1 - r4) is zR^2 = sn^2(F0) (the fourth root is not kept)
-                        S5_FPC_RADIUS
-                        const double z2q = (zR * zR) * Q;
-                        const double dnm = z2q - Pn;
-                        r = mdiv(ra * z2q - rb * Pn, dnm);
-                        if (by_add && !(dnm > 0.0)) beyond = true;             // sn^2(w - F0) >= sn^2(F0): w >= 2 F0
-                    } else if (rcx) {
-                        S5_FPC_RADIUS
-                        const double Aq = A, Bq = Bkeep;
-                        r = mdiv((rb * Aq - ra * Bq) * Y - (rb * Aq + ra * Bq) * X, (Aq - Bq) * Y - (Aq + Bq) * X);
-                    } else r = NAN;
-                    if (beyond) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; r = NAN; }
-#else
                     double sn = 0.0, cn = 1.0, dn = 1.0;
                     if (wave_any(use_ladder)) {
 #ifdef S5_KO_RAD
@@ -614,10 +497,9 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
                         const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
                         r = mdiv(rb * Aq - ra * Bq - (rb * Aq + ra * Bq) * cn, (Aq - Bq) - (Aq + Bq) * cn);
                     } else r = NAN;
-#endif
                     if (r >= p.rms) {
                         cls_m = (order == 0) ? PX_HIT0 : PX_HIT1;
-                        r_m = r; P_m = P; dP_m = dP;
+                        r_m = r; P_m = P; dP_m = Rpc - P;
                         done = true;
                     }
                 }
@@ -656,6 +538,341 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     }
 #endif
 }
+
+
+#if S5_RPC_ADD
+// ---------------------------------------------------------------------------------------------------------------------------
+// FAST VARIANT.  Same sequence, with two differences in how r(P) is reached (everything else is the arithmetic of the
+// routine above, #if S5_FAST branches taken):
+//
+//  * THE RADIAL INTEGRAL Rpc IS NOT EVALUATED.  r(P) takes sn or cn of c (Rpc - P) = F0 - w, where w = c P and F0 = c Rpc is
+//    an inverse Jacobi function of an ALGEBRAIC argument: sn(F0) = zR (RR), cn(F0) = zR (RC) -- the very argument the R_F
+//    of the radial integral would be called with.  So sn, cn, dn of w come from the ladder, those of F0 from zR, and the
+//    addition theorem gives sn(w - F0) or cn(F0 - w): no inverse function, one R_F (of three) less per ray pair.  The
+//    comparisons of P with Rpc and 2 Rpc (ref :303-309, :336, :881) become sign tests on the same quantities; they need
+//    w < 2 K(mR) (RR) or 4 K(mR) (RC) to be unambiguous, and K(mR) = pi / (2 c_N) is the last mean of the ladder that is
+//    climbed anyway -- as a bound on the angle w c_N the descent starts from.  The descent stays in the fraction form
+//    (ladder_descend_fractions): sn^2 = Pn / Q and cn = X / Y enter the r(P) formulas without having been divided.
+//  * Rays the addition theorem does not serve take the reference's sequence OUT OF LINE (radial_integral_cold,
+//    crossing_cold: generic inverse functions with their special cases, the complete descent): geodesics with complex
+//    roots only (CC: r(P) is NaN, but the class of the pixel depends on P > 2 Rpc), the special cases of the inverse
+//    functions (modulus within 1e-8 of 0 or 1, ...), and ILL-CONDITIONED sums -- the denominator 1 - m sn^2(w) sn^2(F0)
+//    of the theorem cancels when m, sn(w) and sn(F0) are all close to 1 (rays that wind around the photon orbit of a fast
+//    hole: one in ~1e4; seen as 2e-8 in r on a second-order image at a = 0.9999 before this rule), so below 1e-3 of its
+//    terms the ray is handed to the direct evaluation.
+// A ray's result still depends on its own arguments only (which path a lane takes is decided by its own values).
+// ---------------------------------------------------------------------------------------------------------------------------
+enum : int { CROSS_FORMULA = 0, CROSS_BEYOND = 1, CROSS_NONE = 2 };
+
+template <bool WANT_STATE, int KNOWN, bool PAIR>
+S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+                             const double l, const double q, const double alpha, const double beta, int err, const int type_in,
+                             const double ra, const double rb, const double rc_, const double rd_)
+{
+    S5_FPC_FINISH
+    using namespace s5abi;
+    constexpr double S5_PI = 3.14159265358979323846;
+    const int type = (KNOWN >= 0) ? KNOWN : type_in;
+    const double a2 = a * a, l2 = l * l;
+    // ---------------- per-class set-up of the radial motion (ref :1051-1100) ----------------
+    // modulus mR and argument zR of the inverse function in Rpc = pre * inverse-Jacobi(zR | mR); sqAB scales P in r(P)
+    double mR, zR, sqAB;              // sqAB: CC keeps the prefactor of Rpc here (it has no r(P))
+    double Aq = 0.0, Bq = 0.0;       // RC: |r1 - (u + i v)|, |r2 - (u + i v)|, kept for r(P);  CC: Aq holds the pericentre rp
+                                     // (RR and RC: rp = r1; one register pair for the class-specific constant)
+    if (type == T_RR || type == T_RR_DBL) {
+        // 1/sqAB also gives the denominator of the modulus: 1/((ra-rc)(rb-rd)) = (1/sqAB)^2
+        double pre;
+        sqrt_rsqrt_pos((ra - rc_) * (rb - rd_), sqAB, pre);
+        mR = ((rb - rc_) * (ra - rd_)) * (pre * pre);
+        zR = msqrt(mdiv(rb - rd_, ra - rd_));
+    } else if (type == T_RC) {
+        Aq = msqrt(sq(ra - rc_) + sq(rd_));
+        Bq = msqrt(sq(rb - rc_) + sq(rd_));
+        double pre;
+        sqrt_rsqrt_pos(Aq * Bq, sqAB, pre);
+        mR = (sq(Aq + Bq) - sq(ra - rb)) * (0.25 * (pre * pre));       // 1/(A B) = (1/sqrt(A B))^2
+        zR = mdiv(Aq - Bq, Aq + Bq);
+    } else {
+        const double b1 = ra, a1 = rb, b2 = rc_, a2c = rd_;
+        const double Ac = msqrt(sq(b1 - b2) + sq(a1 + a2c));
+        const double Bc = msqrt(sq(b1 - b2) + sq(a1 - a2c));
+        const double g1 = msqrt(mdiv(4. * sq(a1) - sq(Ac - Bc), sq(Ac + Bc) - 4. * sq(a1)));
+        mR = mdiv(4. * Ac * Bc, sq(Ac + Bc));
+        sqAB = mdiv(2., Ac + Bc);    // the prefactor of Rpc
+        zR = mdiv(-1., g1);
+        Aq = b1 - a1 * g1;           // rp
+    }
+#define S5_THIN_RP ((type == T_CC) ? Aq : ra)
+
+    // ---------------- roots of the polar potential (ref :1110-1184, device branch) ----------------
+    const double qla = q + l2 - a2;
+    const double XT = msqrt(sq(qla) + 4. * q * a2) + qla;
+    const double m2m = XT * p.inv_2a2;
+    const double m2p = mdiv(q + q, XT);
+    double s_m2p, rs_m2p;                                   // sqrt(m2p) and its reciprocal, used three times
+    sqrt_rsqrt_pos(m2p, s_m2p, rs_m2p);
+    double mmT = 0.0, mK = 0.0;
+    if (err == GD_OK) {
+        if ((m2p <= 0.0) || (m2p >= 1.0)) err = GD_E_MUPLUS;
+        else if (q > 0.0) {
+            // mK = 1/sqrt(a^2 (m2p + m2m)) first; the modulus m2p/(m2p + m2m) is then m2p a^2 mK^2
+            const double rk = rsqrt_pos(a2 * (m2p + m2m));
+            mmT = (m2p * a2) * (rk * rk);
+            if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
+            else if (fabs(p.cos_i) > s_m2p) err = GD_E_MU0;
+            else mK = rk;
+        } else if (q < 0.0) {
+            mmT = mdiv(m2p + m2m, m2p);
+            if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
+            else if ((fabs(p.cos_i) > s_m2p) || (fabs(p.cos_i) < msqrt(-m2m))) err = GD_E_MU0;
+            else mK = mdiv(1., msqrt(a2 * m2p));
+        } else {
+            err = GD_E_Q_RANGE;
+        }
+    }
+    out.err = err;
+    const bool ok = (err == GD_OK);
+    const double u_i = p.cos_i * rs_m2p;
+
+    // ---------------- what the crossing search needs to know about the ray ----------------
+    const bool plain0 = (type == T_RC) ? icn_plain(zR, mR) : isn_plain(mR);      // (CC rays never take the addition path)
+    const bool plain2 = icn_plain(u_i, mmT);
+    const bool q_pos = (q > 0.0);
+    double uu = u_i;
+    const bool u_bad = (uu < -1.0 - 1e-4) || (uu > +1.0 + 1e-4);
+    if (uu < -1.0) uu = -1.0;
+    if (uu > +1.0) uu = +1.0;
+    const bool ladder_class = (type == T_RR) || (type == T_RC);
+    const bool may_cross = q_pos && !u_bad;
+    // r(P) needs sn (RR) or cn (RC) of modulus mR: the rungs of its Landen ladder are climbed ONCE per ray -- they serve
+    // every crossing order and both rays of a pair -- and kept in LDS; lanes that cannot use them climb a short dummy
+    LadderLds lad{thin_disk_ladder_column()};
+    LadderState lst{};
+#ifndef S5_KO_RAD
+    if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
+#endif
+    const bool by_add = ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
+
+    // ---------------- the polar integrals: cn^-1(u_i | mmT) by R_F, K(mmT) from the table ----------------
+    double icn_i;
+    {
+        // x = u_i^2 was formed as a square, its root is |u_i| (first pass of the duplication with one square root);
+        // plain lanes have x, y > 0 by construction (u^2 < 1, modulus in [0,1)); the others are redone out of line
+        const double z2 = u_i * u_i;
+#ifdef S5_KO_RF                  // diagnostic knock-outs: timing-breakdown builds only, never shipped
+        icn_i = sqrt_pos(1. - z2) * (1.5 + 0.1 * z2 + 0.01 * mmT);
+#elif defined(S5_NO_RF_ROOT_X)
+        icn_i = sqrt_pos(1. - z2) * carlson_rf_positive(z2, 1.0 - mmT * (1. - z2), 1.0);
+#else
+        icn_i = sqrt_pos(1. - z2) * carlson_rf_root_x(fabs(u_i), z2, 1.0 - mmT * (1. - z2));
+#endif
+    }
+    double K;
+    {
+        // K(mm): from the table (kernels.hpp KT_*: 128 polynomials of degree 7 on [0, 0.9], 2e-16) where it reaches,
+        // by the arithmetic-geometric mean elsewhere (the lanes' wave with them)
+        const bool tab = (p.ktab != nullptr) && (mmT >= 0.0) && (mmT < KT_MMAX);
+        K = 0.0;
+        if (tab) {
+            const double u = mmT * ((double)KT_N / KT_MMAX);
+            int i = (int)u;
+            i = i < KT_N - 1 ? i : KT_N - 1;
+            const double tau = 2.0 * (u - (double)i) - 1.0;
+            const double* c = p.ktab + (size_t)i * (KT_DEG + 1);
+            double acc = c[KT_DEG];
+#pragma unroll
+            for (int k = KT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
+            K = acc;
+        }
+#ifndef S5_KO_KAGM
+        if (wave_any(!tab)) {
+            if (!tab) K = ell_K(mmT);
+        }
+#endif
+    }
+    if (wave_any(ok && !plain2)) {
+        if (ok && !plain2) icn_i = inv_cn_cold(u_i, mmT);
+    }
+    if (WANT_STATE) {
+        out.a = a; out.l = l; out.q = q; out.beta = beta; out.rp = S5_THIN_RP; out.dP = NAN;
+        out.Tpp = 2. * (mK * K); out.Tip = mK * icn_i;
+        if (PAIR) {
+            out2.a = a; out2.l = l; out2.q = q; out2.beta = -beta; out2.rp = out.rp; out2.dP = NAN;
+            out2.Tpp = out.Tpp; out2.Tip = out.Tip;
+        }
+    }
+    if (PAIR) out2.err = err;
+    if (!ok) return;
+    out.gtype = type;
+    out.cls = PX_MISS;
+    if (PAIR) { out2.gtype = type; out2.cls = PX_MISS; }
+
+    // ---------------- equatorial crossings and r(P) (ref :846-885, :291-357) ----------------
+    double icn_u = icn_i;
+    if (wave_any(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
+        if (uu != u_i && !u_bad && q_pos) icn_u = inv_cn_cold(uu, mmT);
+    }
+    // mK distributed over the sum in P (two products formed once per ray, not three factors kept per crossing)
+    const double mKK = mK * K, mKi = mK * icn_u;
+    // constants of the addition theorem: sn, cn, dn of F0 as products.  Few, and the cheap ones are re-formed where they
+    // are used: every double kept across the crossing loop is two of the kernel's 128 registers.
+    double add_s = 0.0, add_d = 0.0;             // RC: sn(F0), dn(F0);  RR: add_s = cn(F0) dn(F0)
+    if (wave_any(by_add)) {
+        if (type == T_RC) {
+            const double s2 = 1. - zR * zR;                     // sn^2(F0)
+            add_s = sqrt_pos(s2); add_d = sqrt_pos(1. - mR * s2);
+        } else {
+            const double z2 = zR * zR;                          // sn^2(F0)
+            add_s = sqrt_pos((1. - z2) * (1. - mR * z2));       // cn(F0) dn(F0)
+        }
+    }
+#ifdef S5_DEBUG_TOP                 // diagnostic: the ladder depth of the ray in the gtype plane
+    out.gtype = (ladder_class && may_cross) ? lst.top : -2;
+    if (PAIR) out2.gtype = out.gtype;
+#endif
+#ifndef S5_PAIR_MEMBERS
+#define S5_PAIR_MEMBERS 2                    // 1: timing experiments only (the mirror image is not traced)
+#endif
+    constexpr int MEMBERS = PAIR ? S5_PAIR_MEMBERS : 1;
+    // a ray that may cross but is not served by the addition theorem goes the reference's way, after the loops
+    bool cold[2] = {may_cross && !by_add, may_cross && !by_add};
+    // two inlined passes rather than a run-time loop: as a loop the compiler predicates the pass on per-lane state and the
+    // lanes used fall from 97 % to 91 % (measured: +6.5 % VALU instructions, +4.5 % time)
+#ifdef S5_PAIR_ROLLED
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+    for (int member = 0; member < MEMBERS; ++member) {
+        const double beta_m = (member == 0) ? beta : -beta;
+        int cls_m = PX_MISS;
+        double r_m = NAN, P_m = NAN, dP_m = NAN;
+        bool done = cold[member];
+#pragma unroll 1
+        for (int order = 0; order < p.max_order; ++order) {
+            if (!wave_any(!done)) break;
+            if (!done) {
+                double P;
+                if (!may_cross) P = NAN;
+                else {
+                    if (beta_m > 0.0) P = (2. * (double)order + 1.) * mKK + mKi;
+                    else if (beta_m < 0.0) P = (2. * (double)order + 1.) * mKK - mKi;
+                    else P = (2. * (double)order + 1.) * mKK;
+                }
+                const double wc = (((type == T_RC) ? sqAB : 0.5 * sqAB) * P) * lst.c;    // the angle the descent starts from
+                // beyond 2 Rpc for sure: RR (F0 < K) from w = 2 K(mR), RC (F0 < 2 K) from w = 4 K(mR), i.e. w c_N from pi, 2 pi
+                if (may_cross && !(wc < ((type == T_RC) ? 2. * S5_PI : S5_PI))) P = NAN;
+                if (isnan(P)) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; }
+                else {
+                    // sn^2(w - F0) = Pn / Q (RR), cn(F0 - w) = X / Y (RC)
+                    double Pn = 0.0, Q = 1.0, X = 1.0, Y = 1.0, dP = NAN, r = NAN;
+                    int code = CROSS_FORMULA;
+#ifdef S5_KO_RAD                 // diagnostic knock-out: timing-breakdown builds only, never shipped
+                    Pn = 0.05 + 1e-4 * P; Q = 1.0; X = 0.9 - 1e-3 * P; Y = 1.0; dP = 1.0;
+#else
+                    {
+                        double s0, c0, C, ga, N, D;
+                        msincos(wc, s0, c0);                               // RR: 0 < w c < pi, RC: < 2 pi
+                        ladder_descend_fractions(lad, lst, s0, c0, C, ga, N, D);
+                        // numerators of sn(w) and cn(w) over rho (the signs as ladder_descend assigns them)
+                        const double S = (s0 >= 0.0) ? fabs(ga) : -fabs(ga);
+                        const double Cc = ((ga >= 0.0) == (s0 >= 0.0)) ? C : -C;
+                        const double rho2 = C * C + ga * ga;
+                        // 1 - m sn^2(w) sn^2(F0) over rho^2: the theorem's denominator; where it cancels, the direct way
+                        const double mz2 = mR * ((type == T_RC) ? 1. - zR * zR : zR * zR);
+                        const double den0 = rho2 - mz2 * (S * S);
+                        if (!(den0 > 1e-3 * rho2)) { cold[member] = true; done = true; code = CROSS_NONE; }
+                        if (type == T_RC) {
+                            // cn(F0 - w) = rho (zR Cc D + sn dn(F0) S N) / (D den0).  F0 - w lies in (-4K, 2K): for
+                            // w < 2K the sign of sn(F0 - w), i.e. of (sn(F0) Cc N - zR S dn(F0) D) D, says whether
+                            // P <= Rpc (for w >= 2K > F0 it is not); past Rpc the ray is still inside 2 Rpc while
+                            // cn(F0 - w) > cn(F0) = zR (|F0 - w| < 4K - F0 here)
+                            const double rho = sqrt_pos(rho2);
+                            X = rho * (zR * Cc * D + (add_s * add_d) * S * N);
+                            Y = D * den0;
+                            dP = (add_s * Cc * N - zR * S * add_d * D) * D;
+                            if (code == CROSS_FORMULA && (!(dP >= 0.0) || !(wc < S5_PI)))
+                                code = ((X - zR * Y) * Y > 0.0) ? CROSS_NONE : CROSS_BEYOND;
+                        } else {
+                            // sn(w - F0) = rho (S cn dn(F0) D - zR Cc N) / (D den0); its sign is that of P - Rpc
+                            const double num = S * add_s * D - zR * Cc * N;
+                            const double den = D * den0;
+                            Pn = rho2 * (num * num);
+                            Q = den * den;
+                            dP = -(num * D);
+                        }
+                    }
+#endif
+                    if (code == CROSS_FORMULA) {
+                        if (type == T_RR) {
+                            // ref :320 divided through by r1 - r4: (r2 - r4)/(r1 - r4) is zR^2 = sn^2(F0)
+                            S5_FPC_RADIUS
+                            const double z2q = (zR * zR) * Q;
+                            const double dnm = z2q - Pn;
+                            r = mdiv(ra * z2q - rb * Pn, dnm);
+                            if (!(dnm > 0.0)) { code = CROSS_BEYOND; r = NAN; }       // sn^2(w - F0) >= sn^2(F0): w >= 2 F0
+                        } else if (type == T_RC) {
+                            S5_FPC_RADIUS
+                            r = mdiv((rb * Aq - ra * Bq) * Y - (rb * Aq + ra * Bq) * X, (Aq - Bq) * Y - (Aq + Bq) * X);
+                        }
+                    }
+                    if (code == CROSS_BEYOND) { cls_m = (order == 0) ? PX_NAN0 : PX_NAN1; done = true; }
+                    if (r >= p.rms) {
+                        cls_m = (order == 0) ? PX_HIT0 : PX_HIT1;
+                        r_m = r; P_m = P; dP_m = dP;
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; if (WANT_STATE) out.dP = dP_m; }
+        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; if (WANT_STATE) out2.dP = dP_m; }
+    }
+    // ---------------- g-factor and flux of the accepted crossings ----------------
+    bool cf0 = false, cf1 = false;               // the flux of the ray is owed by the closed form (below)
+#pragma unroll
+    for (int member = 0; member < MEMBERS; ++member) {
+        ThinRay& o = (member == 0) ? out : out2;
+        if (o.cls == PX_HIT0 || o.cls == PX_HIT1) {
+            bool cf = false;
+#if !defined(S5_KO_G) && !defined(S5_KO_FLUX)
+            double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
+            sqrt_rsqrt_pos(o.r, x, rx);                   // r >= rms > 0
+            o.g = gfactor_kepler_x(o.r, x, a_in, l);
+            o.flux = disk_flux_table(p.disk, o.r, x, rx, cf);
+#else
+#ifdef S5_KO_G
+            o.g = 0.5 + 1e-3 * o.r;
+#else
+            o.g = gfactor_kepler(o.r, a_in, l);
+#endif
+#ifdef S5_KO_FLUX
+            o.flux = 1e20 * o.r;
+#else
+            o.flux = disk_flux(p.disk, o.r);
+#endif
+#endif
+            if (member == 0) cf0 = cf; else cf1 = cf;
+        }
+    }
+#if !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
+    // the closed form of the flux for the few rays the table does not serve (s5_disk.hpp), outside the loop above
+    if (wave_any(cf0 || cf1)) {
+        // constants from the disk model's device block, not from the kernel arguments: referenced here they would sit in
+        // ~30 SGPRs of every wave from the first instruction (the launchers always attach the block: capi_core.hip)
+        const double* cold_block = p.disk.cold;
+        if (cf0) { double x, rx; sqrt_rsqrt_pos(out.r, x, rx); out.flux = cold_block ? disk_flux_closed_form_mem(cold_block, out.r, x) : NAN; }
+        if (PAIR && cf1) { double x, rx; sqrt_rsqrt_pos(out2.r, x, rx); out2.flux = cold_block ? disk_flux_closed_form_mem(cold_block, out2.r, x) : NAN; }
+    }
+#endif
+    // ---------------- the rays left to the direct evaluation ----------------
+    // marked for the caller (trace_thin_disk_impl), which runs the direct routine for them from the pixel's coordinates:
+    // nothing of this routine's state has to stay alive for it
+    if (cold[0]) out.cls = PX_COLD_MARK;
+    if (MEMBERS > 1 && cold[1]) out2.cls = PX_COLD_MARK;
+}
+#undef S5_THIN_RP
+#endif   // S5_RPC_ADD
 
 // Image-plane coordinates of a pixel (ref disk-image.c:57-58).  The fast variant multiplies by the reciprocals of the
 // image size instead of dividing, and forms beta from the exact odd integer 2 iy + 1 - ny: rows iy and ny - 1 - iy then get
