@@ -385,6 +385,11 @@ typedef struct sim5gpu_image_desc {
                                  * is written at its image row instead of packed -- a rank that assembles the image (the root of
                                  * a gather) traces its own stripes and its band straight into the final image.  The aux planes,
                                  * if given, are whole-image planes too. */
+#define SIM5GPU_IMG_DIRECT  8   /* fast variant only: every ray takes the reference's own sequence (radial integral Rpc by R_F, the
+                                   comparisons of P with Rpc and 2 Rpc, ref src/sim5kerr-geod.c:303-352, :881) with the fast arithmetic,
+                                   instead of the addition-theorem form of r(P).  The default routine hands a few rays per million to
+                                   that sequence by itself (sim5_amd/csrc/s5_thindisk.hpp); the flag is how a caller -- or a test --
+                                   runs a whole image through it.  Same classes, values within rounding; ~15 % slower.              */
 
 /* optional full-precision outputs (any pointer may be NULL) */
 typedef struct sim5gpu_image_aux {

@@ -850,19 +850,20 @@ def blackbody_photons_total(T, hardf):
 
 
 # ---- whole-job kernels --------------------------------------------------------------------------
-IMG_DEFAULT, IMG_STRICT, IMG_MIRROR, IMG_INPLACE = 0, 1, 2, 4
+IMG_DEFAULT, IMG_STRICT, IMG_MIRROR, IMG_INPLACE, IMG_DIRECT = 0, 1, 2, 4, 8
 
 
 def image_desc(nx, ny, a, incl_rad, y0=0, y1=None, rmax=0.0, rms=0.0, bh_mass=10.0, mdot=0.1,
                alpha_visc=0.1, max_order=2, pol_degree=0.0, strict=False, stripe_rows=0, stripe_step=0,
-               disk_spin=-1.0, mirror=False, inplace=False):
+               disk_spin=-1.0, mirror=False, inplace=False, direct=False):
     """Job description; defaults are those of the reference example (disk-image.c:41-45).
     strict=True selects the reference-parameter arithmetic variant (SIM5GPU_IMG_STRICT); mirror=True adds the mirror
     images ny-1-y of the named rows, which must lie in the upper half (SIM5GPU_IMG_MIRROR); inplace=True: the outputs are
-    whole-image planes and every traced row is written at its image row (SIM5GPU_IMG_INPLACE)."""
+    whole-image planes and every traced row is written at its image row (SIM5GPU_IMG_INPLACE); direct=True: every ray through
+    the reference's own sequence with the fast arithmetic (SIM5GPU_IMG_DIRECT)."""
     return ImageDesc(nx=nx, ny=ny, y0=y0, y1=ny if y1 is None else y1, a=a, incl=incl_rad,
                      rmax=rmax, rms=rms, bh_mass=bh_mass, mdot=mdot, alpha_visc=alpha_visc,
-                     max_order=max_order, flags=(IMG_STRICT if strict else IMG_DEFAULT) | (IMG_MIRROR if mirror else 0) | (IMG_INPLACE if inplace else 0),
+                     max_order=max_order, flags=(IMG_STRICT if strict else IMG_DEFAULT) | (IMG_MIRROR if mirror else 0) | (IMG_INPLACE if inplace else 0) | (IMG_DIRECT if direct else 0),
                      pol_degree=pol_degree,
                      stripe_rows=stripe_rows, stripe_step=stripe_step, disk_spin=disk_spin)
 

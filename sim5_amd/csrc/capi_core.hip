@@ -285,6 +285,7 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_
     p.nrows = sim5gpu_image_rows(desc);
     p.mirror = (desc->flags & SIM5GPU_IMG_MIRROR) ? 1 : 0;
     p.inplace = (desc->flags & SIM5GPU_IMG_INPLACE) ? 1 : 0;
+    p.direct = (desc->flags & SIM5GPU_IMG_DIRECT) ? 1 : 0;
     p.nrows_top = image_rows_top(desc);
     p.inv_nx = 1.0 / (double)desc->nx; p.inv_ny = 1.0 / (double)desc->ny;
     p.ny_over_nx = (double)desc->ny / (double)desc->nx;

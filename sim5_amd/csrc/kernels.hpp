@@ -49,6 +49,7 @@ struct ImageParams {
     int nrows_top;                     // rows named by y0, y1 and the striping (== nrows without mirror)
     int max_order;
     int inplace;                       // SIM5GPU_IMG_INPLACE: the outputs are whole-image planes, a traced row is written at its image row
+    int direct;                        // SIM5GPU_IMG_DIRECT: every ray through the direct routine (fast variant)
     double a, incl, sin_i, cos_i;      // sin/cos from the host libm
     double rmax, rms;
     double inv_nx, inv_ny, ny_over_nx; // 1/nx, 1/ny, ny/nx (host doubles; used by the fast variant)

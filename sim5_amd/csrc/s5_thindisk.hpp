@@ -241,7 +241,6 @@ S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, T
         const double Aq = msqrt(sq(ra - rc_) + sq(rd_));
         const double Bq = msqrt(sq(rb - rc_) + sq(rd_));
 #if S5_FAST
-        double pre;
         sqrt_rsqrt_pos(Aq * Bq, sqAB, pre);
         mR = (sq(Aq + Bq) - sq(ra - rb)) * (0.25 * (pre * pre));       // 1/(A B) = (1/sqrt(A B))^2
 #else
@@ -524,6 +523,7 @@ S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, T
 #endif
 #endif
         }
+        (void)cf0; (void)cf1;                   // (used by the fast variant's closed-form pass below only)
         if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; cf0 = cf_m; if (WANT_STATE) out.dP = dP_m; }
         else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; cf1 = cf_m; if (WANT_STATE) out2.dP = dP_m; }
     }
@@ -651,7 +651,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #ifndef S5_KO_RAD
     if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
-    const bool by_add = ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
+    const bool by_add = !p.direct && ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
 
     // ---------------- the polar integrals: cn^-1(u_i | mmT) by R_F, K(mmT) from the table ----------------
     double icn_i;

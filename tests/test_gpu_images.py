@@ -462,3 +462,35 @@ def test_in_place_rows_and_share_placement(capi):
         capi.synchronize()
         got = full.to_numpy(np.float32, (2, ny, nx))
         assert np.array_equal(got, want), (nx, ny, world, dealt, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("a,inc,n,order", [(0.998, 70.0, 512, 2), (0.9, 70.0, 384, 2), (0.0, 60.0, 64, 1), (0.9999, 83.0, 200, 2), (0.5, 20.0, 300, 2)])
+def test_direct_flag_runs_the_direct_routine_everywhere(capi, a, inc, n, order):
+    """SIM5GPU_IMG_DIRECT sends every ray of the fast variant through the routine that the default one hands a few rays
+    per million to (radial integral by R_F, the reference's comparisons with Rpc): that path is exercised on whole images
+    here -- same classes as the default routine and as the strict variant, r and g within 1e-9, flux within 1e-6; the
+    polarized kernel's Stokes planes likewise."""
+    mk = lambda **kw: capi.disk_image(capi.image_desc(n, n, a, math.radians(inc), max_order=order, **kw), full=True)
+    f, d, s = mk(), mk(direct=True), mk(strict=True)
+    assert np.array_equal(f["cls"], d["cls"]) and np.array_equal(f["gtype"], d["gtype"])
+    assert np.array_equal(s["cls"], d["cls"])
+    hit = np.isfinite(f["r"])
+    assert hit.sum() > 100
+    # a handful of second-order rays near the photon orbit of a fast hole amplify a last-bit difference by ~1e8 (DESIGN.md 5)
+    er = np.abs(d["r"][hit] / f["r"][hit] - 1)
+    assert np.sort(er)[-max(1, hit.sum() // 2000):].max() < 1e-6 and np.median(er) < 1e-13, (er.max(), np.median(er))
+    assert (er > 1e-9).sum() <= max(1, hit.sum() // 2000), int((er > 1e-9).sum())
+    ok = hit & (np.abs(d["r"] / np.where(hit, f["r"], 1.0) - 1) < 1e-9)
+    assert np.abs(d["g"][ok] - f["g"][ok]).max() < 1e-9
+    fl = np.maximum(np.abs(f["flux"][ok]), 1e-9 * np.abs(f["flux"]).max())
+    assert (np.abs(d["flux"][ok] - f["flux"][ok]) / fl).max() < 1e-6
+    # the polarized kernel takes the same routine with the ray's state
+    st = [capi.DeviceBuffer(3 * n * n * 8) for _ in range(2)]
+    for k, direct in enumerate((False, True)):
+        capi.disk_image_polarized_device(capi.image_desc(n, n, a, math.radians(inc), max_order=order, pol_degree=0.1, direct=direct), st[k].ptr, None)
+    capi.synchronize()
+    S0, S1 = st[0].to_numpy(np.float64, (3, n, n)), st[1].to_numpy(np.float64, (3, n, n))
+    lit = ok & (S0[0] > 1e-9 * S0[0].max())
+    assert lit.sum() > 100
+    for k in range(3):
+        assert (np.abs(S1[k][lit] - S0[k][lit]) / S0[0][lit]).max() < 1e-6, k

@@ -1,0 +1,26 @@
+"""One case of tests/tools/fuzz_images.py in detail (run on the GPU box): the pixel where fast and strict differ most in r,
+with the CPU oracle's value beside them.   usage: python tests/tools/fuzz_case.py <seed> <case>"""
+import sys, math, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sim5_amd.capi as capi
+import oraclelib as ol
+seed, want = int(sys.argv[1]), int(sys.argv[2])
+rng = np.random.default_rng(seed)
+for case in range(want + 1):
+    a = float(rng.choice([0.0, 1e-5, 0.3, 0.7, 0.9, 0.998, 0.9999, rng.uniform(0, 0.999)]))
+    inc = float(rng.uniform(3.0, 87.0))
+    nx, ny = int(rng.integers(17, 300)), int(rng.integers(2, 300))
+    order = int(rng.choice([1, 2]))
+    rmax = float(rng.choice([0.0, rng.uniform(3.0, 60.0)]))
+print("case %d: a=%r inc=%r %dx%d order=%d rmax=%r" % (want, a, inc, nx, ny, order, rmax))
+mk = lambda strict: capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), max_order=order, rmax=rmax, strict=strict), full=True)
+f, s = mk(False), mk(True)
+c = ol.cpu_disk_image("port", nx, ny, a, inc, nthreads=8, full=True) if (order == 2 and rmax == 0.0) else None
+same = (f["cls"] == s["cls"]) & np.isfinite(s["r"])
+er = np.where(same, np.abs(f["r"] / s["r"] - 1), 0)
+for (iy, ix) in np.argwhere(er > 1e-10)[:12]:
+    print("pixel (%d,%d) cls %d gtype %d  r fast %.15g strict %.15g %s  rel %.2e | g fast %.12g strict %.12g" % (
+        iy, ix, f["cls"][iy, ix], f["gtype"][iy, ix], f["r"][iy, ix], s["r"][iy, ix],
+        ("oracle %.15g (strict-oracle %.1e, fast-oracle %.1e)" % (c["r"][iy, ix], abs(s["r"][iy, ix] / c["r"][iy, ix] - 1), abs(f["r"][iy, ix] / c["r"][iy, ix] - 1))) if c is not None else "",
+        er[iy, ix], f["g"][iy, ix], s["g"][iy, ix]))
+print("pixels with r rel > 1e-10:", int((er > 1e-10).sum()), "of", int(same.sum()))
