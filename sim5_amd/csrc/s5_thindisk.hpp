@@ -173,7 +173,9 @@ S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, doub
         return;
     } else {
 #if S5_RPC_ADD
-    if (!wave_any(type != T_RR)) thin_disk_finish<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+    // (SIM5GPU_IMG_DIRECT, read here and nowhere else: the whole wave is left to the direct routine below)
+    if (p.direct) { out.cls = PX_COLD_MARK; if (PAIR) out2.cls = PX_COLD_MARK; }
+    else if (!wave_any(type != T_RR)) thin_disk_finish<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
     else if (!wave_any(type != T_RC)) thin_disk_finish<WANT_STATE, T_RC, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
     else thin_disk_finish<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
     // The rays the fast routine left to the direct one: run HERE, inlined, from the pixel's coordinates -- the fast path's state
@@ -651,7 +653,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #ifndef S5_KO_RAD
     if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
-    const bool by_add = !p.direct && ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
+    const bool by_add = ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
 
     // ---------------- the polar integrals: cn^-1(u_i | mmT) by R_F, K(mmT) from the table ----------------
     double icn_i;
