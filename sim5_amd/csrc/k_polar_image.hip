@@ -35,7 +35,55 @@ S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const 
     double sdm = (t.beta >= 0.0) ? +1.0 : -1.0;
     double T = (sdm > 0.0) ? -(t.Tpp - t.Tip) : -(t.Tip);
     for (int it = 0; it < 4096 && (t.P > T + t.Tpp); ++it) { T += t.Tpp; sdm = -sdm; }
-    double k[4], n[4], floc[4], fv[4], wp[2];
+    double wp[2];
+#if S5_FAST
+    // The chain photon_momentum -> kerr_metric -> tetrad_azimuthal -> bl2on -> on2bl -> normalise -> polarization_constant of
+    // the strict branch below, WRITTEN OUT for its one use: an emitter in the equatorial plane (m = 0) on a Keplerian orbit.
+    // Called with the literal m = 0 the generic routines still multiply through their sixteen-entry tetrad and the cos(theta)
+    // terms (x * 0.0 is not foldable in IEEE arithmetic), ~300 issue slots with ten divisions and square roots; here ~110.
+    // The Walker-Penrose constant is bilinear in (k, f) and f is linear in k, and only the DIRECTION of (wp0, wp1) enters
+    // chi (the angle of ref src/sim5polarization.c:272-285 is an atan2 of two numbers with a common denominator), so every
+    // positive common factor is dropped: 1/r^2 of the momentum, u^t and 1/sqrt(Delta) of the tetrad, 1/sqrt(g11), the
+    // normalisation of f, the factor r of kappa.  Same numbers up to rounding; NaN where the generic chain gives NaN (k^theta
+    // imaginary, orbit not time-like).
+    {
+        const double r = t.r, r2 = r * r;
+        const double ak = t.a, am = p.a;                   // the geodesic's spin (clamped at 1e-4) and the job's, as below
+        // r^2 k^mu  (ref src/sim5kerr.c:1151-1213 at m = 0)
+        const double Dk = r2 - 2. * r + ak * ak;
+        const double Tk = r2 + ak * ak - ak * t.l;
+        double Rk = Tk * Tk - Dk * (sq(t.l - ak) + t.q);
+        double Mk = t.q;
+        if ((Mk < 0.0) && (-Mk < 1e-8)) Mk = 0.0;
+        if ((Rk < 0.0) && (-Rk < 1e-8)) Rk = 0.0;
+        const double iDk = mrcp(Dk);
+        const double TD = Tk * iDk;
+        const double K0 = (r2 + ak * ak) * TD - ak * (ak - t.l);
+        const double K3 = ak * TD - (ak - t.l);
+        const double K1 = (t.dP > 0.0) ? -msqrt(Rk) : msqrt(Rk);
+        const double K2 = (sdm < 0.0) ? -msqrt(Mk) : msqrt(Mk);           // NaN for Mk < 0, as there
+        // metric of the equatorial plane (ref :75-101 at m = 0)
+        const double ir = mrcp(r);
+        const double g00 = -1. + 2. * ir, g03 = -2. * am * ir, g33 = r2 + am * am + 2. * (am * am) * ir;
+        const double g11 = r2 * ((ak == am) ? iDk : mrcp(r2 - 2. * r + am * am));
+        // Keplerian orbit: u ~ (1, 0, 0, Omega); c1 = u.d_t / u^t, c2 = u.d_phi / u^t; the azimuthal leg of the tetrad is
+        // sign(c1) (-c2, 0, 0, c1) / (u^t sqrt(Delta))  (ref :766-814)
+        const double Om = mrcp(am + r * sqrt_pos(r));
+        const double c1 = g00 + Om * g03, c2 = g03 + Om * g33;
+        const double sg = (c1 >= 0.0) ? 1.0 : -1.0;
+        const bool timelike = (c1 + Om * c2) < 0.0;
+        // local components of k along the radial and azimuthal legs, f = n3 e_r - n1 e_phi  (ref: the recipe of SURVEY 3.4)
+        const double N1 = K1 * g11;
+        const double N3 = sg * (c1 * (K3 * g33 + K0 * g03) - c2 * (K0 * g00 + K3 * g03));
+        const double F0 = sg * (N1 * c2), F3 = -sg * (N1 * c1);           // F1 = N3, F2 = 0
+        // kappa / r  (ref src/sim5polarization.c:145-168 at m = 0)
+        const double A1 = (K0 * N3 - K1 * F0) + am * (K1 * F3 - K3 * N3);
+        const double A2 = K2 * (am * F0 - (r2 + am * am) * F3);
+        wp[0] = timelike ? A1 : NAN;
+        wp[1] = timelike ? -A2 : NAN;
+    }
+#else
+    double k[4], n[4], floc[4], fv[4];
     photon_momentum(t.a, t.r, 0.0, t.l, t.q, (t.dP > 0.0 ? -1. : +1.), sdm, k);
     Metric mt;
     kerr_metric(p.a, t.r, 0.0, mt);
@@ -46,6 +94,7 @@ S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const 
     on2bl(floc, fv, tt);
     normalize_to(fv, 1.0, mt);
     polarization_constant(k, fv, mt, wp);
+#endif
 #if S5_FAST
     // chi = atan2(Y, X) with X, Y sharing the positive denominator S^2 + T^2 (ref src/sim5polarization.c:279-283):
     // the angle needs neither division, cos 2chi = (X^2 - Y^2)/(X^2 + Y^2) and sin 2chi = 2XY/(X^2 + Y^2) need no
