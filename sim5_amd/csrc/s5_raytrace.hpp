@@ -108,7 +108,7 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
             for (int i = 0; i < 4; ++i) di[i] = s.dk[i];
         } else {
             double sd, cd;
-            msincos(xp[2], sd, cd);
+            msincos_small(xp[2], sd, cd);
             rt_connection(s, xp[1], m0 * cd - sn0 * sd, G);
             transport_self(G, ki, di);
         }
@@ -128,7 +128,7 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
 #if S5_FAST
     {
         double sd, cd;
-        msincos(x[2], sd, cd);
+        msincos_small(x[2], sd, cd);
         x[2] = m0 * cd - sn0 * sd;
     }
     if (s.opt_gr) kerr_metric_connection(s.bh_spin, x[1], x[2], g, G);
@@ -193,7 +193,7 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
         // and cos (the reference's form, ref :177, stays in the strict variant); same step counts on the C4 job
         const double d = k[2] * dl + dk[2] * half_dl2;
         double sd, cd;
-        msincos(d, sd, cd);
+        msincos_small(d, sd, cd);
         xp[2] = x[2] * cd - msqrt(1. - x[2] * x[2]) * sd;
     }
 #else
