@@ -24,3 +24,23 @@ for (iy, ix) in np.argwhere(er > 1e-10)[:12]:
         ("oracle %.15g (strict-oracle %.1e, fast-oracle %.1e)" % (c["r"][iy, ix], abs(s["r"][iy, ix] / c["r"][iy, ix] - 1), abs(f["r"][iy, ix] / c["r"][iy, ix] - 1))) if c is not None else "",
         er[iy, ix], f["g"][iy, ix], s["g"][iy, ix]))
 print("pixels with r rel > 1e-10:", int((er > 1e-10).sum()), "of", int(same.sum()))
+# conditioning of the worst pixel in the CHECKER itself: its (alpha, beta) by the reference's expression, then the same ray with
+# beta and alpha moved by one unit in the last place -- how far does the checker's own r move?
+bad = np.argwhere(er > 1e-10)
+if len(bad) and order == 2 and rmax == 0.0:
+    iy, ix = bad[np.argmax(er[tuple(bad.T)])]
+    o = ol.Oracle()
+    rms = ol.cpu_r_ms(a) if hasattr(ol, "cpu_r_ms") else None
+    z1 = 1 + (1 - a * a) ** (1 / 3) * ((1 + a) ** (1 / 3) + (1 - a) ** (1 / 3)); z2 = math.sqrt(3 * a * a + z1 * z1)
+    rms = 3 + z2 - math.sqrt((3 - z1) * (3 + z1 + 2 * z2))
+    o.disk_nt_setup(10.0, a, 0.1, 0.1, 0)
+    rm = rms + 8.0
+    al = ((ix + .5) / nx - 0.5) * 2.0 * rm
+    be = ((iy + .5) / ny - 0.5) * 2.0 * rm * (ny / nx)
+    r0 = o.disk_pixel(math.radians(inc), a, rms, al, be).r
+    print("checker at the reference's (alpha, beta): r = %.15g" % r0)
+    for name, da, db in (("beta + 1 ulp", 0, 1), ("beta - 1 ulp", 0, -1), ("alpha + 1 ulp", 1, 0), ("alpha - 1 ulp", -1, 0)):
+        a2 = np.nextafter(al, math.inf if da > 0 else -math.inf) if da else al
+        b2 = np.nextafter(be, math.inf if db > 0 else -math.inf) if db else be
+        r1 = o.disk_pixel(math.radians(inc), a, rms, float(a2), float(b2)).r
+        print("  %-14s r = %.15g   moved by %.2e (relative)" % (name, r1, abs(r1 / r0 - 1)))
