@@ -16,6 +16,7 @@ print("case %d: a=%r inc=%r %dx%d order=%d rmax=%r" % (want, a, inc, nx, ny, ord
 mk = lambda strict: capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), max_order=order, rmax=rmax, strict=strict), full=True)
 f, s = mk(False), mk(True)
 c = ol.cpu_disk_image("port", nx, ny, a, inc, nthreads=8, full=True) if (order == 2 and rmax == 0.0) else None
+print("classes of fast and strict equal:", bool(np.array_equal(f["cls"], s["cls"])))
 same = (f["cls"] == s["cls"]) & np.isfinite(s["r"])
 er = np.where(same, np.abs(f["r"] / s["r"] - 1), 0)
 for (iy, ix) in np.argwhere(er > 1e-10)[:12]:
@@ -27,14 +28,14 @@ print("pixels with r rel > 1e-10:", int((er > 1e-10).sum()), "of", int(same.sum(
 # conditioning of the worst pixel in the CHECKER itself: its (alpha, beta) by the reference's expression, then the same ray with
 # beta and alpha moved by one unit in the last place -- how far does the checker's own r move?
 bad = np.argwhere(er > 1e-10)
-if len(bad) and order == 2 and rmax == 0.0:
+if len(bad):
     iy, ix = bad[np.argmax(er[tuple(bad.T)])]
     o = ol.Oracle()
     rms = ol.cpu_r_ms(a) if hasattr(ol, "cpu_r_ms") else None
     z1 = 1 + (1 - a * a) ** (1 / 3) * ((1 + a) ** (1 / 3) + (1 - a) ** (1 / 3)); z2 = math.sqrt(3 * a * a + z1 * z1)
     rms = 3 + z2 - math.sqrt((3 - z1) * (3 + z1 + 2 * z2))
     o.disk_nt_setup(10.0, a, 0.1, 0.1, 0)
-    rm = rms + 8.0
+    rm = rmax if rmax > 0.0 else rms + 8.0
     al = ((ix + .5) / nx - 0.5) * 2.0 * rm
     be = ((iy + .5) / ny - 0.5) * 2.0 * rm * (ny / nx)
     r0 = o.disk_pixel(math.radians(inc), a, rms, al, be).r
