@@ -37,7 +37,8 @@ struct RayCols {                 // start state, structure of arrays: column c o
 };
 
 __global__ __launch_bounds__(256, 2)
-void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok)
+void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __restrict__ order,
+                        unsigned long long* __restrict__ counters)
 {
     double* __restrict__ cols = st.d;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -90,6 +91,73 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok)
     cols[COL_DK2 * n + i] = s.dk[2]; cols[COL_DK3 * n + i] = s.dk[3];
     cols[COL_KT * n + i] = s.kt; cols[COL_Q * n + i] = s.Q;
     ok[i] = good;
+
+    // ORDER OF THE MARCH (scheduling only: a ray's result does not depend on it).  The march kernel hands rays out along
+    // `order`; a ray that needs 2 000 raytrace() calls handed out last keeps one lane of one wave busy for ~10 ms after
+    // everything else is done (measured: T = 9.9 ms + steps / 2.7e10 per s over jobs of 512^2 .. 2048^2 rays in row-major
+    // order).  The long rays are known by their constants of motion: those that wind around the photon orbit -- the radial
+    // turning point nearly a double root, (r1 - r2)/r1 < 0.2, or the complex pair of a plunging ray nearly real, |Im r3| <
+    // 0.2 |Re r3| -- and those that pass the polar axis (1 - m2p < 0.01: the step size follows sin theta).  On the C4 job
+    // that rule marks 7.7 % of the rays, among them every ray above 1 000 calls and 89 % of those above 800 (median 506;
+    // tests/tools/torus_long_predict.py).  They go FIRST, everything else after them from the last ray backwards; a ray
+    // wrongly taken for long costs nothing.
+    // ... and the SHORTEST rays go last: those that fall into the hole (complex roots: 250 - 450 calls), so that the last
+    // rays handed out keep their lanes for as short a time as any can.
+    int cls = 0;                                                         // 0 ordinary, 1 long, 2 short
+    if (good && !(p.options & 1)) {
+        const double crit = (gd.nrr == 4) ? (gd.r1[0] - gd.r2[0]) / gd.r1[0]
+                          : (gd.nrr == 2) ? fabs(gd.r3[1]) / fmax(fabs(gd.r3[0]), 1e-9) : 9.0;
+        if ((crit < 0.2) || (1.0 - gd.m2p < 0.01)) cls = 1;
+        else if (gd.nrr != 4) cls = 2;
+    }
+    if (!good) cls = 2;                                                  // (rejected at start-up: no work at all)
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long below = (lane == 0u) ? 0ull : (~0ull >> (64u - lane));
+    unsigned long long m[3], base[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m[c] = __builtin_amdgcn_ballot_w64(cls == c);
+    const int src = __builtin_ctzll(m[0] | m[1] | m[2]);
+    if ((int)lane == src) {                                              // one lane of the wave: an atomic per class present
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (m[c]) base[c] = atomicAdd(&counters[c], (unsigned long long)__builtin_popcountll(m[c]));
+    }
+    // rank of the ray within its class; torus_order_kernel turns (class, rank) into the position once the counts are final
+    unsigned long long rk = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long b = ((unsigned long long)(unsigned)__shfl((int)(base[c] >> 32), src, 64) << 32) |
+                                     (unsigned long long)(unsigned)__shfl((int)(unsigned)base[c], src, 64);
+        if (cls == c) rk = b + (unsigned long long)__builtin_popcountll(m[c] & below);
+    }
+    order[i] = (int)(((unsigned)cls << 30) | (unsigned)rk);
+}
+
+// The order of the march from the ranks.  The long rays are DEALT into the head of the order, one in every M positions (M = 4
+// when they are under a quarter of the job), the ordinary ones fill the gaps in their own order and follow, the short ones
+// close.  Dealt rather than put in front: a pool needs rays of both kinds -- Verlet attempts and RK4 fallbacks -- to fill its
+// batches, and the long rays are the ones that fall back at almost every step (all of them first: -8 % asymptotic rate,
+// measured).
+#ifndef S5_ORDER_DEAL
+#define S5_ORDER_DEAL 4
+#endif
+__global__ __launch_bounds__(256)
+void torus_order_kernel(size_t n, const int* __restrict__ ranks, const unsigned long long* __restrict__ counters, int* __restrict__ order)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long n_long = counters[1], n_short = counters[2];
+    const unsigned long long head = (unsigned long long)n - n_short;             // ordinary + long
+    unsigned long long M = (n_long == 0) ? 1ull : head / n_long;
+    M = M < 1ull ? 1ull : (M > (unsigned long long)S5_ORDER_DEAL ? (unsigned long long)S5_ORDER_DEAL : M);
+    const unsigned v = (unsigned)ranks[i];
+    const unsigned cls = v >> 30;
+    const unsigned long long j = (unsigned long long)(v & 0x3fffffffu);
+    unsigned long long pos;
+    if (cls == 1u) pos = M * j;
+    else if (cls == 2u) pos = head + j;
+    else if (M > 1ull && j < (M - 1ull) * n_long) pos = j + j / (M - 1ull) + 1ull;
+    else pos = j + n_long;
+    order[pos] = (int)i;
 }
 
 S5_DEV double torus_density(const TorusParams& p, double r, double m)
@@ -217,7 +285,7 @@ S5_DEV void wave_lds_fence()
 }
 
 __global__ __launch_bounds__(256, S5_MARCH_WAVES)
-void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__ ok,
+void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__ ok, const int* __restrict__ order,
                        unsigned long long* __restrict__ cursor, sim5gpu_stokes* __restrict__ out, TorusAux aux)
 {
     extern __shared__ char pool_raw[];
@@ -305,7 +373,7 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
                 if (base + cnt >= n) drained = true;
                 const unsigned long long mine = base + rank;
                 if (want && mine < n) {
-                    const size_t ray = (size_t)mine;
+                    const size_t ray = (size_t)order[mine];         // (torus_start_kernel: the long rays first)
                     if (!ok[ray]) {
                         // rejected at start-up: an empty record, the slot stays empty
                         sim5gpu_stokes z = { 0.0, 0.0, 0.0, 0.0, 0.0 };
@@ -502,10 +570,10 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
     if (dev < 0 || dev >= MAX_DEVICES) return (int)hipErrorInvalidDevice;
     TorusWorkspace& g_ws = g_ws_dev[dev];
     const size_t n = p.nrays;
-    if (n > 0x7ffffff0ull) return (int)hipErrorInvalidValue;            // ray numbers are kept as int in the pool
+    if (n > 0x3ffffff0ull) return (int)hipErrorInvalidValue;            // ray numbers are kept as int in the pool, class and rank in 32 bits
     const size_t dcol_bytes = (sizeof(double) * NCOL * n + 255) & ~size_t(255);
     const size_t ok_bytes = (sizeof(int) * n + 255) & ~size_t(255);
-    const size_t need = dcol_bytes + ok_bytes + 256;
+    const size_t need = dcol_bytes + 3 * ok_bytes + 256;        // start columns, start-up flags, class ranks, order of the march, cursor + 2 counters
     if (g_ws.used && g_ws.last != stream) {
         if ((e = hipStreamSynchronize(g_ws.last)) != hipSuccess) return (int)e;
     }
@@ -523,11 +591,15 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
     start.d = (double*)g_ws.base;
     start.cap = n;
     int* ok = (int*)(g_ws.base + dcol_bytes);
-    unsigned long long* cursor = (unsigned long long*)(g_ws.base + dcol_bytes + ok_bytes);
-    if ((e = hipMemsetAsync(cursor, 0, sizeof(unsigned long long), stream)) != hipSuccess) return (int)e;
+    int* ranks = (int*)(g_ws.base + dcol_bytes + ok_bytes);
+    int* order = (int*)(g_ws.base + dcol_bytes + 2 * ok_bytes);
+    unsigned long long* cursor = (unsigned long long*)(g_ws.base + dcol_bytes + 3 * ok_bytes);
+    if ((e = hipMemsetAsync(cursor, 0, 4 * sizeof(unsigned long long), stream)) != hipSuccess) return (int)e;
 
     const unsigned blocks_a = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(torus_start_kernel, dim3(blocks_a), dim3(256), 0, stream, p, start, ok);
+    hipLaunchKernelGGL(torus_start_kernel, dim3(blocks_a), dim3(256), 0, stream, p, start, ok, ranks, cursor + 1);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(torus_order_kernel, dim3(blocks_a), dim3(256), 0, stream, n, ranks, cursor + 1, order);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
 
     // persistent grid: 2 workgroups of 4 waves per CU (VGPR-bound occupancy 2 waves/SIMD; 2 x 71 KB of LDS),
@@ -542,7 +614,7 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
         if ((e = hipFuncSetAttribute((const void*)torus_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
         g_ws.attr_set = true;
     }
-    hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(256), lds, stream, p, start, ok, cursor, out, aux);
+    hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(256), lds, stream, p, start, ok, order, cursor, out, aux);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     return 0;
 }
