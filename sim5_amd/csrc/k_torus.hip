@@ -132,13 +132,14 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
     order[i] = (int)(((unsigned)cls << 30) | (unsigned)rk);
 }
 
-// The order of the march from the ranks.  The long rays are DEALT into the head of the order, one in every M positions (M = 4
-// when they are under a quarter of the job), the ordinary ones fill the gaps in their own order and follow, the short ones
+// The order of the march from the ranks.  The long rays are DEALT into the head of the order, every M-th position (M = 2
+// when they are under half of the job), the ordinary ones fill the gaps in their own order and follow, the short ones
 // close.  Dealt rather than put in front: a pool needs rays of both kinds -- Verlet attempts and RK4 fallbacks -- to fill its
-// batches, and the long rays are the ones that fall back at almost every step (all of them first: -8 % asymptotic rate,
-// measured).
+// batches, and the long rays are the ones that fall back at almost every step.  Measured on MI355X, one call, 1024^2 / 2048^2
+// rays: row-major 29.1 / 90.6 ms; all long rays first 26.5 / 95.4 (-8 % asymptotic rate); dealt 1:2 25.9 / 89.8; 1:3 29.2 /
+// 92.7; 1:4 27.4 / 89.8.
 #ifndef S5_ORDER_DEAL
-#define S5_ORDER_DEAL 4
+#define S5_ORDER_DEAL 2
 #endif
 __global__ __launch_bounds__(256)
 void torus_order_kernel(size_t n, const int* __restrict__ ranks, const unsigned long long* __restrict__ counters, int* __restrict__ order)
