@@ -41,8 +41,9 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
                         unsigned long long* __restrict__ counters)
 {
     double* __restrict__ cols = st.d;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.nrays) return;
+    const size_t i_raw = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i_raw < p.nrays;              // (no early exit: the workgroup meets at a barrier below)
+    const size_t i = valid ? i_raw : p.nrays - 1;    // lanes past the end redo the last ray and store nothing
     const int ix = (int)(i % (size_t)p.nx);
     const int iy = p.y0 + (int)(i / (size_t)p.nx);
     const double alpha = (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
@@ -85,12 +86,14 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
         }
     }
     const size_t n = st.cap;
+    if (valid) {
     cols[COL_X0 * n + i] = x[0]; cols[COL_X1 * n + i] = x[1]; cols[COL_X2 * n + i] = x[2]; cols[COL_X3 * n + i] = x[3];
     cols[COL_K0 * n + i] = k[0]; cols[COL_K1 * n + i] = k[1]; cols[COL_K2 * n + i] = k[2]; cols[COL_K3 * n + i] = k[3];
     cols[COL_DK0 * n + i] = s.dk[0]; cols[COL_DK1 * n + i] = s.dk[1];
     cols[COL_DK2 * n + i] = s.dk[2]; cols[COL_DK3 * n + i] = s.dk[3];
     cols[COL_KT * n + i] = s.kt; cols[COL_Q * n + i] = s.Q;
     ok[i] = good;
+    }
 
     // ORDER OF THE MARCH (scheduling only: a ray's result does not depend on it).  The march kernel hands rays out along
     // `order`; a ray that needs 2 000 raytrace() calls handed out last keeps one lane of one wave busy for ~10 ms after
@@ -111,23 +114,33 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
         else if (gd.nrr != 4) cls = 2;
     }
     if (!good) cls = 2;                                                  // (rejected at start-up: no work at all)
-    const unsigned lane = threadIdx.x & 63u;
+    // rank of the ray within its class: counted per wave (ballot), summed per workgroup in LDS, ONE atomic per class and
+    // workgroup on the global counters (an atomic per wave and class: 49 k atomics on three addresses, 0.18 ms -- measured);
+    // torus_order_kernel turns (class, rank) into the position once the counts are final
+    __shared__ unsigned s_cnt[3][4];                 // [class][wave]
+    __shared__ unsigned long long s_base[3];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long below = (lane == 0u) ? 0ull : (~0ull >> (64u - lane));
-    unsigned long long m[3], base[3] = {0, 0, 0};
+    unsigned long long m[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) m[c] = __builtin_amdgcn_ballot_w64(cls == c);
-    const int src = __builtin_ctzll(m[0] | m[1] | m[2]);
-    if ((int)lane == src) {                                              // one lane of the wave: an atomic per class present
-#pragma unroll
-        for (int c = 0; c < 3; ++c) if (m[c]) base[c] = atomicAdd(&counters[c], (unsigned long long)__builtin_popcountll(m[c]));
+    for (int c = 0; c < 3; ++c) {
+        m[c] = __builtin_amdgcn_ballot_w64(valid && cls == c);
+        if (lane == 0u) s_cnt[c][wave] = (unsigned)__builtin_popcountll(m[c]);
     }
-    // rank of the ray within its class; torus_order_kernel turns (class, rank) into the position once the counts are final
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        const unsigned c = threadIdx.x;
+        const unsigned tot = s_cnt[c][0] + s_cnt[c][1] + s_cnt[c][2] + s_cnt[c][3];
+        s_base[c] = tot ? atomicAdd(&counters[c], (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    if (!valid) return;
     unsigned long long rk = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const unsigned long long b = ((unsigned long long)(unsigned)__shfl((int)(base[c] >> 32), src, 64) << 32) |
-                                     (unsigned long long)(unsigned)__shfl((int)(unsigned)base[c], src, 64);
-        if (cls == c) rk = b + (unsigned long long)__builtin_popcountll(m[c] & below);
+        unsigned before = 0;
+        for (unsigned w = 0; w < wave; ++w) before += s_cnt[c][w];
+        if (cls == c) rk = s_base[c] + before + (unsigned long long)__builtin_popcountll(m[c] & below);
     }
     order[i] = (int)(((unsigned)cls << 30) | (unsigned)rk);
 }
