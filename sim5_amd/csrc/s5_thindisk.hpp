@@ -1,28 +1,28 @@
 // s5_thindisk.hpp -- one image-plane ray of the thin-disk problem, fused for the wave64 machine.
 //
 // Same algorithm as geodesic_init_inf -> geodesic_find_midplane_crossing -> geodesic_position_rad
-// (s5_geod.hpp, i.e. ref: /root/reference/src/sim5kerr-geod.c:42-100, 846-885, 291-357).  In the strict variant
-// every value is produced by the same expression and the same R_F / sncndn routines as there (bit-identical
-// results); the fast variant additionally uses algebraically equal, cheaper forms (#if S5_FAST blocks) and
-// agrees to rounding.  The routine is arranged so that a wave executes ONE copy of each expensive loop
-// whatever mixture of geodesic classes its lanes hold:
+// (s5_geod.hpp, i.e. ref: /root/reference/src/sim5kerr-geod.c:42-100, 846-885, 291-357).  Two routines follow the closed-form
+// quartic of trace_thin_disk_impl:
 //
-//  * the three or four Carlson R_F evaluations a ray needs (radial integral to the turning point, K(mm),
-//    cn^-1 of the observer's polar position, and for RC rays with a negative argument the second term of
-//    cn^-1) go through one loop over "slots": per slot each lane selects its own arguments, the single
-//    inlined R_F body runs once for the whole wave, and each lane scales its own result.  RR, RC and CC
-//    lanes share that loop instead of serialising three inlined copies of it;
-//  * r(P) needs sn (RR) or cn (RC) of different arguments: the lanes select (u, m) and ONE Landen ladder
-//    serves both;
-//  * the special cases of the inverse Jacobi functions (m within 1e-8 of 0 or 1, z = 0, z = 1: asin, acos,
-//    log forms, ref src/sim5elliptic.c:483-503) are flagged per lane and, if any lane of the wave has one,
-//    re-evaluated by the generic routine out of line -- they keep their exact semantics without costing
-//    registers or instruction-cache on the common path.
+//  thin_disk_finish_direct -- the reference's sequence.  In the strict variant every value is produced by the same
+//    expression and the same R_F / sncndn routines as there (bit-identical results); in the fast variant the same sequence
+//    with algebraically equal, cheaper forms (#if S5_FAST blocks).  It is the strict variant's only path; in the fast variant
+//    it serves the few rays the routine below hands back (and whole images under SIM5GPU_IMG_DIRECT).  Arranged so that a
+//    wave executes ONE copy of each expensive loop whatever mixture of geodesic classes its lanes hold:
+//     * the three or four Carlson R_F evaluations a ray needs (radial integral to the turning point, K(mm), cn^-1 of the
+//       observer's polar position, and for RC rays with a negative argument the second term of cn^-1) go through one loop
+//       over "slots": per slot each lane selects its own arguments, the single inlined R_F body runs once for the whole
+//       wave, and each lane scales its own result;
+//     * r(P) needs sn (RR) or cn (RC) of different arguments: the lanes select (u, m) and ONE Landen ladder serves both;
+//     * the special cases of the inverse Jacobi functions (m within 1e-8 of 0 or 1, z = 0, z = 1: asin, acos, log forms,
+//       ref src/sim5elliptic.c:483-503) are flagged per lane and, if any lane of the wave has one, re-evaluated by the
+//       generic routine out of line.
+//  thin_disk_finish (fast variant only) -- r(P) from the addition theorem of the Jacobi functions instead of the radial
+//    integral: see the comment at its head.
 //
-//  * a wave whose lanes all have the same class (the usual case: image neighbours) takes an instantiation of
-//    the second half of the routine with the class as a compile-time constant (thin_disk_finish<.., KNOWN>);
-//  * the Landen ladder keeps its rungs in LDS (thin_disk_ladder_column): 256-thread one-dimensional workgroups only;
-//    it is climbed once per ray and descended once per crossing tried (and per ray of a mirrored pair, below).
+//  Both: a wave whose lanes all have the same class (the usual case: image neighbours) takes an instantiation with the class
+//  as a compile-time constant (<.., KNOWN>); the Landen ladder keeps its rungs in LDS (thin_disk_ladder_column: 256-thread
+//  one-dimensional workgroups only), climbed once per ray and descended once per crossing tried (and per ray of a mirrored pair).
 //
 // The per-ray state that callers need afterwards (polarization, tests) is returned in ThinRay.
 #pragma once
