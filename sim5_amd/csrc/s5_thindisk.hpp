@@ -637,8 +637,11 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
     const double u_i = p.cos_i * rs_m2p;
 
     // ---------------- what the crossing search needs to know about the ray ----------------
-    const bool plain0 = (type == T_RC) ? icn_plain(zR, mR) : isn_plain(mR);      // (CC rays never take the addition path)
-    const bool plain2 = icn_plain(u_i, mmT);
+    // "no special case of the inverse function": CONSERVATIVE forms of isn_plain / icn_plain (a handful of comparisons
+    // instead of their dozen: whatever they exclude besides the special cases only takes the generic routine, which is right
+    // for every argument)
+    const bool plain0 = (mR > 1e-8) && (mR < 1.0 - 1e-8) && ((type != T_RC) || ((fabs(zR) < 1.0) && (zR != 0.0)));   // (CC rays never take the addition path)
+    const bool plain2 = (u_i > 0.0) && (u_i < 1.0) && (mmT > 0.0) && (mmT < 1.0);
     const bool q_pos = (q > 0.0);
     double uu = u_i;
     const bool u_bad = (uu < -1.0 - 1e-4) || (uu > +1.0 + 1e-4);
