@@ -110,7 +110,11 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
     if (good && !(p.options & 1)) {
         const double crit = (gd.nrr == 4) ? (gd.r1[0] - gd.r2[0]) / gd.r1[0]
                           : (gd.nrr == 2) ? fabs(gd.r3[1]) / fmax(fabs(gd.r3[0]), 1e-9) : 9.0;
-        if ((crit < 0.2) || (1.0 - gd.m2p < 0.01)) cls = 1;
+#ifndef S5_LONG_CRIT
+#define S5_LONG_CRIT 0.2
+#define S5_LONG_POLE 0.01
+#endif
+        if ((crit < S5_LONG_CRIT) || (1.0 - gd.m2p < S5_LONG_POLE)) cls = 1;
         else if (gd.nrr != 4) cls = 2;
     }
     if (!good) cls = 2;                                                  // (rejected at start-up: no work at all)
