@@ -879,14 +879,17 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 #undef S5_THIN_RP
 #endif   // S5_RPC_ADD
 
-// Image-plane coordinates of a pixel (ref disk-image.c:57-58).  The fast variant multiplies by the reciprocals of the
-// image size instead of dividing, and forms beta from the exact odd integer 2 iy + 1 - ny: rows iy and ny - 1 - iy then get
-// beta values that are each other's negatives bit for bit (alpha, beta move by an ulp or two against the reference's
-// expression).  That is what lets the mirrored kernel below give the very image of the plain one.
+// Image-plane coordinates of a pixel (ref disk-image.c:57-58).  Rows iy and ny - 1 - iy must get beta values that are each
+// other's negatives bit for bit: that is what lets the mirrored kernel give the very image of the plain one.  For image sizes
+// that are powers of two the fast variant's products with the reciprocals are the reference's numbers exactly; for other
+// sizes see the two routines.
 S5_DEV double pixel_alpha(const s5abi::ImageParams& p, int ix)
 {
 #if S5_FAST
-    return (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;
+    // the product with 1/nx is the reference's quotient bit for bit when nx is a power of two (every BASELINE size); for the
+    // other widths the quotient itself (IEEE division, once per lane): alpha is then the reference's number for every pixel
+    if ((p.nx & (p.nx - 1)) == 0) return (((double)(ix) + .5) * p.inv_nx - 0.5) * 2.0 * p.rmax;
+    return (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
 #else
     return (((double)(ix) + .5) / (double)(p.nx) - 0.5) * 2.0 * p.rmax;
 #endif
@@ -895,7 +898,16 @@ S5_DEV double pixel_alpha(const s5abi::ImageParams& p, int ix)
 S5_DEV double pixel_beta(const s5abi::ImageParams& p, int iy)
 {
 #if S5_FAST
-    return ((double)(2 * iy + 1 - p.ny) * (0.5 * p.inv_ny)) * 2.0 * p.rmax * p.ny_over_nx;
+    // ny a power of two (every BASELINE size): the product below IS the reference's expression, bit for bit, and antisymmetric.
+    // Other heights: the reference's own expression for the rows of the upper half, and for a row of the lower half MINUS the
+    // value of its mirror row -- the two rows of a mirrored pair must get opposite beta exactly (the reference's quotients of
+    // rows iy and ny-1-iy are not always each other's complement in the last bit), so the upper half has the reference's
+    // number and the lower half is within an ulp of it
+    if ((p.ny & (p.ny - 1)) == 0) return ((double)(2 * iy + 1 - p.ny) * (0.5 * p.inv_ny)) * 2.0 * p.rmax * p.ny_over_nx;
+    const bool lower = (2 * iy + 1 > p.ny);
+    const int jy = lower ? p.ny - 1 - iy : iy;
+    const double b = (((double)(jy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax * p.ny_over_nx;
+    return lower ? -b : b;
 #else
     return (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax * ((double)p.ny / (double)p.nx);
 #endif
