@@ -188,7 +188,13 @@ S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clam
                     else if (w.r > 1.1 * w.r0) {                                      // :325 retry from further out
                         ++w.iteration;
                         if (w.iteration > 3) w.state = ST_DONE;
+#if S5_FAST
+                        // (the caller passes alpha_beta / cos_view in alpha_beta and max(200, 1.1 rp) in rp: two doubles kept
+                        // through the walk instead of three -- the walk sits one register under its occupancy bound)
+                        else { w.r0 = fmax(rp, (0.5 + w.iteration) * alpha_beta); w.grow = 0; w.state = ST_GROW; }
+#else
                         else { w.r0 = fmax(fmax(200.0, 1.1 * rp), (0.5 + w.iteration) * alpha_beta / cos_view); w.grow = 0; w.state = ST_GROW; }
+#endif
                     }
                     else if (w.m < 0.0) w.state = ST_DONE;                            // :326
                     else if (w.step < accuracy / 2.) w.state = ST_DONE;               // :327
@@ -248,10 +254,13 @@ void surface_setup_kernel(SurfaceParams p, SurfaceWork wk, const double* __restr
 #ifndef S5_SURF_WAVES
 #define S5_SURF_WAVES 3
 #endif
+#ifndef S5_SURF_WAVES_FAST_PLAIN
+#define S5_SURF_WAVES_FAST_PLAIN 3
+#endif
 // NST = WALK_RUNGS, DEEP = false: the rays whose ladders fit (nearly all);  NST = LADDER_RUNGS_VALID, DEEP = true: the
 // few that need the full ladders (64 KB of LDS per workgroup; launched beside the other on a second stream)
 template <int NST, bool DEEP>
-__global__ __launch_bounds__(SURF_BLOCK, DEEP ? 2 : S5_SURF_WAVES)
+__global__ __launch_bounds__(SURF_BLOCK, DEEP ? 2 : (S5_FAST ? S5_SURF_WAVES_FAST_PLAIN : S5_SURF_WAVES))
 void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH)
 {
     extern __shared__ double lds[];
@@ -277,7 +286,11 @@ void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restri
         alpha_beta = sqrt(gd.alpha * gd.alpha + gd.beta * gd.beta);
         cos_view = cos(gd.incl + disk_theta);
     }
+#if S5_FAST
+    follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, fmax(200.0, 1.1 * trk.rp), alpha_beta / cos_view, 1.0, sR, sH, p.n_table);
+#else
     follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, trk.rp, alpha_beta, cos_view, sR, sH, p.n_table);
+#endif
     wk.ws[i] = w;
 }
 

@@ -188,8 +188,8 @@ S5_DEV double torus_density(const TorusParams& p, double r, double m)
 }
 
 #ifndef S5_MARCH_WAVES
-#define S5_MARCH_WAVES 2
-#endif
+#define S5_MARCH_WAVES (S5_FAST ? 2 : 1)   // strict: its bodies need ~261 registers -- one wave per SIMD and no scratch rather than two with
+#endif                                     // six registers spilled (a spilled register in an image kernel went wrong in round 3: DESIGN.md 4)
 // Emission and absorption picked up over one accepted step (see the header comment for the model).  `g` is the
 // metric at the end point of the step, which both halves of raytrace() have just evaluated there.
 S5_DEV void accumulate_transfer(const TorusParams& p, const bool no_absorption, const RayState& s, const Metric& g, const double x[4],

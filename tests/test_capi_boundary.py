@@ -257,8 +257,12 @@ def test_no_register_spills_in_the_image_kernels():
     assert len(image) >= 9, sorted(meta)
     for k, v in image.items():
         assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
-    march = [v for k, v in meta.items() if "s5f" in k and "torus_pool_kernel" in k]
-    assert march and all(v["vgpr_spill_count"] == 0 for v in march), march
+    march = [v for k, v in meta.items() if "torus_pool_kernel" in k]
+    assert len(march) == 2 and all(v["vgpr_spill_count"] == 0 for v in march), march          # both variants
+    # nothing else of the library spills a register either, but for the set-up kernel of the surface search in its strict
+    # variant (293 registers with its accumulation registers; once per ray, checked against the CPU every round)
+    spilling = sorted(k for k, v in meta.items() if v.get("vgpr_spill_count", 0) > 0)
+    assert all("surface_setup_kernel" in k and "s5f" not in k for k in spilling), spilling
     # the occupancy the launchers count on: four waves per SIMD for the unpolarized kernels, three for the polarized pairs
     for k, v in image.items():
         cap = 168 if "polarized" in k else 128
