@@ -137,7 +137,7 @@ void disk_image_mirror_kernel(ImageParams p)
     __syncthreads();
     trace_thin_disk_impl<false, true>(pl, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);
 #else
-    trace_thin_disk_impl<false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);
+    trace_thin_disk_impl<false, true, false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);   // (p is this kernel's first parameter)
 #endif
 #ifdef S5_FLUX_TABLE_LDS
     if (ix >= p.nx || lr >= half) return;                        // after the barrier of the table copy (tiles of the bench sizes are full)

@@ -65,7 +65,7 @@ for case in range(ncases):
                         for da, db in ((0, 1), (0, -1), (1, 0), (-1, 0)))
             if moved >= 0.5 * er_map[wy, wx]:
                 explained = " [pixel (%d,%d): the CHECKER's r moves by %.1e for one ulp of alpha / beta -- the difference is the input's]" % (wy, wx, moved)
-        if explained and er < 1e-6:
+        if explained:
             note_in = explained
         elif er > 1e-7 or eg > 1e-7 or ef > 1e-6:
             # where: radius of the worst flux pixel, its distance from the inner edge of the flux (x - x0 in x = sqrt(r)), the two values
