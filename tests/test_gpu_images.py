@@ -484,6 +484,18 @@ def test_direct_flag_runs_the_direct_routine_everywhere(capi, a, inc, n, order):
     assert np.abs(d["g"][ok] - f["g"][ok]).max() < 1e-9
     fl = np.maximum(np.abs(f["flux"][ok]), 1e-9 * np.abs(f["flux"]).max())
     assert (np.abs(d["flux"][ok] - f["flux"][ok]) / fl).max() < 1e-6
+    # the instantiation without full-precision planes (the production one: its direct routine reads the job's parameters from
+    # the kernel's argument segment): the two f32 planes of the direct image against the default one
+    planes = []
+    for direct in (False, True):
+        bf, bg = capi.DeviceBuffer(n * n * 4), capi.DeviceBuffer(n * n * 4)
+        capi.disk_image_device(capi.image_desc(n, n, a, math.radians(inc), max_order=order, direct=direct), bf.ptr, bg.ptr)
+        capi.synchronize()
+        planes.append((bf.to_numpy(np.float32, (n, n)), bg.to_numpy(np.float32, (n, n))))
+    assert np.array_equal(planes[0][1] > 0, planes[1][1] > 0) and np.array_equal(planes[1][1] > 0, hit)
+    assert np.abs(planes[1][1][ok] / planes[0][1][ok] - 1).max() < 1e-6
+    lit32 = ok & (planes[0][0] > 1e-9 * planes[0][0].max())
+    assert np.abs(planes[1][0][lit32] / planes[0][0][lit32] - 1).max() < 1e-5
     # the polarized kernel takes the same routine with the ray's state
     st = [capi.DeviceBuffer(3 * n * n * 8) for _ in range(2)]
     for k, direct in enumerate((False, True)):
