@@ -565,13 +565,12 @@ S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, T
 //    w < 2 K(mR) (RR) or 4 K(mR) (RC) to be unambiguous, and K(mR) = pi / (2 c_N) is the last mean of the ladder that is
 //    climbed anyway -- as a bound on the angle w c_N the descent starts from.  The descent stays in the fraction form
 //    (ladder_descend_fractions): sn^2 = Pn / Q and cn = X / Y enter the r(P) formulas without having been divided.
-//  * Rays the addition theorem does not serve take the reference's sequence OUT OF LINE (radial_integral_cold,
-//    crossing_cold: generic inverse functions with their special cases, the complete descent): geodesics with complex
-//    roots only (CC: r(P) is NaN, but the class of the pixel depends on P > 2 Rpc), the special cases of the inverse
-//    functions (modulus within 1e-8 of 0 or 1, ...), and ILL-CONDITIONED sums -- the denominator 1 - m sn^2(w) sn^2(F0)
-//    of the theorem cancels when m, sn(w) and sn(F0) are all close to 1 (rays that wind around the photon orbit of a fast
-//    hole: one in ~1e4; seen as 2e-8 in r on a second-order image at a = 0.9999 before this rule), so below 1e-3 of its
-//    terms the ray is handed to the direct evaluation.
+//  * Rays the addition theorem does not serve are MARKED (cls = PX_COLD_MARK) and traced by thin_disk_finish_direct, which the
+//    caller (trace_thin_disk_impl) runs after this routine from the pixel's coordinates: geodesics with complex roots only
+//    (CC: r(P) is NaN, but the class of the pixel depends on P > 2 Rpc), the special cases of the inverse functions (modulus
+//    within 1e-8 of 0 or 1, ...), and ILL-CONDITIONED sums -- the denominator 1 - m sn^2(w) sn^2(F0) of the theorem cancels
+//    when m, sn(w) and sn(F0) are all close to 1 (rays that wind around the photon orbit of a fast hole), so below 1e-3 of
+//    its terms the ray is handed to the direct evaluation.
 // A ray's result still depends on its own arguments only (which path a lane takes is decided by its own values).
 // ---------------------------------------------------------------------------------------------------------------------------
 enum : int { CROSS_FORMULA = 0, CROSS_BEYOND = 1, CROSS_NONE = 2 };
