@@ -104,8 +104,8 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
     // that rule marks 7.7 % of the rays, among them every ray above 1 000 calls and 89 % of those above 800 (median 506;
     // tests/tools/torus_long_predict.py).  They go FIRST, everything else after them from the last ray backwards; a ray
     // wrongly taken for long costs nothing.
-    // ... and the SHORTEST rays go last: those that fall into the hole (complex roots: 250 - 450 calls), so that the last
-    // rays handed out keep their lanes for as short a time as any can.
+    // (A third class -- the SHORTEST rays last: those that fall into the hole, 250 - 450 calls -- is built and measured,
+    // -DS5_SHORT_CLASS: 25.85 against 25.55 ms without it; not used.)
     int cls = 0;                                                         // 0 ordinary, 1 long, 2 short
     if (good && !(p.options & 1)) {
         const double crit = (gd.nrr == 4) ? (gd.r1[0] - gd.r2[0]) / gd.r1[0]
@@ -115,9 +115,13 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
 #define S5_LONG_POLE 0.01
 #endif
         if ((crit < S5_LONG_CRIT) || (1.0 - gd.m2p < S5_LONG_POLE)) cls = 1;
+#ifdef S5_SHORT_CLASS
         else if (gd.nrr != 4) cls = 2;
+#endif
     }
+#ifdef S5_SHORT_CLASS
     if (!good) cls = 2;                                                  // (rejected at start-up: no work at all)
+#endif
     // rank of the ray within its class: counted per wave (ballot), summed per workgroup in LDS, ONE atomic per class and
     // workgroup on the global counters (an atomic per wave and class: 49 k atomics on three addresses, 0.18 ms -- measured);
     // torus_order_kernel turns (class, rank) into the position once the counts are final
