@@ -241,6 +241,13 @@ def make_placer(capi, sharding, n, world, dealt, stream):
     return place
 
 
+def plane_checksums(torch, img):
+    """[sum of the 32-bit patterns of plane 0, of plane 1] as Python ints: equal images have equal checksums, and a single
+    differing pixel changes one (tests: the image assembled from the ranks' shares against one launch)"""
+    v = img.view(torch.int32).to(torch.int64)
+    return [int(v[0].sum().item()), int(v[1].sum().item())]
+
+
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
@@ -460,8 +467,15 @@ def main():
         torch.cuda.synchronize()
         time.sleep(0.3)
         cold_ms = timed_kernel(capi, stream, lambda: jobs[0].trace(pipe.full[0], True), 3, 0)
-    check_every_step = os.environ.get("SIM5_BENCH_CHECK_EVERY_STEP") == "1"        # tests: hit count of every assembled image
-    step_hits = []
+    check_every_step = os.environ.get("SIM5_BENCH_CHECK_EVERY_STEP") == "1"        # tests: every assembled image, bit for bit
+    step_hits, step_sums = [], []
+    single = single_sums = None
+    if check_every_step and rank == 0 and not c5:
+        # the image of ONE launch on this GPU: what every assembled image must equal, bit for bit (checksum of both planes)
+        single = torch.zeros((2, n, n), dtype=torch.float32, device=dev)
+        capi.disk_image_device(capi.image_desc(n, n, SPIN, INCL_DEG / 180.0 * math.pi), single[0].data_ptr(), single[1].data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        single_sums = plane_checksums(torch, single)
 
     def step(i):
         for job in jobs:                    # one image per inclination: trace my share, gather (overlapped), rank 0: its band,
@@ -470,6 +484,8 @@ def main():
                 # the image of the previous step is complete on this stream from here on (no drain: that is the claim tested)
                 prev = pipe.full[(pipe.count - 2) % pipe.nbuf]
                 step_hits.append(int((prev[1] > 0).sum().item()))
+                if single is not None:
+                    step_sums.append(plane_checksums(torch, prev) + [bool(torch.equal(prev.view(torch.int32), single.view(torch.int32)))])
 
     def fence():
         pipe.drain()
@@ -574,6 +590,10 @@ def main():
     if check_every_step and rank == 0 and not c5:
         out["hits_of_every_assembled_image"] = step_hits
         ok = ok and all(h == hits_ref for h in step_hits) and len(step_hits) > 0
+        # [checksum of the F g^4 plane, of the g plane (sums of the 32-bit patterns), every word equal to the single launch]
+        out["plane_checksums_single_launch"] = single_sums
+        out["plane_checksums_of_every_assembled_image"] = step_sums
+        ok = ok and len(step_sums) > 0 and all(c[2] and c[:2] == single_sums for c in step_sums)
         out["ok"] = ok
     rays_launch = sum(job.rays for job in jobs)            # rays rank 0 traces per step
     achieved = rays_launch * W_ELL / (kstep * 1e-3) / 1e12

@@ -414,6 +414,11 @@ int sim5gpu_image_row_map(const sim5gpu_image_desc *desc, int *rows, int capacit
 int sim5gpu_image_place_shares(int n_shares, const sim5gpu_image_desc *descs, const float *d_shares, size_t share_rows,
                                float *d_image_f, float *d_image_g, void *stream);
 
+/* Self-check utility of the multi-GPU assembly: the number of 32-bit words in which two DEVICE buffers differ (bit
+ * comparison, synchronous on the default stream) -- an assembled image against a single-launch one without a 134 MB
+ * copy to the host.  No counterpart in the reference (its images live in host memory: memcmp). */
+int sim5gpu_words_differ(const void *d_a, const void *d_b, size_t n_words, unsigned long long *h_count);
+
 /* The caller loop of ref examples/04-disk-image-eqplane/disk-image.c:53-105 as one kernel:
  * image_f = (float)(F g^4), image_g = (float)g, zero where the ray does not hit the disk. */
 int sim5gpu_disk_image(const sim5gpu_image_desc *desc, float *d_image_f, float *d_image_g,

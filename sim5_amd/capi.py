@@ -201,6 +201,13 @@ class DeviceBuffer:
             pass
 
 
+def words_differ(d_a, d_b, n_words):
+    """number of 32-bit words in which two device buffers differ (bit comparison on the device, synchronous)"""
+    n = C.c_ulonglong(0)
+    _check(_lib.sim5gpu_words_differ(VP(d_a), VP(d_b), SZ(int(n_words)), C.byref(n)), "sim5gpu_words_differ")
+    return int(n.value)
+
+
 # ---- batch forms of the SIM5 per-ray API -----------------------------------------------------
 def geodesic_init_inf(incl, a, alpha, beta):
     alpha = _f64(alpha).ravel()

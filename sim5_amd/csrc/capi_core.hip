@@ -606,4 +606,22 @@ int sim5gpu_image_place_shares(int n_shares, const sim5gpu_image_desc* descs, co
     return SIM5GPU_OK;
 }
 
+/* self-check utility: number of 32-bit words in which two DEVICE buffers differ (synchronous; bit comparison) */
+int sim5gpu_words_differ(const void* d_a, const void* d_b, size_t n_words, unsigned long long* h_count)
+{
+    if (!h_count || ((!d_a || !d_b) && n_words)) { snprintf(g_err, sizeof g_err, "words_differ: NULL pointer argument"); return SIM5GPU_E_ARG; }
+    *h_count = 0;
+    if (n_words == 0) return SIM5GPU_OK;
+    if ((((size_t)d_a | (size_t)d_b) & 3) != 0) { snprintf(g_err, sizeof g_err, "words_differ: buffers must be 4-byte aligned"); return SIM5GPU_E_ARG; }
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    DevBuf<unsigned long long> cnt(1);
+    if (!cnt.ok() || !cnt.ptr) { snprintf(g_err, sizeof g_err, "words_differ: device allocation failed"); return SIM5GPU_E_HIP; }
+    if (cnt.pinned) *cnt.ptr = 0; else S5_HIP(hipMemset(cnt.ptr, 0, sizeof(unsigned long long)));
+    hipError_t e = (hipError_t)s5_launch_words_differ(d_a, d_b, n_words, cnt.ptr, nullptr);
+    if (e != hipSuccess) { set_error("words_differ launch", e); return SIM5GPU_E_HIP; }
+    S5_HIP(hipStreamSynchronize(nullptr));
+    S5_HIP(cnt.to_host(h_count));
+    return SIM5GPU_OK;
+}
+
 } // extern "C"

@@ -43,7 +43,38 @@ void place_shares_kernel(PlaceArgs a)
     }
 }
 
+// number of 32-bit words in which two device buffers differ (bit comparison: NaN patterns count like any other word): the
+// self-check of an assembled image against a single-launch one without bringing 134 MB to the host.  HBM-bound, 16-byte loads.
+__global__ __launch_bounds__(256)
+void words_differ_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, unsigned long long* count)
+{
+    unsigned mine = 0;
+    const size_t n4 = ((((size_t)a | (size_t)b) & 15) == 0) ? n / 4 : 0;
+    const uint4* __restrict__ a4 = (const uint4*)a;
+    const uint4* __restrict__ b4 = (const uint4*)b;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const uint4 x = a4[i], y = b4[i];
+        mine += (x.x != y.x) + (x.y != y.y) + (x.z != y.z) + (x.w != y.w);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) mine += (a[i] != b[i]);
+    // one atomic per wave that found something (the usual answer is zero: no atomics at all)
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
+}
+
 } // namespace s5asm
+
+int s5_launch_words_differ(const void* a, const void* b, size_t n_words, unsigned long long* d_count, hipStream_t stream)
+{
+    using namespace s5asm;
+    if (n_words == 0) return 0;
+    size_t blocks = (n_words / 4 + 1023) / 1024;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(words_differ_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint32_t*)a, (const uint32_t*)b, n_words, d_count);
+    return (int)hipGetLastError();
+}
 
 int s5_launch_place_shares(int n_shares, const s5abi::RowMap* maps, const float* shares, size_t share_rows, int nx,
                            float* image_f, float* image_g, hipStream_t stream)

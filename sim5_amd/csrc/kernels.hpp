@@ -126,6 +126,8 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
 // k_assemble.hip: rows of n shares ([2][share_rows][nx] floats each, share i at shares + i * 2 * share_rows * nx) to their image rows
 int s5_launch_place_shares(int n_shares, const s5abi::RowMap* maps, const float* shares, size_t share_rows, int nx,
                            float* image_f, float* image_g, hipStream_t stream);
+// k_assemble.hip: *d_count += number of 32-bit words in which the two device buffers differ
+int s5_launch_words_differ(const void* a, const void* b, size_t n_words, unsigned long long* d_count, hipStream_t stream);
 int s5_launch_disk_image_polarized_fast(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream_t stream);
 int s5_launch_disk_spectrum_fast(const s5abi::ImageParams& p, const s5abi::SpectrumParams& sp,

@@ -63,6 +63,9 @@ def test_two_ranks_on_one_gpu(mode, band):
         assert pr["assemblies_in_timed_region"] == 3
         hs = o["hits_of_every_assembled_image"]
         assert len(hs) >= 3 and all(h == 15865362 for h in hs), hs
+        # ... and is the single-launch image BIT FOR BIT (checksums of both planes + a word-by-word comparison on the device)
+        cs = o["plane_checksums_of_every_assembled_image"]
+        assert len(cs) == len(hs) and all(c[2] is True and c[:2] == o["plane_checksums_single_launch"] for c in cs), cs
         assert o["value_kernel_only"] > o["value"] > 0 and o["kernel_ms_per_step_max_over_ranks"] == max(pr["kernel_ms_per_step"])
         plan = pr["root_band_plan"]
         dealt = plan["dealt_rows_of_upper_half"]
@@ -95,6 +98,8 @@ def test_four_ranks_on_one_gpu():
     pr = o["per_rank"]
     assert len(pr["kernel_ms_per_step"]) == 4 and sum(pr["rays_per_launch"]) == 4096 * 4096
     assert all(h == 15865362 for h in o["hits_of_every_assembled_image"]) and len(o["hits_of_every_assembled_image"]) >= 3
+    cs = o["plane_checksums_of_every_assembled_image"]
+    assert len(cs) >= 3 and all(c[2] is True and c[:2] == o["plane_checksums_single_launch"] for c in cs), cs
     dealt = pr["root_band_plan"]["dealt_rows_of_upper_half"]
     assert dealt % 256 == 0 and pr["rays_per_launch"][1] == pr["rays_per_launch"][2] == pr["rays_per_launch"][3] == dealt // 2 * 4096
 

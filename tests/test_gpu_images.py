@@ -14,9 +14,32 @@ pytestmark = pytest.mark.gpu
 HIT = (2, 4)
 
 
+def production_planes_equal(capi, d, out):
+    """The instantiation every production job runs -- no full-precision planes: disk_image_mirror_kernel<false> /
+    disk_image_grid_kernel<false>, the one bench.py, the sharded path and every caller without aux planes launch -- gives
+    the two f32 planes of the aux instantiation bit for bit (the benchmarked kernel was never
+    value-checked, only counted)."""
+    prod = capi.disk_image(d, full=False)
+    for k in ("image_f", "image_g"):
+        assert np.array_equal(prod[k].view(np.uint32), out[k].view(np.uint32)), \
+            "production instantiation: %s differs on %d pixels" % (k, int((prod[k].view(np.uint32) != out[k].view(np.uint32)).sum()))
+
+
+def image_both(capi, d):
+    """the job with the full-precision planes, after checking that the production instantiation gives the same f32 planes"""
+    out = capi.disk_image(d, full=True)
+    production_planes_equal(capi, d, out)
+    return out
+
+
 def run(capi, n, a, inc_deg, full=True, y0=0, y1=None, **kw):
+    """full=True: the aux instantiation (class, type, r, g, flux planes for the comparisons) AND the production one, whose
+    f32 planes must be the same bits -- so every golden / live-reference comparison below holds for the kernel that is timed."""
     d = capi.image_desc(n, n, a, inc_deg / 180.0 * math.pi, y0=y0, y1=y1, **kw)
-    return capi.disk_image(d, full=full)
+    out = capi.disk_image(d, full=full)
+    if full:
+        production_planes_equal(capi, d, out)
+    return out
 
 
 def flux_floor(flux):
@@ -150,7 +173,7 @@ def test_mirrored_pairs_give_the_plain_image(capi):
         for (y0, y1) in [(0, ny), (ny // 3, ny - ny // 3)]:
             if y1 - y0 < 2:
                 continue
-            mk = lambda lo, hi: capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), y0=lo, y1=hi, max_order=order), full=True)
+            mk = lambda lo, hi: image_both(capi, capi.image_desc(nx, ny, a, math.radians(inc), y0=lo, y1=hi, max_order=order))
             sym = mk(y0, y1)
             cut = y0 + (y1 - y0) // 2 + 1                       # asymmetric pieces: the plain kernel
             top, bot = mk(y0, cut), mk(cut, y1)
@@ -170,11 +193,13 @@ def test_random_image_shapes_and_parameters(capi):
       * a symmetric row range (the pairing kernel) gives the plain kernel's image bit for bit;
       * fast and strict variants: identical classes, r and g within 1e-7, flux within 1e-6 of max(F, 1e-9 F_peak);
       * strict variant and CPU oracle: identical classes, r within 1e-9.
-    Left out of the class comparisons, and counted: the central column of an odd-width image and the central row of an
-    odd-height one.  On the column alpha = 0 exactly, so l = 0 and the radial quartic is degenerate; on the row beta = 0 (the
-    reference replaces it by 1e-6), the observer sits on the polar turning point and the test |cos i| > sqrt(m2p) is decided
-    by rounding.  The reference's own class there is rounding noise (the oracle's, the strict and the fast variant's patterns
-    all differ: different libm, same algorithm)."""
+    Left out of the class comparisons, and counted: the central column of an odd-width image.  There alpha = 0 exactly, so
+    l = 0 and the radial quartic is degenerate: the LIVE reference changes its own class on 10 - 55 % of that column when its
+    spin or inclination moves by one unit in the last place, and on no other pixel (test_degenerate_sets_against_the_live_
+    reference, profiles/r04_degenerate_sets_vs_live_reference.json).  The central ROW of an odd height (beta = 0, which the
+    reference replaces by 1e-6) was left out as well until round 4; against the live reference both variants have the
+    reference's class on every pixel of it, so it is compared like any other row (values there: r within 1e-5 only -- the
+    inverse cn is evaluated at its square-root singularity -- so the VALUE comparisons below leave that row out)."""
     rng = np.random.default_rng(2026)
     col_px = col_diff = 0
     for case in range(40):
@@ -184,8 +209,8 @@ def test_random_image_shapes_and_parameters(capi):
         order = int(rng.choice([1, 2]))
         rmax = float(rng.choice([0.0, rng.uniform(3.0, 60.0)]))
         what = (case, a, inc, nx, ny, order, rmax)
-        mk = lambda lo, hi, strict=False: capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), y0=lo, y1=hi,
-                                                                      max_order=order, rmax=rmax, strict=strict), full=True)
+        mk = lambda lo, hi, strict=False: image_both(capi, capi.image_desc(nx, ny, a, math.radians(inc), y0=lo, y1=hi,
+                                                                           max_order=order, rmax=rmax, strict=strict))
         sym = mk(0, ny)
         cut = ny // 2 + 1 if ny > 2 else 1
         top, bot = mk(0, cut), mk(cut, ny)
@@ -195,11 +220,12 @@ def test_random_image_shapes_and_parameters(capi):
         col = np.ones((ny, nx), bool)
         if nx % 2 == 1:
             col[:, nx // 2] = False
-        if ny % 2 == 1:
-            col[ny // 2, :] = False
         col_px += int((~col).sum()); col_diff += int((st["cls"] != sym["cls"])[~col].sum())
         assert np.array_equal(st["cls"][col], sym["cls"][col]), what
-        ok = np.isfinite(st["r"]) & col
+        val = col.copy()
+        if ny % 2 == 1:
+            val[ny // 2, :] = False
+        ok = np.isfinite(st["r"]) & val
         if ok.any():
             assert np.abs(sym["r"][ok] / st["r"][ok] - 1).max() < 1e-7 and np.abs(sym["g"][ok] - st["g"][ok]).max() < 1e-7, what
             fl = np.maximum(np.abs(st["flux"][ok]), 1e-9 * np.abs(st["flux"]).max() + 1e-300)
@@ -207,10 +233,76 @@ def test_random_image_shapes_and_parameters(capi):
         if order == 2 and rmax == 0.0 and nx * ny <= 40000:
             c = ol.cpu_disk_image("port", nx, ny, a, inc, nthreads=8, full=True)
             assert np.array_equal(c["cls"][col], st["cls"][col]), what
-            ok = np.isfinite(c["r"]) & col
+            ok = np.isfinite(c["r"]) & val
             if ok.any():
                 assert np.abs(st["r"][ok] / c["r"][ok] - 1).max() < 1e-9, what
     print("central columns / rows (alpha = 0, beta = 0): %d pixels, fast and strict classes differ on %d" % (col_px, col_diff))
+
+
+DEGENERATE_JOBS = [(0.9, 60.0, 201, 128), (0.998, 70.0, 301, 200), (0.5, 30.0, 151, 100), (0.0, 45.0, 99, 64),
+                   (0.9, 60.0, 128, 201), (0.998, 70.0, 200, 301), (0.5, 30.0, 100, 151), (0.0, 45.0, 64, 99), (0.7, 80.0, 255, 255)]
+
+
+def degenerate_sets_report(capi):
+    """The two degenerate pixel sets -- central column of an odd width (alpha = 0 exactly), central row of an odd height
+    (beta = 0, which the reference replaces by 1e-6) -- against the LIVE reference (third bullet), job by job:
+      * classes of the fast and of the strict variant against the reference's, on the set and off it;
+      * how the REFERENCE's own classes move when its spin or inclination is changed by one to three units in the last
+        place (twelve probes): pixels of the set that flip in at least one probe, and pixels off the set that do (none ever did)."""
+    import os
+    rows = []
+    for (a, inc, nx, ny) in DEGENERATE_JOBS:
+        ref = ol.cpu_disk_image("reference", nx, ny, a, inc, nthreads=min(16, os.cpu_count() or 1), full=True)
+        sel_col = np.zeros((ny, nx), bool); sel_row = np.zeros((ny, nx), bool)
+        if nx % 2:
+            sel_col[:, nx // 2] = True
+        if ny % 2:
+            sel_row[ny // 2, :] = True
+        flips = np.zeros((ny, nx), bool)
+        probes = []
+        for k in (1, 2, 3):                                  # spin and inclination (degrees) moved by 1, 2, 3 units in the last place
+            au, ad, iu, idn = a, a, inc, inc
+            for _ in range(k):
+                au, ad, iu, idn = np.nextafter(au, 1), np.nextafter(ad, -1), np.nextafter(iu, 90), np.nextafter(idn, 0)
+            probes += [(au, inc), (ad, inc), (a, iu), (a, idn)]
+        for a2, inc2 in probes:
+            if a2 < 0:
+                continue
+            p = ol.cpu_disk_image("reference", nx, ny, float(a2), float(inc2), nthreads=min(16, os.cpu_count() or 1), full=True)
+            flips |= (p["cls"] != ref["cls"])
+        rec = {"a": a, "incl_deg": inc, "nx": nx, "ny": ny}
+        off = ~(sel_col | sel_row)
+        rec["reference_flips_under_1_to_3_ulp_of_spin_or_inclination"] = {"column": int(flips[sel_col].sum()), "row": int(flips[sel_row].sum()), "elsewhere": int(flips[off].sum())}
+        for strict in (False, True):
+            o = capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), strict=strict), full=True)
+            d = o["cls"] != ref["cls"]
+            rec["strict" if strict else "fast"] = {"column_px": int(sel_col.sum()), "column_differs": int(d[sel_col].sum()),
+                                                    "column_differs_where_reference_is_stable": int((d & ~flips)[sel_col].sum()),
+                                                    "row_px": int(sel_row.sum()), "row_differs": int(d[sel_row].sum()),
+                                                    "row_differs_where_reference_is_stable": int((d & ~flips)[sel_row].sum()),
+                                                    "elsewhere_differs": int(d[off].sum())}
+        rows.append(rec)
+    return rows
+
+
+def test_degenerate_sets_against_the_live_reference(capi):
+    """What the class comparisons of the randomised tests leave out, shown against the unmodified reference run live on this
+    box: off the two sets every class is the reference's; on them the record says how often the variants differ from it, and
+    how often the reference differs from ITSELF for one ulp of its own inputs.  The record goes to gpurun_out/ (committed
+    under profiles/)."""
+    import json, os
+    if not ol.have_reference():
+        pytest.skip("oracle/_ref/libsim5ref.so is not on this box")
+    rows = degenerate_sets_report(capi)
+    print("degenerate sets vs live reference:", json.dumps(rows))
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(outdir):
+        with open(os.path.join(outdir, "degenerate_sets_vs_live_reference.json"), "w") as fh:
+            json.dump(rows, fh, indent=1)
+    for rec in rows:
+        assert rec["reference_flips_under_1_to_3_ulp_of_spin_or_inclination"]["elsewhere"] == 0, rec
+        for v in ("fast", "strict"):
+            assert rec[v]["elsewhere_differs"] == 0, rec
 
 
 def test_fast_and_strict_variants_agree(capi):
@@ -335,7 +427,7 @@ def test_striped_launch_equals_separate_stripes(capi, strict):
                 continue
             d = capi.image_desc(n, n, a, inc / 180.0 * math.pi, strict=strict, **kw)
             assert capi.image_rows(d) == sharding.local_rows(n, rank, world)
-            t = capi.disk_image(d, full=True)
+            t = image_both(capi, d)
             rows = sharding.stripes_for_rank(n, rank, world)
             for k in ("image_g", "image_f", "cls", "r", "flux"):
                 ref = np.concatenate([whole[k][y0:y1] for (y0, y1) in rows])
@@ -464,13 +556,74 @@ def test_in_place_rows_and_share_placement(capi):
         assert np.array_equal(got, want), (nx, ny, world, dealt, int((got != want).sum()))
 
 
+def test_words_differ_utility(capi):
+    """sim5gpu_words_differ counts differing 32-bit words (NaN patterns included), aligned and unaligned lengths"""
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 4, 1023, 1 << 16, (1 << 20) + 5):
+        x = rng.integers(0, 2 ** 32, n, dtype=np.uint32)
+        y = x.copy()
+        k = min(n, 17)
+        idx = rng.choice(n, k, replace=False)
+        y[idx] ^= 0x80000000
+        a, b = capi.DeviceBuffer(4 * n), capi.DeviceBuffer(4 * n)
+        a.from_numpy(x); b.from_numpy(y)
+        assert capi.words_differ(a.ptr, a.ptr, n) == 0 and capi.words_differ(a.ptr, b.ptr, n) == k
+    nan = capi.DeviceBuffer(4096); nan.fill(0xff)
+    assert capi.words_differ(nan.ptr, nan.ptr, 1024) == 0
+
+
+@pytest.mark.parametrize("world,band", [(2, False), (2, True), (4, False), (4, True), (8, False), (8, True)])
+def test_rank0_inplace_share_stress(capi, world, band):
+    """VERDICT r3 item 1b / ADVICE r3: rank 0's share of the 4096^2 headline image for the world-2/4/8 plans -- striped,
+    mirrored, written IN PLACE into a whole-image buffer by the production instantiation (no aux planes), the launch mode in
+    which a build with one spilled register once produced 8 wrong pixels and a memory fault -- 200 launches each, every one
+    compared bit for bit on the device with those rows of the single-launch image; rows of other ranks must keep the NaN
+    pattern the buffer was filled with.  With a root band (`band`: the plan of bench.py --root-band, here a quarter of the
+    upper half dealt) the band launch into the same buffer is part of every iteration."""
+    from sim5_amd import sharding
+    n, a, inc = 4096, 0.998, math.radians(70.0)
+    plane = n * n * 4
+    dealt = 512 if band else None
+    whole = capi.DeviceBuffer(2 * plane)
+    capi.disk_image_device(capi.image_desc(n, n, a, inc), whole.ptr, whole.ptr + plane)
+    capi.synchronize()
+    w = whole.to_numpy(np.float32, (2, n, n))
+    assert int((w[1] > 0).sum()) == 15865362
+    own = np.zeros(n, bool)
+    for (y0, y1) in sharding.stripes_for_rank(n, 0, world, dealt=dealt):
+        own[y0:y1] = True
+    rb = sharding.root_band(n, dealt)
+    if rb:
+        own[rb[0]:rb[1]] = True
+    assert band == bool(rb) and 0 < own.sum() < n
+    want = np.full((2, n, n), np.nan, np.float32).view(np.uint32)
+    want[:] = 0xffffffff
+    want[:, own] = w.view(np.uint32)[:, own]
+    expect = capi.DeviceBuffer(2 * plane); expect.from_numpy(want)
+    del w, want
+    kw = sharding.job_rows(n, 0, world, dealt=dealt)
+    d0 = capi.image_desc(n, n, a, inc, inplace=True, **kw)
+    db = capi.image_desc(n, n, a, inc, y0=rb[0], y1=rb[1]) if rb else None
+    buf = capi.DeviceBuffer(2 * plane)
+    bad = []
+    for it in range(200):
+        buf.fill(0xff)
+        capi.disk_image_device(d0, buf.ptr, buf.ptr + plane)
+        if db is not None:
+            capi.disk_image_device(db, buf.ptr + rb[0] * n * 4, buf.ptr + plane + rb[0] * n * 4)
+        nd = capi.words_differ(buf.ptr, expect.ptr, 2 * n * n)
+        if nd:
+            bad.append((it, nd))
+    assert not bad, "in-place share of rank 0 (world %d, band %s): %d of 200 launches differ, first %s" % (world, band, len(bad), bad[:5])
+
+
 @pytest.mark.parametrize("a,inc,n,order", [(0.998, 70.0, 512, 2), (0.9, 70.0, 384, 2), (0.0, 60.0, 64, 1), (0.9999, 83.0, 200, 2), (0.5, 20.0, 300, 2)])
 def test_direct_flag_runs_the_direct_routine_everywhere(capi, a, inc, n, order):
     """SIM5GPU_IMG_DIRECT sends every ray of the fast variant through the routine that the default one hands a few rays
     per million to (radial integral by R_F, the reference's comparisons with Rpc): that path is exercised on whole images
     here -- same classes as the default routine and as the strict variant, r and g within 1e-9, flux within 1e-6; the
     polarized kernel's Stokes planes likewise."""
-    mk = lambda **kw: capi.disk_image(capi.image_desc(n, n, a, math.radians(inc), max_order=order, **kw), full=True)
+    mk = lambda **kw: image_both(capi, capi.image_desc(n, n, a, math.radians(inc), max_order=order, **kw))
     f, d, s = mk(), mk(direct=True), mk(strict=True)
     assert np.array_equal(f["cls"], d["cls"]) and np.array_equal(f["gtype"], d["gtype"])
     assert np.array_equal(s["cls"], d["cls"])
