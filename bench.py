@@ -248,6 +248,48 @@ def plane_checksums(torch, img):
     return [int(v[0].sum().item()), int(v[1].sum().item())]
 
 
+class RankFailure(Exception):
+    pass
+
+
+def agree(dist, torch, cdev, rank, world, ok_local, what, err=None):
+    """Collective-safe abort (N > 1): every rank joins one all-reduce of an error flag at the end of a phase that can fail
+    on one rank alone; if any rank failed, EVERY rank leaves with a non-zero exit code instead of walking into the next
+    collective and waiting for the others until the process-group timeout.  `ok_local` False on this rank: `err` is printed."""
+    if not ok_local:
+        sys.stderr.write("bench.py: rank %d failed in phase '%s': %s\n" % (rank, what, err))
+        sys.stderr.flush()
+    if world <= 1:
+        if not ok_local:
+            raise RankFailure(what)
+        return
+    t = torch.tensor([0.0 if ok_local else 1.0], dtype=torch.float32, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if float(t.item()) > 0.0:
+        if rank == 0:
+            print(json.dumps({"ok": False, "error": "a rank failed in phase '%s' (see stderr); all %d ranks stopped before the next collective" % (what, world),
+                              "n_gpus": world}))
+            sys.stdout.flush()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        sys.exit(3)
+
+
+def guarded(dist, torch, cdev, rank, world, what, fn):
+    """fn() on this rank, then the agreement above: an exception on one rank stops all ranks (fn must not contain a
+    collective that the failing rank would skip -- a phase that does is bounded by the process-group timeout instead)"""
+    try:
+        out = fn()
+        err = None
+    except Exception as e:                                 # noqa: BLE001 -- reported, and every rank leaves
+        import traceback
+        out, err = None, "%r\n%s" % (e, traceback.format_exc())
+    agree(dist, torch, cdev, rank, world, err is None, what, err)
+    return out
+
+
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
@@ -432,22 +474,43 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     from sim5_amd.build import build
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu_test:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if rank == 0:
-        build()                             # no-op when the in-tree library is up to date
-    if world > 1:
-        dist.barrier()                      # nobody loads the library while rank 0 may be writing it
-    import sim5_amd.capi as capi            # raises if libsim5gpu.so is missing
-    from sim5_amd import sharding
-    capi.set_device(local_rank)
-
     dev = torch.device("cuda", local_rank)
     cdev = "cpu" if one_gpu_test else dev   # where small control tensors of a collective live
+    if world > 1:
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # every collective of this program is bounded: a rank that dies or never arrives ends the job after `timeout`
+        # (RCCL's watchdog aborts the communicator and the process) instead of holding the node
+        timeout = datetime.timedelta(seconds=float(os.environ.get("SIM5_BENCH_TIMEOUT_S", "180")))
+        if one_gpu_test:
+            dist.init_process_group("gloo", timeout=timeout)
+        else:
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")       # a timed-out collective tears the process down
+            dist.init_process_group("nccl", device_id=dev, timeout=timeout)
+    # rank 0 builds (a no-op when the in-tree library is up to date); nobody loads the library while it may be written
+    guarded(dist, torch, cdev, rank, world, "build", (lambda: build()) if rank == 0 else (lambda: None))
+
+    def load():
+        import sim5_amd.capi as capi_       # raises if libsim5gpu.so is missing
+        capi_.set_device(local_rank)
+        return capi_
+    capi = guarded(dist, torch, cdev, rank, world, "load libsim5gpu.so", load)
+    from sim5_amd import sharding
+    # who takes part: world size as the process group reports it, and every rank's device (PCI bus id) -- "RCCL saw N ranks
+    # on N distinct GPUs" is in the record, not assumed
+    me = {"rank": rank, "local_rank": local_rank, "device_index": local_rank, "pci_bus_id": capi.device_bus_id(local_rank),
+          "device_name": torch.cuda.get_device_name(local_rank), "pid": os.getpid()}
+    if world > 1:
+        roster = [None] * world
+        dist.all_gather_object(roster, me)
+        group = {"world_size_reported_by_process_group": dist.get_world_size(), "backend": dist.get_backend(),
+                 "ranks": roster, "distinct_devices": len({r["pci_bus_id"] for r in roster}),
+                 "collective_timeout_s": timeout.total_seconds()}
+        if not one_gpu_test:
+            agree(dist, torch, cdev, rank, world, group["distinct_devices"] == world and group["world_size_reported_by_process_group"] == world,
+                  "one GPU per rank", "ranks share a device: %r" % [r["pci_bus_id"] for r in roster])
+    else:
+        group = {"world_size_reported_by_process_group": 1, "backend": None, "ranks": [me], "distinct_devices": 1}
     stream = torch.cuda.current_stream().cuda_stream
     striped = world > 1 and args.mode == "stripes"
     c5 = args.workload == "c5"
@@ -455,10 +518,22 @@ def main():
     inclinations = C5_INCLINATIONS if c5 else (INCL_DEG,)
     dealt, plan = None, None
     if striped:
+        # preflight (no collective inside): this rank can allocate and trace a share of the image at all; a rank that cannot
+        # stops everybody here, before the first gather
+        def preflight():
+            job = ImageJob(capi, sharding, n, INCL_DEG, rank, world, True, stream)
+            buf = torch.zeros((2, n if rank == 0 else max(1, sharding.max_local_rows(n, world)), n), dtype=torch.float32, device=dev)
+            job.trace(buf, rank == 0)
+            torch.cuda.synchronize()
+        guarded(dist, torch, cdev, rank, world, "preflight: trace one share", preflight)
         dealt, plan = plan_root_band(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, one_gpu_test, args.root_band)
-    jobs = [ImageJob(capi, sharding, n, inc, rank, world, striped, stream, dealt=dealt) for inc in inclinations]
-    pipe = sharding.TilePipeline(torch, dist, rank, world if striped else 1, n, n, dev, host_staged=one_gpu_test, dealt=dealt,
-                                 place=make_placer(capi, sharding, n, world, dealt, stream) if (striped and rank == 0) else None)
+
+    def make_jobs():
+        jobs_ = [ImageJob(capi, sharding, n, inc, rank, world, striped, stream, dealt=dealt) for inc in inclinations]
+        pipe_ = sharding.TilePipeline(torch, dist, rank, world if striped else 1, n, n, dev, host_staged=one_gpu_test, dealt=dealt,
+                                      place=make_placer(capi, sharding, n, world, dealt, stream) if (striped and rank == 0) else None)
+        return jobs_, pipe_
+    jobs, pipe = guarded(dist, torch, cdev, rank, world, "allocate the image and gather buffers", make_jobs)
     cold_ms = None
     if world == 1 and not c5:
         # what a caller sees who renders ONE image on an idle GPU: after the first launch (code and tables are loaded) the
@@ -526,6 +601,9 @@ def main():
         kstep_max = max(float(v[1].item()) for v in allv)
         per_rank = {"kernel_ms_per_step": [float(v[1].item()) for v in allv],
                     "rays_per_launch": [sharding.rank_rows(n, r, world, dealt=dealt) * n if striped else n * n for r in range(world)]}
+    # the timed region is over on every rank (the all_gather above); the phases below are optional measurements, each entered
+    # only after all ranks have agreed that they are still sound
+    agree(dist, torch, cdev, rank, world, bool(kstep == kstep), "timed region", "kernel timing is NaN")
     # one gather on its own (not overlapped), after the timed region: the exchange time next to the compute time
     if striped:
         last = pipe.last_image().clone() if rank == 0 else None      # the measurement below reuses buffer 0
@@ -540,10 +618,11 @@ def main():
             per_rank["place_ms_alone"] = timed_kernel(capi, stream, lambda: pl(src, pipe.full[0]), 10, 2)
             per_rank["assemblies_in_timed_region"] = args.steps * len(inclinations)
         per_rank["root_band_plan"] = plan
+    c5_scan = None
+    if world > 1 and not args.no_extra and not c5 and striped:
+        # collective: every rank enters it, and every rank learns whether all came through
+        c5_scan = run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, dealt_4096=dealt)
     if rank != 0:
-        extra = None
-        if world > 1 and not args.no_extra and not c5 and striped:
-            run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, dealt_4096=dealt)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -632,8 +711,26 @@ def main():
                 "they share l, q, the roots and the three R_F integrals -- and reads the flux and K(m) from tables, so it "
                 "EXECUTES fewer FP64 operations per ray than the algorithmic count: executed_* is the hardware-utilisation figure",
     }
+    out["process_group"] = group
     if per_rank:
         out["per_rank"] = per_rank
+    if striped and plan:
+        # Why `value` does not follow the GPU count: a gather to ONE GPU moves (N-1)/N of every image over rank 0's inbound
+        # xGMI links, one link per peer, and a GPU writes image rows several times faster than a link carries them
+        # (DESIGN.md 8).  The plan's prediction for the chosen split (from the kernel and gather times measured before the
+        # timed region) next to what the timed region measured; the kernels themselves scale with the rows (value_kernel_only).
+        cand = (plan.get("candidates_dealt_rows") or {}).get(str(dealt))
+        measured = 1e3 * dt / args.steps / len(inclinations)
+        out["link_bound"] = {
+            "predicted_ms_per_image": cand["predicted_step_ms"] if cand else None,
+            "predicted_root_trace_ms": cand["root_trace_ms"] if cand else None,
+            "predicted_peer_gather_ms": cand["peer_gather_ms"] if cand else None,
+            "measured_ms_per_image": measured,
+            "kernel_ms_per_image_slowest_rank": kstep_max / len(inclinations),
+            "gather_ms_alone": per_rank.get("gather_ms_alone"),
+            "one_gpu_kernel_ms_full_image": plan.get("kernel_ms_full_image"),
+            "statement": "gather-to-root over point-to-point xGMI: beyond N = 2 the step is bound by the inbound links of rank 0, "
+                         "not by tracing; value_kernel_only is the rate of the kernels alone"}
     if not args.no_extra and not c5:
         try:
             if world == 1:
@@ -641,8 +738,7 @@ def main():
                 extra["c5_8192_x8_inclinations"] = c5_on_one_gpu(torch, capi, dev, stream)
                 ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
             elif striped:
-                extra = {"c5_8192_x8_inclinations": run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test,
-                                                                dealt_4096=dealt)}
+                extra = {"c5_8192_x8_inclinations": c5_scan}
                 ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
             else:
                 extra = None
@@ -671,9 +767,12 @@ def run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one
     # the plan of the 4096^2 image carries over: kernel and gather times per row both double with the row length, so the
     # balance point is the same fraction of the image
     dealt = None if dealt_4096 is None or dealt_4096 >= sharding.upper_half(4096) else 2 * dealt_4096
-    jobs = [ImageJob(capi, sharding, n, inc, rank, world, True, stream, dealt=dealt) for inc in C5_INCLINATIONS]
-    pipe = sharding.TilePipeline(torch, dist, rank, world, n, n, dev, host_staged=one_gpu_test, dealt=dealt,
-                                 place=make_placer(capi, sharding, n, world, dealt, stream) if rank == 0 else None)
+    def make():
+        jobs_ = [ImageJob(capi, sharding, n, inc, rank, world, True, stream, dealt=dealt) for inc in C5_INCLINATIONS]
+        pipe_ = sharding.TilePipeline(torch, dist, rank, world, n, n, dev, host_staged=one_gpu_test, dealt=dealt,
+                                      place=make_placer(capi, sharding, n, world, dealt, stream) if rank == 0 else None)
+        return jobs_, pipe_
+    jobs, pipe = guarded(dist, torch, cdev, rank, world, "C5 scan: allocate 8192^2 buffers", make)
     ref = reference_hits_c5()
     hits = {}
 

@@ -2,7 +2,9 @@
  * disk_image_sharded.c -- the thin-disk image of the reference example (ref examples/04-disk-image-eqplane/disk-image.c:
  * 53-105) on N GPUs from C: one process per GPU, each tracing its mirrored row stripes, ONE RCCL gather per image, the
  * image assembled on rank 0 (include/sim5gpu_rccl.h).  The ranks find each other through a file that rank 0 writes the
- * 128-byte communicator id to; start them before anything touches the GPU, e.g.
+ * 128-byte communicator id to.  The file's name carries a per-run nonce -- SIM5_EXAMPLE_NONCE, or the parent process id,
+ * which the ranks of one shell loop share -- and rank 0 removes it before it writes and when it exits, so a second run of
+ * the same command never reads the id of the first.  Start the ranks before anything touches the GPU, e.g.
  *
  *     for r in 0 1 2 3 4 5 6 7; do HIP_VISIBLE_DEVICES=$r ./disk_image_sharded $r 8 /tmp/s5.id 0.998 70 4096 20 & done; wait
  *
@@ -32,7 +34,12 @@ int main(int argc, char **argv)
 {
     if (argc < 4) { fprintf(stderr, "usage: %s rank world id-file [spin incl_deg n images]\n", argv[0]); return 2; }
     const int rank = atoi(argv[1]), world = atoi(argv[2]);
-    const char *idfile = argv[3];
+    char idfile[4096];
+    {
+        const char *nonce = getenv("SIM5_EXAMPLE_NONCE");
+        if (nonce && *nonce) snprintf(idfile, sizeof idfile, "%s.%s", argv[3], nonce);
+        else snprintf(idfile, sizeof idfile, "%s.%ld", argv[3], (long)getppid());
+    }
     const double a = argc > 4 ? atof(argv[4]) : 0.998, inc = (argc > 5 ? atof(argv[5]) : 70.0) / 180.0 * M_PI;
     const int n = argc > 6 ? atoi(argv[6]) : 4096, images = argc > 7 ? atoi(argv[7]) : 10;
     char id[SIM5GPU_RCCL_ID_BYTES];
@@ -41,7 +48,8 @@ int main(int argc, char **argv)
 
     if (world > 1) {
         if (rank == 0) {                                  /* the id travels through a file: write, then rename into place */
-            char tmp[4096];
+            char tmp[4200];
+            unlink(idfile);                               /* a file left by a run that died: never handed to this run's peers */
             CHECK(sim5gpu_rccl_unique_id(id));
             snprintf(tmp, sizeof tmp, "%s.tmp", idfile);
             FILE *f = fopen(tmp, "wb");
@@ -84,7 +92,7 @@ int main(int argc, char **argv)
         if (i > 0) CHECK(sim5gpu_shard_image_end(sh, NULL));
         STAGE("image begun");
     }
-    CHECK(sim5gpu_shard_image_end(sh, NULL));
+    if (images > 0) CHECK(sim5gpu_shard_image_end(sh, NULL));
     CHECK(sim5gpu_synchronize(NULL));
     const double dt = now() - t0;
     STAGE("timed images done");
@@ -94,7 +102,7 @@ int main(int argc, char **argv)
         long hits = 0;
         for (size_t i = 0; i < (size_t)n * n; i++) hits += g[i] > 0.0f;
         printf("ranks %d  image %d x %d  rows on rank 0: %d  images %d  %.3f ms per image  %.4e rays/s  disk hits %ld\n",
-               world, n, n, rows, images, 1e3 * dt / images, (double)n * n * images / dt, hits);
+               world, n, n, rows, images, images > 0 ? 1e3 * dt / images : 0.0, images > 0 ? (double)n * n * images / dt : 0.0, hits);
         free(g);
         fflush(stdout);
         sim5gpu_free(d_f); sim5gpu_free(d_g);
@@ -102,5 +110,6 @@ int main(int argc, char **argv)
     STAGE("image planes released");
     CHECK(sim5gpu_shard_destroy(sh));
     if (comm) CHECK(sim5gpu_rccl_comm_destroy(comm));
+    if (world > 1 && rank == 0) unlink(idfile);           /* every peer has joined the communicator by now */
     return 0;
 }

@@ -414,6 +414,14 @@ int sim5gpu_image_row_map(const sim5gpu_image_desc *desc, int *rows, int capacit
 int sim5gpu_image_place_shares(int n_shares, const sim5gpu_image_desc *descs, const float *d_shares, size_t share_rows,
                                float *d_image_f, float *d_image_g, void *stream);
 
+/* A job description checked as the image launchers check it (geometry, striping, mirror rows, disk parameters): host
+ * arithmetic only, no GPU.  0 or SIM5GPU_E_ARG with the reason in sim5gpu_last_error(). */
+int sim5gpu_image_desc_check(const sim5gpu_image_desc *desc);
+
+/* PCI bus id of a HIP device as text ("0000:05:00.0", len >= 16): lets the ranks of a multi-process job show that
+ * they run on distinct GPUs. */
+int sim5gpu_device_bus_id(int device, char *buf, int len);
+
 /* Self-check utility of the multi-GPU assembly: the number of 32-bit words in which two DEVICE buffers differ (bit
  * comparison, synchronous on the default stream) -- an assembled image against a single-launch one without a 134 MB
  * copy to the host.  No counterpart in the reference (its images live in host memory: memcmp). */

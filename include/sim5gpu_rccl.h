@@ -56,12 +56,19 @@ int sim5gpu_shard_destroy(sim5gpu_shard *shard);
  *   end:    `stream` waits for the gather of the OLDEST image begun, rank 0 puts the peers' rows at their image rows
  *           (sim5gpu_image_place_shares): work enqueued on `stream` after end() sees that image complete.
  * Two images may be in flight: begin(i+1) before end(i) overlaps the gather of image i with the tracing of image i+1.
- * sim5gpu_disk_image_sharded = begin + end. */
+ * sim5gpu_disk_image_sharded = begin + end.
+ * Failure modes: begin() validates the description and this rank's launches before it enqueues anything -- every rank
+ * applies the same tests to the same description, so a refused image is refused by all and no collective is entered.  A
+ * HIP error after that point is reported, but the rank still joins the gather (its peers are never left waiting); the
+ * shard is then marked (sim5gpu_shard_poisoned) and the image in that slot holds invalid rows of this rank: callers agree
+ * on the status across ranks (MPI_Allreduce of the return codes, ...) before they use an image.  The whole-image
+ * description may carry SIM5GPU_IMG_STRICT and SIM5GPU_IMG_DIRECT; both reach every launch of the split. */
 int sim5gpu_shard_image_begin(sim5gpu_shard *shard, const sim5gpu_image_desc *image, float *d_image_f, float *d_image_g,
                               void *stream);
 int sim5gpu_shard_image_end(sim5gpu_shard *shard, void *stream);
 int sim5gpu_disk_image_sharded(sim5gpu_shard *shard, const sim5gpu_image_desc *image, float *d_image_f, float *d_image_g,
                                void *stream);
+int sim5gpu_shard_poisoned(const sim5gpu_shard *shard);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,13 @@ def set_device(dev):
     _check(_lib.sim5gpu_set_device(I(dev)), "sim5gpu_set_device")
 
 
+def device_bus_id(dev):
+    """PCI bus id of a HIP device ("0000:05:00.0")"""
+    buf = C.create_string_buffer(64)
+    _check(_lib.sim5gpu_device_bus_id(I(dev), buf, I(64)), "sim5gpu_device_bus_id")
+    return buf.value.decode()
+
+
 def version():
     return _lib.sim5gpu_version().decode()
 

@@ -570,6 +570,25 @@ int sim5gpu_disk_image_host(const sim5gpu_image_desc* desc, float* h_image_f, fl
     return SIM5GPU_OK;
 }
 
+/* validation of a job description as the image launchers apply it, host arithmetic only (no GPU): 0 or SIM5GPU_E_ARG */
+int sim5gpu_image_desc_check(const sim5gpu_image_desc* desc)
+{
+    ImageParams p;
+    const int rc = fill_image_params(desc, p, true);
+    if (rc) return rc;
+    if (p.nrows <= 0) { snprintf(g_err, sizeof g_err, "image description names no rows"); return SIM5GPU_E_ARG; }
+    return SIM5GPU_OK;
+}
+
+/* PCI bus id of a device ("0000:05:00.0"), so that a multi-process job can show that its ranks sit on distinct GPUs */
+int sim5gpu_device_bus_id(int device, char* buf, int len)
+{
+    if (!buf || len < 16) return SIM5GPU_E_ARG;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipDeviceGetPCIBusId(buf, len, device));
+    return SIM5GPU_OK;
+}
+
 /* image row of every packed output row of a job description (host arithmetic, no GPU): rows[i] for i < min(count, capacity) */
 int sim5gpu_image_row_map(const sim5gpu_image_desc* desc, int* rows, int capacity)
 {

@@ -47,6 +47,7 @@ struct sim5gpu_shard {
     sim5gpu_image_desc peers[16];         // rank 0: job descriptions (row geometry) of ranks 1 .. world-1
     int n_peers;
     unsigned long long begun, ended;
+    int poisoned;                         // a launch of this rank failed after validation: its rows of some image are not valid
 };
 
 extern "C" {
@@ -96,7 +97,12 @@ int sim5gpu_shard_plan(const sim5gpu_image_desc* image, int rank, int world, int
     d.y1 = dealt;
     d.stripe_rows = SIM5GPU_SHARD_STRIPE_ROWS;
     d.stripe_step = world * SIM5GPU_SHARD_STRIPE_ROWS;
-    d.flags = (image->flags & SIM5GPU_IMG_STRICT) | SIM5GPU_IMG_MIRROR | (rank == 0 ? SIM5GPU_IMG_INPLACE : 0);
+    if (image->flags & ~(SIM5GPU_IMG_STRICT | SIM5GPU_IMG_DIRECT)) {
+        snprintf(g_rccl_err, sizeof g_rccl_err, "shard_plan: the whole-image description may carry SIM5GPU_IMG_STRICT and SIM5GPU_IMG_DIRECT only (flags 0x%x)", image->flags);
+        return SIM5GPU_E_ARG;
+    }
+    // the arithmetic variant of the caller's description travels to every launch of the split (share and band)
+    d.flags = (image->flags & (SIM5GPU_IMG_STRICT | SIM5GPU_IMG_DIRECT)) | SIM5GPU_IMG_MIRROR | (rank == 0 ? SIM5GPU_IMG_INPLACE : 0);
     int rows = (d.y0 < d.y1) ? sim5gpu_image_rows(&d) : 0;
     int b0 = 0, b1 = 0;
     if (dealt < half && ny - dealt > dealt) { b0 = dealt; b1 = ny - dealt; }
@@ -183,31 +189,48 @@ int sim5gpu_shard_image_begin(sim5gpu_shard* s, const sim5gpu_image_desc* image,
     if (s->begun - s->ended >= 2) { snprintf(g_rccl_err, sizeof g_rccl_err, "shard_image_begin: two images are in flight already: call shard_image_end"); return SIM5GPU_E_ARG; }
     const int b = (int)(s->begun & 1ull);
     hipStream_t st = (hipStream_t)stream;
-    sim5gpu_image_desc d;
+    // ---- everything that can be refused is checked BEFORE anything is enqueued: a rank that returns from here has not
+    //      touched the collective, and by the same test on the same description every rank returns (or none does)
+    sim5gpu_image_desc d, band;
     int rows, b0, b1, rc;
     if ((rc = sim5gpu_shard_plan(image, s->rank, s->world, s->dealt, &rows, &b0, &b1, &d)) != 0) return rc;
     const bool have_rows = d.y0 < d.y1;
+    const bool have_band = (s->rank == 0 && b1 > b0);
+    {   // the rank-independent part (physics, disk, image size) on the whole-image description, then this rank's own launches
+        if ((rc = sim5gpu_image_desc_check(image)) != 0) return fail_base("shard_image_begin: image description", rc);
+        if (have_rows && (rc = sim5gpu_image_desc_check(&d)) != 0) return fail_base("shard_image_begin: share description", rc);
+        band = *image;
+        band.y0 = b0; band.y1 = b1;
+        if (have_band && (rc = sim5gpu_image_desc_check(&band)) != 0) return fail_base("shard_image_begin: band description", rc);
+    }
+    // ---- from here on the rank ALWAYS joins the gather: a launch that fails now (a HIP error) poisons the shard and is
+    //      reported, but the peers are not left waiting in a collective
+    int bad = 0;
     if (s->rank == 0) {
-        if (have_rows && (rc = sim5gpu_disk_image(&d, d_image_f, d_image_g, nullptr, stream)) != 0) return fail_base("sim5gpu_disk_image (share of rank 0, in place)", rc);
+        if (have_rows && (rc = sim5gpu_disk_image(&d, d_image_f, d_image_g, nullptr, stream)) != 0) bad = fail_base("sim5gpu_disk_image (share of rank 0, in place)", rc);
         s->image_f[b] = d_image_f; s->image_g[b] = d_image_g;
     } else {
         float* pf = s->payload[b];
-        if (have_rows && (rc = sim5gpu_disk_image(&d, pf, pf + (size_t)s->rows_max * (size_t)s->nx, nullptr, stream)) != 0) return fail_base("sim5gpu_disk_image (share)", rc);
+        if (have_rows && (rc = sim5gpu_disk_image(&d, pf, pf + (size_t)s->rows_max * (size_t)s->nx, nullptr, stream)) != 0) bad = fail_base("sim5gpu_disk_image (share)", rc);
     }
     if (s->comm) {                                            // also with a world of one: the collective degenerates, the path is the same
-        HIPCHK(hipEventRecord(s->traced[b], st));
-        HIPCHK(hipStreamWaitEvent(s->comm_stream, s->traced[b], 0));
+        hipError_t e = hipEventRecord(s->traced[b], st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s->comm_stream, s->traced[b], 0);
+        if (e != hipSuccess && !bad) bad = fail_hip("shard_image_begin: event before the gather", e);
         // in place on the root (sendbuff == recvbuff + rank * sendcount): its block is never read
-        NCCLCHK(ncclGather(s->payload[b], s->rank == 0 ? s->payload[b] : nullptr, s->block, ncclFloat, 0, s->comm, s->comm_stream));
-        HIPCHK(hipEventRecord(s->gathered[b], s->comm_stream));
+        const ncclResult_t r = ncclGather(s->payload[b], s->rank == 0 ? s->payload[b] : nullptr, s->block, ncclFloat, 0, s->comm, s->comm_stream);
+        if (r != ncclSuccess) { s->poisoned = 1; return fail_nccl("ncclGather", r); }      // not enqueued: the slot is not in flight
+        s->begun++;                                           // the gather is in flight: the slot is tracked from here, whatever follows
+        e = hipEventRecord(s->gathered[b], s->comm_stream);
+        if (e != hipSuccess && !bad) bad = fail_hip("shard_image_begin: event after the gather", e);
+    } else {
+        s->begun++;
     }
-    if (s->rank == 0 && b1 > b0) {                            // the band, while the gather is in flight
-        sim5gpu_image_desc band = *image;
-        band.y0 = b0; band.y1 = b1;
+    if (have_band && !bad) {                                  // the band, while the gather is in flight
         const size_t off = (size_t)b0 * (size_t)s->nx;
-        if ((rc = sim5gpu_disk_image(&band, d_image_f + off, d_image_g + off, nullptr, stream)) != 0) return fail_base("sim5gpu_disk_image (band)", rc);
+        if ((rc = sim5gpu_disk_image(&band, d_image_f + off, d_image_g + off, nullptr, stream)) != 0) bad = fail_base("sim5gpu_disk_image (band)", rc);
     }
-    s->begun++;
+    if (bad) { s->poisoned = 1; return bad; }                 // the image in this slot is not valid; shard_image_end still has to be called for it
     return SIM5GPU_OK;
 }
 
@@ -230,9 +253,15 @@ int sim5gpu_shard_image_end(sim5gpu_shard* s, void* stream)
 
 int sim5gpu_disk_image_sharded(sim5gpu_shard* s, const sim5gpu_image_desc* image, float* d_image_f, float* d_image_g, void* stream)
 {
-    int rc = sim5gpu_shard_image_begin(s, image, d_image_f, d_image_g, stream);
-    if (rc) return rc;
-    return sim5gpu_shard_image_end(s, stream);
+    if (!s) return SIM5GPU_E_ARG;
+    const unsigned long long before = s->begun;
+    const int rc = sim5gpu_shard_image_begin(s, image, d_image_f, d_image_g, stream);
+    if (rc && s->begun == before) return rc;                  // refused before anything was enqueued
+    const int rc2 = sim5gpu_shard_image_end(s, stream);       // the slot is in flight: it is ended either way
+    return rc ? rc : rc2;
 }
+
+/* 1 if a launch of this rank failed after its gather had been joined (some image holds invalid rows of this rank) */
+int sim5gpu_shard_poisoned(const sim5gpu_shard* s) { return s ? s->poisoned : 0; }
 
 } // extern "C"

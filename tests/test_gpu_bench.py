@@ -31,6 +31,7 @@ def test_single_gpu_line_carries_every_config():
     assert r.returncode == 0, r.stderr[-2000:]
     o = _line(r.stdout)
     assert o["ok"] is True and o["n_gpus"] == 1 and o["config"]["disk_hits"] == 15865362
+    assert o["process_group"]["world_size_reported_by_process_group"] == 1 and len(o["process_group"]["ranks"][0]["pci_bus_id"]) >= 7
     assert o["roofline"]["frac"] > 0.2 and o["roofline"]["rays_per_launch"] == 4096 * 4096
     assert 0.1 < o["roofline"]["executed_frac"] < o["roofline"]["frac"] and "frac_with_counted_flops" not in o["roofline"]
     assert o["cold_clock"]["kernel_ms"] > 0 and "variant" in o["extra"]["c4_1024_torus_verlet"]
@@ -53,7 +54,16 @@ def test_two_ranks_on_one_gpu(mode, band):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     o = _line(r.stdout)
     assert o["ok"] is True and o["n_gpus"] == 2 and o["config"]["disk_hits"] == 15865362
+    # who took part is in the record: world size as the process group reports it, every rank's device by PCI bus id
+    pg = o["process_group"]
+    assert pg["world_size_reported_by_process_group"] == 2 and pg["backend"] == "gloo" and pg["collective_timeout_s"] > 0
+    assert [r["rank"] for r in pg["ranks"]] == [0, 1] and all(len(r["pci_bus_id"]) >= 7 for r in pg["ranks"])
+    assert pg["distinct_devices"] == 1                       # the test hook: both ranks on GPU 0 (the driver's run: N)
     if mode == "stripes":
+        lb = o["link_bound"]
+        assert lb["measured_ms_per_image"] > 0 and lb["kernel_ms_per_image_slowest_rank"] > 0 and "xGMI" in lb["statement"]
+        if band == "auto":
+            assert lb["predicted_ms_per_image"] > 0 and lb["predicted_root_trace_ms"] > 0 and lb["predicted_peer_gather_ms"] > 0
         assert o["scaling"] == "strong" and o["config"]["rays_per_step"] == 4096 * 4096
         pr = o["per_rank"]
         assert len(pr["kernel_ms_per_step"]) == 2 and sum(pr["rays_per_launch"]) == 4096 * 4096
