@@ -284,6 +284,13 @@ int sim5gpu_flat_metric(size_t n, const double *r, const double *m, sim5gpu_metr
 int sim5gpu_flat_metric_contravariant(size_t n, const double *r, const double *m, sim5gpu_metric *metric);
 int sim5gpu_kerr_metric_contravariant(size_t n, const double *a, const double *r, const double *m,
                                       sim5gpu_metric *metric);
+/* kerr_newman_metric / kerr_newman_metric_contravariant / kerr_newman_connection (charge Q;
+ * ref src/sim5kerr.h:49,52,61, src/sim5kerr.c:136-194, 321-397); G is n x 64 as for kerr_connection */
+int sim5gpu_kerr_newman_metric(size_t n, const double *a, const double *Q, const double *r, const double *m,
+                               sim5gpu_metric *metric);
+int sim5gpu_kerr_newman_metric_contravariant(size_t n, const double *a, const double *Q, const double *r, const double *m,
+                                             sim5gpu_metric *metric);
+int sim5gpu_kerr_newman_connection(size_t n, const double *a, const double *Q, const double *r, const double *m, double *G);
 int sim5gpu_flat_connection(size_t n, const double *r, const double *m, double *G);
 
 /* Gamma: -G^i_(jk) U^j V^k for a connection handed in by the caller (ref src/sim5kerr.c:422-440) */

@@ -841,6 +841,38 @@ def kat_boundary():
     save("kat_boundary.npz", **out)
 
 
+def kat_kerr_newman():
+    """kerr_newman_metric / _contravariant / _connection of the unmodified reference (ref src/sim5kerr.h:49,52,61,
+    src/sim5kerr.c:136-194, 321-397) on 500 points: spins 0.1 .. 0.998 (the connection divides by a), charges with
+    a^2 + Q^2 < 1 and Q = 0 (where the routines must reduce to the Kerr ones), radii outside the outer horizon."""
+    L = C.CDLL(ol.REF_SO)
+    D, PM, G444 = ol.D, ol.PM, ol.G444
+    for name, args in (("kerr_newman_metric", [D, D, D, D, PM]), ("kerr_newman_metric_contravariant", [D, D, D, D, PM]),
+                       ("kerr_newman_connection", [D, D, D, D, G444]), ("kerr_metric", [D, D, D, PM]), ("kerr_connection", [D, D, D, G444])):
+        fn = getattr(L, name); fn.restype = None; fn.argtypes = args
+    rng = np.random.default_rng(20261104)
+    n = 500
+    a = rng.choice([0.1, 0.5, 0.9, 0.998], n)
+    Q = np.sqrt(1.0 - a * a) * rng.uniform(0.0, 0.95, n)
+    Q[:60] = 0.0
+    rh = 1.0 + np.sqrt(1.0 - a * a - Q * Q)
+    r = rh * (1.05 + 30.0 * rng.random(n) ** 2)
+    m = rng.uniform(-0.97, 0.97, n)
+    m[60:90] = 0.0
+    km = np.zeros((n, 8)); kmc = np.zeros((n, 8)); kc = np.zeros((n, 64))
+    for i in range(n):
+        g = ol.Metric(); G = G444()
+        L.kerr_newman_metric(a[i], Q[i], r[i], m[i], C.byref(g)); km[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        L.kerr_newman_metric_contravariant(a[i], Q[i], r[i], m[i], C.byref(g)); kmc[i] = np.frombuffer(ol.struct_bytes(g), np.float64)
+        L.kerr_newman_connection(a[i], Q[i], r[i], m[i], G); kc[i] = np.frombuffer(bytes(memoryview(G)), np.float64)
+    # Q = 0: the reference's Kerr-Newman metric is its Kerr metric (same expressions); recorded as a known answer
+    g = ol.Metric(); g2 = ol.Metric()
+    for i in range(60):
+        L.kerr_newman_metric(a[i], 0.0, r[i], m[i], C.byref(g)); L.kerr_metric(a[i], r[i], m[i], C.byref(g2))
+        assert ol.struct_bytes(g) == ol.struct_bytes(g2)
+    save("kat_kerr_newman.npz", a=a, Q=Q, r=r, m=m, metric=km, metric_contra=kmc, connection=kc)
+
+
 def main():
     if not ol.have_reference():
         sys.exit("oracle/_ref/libsim5ref.so missing: run `make -C oracle` in the build container")
@@ -869,6 +901,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "boundary":
             kat_boundary()
             return
+        if len(sys.argv) > 1 and sys.argv[1] == "kerr_newman":
+            kat_kerr_newman()
+            return
         kat_elliptic(ref, rng)
         kat_geodesic(ref, rng)
         kat_kerr(ref, rng)
@@ -883,6 +918,7 @@ def main():
         kat_disk_model()
         kat_vectors(ref)
         kat_boundary()
+        kat_kerr_newman()
     finally:
         os.dup2(saved, 2)
 

@@ -650,6 +650,87 @@ void orc_kerr_metric_contravariant(double a, double r, double m, orc_metric *g)
     g->g03 = -2. * a * r / SD;
 }
 
+/* Kerr-Newman metric (charge Q), covariant and contravariant; ref: src/sim5kerr.c:136-163, 168-194 */
+void orc_kerr_newman_metric(double a, double Q, double r, double m, orc_metric *g)
+{
+    double rQ = SQ(Q), r2 = SQ(r), a2 = SQ(a), m2 = SQ(m);
+    double S = r2 + a2 * m2;
+    double s2_S = (1.0 - m2) / S;
+    g->a = a; g->r = r; g->m = m;
+    g->g00 = -1. + (2.0 * r - rQ) / S;
+    g->g11 = S / (r2 - 2. * r + a2 + rQ);
+    g->g22 = S;
+    g->g33 = ((a2 + r2) * S + (2. * r - rQ) * a2 * s2_S * S) * s2_S;
+    g->g03 = -a * (2. * r - rQ) * s2_S;
+}
+
+void orc_kerr_newman_metric_contravariant(double a, double Q, double r, double m, orc_metric *g)
+{
+    double rQ = SQ(Q), r2 = SQ(r), a2 = SQ(a), m2 = SQ(m);
+    double S = r2 + a2 * m2;
+    double SD = S * (r2 - 2. * r + a2 + rQ);
+    g->a = a; g->r = r; g->m = m;
+    g->g00 = -SQ(r2 + a2) / SD + a2 * (1. - m2) / S;
+    g->g11 = (r2 - 2. * r + a2 + rQ) / S;
+    g->g22 = 1. / S;
+    g->g33 = 1. / S / (1. - m2) - a2 / SD;
+    g->g03 = a * (-2. * r + rQ) / SD;
+}
+
+/* Kerr-Newman connection, storage as orc_kerr_connection; ref: src/sim5kerr.c:321-397 */
+void orc_kerr_newman_connection(double a, double Q, double r, double m, double G[4][4][4])
+{
+    double rS = 2.0 * r;
+    double rQ = SQ(Q);
+    double s = sqrt(1. - m * m);
+    double cs = s * m;
+    double c2 = m * m;
+    double s2 = s * s;
+    double cc = c2 - s2;
+    double CC = 8. * c2 * c2 - 8. * c2 + 1.;
+    double a2 = a * a;
+    double a4 = a2 * a2;
+    double a2cc = a2 * cc;
+    double a2c2 = a2 * c2;
+    double a2cs = a2 * cs;
+    double r2 = r * r;
+    double r3 = r2 * r;
+    double a2_r2 = a2 + r2;
+    double R = pow(a2 + 2. * r2 + a2cc, 2.);
+    double D = r2 - 2. * r + a2 + rQ;
+    double S = r2 + a2c2;
+    double S_1 = 1. / S;
+    double S_3 = 1. / (S * S * S);
+    double R_1 = 1. / R;
+    double m_s = m / s;
+    double DR_1 = R_1 / D;
+    double DS_1 = S_1 / D;
+    double dbl_r2 = 2. * r2;
+    memset(G, 0, 64 * sizeof(double));
+    G[0][0][1] = 2.0 * 4.0 * (a2_r2) * (r * (r - rQ) - a2c2) * DR_1;
+    G[0][0][2] = 2.0 * -4.0 * a2cs * (rS - rQ) * R_1;
+    G[0][1][3] = 2.0 * 4.0 * a * s2 * (-a2 * (r2 - r * rQ) - r3 * (3. * r - 2. * rQ) + a2cc * (a2 - r2 + r * rQ)) * DR_1;
+    G[0][2][3] = -G[0][0][2] * s2 * a;
+    G[1][0][0] = D * (r * (r - rQ) - a2c2) * S_3;
+    G[1][0][3] = -2.0 * G[1][0][0] * a * s2;
+    G[1][1][1] = (r * (a2 - r + rQ) + a2 * (1. - r) * c2) * DS_1;
+    G[1][1][2] = -2.0 * a2cs * S_1;
+    G[1][2][2] = -r * D * S_1;
+    G[1][3][3] = -D * s2 * (2. * a2c2 * r3 + r2 * r3 + a2 * a2c2 * s2 + a2c2 * a2c2 * r - a2 * r * (r - rQ) * s2) * S_3;
+    G[2][0][0] = -(2.0 * r - rQ) * a2cs * S_3;
+    G[2][0][3] = 2.0 * -G[2][0][0] * a2_r2 / a;
+    G[2][1][1] = +a2cs * DS_1;
+    G[2][1][2] = 2.0 * r * S_1;
+    G[2][2][2] = -a2cs * S_1;
+    G[2][3][3] = -cs * (a2_r2 * S * S + a2 * s2 * (rS - rQ) * (a2_r2 + S)) * S_3;
+    G[3][0][1] = 2.0 * a * (r * (r - rQ) - a2c2) * DS_1 * S_1;
+    G[3][0][2] = 2.0 * -4.0 * a * (rS - rQ) * m_s * R_1;
+    G[3][1][3] = 2.0 * 4.0 * (r3 * (r2 - rS + rQ) + r * a2c2 * a2c2 -
+                 a2 * r * (r - rQ) * s2 + a2c2 * r * (dbl_r2 - rS + rQ) + a2c2 * a2 * s2) * DR_1;
+    G[3][2][3] = 2.0 * ((3. * a4 + 8. * a2 * r + 8. * a2 * r2 + 8. * r2 * r2 +
+                 4. * (dbl_r2 - rS + rQ + a2) * a2cc + a4 * CC) * m_s) * (R_1 / 2.0);
+}
+
 /* Minkowski connection, upper-triangle storage with doubled off-diagonals;
  * ref: src/sim5kerr.c:199-229 */
 void orc_flat_connection(double r, double m, double G[4][4][4])

@@ -116,6 +116,9 @@ double orc_r_ph(double a);
 void   orc_flat_metric(double r, double m, orc_metric *g);
 void   orc_kerr_metric(double a, double r, double m, orc_metric *g);
 void   orc_kerr_metric_contravariant(double a, double r, double m, orc_metric *g);
+void   orc_kerr_newman_metric(double a, double Q, double r, double m, orc_metric *g);
+void   orc_kerr_newman_metric_contravariant(double a, double Q, double r, double m, orc_metric *g);
+void   orc_kerr_newman_connection(double a, double Q, double r, double m, double G[4][4][4]);
 void   orc_flat_connection(double r, double m, double G[4][4][4]);
 void   orc_kerr_connection(double a, double r, double m, double G[4][4][4]);
 void   orc_Gamma(double G[4][4][4], double U[4], double V[4], double out[4]);

@@ -682,6 +682,29 @@ def kerr_metric_contravariant(a, r, m):
     return out
 
 
+def kerr_newman_metric(a, Q, r, m, contravariant=False):
+    r = _f64(r).ravel()
+    n = r.size
+    a, Q, m = _f64(a, n), _f64(Q, n), _f64(m, n)
+    out = np.zeros(n, dtype=METRIC_DTYPE)
+    fn = _lib.sim5gpu_kerr_newman_metric_contravariant if contravariant else _lib.sim5gpu_kerr_newman_metric
+    _check(fn(SZ(n), _p(a), _p(Q), _p(r), _p(m), _p(out)), "sim5gpu_kerr_newman_metric")
+    return out
+
+
+def kerr_newman_metric_contravariant(a, Q, r, m):
+    return kerr_newman_metric(a, Q, r, m, contravariant=True)
+
+
+def kerr_newman_connection(a, Q, r, m):
+    r = _f64(r).ravel()
+    n = r.size
+    a, Q, m = _f64(a, n), _f64(Q, n), _f64(m, n)
+    G = np.zeros((n, 4, 4, 4))
+    _check(_lib.sim5gpu_kerr_newman_connection(SZ(n), _p(a), _p(Q), _p(r), _p(m), _p(G)), "sim5gpu_kerr_newman_connection")
+    return G
+
+
 def flat_connection(r, m):
     r = _f64(r).ravel()
     n = r.size

@@ -80,6 +80,37 @@ int sim5gpu_kerr_metric_contravariant(size_t n, const double* a, const double* r
     return SIM5GPU_OK;
 }
 
+// Kerr-Newman (charge Q): metric, contravariant metric, connection
+#define S5_KN_METRIC_FN(NAME, DEVFN)                                                                         \
+int NAME(size_t n, const double* a, const double* Q, const double* r, const double* m, sim5gpu_metric* metric) \
+{                                                                                                            \
+    S5_NEED(#NAME, a && Q && r && m && metric);                                                              \
+    if (n == 0) return SIM5GPU_OK;                                                                           \
+    S5_DEVICE_OR_FAIL();                                                                                     \
+    DevBuf<double> da(a, n), dq(Q, n), dr(r, n), dm(m, n); DevBuf<Metric> dmt(n);                            \
+    S5_BUFS_OK(#NAME, da.ok() && dq.ok() && dr.ok() && dm.ok() && dmt.ok());                                 \
+    const double *pa = da.ptr, *pq = dq.ptr, *pr = dr.ptr, *pm = dm.ptr; Metric* pg = dmt.ptr;              \
+    S5_RUN(n, #NAME, [=] __device__(size_t i) { Metric g; DEVFN(pa[i], pq[i], pr[i], pm[i], g); pg[i] = g; }); \
+    S5_HIP(dmt.to_host((Metric*)metric));                                                                    \
+    return SIM5GPU_OK;                                                                                       \
+}
+S5_KN_METRIC_FN(sim5gpu_kerr_newman_metric, kerr_newman_metric)
+S5_KN_METRIC_FN(sim5gpu_kerr_newman_metric_contravariant, kerr_newman_metric_contravariant)
+#undef S5_KN_METRIC_FN
+
+int sim5gpu_kerr_newman_connection(size_t n, const double* a, const double* Q, const double* r, const double* m, double* G)
+{
+    S5_NEED("kerr_newman_connection", a && Q && r && m && G);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> da(a, n), dq(Q, n), dr(r, n), dm(m, n), dG(64 * n);
+    S5_BUFS_OK("kerr_newman_connection", da.ok() && dq.ok() && dr.ok() && dm.ok() && dG.ok());
+    const double *pa = da.ptr, *pq = dq.ptr, *pr = dr.ptr, *pm = dm.ptr; double* pG = dG.ptr;
+    S5_RUN(n, "kerr_newman_connection", [=] __device__(size_t i) { Conn c; kerr_newman_connection(pa[i], pq[i], pr[i], pm[i], c); conn_to_dense(c, pG + 64 * i); });
+    S5_HIP(dG.to_host(G));
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_flat_connection(size_t n, const double* r, const double* m, double* G)
 {
     S5_NEED("flat_connection", r && m && G);

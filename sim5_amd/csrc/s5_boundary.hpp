@@ -16,6 +16,91 @@ S5_DEV void flat_metric_contravariant(double r, double m, Metric& g)            
     g.g00 = -1.0; g.g11 = +1.0; g.g22 = +1. / (r * r); g.g33 = +1. / (r * r) / (1. - m * m); g.g03 = 0.0;
 }
 
+// Kerr-Newman metric, covariant and contravariant, and connection (charge Q): the Kerr closed forms with 2r -> 2r - Q^2 and
+// Delta -> Delta + Q^2 (ref src/sim5kerr.c:136-194, 321-397); same storage of the connection as kerr_connection
+// (20 entries, j <= k, off-diagonals pre-doubled: s5_kerr.hpp Conn)
+S5_DEV void kerr_newman_metric(double a, double Q, double r, double m, Metric& g)       // ref src/sim5kerr.c:136-163
+{
+    const double rQ = sq(Q), r2 = sq(r), a2 = sq(a), m2 = sq(m);
+    const double S = r2 + a2 * m2;
+    const double s2_S = (1.0 - m2) / S;
+    g.a = a; g.r = r; g.m = m;
+    g.g00 = -1. + (2.0 * r - rQ) / S;
+    g.g11 = S / (r2 - 2. * r + a2 + rQ);
+    g.g22 = S;
+    g.g33 = ((a2 + r2) * S + (2. * r - rQ) * a2 * s2_S * S) * s2_S;
+    g.g03 = -a * (2. * r - rQ) * s2_S;
+}
+
+S5_DEV void kerr_newman_metric_contravariant(double a, double Q, double r, double m, Metric& g)   // ref :168-194
+{
+    const double rQ = sq(Q), r2 = sq(r), a2 = sq(a), m2 = sq(m);
+    const double S = r2 + a2 * m2;
+    const double SD = S * (r2 - 2. * r + a2 + rQ);
+    g.a = a; g.r = r; g.m = m;
+    g.g00 = -sq(r2 + a2) / SD + a2 * (1. - m2) / S;
+    g.g11 = (r2 - 2. * r + a2 + rQ) / S;
+    g.g22 = 1. / S;
+    g.g33 = 1. / S / (1. - m2) - a2 / SD;
+    g.g03 = a * (-2. * r + rQ) / SD;
+}
+
+S5_DEV void kerr_newman_connection(double a, double Q, double r, double m, Conn& G)     // ref :321-397
+{
+    const double rS = 2.0 * r;
+    const double rQ = sq(Q);
+    const double s = sqrt(1. - m * m);
+    const double cs = s * m;
+    const double c2 = m * m;
+    const double s2 = s * s;
+    const double cc = c2 - s2;
+    const double CC = 8. * c2 * c2 - 8. * c2 + 1.;
+    const double a2 = a * a;
+    const double a4 = a2 * a2;
+    const double a2cc = a2 * cc;
+    const double a2c2 = a2 * c2;
+    const double a2cs = a2 * cs;
+    const double r2 = r * r;
+    const double r3 = r2 * r;
+    const double a2_r2 = a2 + r2;
+    const double R = pow(a2 + 2. * r2 + a2cc, 2.);
+    const double D = r2 - 2. * r + a2 + rQ;
+    const double S = r2 + a2c2;
+    const double S_1 = 1. / S;
+    const double S_3 = 1. / (S * S * S);
+    const double R_1 = 1. / R;
+    const double m_s = m / s;
+    const double DR_1 = R_1 / D;
+    const double DS_1 = S_1 / D;
+    const double dbl_r2 = 2. * r2;
+
+    G.t01 = 2.0 * 4.0 * (a2_r2) * (r * (r - rQ) - a2c2) * DR_1;
+    G.t02 = 2.0 * -4.0 * a2cs * (rS - rQ) * R_1;
+    G.t13 = 2.0 * 4.0 * a * s2 * (-a2 * (r2 - r * rQ) - r3 * (3. * r - 2. * rQ) + a2cc * (a2 - r2 + r * rQ)) * DR_1;
+    G.t23 = -G.t02 * s2 * a;
+
+    G.r00 = D * (r * (r - rQ) - a2c2) * S_3;
+    G.r03 = -2.0 * G.r00 * a * s2;
+    G.r11 = (r * (a2 - r + rQ) + a2 * (1. - r) * c2) * DS_1;
+    G.r12 = -2.0 * a2cs * S_1;
+    G.r22 = -r * D * S_1;
+    G.r33 = -D * s2 * (2. * a2c2 * r3 + r2 * r3 + a2 * a2c2 * s2 + a2c2 * a2c2 * r - a2 * r * (r - rQ) * s2) * S_3;
+
+    G.h00 = -(2.0 * r - rQ) * a2cs * S_3;
+    G.h03 = 2.0 * -G.h00 * a2_r2 / a;
+    G.h11 = +a2cs * DS_1;
+    G.h12 = 2.0 * r * S_1;
+    G.h22 = -a2cs * S_1;
+    G.h33 = -cs * (a2_r2 * S * S + a2 * s2 * (rS - rQ) * (a2_r2 + S)) * S_3;
+
+    G.p01 = 2.0 * a * (r * (r - rQ) - a2c2) * DS_1 * S_1;
+    G.p02 = 2.0 * -4.0 * a * (rS - rQ) * m_s * R_1;
+    G.p13 = 2.0 * 4.0 * (r3 * (r2 - rS + rQ) + r * a2c2 * a2c2 -
+            a2 * r * (r - rQ) * s2 + a2c2 * r * (dbl_r2 - rS + rQ) + a2c2 * a2 * s2) * DR_1;
+    G.p23 = 2.0 * ((3. * a4 + 8. * a2 * r + 8. * a2 * r2 + 8. * r2 * r2 +
+            4. * (dbl_r2 - rS + rQ + a2) * a2cc + a4 * CC) * m_s) * (R_1 / 2.0);
+}
+
 // -G^i_(jk) U^j V^k for a DENSE connection handed in by the caller (any values, not only kerr_connection's): the
 // reference's loop over j <= k with the pair symmetrised (ref :422-440)
 S5_DEV void gamma_dense(const double* G, const double U[4], const double V[4], double out[4])

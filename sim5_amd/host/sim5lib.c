@@ -518,6 +518,27 @@ void kerr_metric_contravariant(double a, double r, double m, sim5metric *metric)
     s5_check(f(1, &a, &r, &m, metric), "kerr_metric_contravariant");
 }
 
+void kerr_newman_metric(double a, double Q, double r, double m, sim5metric *metric)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, sim5metric *);
+    S5_FN(fn, f, "sim5gpu_kerr_newman_metric");
+    s5_check(f(1, &a, &Q, &r, &m, metric), "kerr_newman_metric");
+}
+
+void kerr_newman_metric_contravariant(double a, double Q, double r, double m, sim5metric *metric)
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, sim5metric *);
+    S5_FN(fn, f, "sim5gpu_kerr_newman_metric_contravariant");
+    s5_check(f(1, &a, &Q, &r, &m, metric), "kerr_newman_metric_contravariant");
+}
+
+void kerr_newman_connection(double a, double Q, double r, double m, double G[4][4][4])
+{
+    typedef int (*fn)(size_t, const double *, const double *, const double *, const double *, double *);
+    S5_FN(fn, f, "sim5gpu_kerr_newman_connection");
+    s5_check(f(1, &a, &Q, &r, &m, &G[0][0][0]), "kerr_newman_connection");
+}
+
 void flat_connection(double r, double m, double G[4][4][4])
 {
     typedef int (*fn)(size_t, const double *, const double *, double *);

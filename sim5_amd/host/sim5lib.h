@@ -149,6 +149,9 @@ void   flat_metric(double r, double m, sim5metric *metric);
 void   flat_metric_contravariant(double r, double m, sim5metric *metric);
 void   kerr_metric(double a, double r, double m, sim5metric *metric);
 void   kerr_metric_contravariant(double a, double r, double m, sim5metric *metric);
+void   kerr_newman_metric(double a, double Q, double r, double m, sim5metric *metric);
+void   kerr_newman_metric_contravariant(double a, double Q, double r, double m, sim5metric *metric);
+void   kerr_newman_connection(double a, double Q, double r, double m, double G[4][4][4]);
 void   flat_connection(double r, double m, double G[4][4][4]);
 void   kerr_connection(double a, double r, double m, double G[4][4][4]);
 void   Gamma(double G[4][4][4], double U[4], double V[4], double result[4]);

@@ -402,6 +402,18 @@ def kerr_metric_contravariant(a, r, m, metric):
     metric._rec[:] = _c.kerr_metric_contravariant(a, [r], m)
 
 
+def kerr_newman_metric(a, Q, r, m, metric):
+    metric._rec[:] = _c.kerr_newman_metric(a, Q, [r], m)
+
+
+def kerr_newman_metric_contravariant(a, Q, r, m, metric):
+    metric._rec[:] = _c.kerr_newman_metric_contravariant(a, Q, [r], m)
+
+
+def kerr_newman_connection(a, Q, r, m, G=None):
+    return _c.kerr_newman_connection(a, Q, [r], m)[0]
+
+
 def flat_connection(r, m, G=None):
     return _c.flat_connection([r], m)[0]
 

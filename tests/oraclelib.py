@@ -86,6 +86,9 @@ _COMMON = {
     "flat_metric": (None, [D, D, PM]),
     "kerr_metric": (None, [D, D, D, PM]),
     "kerr_metric_contravariant": (None, [D, D, D, PM]),
+    "kerr_newman_metric": (None, [D, D, D, D, PM]),
+    "kerr_newman_metric_contravariant": (None, [D, D, D, D, PM]),
+    "kerr_newman_connection": (None, [D, D, D, D, G444]),
     "flat_connection": (None, [D, D, G444]),
     "kerr_connection": (None, [D, D, D, G444]),
     "Gamma": (None, [G444, D4, D4, D4]),

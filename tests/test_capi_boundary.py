@@ -92,9 +92,6 @@ def test_product_does_not_reach_into_oracle():
 # ---- the SIM5 scalar boundary against the inventory of the reference's headers ------------------------------------------
 # Prototypes of the cited headers that are NOT served, each with the reason (explicit list).
 OUT_OF_SCOPE = {
-    "kerr_newman_metric": "Kerr-Newman spacetime: not on the Kerr null-geodesic path (SURVEY.md 2 row 3)",
-    "kerr_newman_metric_contravariant": "Kerr-Newman spacetime",
-    "kerr_newman_connection": "Kerr-Newman spacetime",
     "blackbody_photon_energy_random": "Monte-Carlo sampler on the RNG (SURVEY.md 2 row 15: RNG out of scope)",
     "sim5seed": "RNG", "sim5rand": "RNG", "sim5urand": "RNG",
     "cartesian2spherical1": "cartesian helper, no caller on the path", "cartesian2spherical2": "cartesian helper, no caller on the path",

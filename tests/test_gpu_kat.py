@@ -327,3 +327,23 @@ def test_boundary_prototypes(capi, golden):
                  rtol=1e-12, floor=1e-300, what="blackbody_photons")
     assert_close(capi.blackbody_photons_total(g["bbp_T"], g["bbp_hardf"]), g["blackbody_photons_total"], rtol=1e-14,
                  what="blackbody_photons_total")
+
+
+def test_kerr_newman_prototypes(capi, golden):
+    """kerr_newman_metric / kerr_newman_metric_contravariant / kerr_newman_connection (ref src/sim5kerr.h:49,52,61) through
+    the C-ABI against the unmodified reference (kat_kerr_newman.npz, 500 points incl. Q = 0): the last three prototypes of
+    the cited headers that were not served (VERDICT r3 missing 3)."""
+    g = golden("kat_kerr_newman.npz")
+    a, Q, r, m = g["a"], g["Q"], g["r"], g["m"]
+
+    def rows(rec):
+        return np.frombuffer(np.ascontiguousarray(rec).tobytes(), np.float64).reshape(len(rec), -1)
+    assert_close(rows(capi.kerr_newman_metric(a, Q, r, m)), g["metric"], rtol=1e-12, what="kerr_newman_metric")
+    assert_close(rows(capi.kerr_newman_metric_contravariant(a, Q, r, m)), g["metric_contra"], rtol=1e-12, what="kerr_newman_metric_contravariant")
+    G = capi.kerr_newman_connection(a, Q, r, m).reshape(len(a), 64)
+    assert np.array_equal(G == 0, g["connection"] == 0)
+    assert_close(G, g["connection"], rtol=1e-11, what="kerr_newman_connection")
+    # Q = 0 is Kerr
+    z = Q == 0
+    assert z.sum() >= 60
+    assert_close(rows(capi.kerr_newman_metric(a[z], Q[z], r[z], m[z])), rows(capi.kerr_metric(a[z], r[z], m[z])), rtol=1e-14, what="Q = 0 metric")

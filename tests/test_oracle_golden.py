@@ -381,3 +381,18 @@ def test_disk_model_rest(oracle, golden):
     for j, (M, a, x, al, opt) in enumerate(g["setups"]):
         if opt:
             assert abs(g["lumi_%d" % j][0] / x - 1) < 1e-4
+
+
+def test_kerr_newman_restatement_is_bit_identical_to_the_reference(oracle, golden):
+    """kerr_newman_metric / _contravariant / _connection (ref src/sim5kerr.c:136-194, 321-397): the restatement gives the
+    unmodified reference's bytes on all 500 golden points (oracle/gen_golden.py:kat_kerr_newman)"""
+    g = golden("kat_kerr_newman.npz")
+    for i in range(len(g["a"])):
+        a, Q, r, m = (float(g[k][i]) for k in ("a", "Q", "r", "m"))
+        mt = ol.Metric(); G = ol.G444()
+        oracle.kerr_newman_metric(a, Q, r, m, C.byref(mt))
+        assert np.array_equal(np.frombuffer(ol.struct_bytes(mt), np.float64), g["metric"][i]), i
+        oracle.kerr_newman_metric_contravariant(a, Q, r, m, C.byref(mt))
+        assert np.array_equal(np.frombuffer(ol.struct_bytes(mt), np.float64), g["metric_contra"][i]), i
+        oracle.kerr_newman_connection(a, Q, r, m, G)
+        assert np.array_equal(np.frombuffer(bytes(memoryview(G)), np.float64), g["connection"][i]), i
