@@ -439,6 +439,15 @@ int sim5gpu_words_differ(const void *d_a, const void *d_b, size_t n_words, unsig
 int sim5gpu_disk_image(const sim5gpu_image_desc *desc, float *d_image_f, float *d_image_g,
                        const sim5gpu_image_aux *d_aux, void *stream);
 
+/* n_jobs image jobs (descs[j] into d_image_f[j], d_image_g[j]; no full-precision planes) with as few launches as the jobs
+ * allow: jobs of the default variant whose rows are symmetric about the middle of the image (whole images, centred bands,
+ * SIM5GPU_IMG_MIRROR shares) run through ONE job-list launch per 16 jobs -- the jobs stream through the GPU back to back, so
+ * small images (the caller loop of ref disk-image.c:53-105 over several spins or inclinations, or a rank's share of a split
+ * image) do not pay a launch ramp and a ragged last round each; other jobs are launched by themselves, in order.  Every image
+ * is what sim5gpu_disk_image gives for its job, bit for bit.  Everything is validated before the first launch. */
+int sim5gpu_disk_image_jobs(int n_jobs, const sim5gpu_image_desc *descs, float *const *d_image_f, float *const *d_image_g,
+                            void *stream);
+
 /* Same job on caller-owned HOST buffers (allocates, launches, copies back, frees). */
 int sim5gpu_disk_image_host(const sim5gpu_image_desc *desc, float *h_image_f, float *h_image_g,
                             const sim5gpu_image_aux *h_aux);

@@ -935,6 +935,16 @@ def disk_image_device(desc, d_image_f, d_image_g, aux=None, stream=None):
            "sim5gpu_disk_image")
 
 
+def disk_image_jobs(descs, d_images_f, d_images_g, stream=None):
+    """Several image jobs with as few launches as they allow (sim5gpu_disk_image_jobs): descs[j] into the device planes
+    d_images_f[j], d_images_g[j] (ints).  Asynchronous on `stream`."""
+    n = len(descs)
+    arr = (ImageDesc * n)(*descs)
+    pf = (VP * n)(*[VP(int(x)) for x in d_images_f])
+    pg = (VP * n)(*[VP(int(x)) for x in d_images_g])
+    _check(_lib.sim5gpu_disk_image_jobs(I(n), arr, pf, pg, VP(stream or 0)), "sim5gpu_disk_image_jobs")
+
+
 def disk_image(desc, full=False):
     """Host-buffer convenience: returns dict(image_f, image_g[, cls, gtype, r, g, flux])."""
     rows, nx = max(image_rows(desc), 0), max(desc.nx, 0)       # bad geometry is rejected by the library

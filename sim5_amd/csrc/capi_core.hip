@@ -508,6 +508,49 @@ int sim5gpu_disk_image(const sim5gpu_image_desc* desc, float* d_image_f, float* 
     return SIM5GPU_OK;
 }
 
+/* Several image jobs, ONE launch where the jobs allow it: jobs of the default (fast) variant whose row set is symmetric about
+ * the middle of the image -- whole images, centred bands, SIM5GPU_IMG_MIRROR shares -- go through the job-list kernel
+ * (k_disk_image.hip: disk_image_jobs_kernel) in groups of up to 16, the jobs of a group streaming through the GPU back to
+ * back; any other job (strict variant, an asymmetric row range) is launched by itself, in order.  Images are the bits
+ * sim5gpu_disk_image gives job by job. */
+int sim5gpu_disk_image_jobs(int n_jobs, const sim5gpu_image_desc* descs, float* const* d_image_f, float* const* d_image_g, void* stream)
+{
+    if (n_jobs == 0) return SIM5GPU_OK;
+    if (n_jobs < 0 || !descs || !d_image_f || !d_image_g) { snprintf(g_err, sizeof g_err, "disk_image_jobs: bad arguments"); return SIM5GPU_E_ARG; }
+    // validate everything before anything is launched
+    std::vector<ImageParams> ps((size_t)n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!d_image_f[j] || !d_image_g[j]) { snprintf(g_err, sizeof g_err, "disk_image_jobs: job %d: output image pointers are NULL", j); return SIM5GPU_E_ARG; }
+        const int rc = fill_image_params(&descs[j], ps[(size_t)j]);
+        if (rc) return rc;
+        ps[(size_t)j].img_f = d_image_f[j]; ps[(size_t)j].img_g = d_image_g[j];
+    }
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    std::vector<ImageParams> group;
+    auto flush = [&]() -> int {
+        if (group.empty()) return SIM5GPU_OK;
+        hipError_t e = (hipError_t)s5_launch_disk_image_jobs_fast(group.data(), (int)group.size(), (hipStream_t)stream);
+        group.clear();
+        if (e != hipSuccess) { set_error("disk_image_jobs launch", e); return SIM5GPU_E_HIP; }
+        return SIM5GPU_OK;
+    };
+    for (int j = 0; j < n_jobs; ++j) {
+        ImageParams& p = ps[(size_t)j];
+        const bool strict = (descs[j].flags & SIM5GPU_IMG_STRICT) != 0;
+        int rc;
+        if (!strict && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
+        if (!strict && s5_jobs_eligible(p)) {
+            group.push_back(p);
+            if ((int)group.size() == s5abi::JOBS_MAX && (rc = flush()) != 0) return rc;
+            continue;
+        }
+        if ((rc = flush()) != 0) return rc;                  // keeps the order of the jobs on the stream
+        hipError_t e = (hipError_t)(strict ? s5_launch_disk_image_strict(p, (hipStream_t)stream) : s5_launch_disk_image_fast(p, (hipStream_t)stream));
+        if (e != hipSuccess) { set_error("disk_image_jobs launch", e); return SIM5GPU_E_HIP; }
+    }
+    return flush();
+}
+
 int sim5gpu_disk_rays(const sim5gpu_image_desc* desc, size_t n, const double* d_alpha,
                       const double* d_beta, float* d_image_f, float* d_image_g,
                       const sim5gpu_image_aux* d_aux, void* stream)

@@ -14,6 +14,7 @@
 // consecutive f32 = half a 128-B line per plane, the workgroup whole lines.  No input is read in grid mode
 // (alpha, beta follow from the pixel index, ref disk-image.c:57-58); in list mode alpha[]/beta[] are read
 // coalesced, 8 B per lane.
+#include <string.h>
 #include "s5_thindisk.hpp"
 #include "kernels.hpp"
 
@@ -145,6 +146,51 @@ void disk_image_mirror_kernel(ImageParams p)
     store_ray<AUX>(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, ray_result(t));
     if (lr2 != lr) store_ray<AUX>(p, (size_t)(p.inplace ? p.ny - 1 - iy : lr2) * (size_t)p.nx + (size_t)ix, ray_result(t2));
 }
+
+// JOB LIST.  The same pairing kernel for up to JOBS_MAX jobs in ONE launch: the grid is the concatenation of the jobs' tiles
+// (blockIdx.x -> job by the prefix sums in the list, then the tile of that job, middle rows first), so the hardware
+// dispatcher streams the jobs through the chip back to back -- no launch gap, no ramp and no ragged last round between
+// them; a small image (1024^2 is two rounds of resident waves) or a rank's share of a split image then costs what its rays
+// cost.  The jobs' parameters are read from the kernel-argument segment through the constant address space (kernels.hpp:
+// JobList): scalar loads at the point of use, the late ones (flux table, output pointers) behind param_reload().  A lane's
+// arithmetic is that of disk_image_mirror_kernel<false>, value for value: images are the same bits.
+__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
+void disk_image_jobs_kernel(JobList list_arg)
+{
+    const S5_AS4 JobList* L = (const S5_AS4 JobList*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int t = (int)blockIdx.x;
+    int j = 0;
+    const int nj = L->njobs;
+    while (j + 1 < nj && t >= L->tile_end[j]) ++j;                       // scalar: <= 15 steps
+    const int t0 = (j > 0) ? L->tile_end[j - 1] : 0;
+    const S5_AS4 FastJob& p = L->job[j];
+    const int nx = p.nx, nrows = p.nrows;
+    const int half = (nrows + 1) / 2;
+    const int tiles_x = (nx + TILE_W - 1) / TILE_W;
+    const int tiles_y = (half + TILE_H - 1) / TILE_H;
+    const int tj = t - t0;                                               // tile within the job, row-major, dispatched in order
+    const int by = tj / tiles_x, bx = tj - by * tiles_x;
+    const int lane_x = threadIdx.x % TILE_W;
+    const int lane_y = threadIdx.x / TILE_W;
+    const int ix = bx * TILE_W + lane_x;
+    const int lr = (tiles_y - 1 - by) * TILE_H + lane_y;                 // middle rows first (as disk_image_mirror_kernel)
+    if (ix >= nx || lr >= half) return;
+    const int lr2 = nrows - 1 - lr;
+    ThinRay t1, t2;
+    const int iy = image_row_top(p, lr);
+    trace_thin_disk_impl<false, true, false, false>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t1, t2);
+    const RayResult r1 = ray_result(t1), r2 = ray_result(t2);
+    const S5_AS4 FastJob& po = param_reload(p);                          // the output side: loaded here, not carried through the trace
+    const int inplace = po.inplace, ny = po.ny;
+    float* __restrict__ img_f = po.img_f;
+    float* __restrict__ img_g = po.img_g;
+    const size_t o1 = (size_t)(inplace ? iy : lr) * (size_t)nx + (size_t)ix;
+    img_f[o1] = r1.image_f; img_g[o1] = r1.image_g;
+    if (lr2 != lr) {
+        const size_t o2 = (size_t)(inplace ? ny - 1 - iy : lr2) * (size_t)nx + (size_t)ix;
+        img_f[o2] = r2.image_f; img_g[o2] = r2.image_g;
+    }
+}
 #endif
 
 __global__ __launch_bounds__(256, 2)
@@ -159,6 +205,42 @@ void disk_image_list_kernel(ImageParams p)
 } // namespace S5NS
 
 #if S5_FAST
+// a job the job-list kernel serves: the fast pairing kernel's row sets, two f32 planes only
+bool s5_jobs_eligible(const s5abi::ImageParams& p)
+{
+    const bool aux = p.cls || p.gtype || p.r || p.g || p.flux;
+    return !aux && !p.alpha && p.img_f && p.img_g && p.nrows >= 2 && (p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny));
+}
+
+int s5_launch_disk_image_jobs_fast(const s5abi::ImageParams* jobs, int n, hipStream_t stream)
+{
+    using namespace S5NS;
+    if (n <= 0) return 0;
+    if (n > JOBS_MAX) return (int)hipErrorInvalidValue;
+    JobList L;
+    memset(&L, 0, sizeof L);
+    L.njobs = n;
+    long long total = 0;
+    for (int j = 0; j < n; ++j) {
+        const ImageParams& p = jobs[j];
+        if (!s5_jobs_eligible(p)) return (int)hipErrorInvalidValue;
+        FastJob& f = L.job[j];
+        f.nx = p.nx; f.ny = p.ny; f.y0 = p.y0; f.y1 = p.y1; f.nrows = p.nrows; f.stripe_rows = p.stripe_rows; f.stripe_step = p.stripe_step;
+        f.mirror = p.mirror; f.nrows_top = p.nrows_top; f.max_order = p.max_order; f.inplace = p.inplace; f.direct = p.direct;
+        f.a = p.a; f.incl = p.incl; f.sin_i = p.sin_i; f.cos_i = p.cos_i; f.rmax = p.rmax; f.rms = p.rms;
+        f.inv_nx = p.inv_nx; f.inv_ny = p.inv_ny; f.ny_over_nx = p.ny_over_nx; f.inv_2a2 = p.inv_2a2; f.ktab = p.ktab;
+        f.disk.rms = p.disk.rms; f.disk.x0 = p.disk.x0; f.disk.scale = p.disk.scale; f.disk.ft_wmin = p.disk.ft_wmin;
+        f.disk.ft_inv_dw = p.disk.ft_inv_dw; f.disk.ftab = p.disk.ftab; f.disk.cold = p.disk.cold;
+        f.img_f = p.img_f; f.img_g = p.img_g;
+        total += (long long)((p.nx + TILE_W - 1) / TILE_W) * (long long)(((p.nrows + 1) / 2 + TILE_H - 1) / TILE_H);
+        if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        L.tile_end[j] = (int)total;
+    }
+    for (int j = n; j < JOBS_MAX; ++j) L.tile_end[j] = (int)total;
+    hipLaunchKernelGGL(disk_image_jobs_kernel, dim3((unsigned)total), dim3(256), 0, stream, L);
+    return (int)hipGetLastError();
+}
+
 int s5_launch_disk_image_fast(const s5abi::ImageParams& p, hipStream_t stream)
 #else
 int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)

@@ -73,9 +73,39 @@ struct ImageParams {
     size_t n;
 };
 
+// ---- job list of the fast pairing kernel (k_disk_image.hip: disk_image_jobs_kernel) ----------------------------------------
+// What that kernel reads of a job, 208 bytes, same member names as ImageParams so that the ray routines take either.  Up to
+// JOBS_MAX of them travel BY VALUE in the kernel-argument segment (3.4 KB of its 4 KB): no device allocation, no copy, and the
+// kernel reads them through the constant address space -- scalar loads where a value is used, instead of ~80 scalar registers
+// of argument block held (and spilled) from the first instruction.
+struct FastDisk {
+    double rms, x0, scale, ft_wmin, ft_inv_dw;
+    const double* ftab;
+    const double* cold;
+};
+struct FastJob {
+    int nx, ny, y0, y1;
+    int nrows, stripe_rows, stripe_step, mirror, nrows_top, max_order, inplace, direct;
+    double a, incl, sin_i, cos_i;
+    double rmax, rms;
+    double inv_nx, inv_ny, ny_over_nx, inv_2a2;
+    const double* ktab;
+    FastDisk disk;
+    float* img_f;
+    float* img_g;
+};
+constexpr int JOBS_MAX = 16;
+struct JobList {
+    int njobs, pad;
+    int tile_end[JOBS_MAX];           // prefix sums of the jobs' workgroup tiles: job j owns blocks [tile_end[j-1], tile_end[j])
+    FastJob job[JOBS_MAX];
+};
+static_assert(sizeof(FastJob) == 208 && sizeof(JobList) <= 4096, "the job list must fit the kernel-argument segment");
+
 // image row of packed (local) output row lr: the rows named by y0, y1 and the striping first, then -- with mirror -- their
 // mirror images ny - 1 - y, so that the packed rows are in increasing image-row order
-__host__ __device__ inline int image_row_top(const ImageParams& p, int t)
+template <class PRM>
+__host__ __device__ inline int image_row_top(const PRM& p, int t)
 {
     return p.stripe_rows > 0 ? p.y0 + (t / p.stripe_rows) * p.stripe_step + t % p.stripe_rows : p.y0 + t;
 }
@@ -122,6 +152,9 @@ struct SurfaceParams {
 
 // fast = tuned FP64 sequences (default); strict = reference parameters, IEEE sqrt/div, no contraction
 int s5_launch_disk_image_fast(const s5abi::ImageParams& p, hipStream_t stream);
+// n <= JOBS_MAX jobs of the fast variant without full-precision planes, each a symmetric row set (s5_jobs_eligible), ONE launch
+int s5_launch_disk_image_jobs_fast(const s5abi::ImageParams* jobs, int n, hipStream_t stream);
+bool s5_jobs_eligible(const s5abi::ImageParams& p);
 int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream);
 // k_assemble.hip: rows of n shares ([2][share_rows][nx] floats each, share i at shares + i * 2 * share_rows * nx) to their image rows
 int s5_launch_place_shares(int n_shares, const s5abi::RowMap* maps, const float* shares, size_t share_rows, int nx,

@@ -103,3 +103,11 @@
 #endif
 
 #define S5_DEV __device__ __forceinline__
+// a comment in the generated assembly (to find a source region in the ISA; no instruction)
+#ifdef S5_ISA_MARKS
+#define S5_MARK(text) asm volatile("; S5MARK " text)
+#else
+#define S5_MARK(text) do {} while (0)
+#endif
+// constant address space (kernel-argument segment, read-only tables): loads through such a pointer are scalar loads
+#define S5_AS4 __attribute__((address_space(4)))

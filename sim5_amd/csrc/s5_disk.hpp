@@ -61,7 +61,8 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
 // row, seven FMAs -- instead of four logarithms and a division.  Lanes the table must not serve -- within 2e-4
 // of the inner edge in x, where the reference's own double evaluation is rounding noise that parity reproduces,
 // and beyond x = 16 -- are reported through `closed_form` and take disk_flux_closed_form(d, r, x).
-S5_DEV double disk_flux_table(const DiskConsts& d, double r, double x, double rx, bool& closed_form)
+template <class DISK>
+S5_DEV double disk_flux_table(const DISK& d, double r, double x, double rx, bool& closed_form)
 {
     S5_FPC_GFLUX
     closed_form = false;

@@ -57,16 +57,63 @@ S5_DEV bool icn_plain(double z, double m)
     return !snap && !(z == 0.0) && !(z == 1.0) && !(m == 0.0) && !(m == 1.0);
 }
 
-template <bool WANT_STATE, int KNOWN, bool PAIR>
-S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+// PRM: the type the job's parameters are read through -- s5abi::ImageParams (a kernel's by-value argument block: the
+// compiler keeps what it reads in scalar registers) or a reference into the CONSTANT address space (s5abi::FastJob in the
+// kernel-argument segment of the job-list kernel, k_disk_image.hip: every read is a scalar load where it is used, and
+// param_reload() below makes the loads of a late phase start there instead of occupying registers from the first instruction)
+template <bool WANT_STATE, int KNOWN, bool PAIR, class PRM>
+S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                              const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_);
-template <bool WANT_STATE, int KNOWN, bool PAIR>
-S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+template <bool WANT_STATE, int KNOWN, bool PAIR, class PRM>
+S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                                     const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                                     const double ra, const double rb, const double rc_, const double rd_);
+
+// Parameters behind a constant-address-space reference: the same object through a pointer the optimiser cannot see through,
+// so the loads that follow are issued from here on (not hoisted to the kernel's head and held -- spilled -- in SGPRs).  The
+// by-value argument block of the other kernels passes through unchanged.
+template <class T> S5_DEV const T& param_reload(const T& p) { return p; }
+template <class T> S5_DEV const S5_AS4 T& param_reload(const S5_AS4 T& p)
+{
+    const S5_AS4 T* q = &p;
+    asm volatile("" : "+s"(q));
+    return *q;
+}
+#ifndef S5_COLD_UNPAIRED
+#define S5_COLD_UNPAIRED 0      // measured by the compiler: 21 spilled SGPRs against 9 with the paired copy; kept for the record
+#endif
 // internal class value: the fast routine leaves this ray to the direct one (never stored)
 constexpr int PX_COLD_MARK = 100;
+// internal flux value (a flux is never negative): the table of the fast variant does not serve this hit -- within 2e-4 of the
+// inner edge in x, beyond x = 16, or no table for this spin (s5_disk.hpp) -- and the closed form is owed.  It is evaluated
+// ONCE, by thin_disk_owed_flux at the end of trace_thin_disk_impl, for both rays of a pair and whichever routine found the
+// crossing: one copy of the four logarithms in a kernel instead of four (a fifth of its code, and the peak of its scalar
+// register pressure: the coefficients of four inlined logarithm kernels hoisted into SGPR pairs).
+constexpr double FLUX_OWED = -1.0;
+
+template <bool PAIR, class PRM>
+S5_DEV void thin_disk_owed_flux(const PRM& p, ThinRay& out, ThinRay& out2)
+{
+#if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
+    const bool f0 = (out.flux < 0.0), f1 = PAIR && (out2.flux < 0.0);
+    S5_MARK("owed flux begin");
+    if (wave_any(f0 || f1)) {
+        // constants from the disk model's device block, not from the kernel arguments: referenced here they would sit in
+        // ~30 SGPRs of every wave from the first instruction (the launchers always attach the block: capi_core.hip)
+        const double* cold = param_reload(p).disk.cold;
+#pragma unroll 1
+        for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
+            const bool f = member ? f1 : f0;
+            if (!wave_any(f)) continue;
+            const double r = member ? out2.r : out.r;
+            double F = 0.0;
+            if (f) { double x, rx; sqrt_rsqrt_pos(r, x, rx); F = cold ? disk_flux_closed_form_mem(cold, r, x) : NAN; }
+            if (f) { if (member) out2.flux = F; else out.flux = F; }
+        }
+    }
+#endif
+}
 
 // PAIR: the lane traces the ray (alpha, beta) into `out` AND its mirror image (alpha, -beta) into `out2`.  The two
 // have the same constants of motion (l, and q through beta^2: ref :76-77), hence the same roots of R(r) and of the
@@ -77,8 +124,8 @@ constexpr int PX_COLD_MARK = 100;
 // behind the fast one then reads the parameters from the kernel's argument segment, where it runs, instead of out of the
 // scalar registers that would have to carry them -- spilled to vector lanes -- through the whole fast path (measured on the
 // pair kernel: SGPR spills 44 -> 28, -1.2 % time; the same pointer made in the kernel and handed down: +3 %).
-template <bool WANT_STATE, bool PAIR, bool DIRECT = false, bool P_FIRST = false>
-S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out, ThinRay& out2)
+template <bool WANT_STATE, bool PAIR, bool DIRECT = false, bool P_FIRST = false, class PRM>
+S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, ThinRay& out, ThinRay& out2)
 {
     S5_FPC_QUARTIC
     using namespace s5abi;
@@ -174,6 +221,7 @@ S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, doub
         else if (!wave_any(type != T_RR)) thin_disk_finish_direct<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
         else if (!wave_any(type != T_RC)) thin_disk_finish_direct<WANT_STATE, T_RC, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
         else thin_disk_finish_direct<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+        if constexpr (!DIRECT) thin_disk_owed_flux<PAIR>(p, out, out2);      // (a DIRECT re-trace leaves it to the routine that called it)
         return;
     } else {
 #if S5_RPC_ADD
@@ -187,6 +235,7 @@ S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, doub
     // routine cost the kernel 8 %: SGPRs saved and restored around the call sites, a stack reserved for every wave; inlined at
     // the routine's end with the roots kept alive for it: 6 %).  It redoes both rays of the lane's pair; the wave waits.
     const bool c0 = (out.cls == PX_COLD_MARK), c1 = PAIR && (out2.cls == PX_COLD_MARK);
+    S5_MARK("cold retrace begin");
     if (wave_any(c0 || c1)) {
         if (c0 || c1) {
             ThinRay d0, d1;
@@ -194,19 +243,28 @@ S5_DEV void trace_thin_disk_impl(const s5abi::ImageParams& p, double alpha, doub
                 const s5abi::ImageParams* pk = (const s5abi::ImageParams*)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(pk));                    // opaque: its reads are not merged with the kernel's own
                 trace_thin_disk_impl<WANT_STATE, PAIR, true>(*pk, alpha, beta_in, d0, PAIR ? d1 : d0);
+            } else if constexpr (PAIR && S5_COLD_UNPAIRED) {
+                // constant-address-space parameters (job-list kernel): the two rays of the pair one after the other through
+                // ONE copy of the UNPAIRED direct routine (a ray of a pair is the unpaired routine's ray, value for value:
+                // tests/test_gpu_images.py::test_mirrored_pairs_give_the_plain_image) -- half the code of the paired copy and
+                // well under its scalar-register need, which was the peak of the whole kernel
+                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, beta_in, d0, d0);
+                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, -beta_in, d1, d1);
             } else {
-                trace_thin_disk_impl<WANT_STATE, PAIR, true>(p, alpha, beta_in, d0, PAIR ? d1 : d0);
+                trace_thin_disk_impl<WANT_STATE, PAIR, true>(param_reload(p), alpha, beta_in, d0, PAIR ? d1 : d0);
             }
-            if (c0) out = d0;
-            if (c1) out2 = d1;
+            // (the marks are read again here rather than kept: a per-lane flag alive across the routine is a scalar register pair)
+            if (out.cls == PX_COLD_MARK) out = d0;
+            if (PAIR && out2.cls == PX_COLD_MARK) out2 = d1;
         }
     }
+    thin_disk_owed_flux<PAIR>(p, out, out2);
 #endif
     }
 }
 
-template <bool WANT_STATE, bool P_FIRST = false>
-S5_DEV void trace_thin_disk(const s5abi::ImageParams& p, double alpha, double beta_in, ThinRay& out)
+template <bool WANT_STATE, bool P_FIRST = false, class PRM>
+S5_DEV void trace_thin_disk(const PRM& p, double alpha, double beta_in, ThinRay& out)
 {
     trace_thin_disk_impl<WANT_STATE, false, false, P_FIRST>(p, alpha, beta_in, out, out);
 }
@@ -223,8 +281,8 @@ S5_DEV double* thin_disk_ladder_column()
 // formulas of the other classes and their special cases are pruned by the compiler.  The arithmetic a lane
 // performs is the same in every instantiation (same expressions, same order), so its result does not depend on
 // which one its wave took -- images stay identical bit for bit whatever the tile shape.
-template <bool WANT_STATE, int KNOWN, bool PAIR>
-S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+template <bool WANT_STATE, int KNOWN, bool PAIR, class PRM>
+S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                              const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_)
 {
@@ -339,7 +397,7 @@ S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, T
     double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
     // unrolled: three inlined R_F bodies (slot 1 is the table, slot 3 rare).  Rolled into one body it once saved the kernel
     // from 256 VGPRs and spills; at today's 108 VGPRs the copies cost nothing and the rolled loop costs 4 % (measured)
-#ifdef S5_SLOT_ROLLED
+#if defined(S5_SLOT_ROLLED)
 #pragma unroll 1
 #else
 #pragma unroll
@@ -454,7 +512,7 @@ S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, T
     bool cf0 = false, cf1 = false;
     // two inlined passes rather than a run-time loop: as a loop the compiler predicates the pass on per-lane state and the
     // lanes used fall from 97 % to 91 % (measured: +6.5 % VALU instructions, +4.5 % time)
-#ifdef S5_PAIR_ROLLED
+#if defined(S5_PAIR_ROLLED)
 #pragma unroll 1
 #else
 #pragma unroll
@@ -535,20 +593,11 @@ S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, T
 #endif
 #endif
         }
-        (void)cf0; (void)cf1;                   // (used by the fast variant's closed-form pass below only)
-        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; cf0 = cf_m; if (WANT_STATE) out.dP = dP_m; }
-        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; cf1 = cf_m; if (WANT_STATE) out2.dP = dP_m; }
+        (void)cf0; (void)cf1;
+        if (cf_m) flux_m = FLUX_OWED;           // the closed form, once, at the end of trace_thin_disk_impl (thin_disk_owed_flux)
+        if (!PAIR || member == 0) { out.cls = cls_m; out.r = r_m; out.P = P_m; out.g = g_m; out.flux = flux_m; if (WANT_STATE) out.dP = dP_m; }
+        else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; out2.g = g_m; out2.flux = flux_m; if (WANT_STATE) out2.dP = dP_m; }
     }
-#if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
-    // the closed form of the flux for the few rays the table does not serve (s5_disk.hpp), outside the loop above
-    if (wave_any(cf0 || cf1)) {
-        // constants from the disk model's device block, not from the kernel arguments: referenced here they would sit in
-        // ~30 SGPRs of every wave from the first instruction (the launchers always attach the block: capi_core.hip)
-        const double* cold = p.disk.cold;
-        if (cf0) { double x, rx; sqrt_rsqrt_pos(out.r, x, rx); out.flux = cold ? disk_flux_closed_form_mem(cold, out.r, x) : NAN; }
-        if (PAIR && cf1) { double x, rx; sqrt_rsqrt_pos(out2.r, x, rx); out2.flux = cold ? disk_flux_closed_form_mem(cold, out2.r, x) : NAN; }
-    }
-#endif
 }
 
 
@@ -575,8 +624,8 @@ S5_DEV void thin_disk_finish_direct(const s5abi::ImageParams& p, ThinRay& out, T
 // ---------------------------------------------------------------------------------------------------------------------------
 enum : int { CROSS_FORMULA = 0, CROSS_BEYOND = 1, CROSS_NONE = 2 };
 
-template <bool WANT_STATE, int KNOWN, bool PAIR>
-S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+template <bool WANT_STATE, int KNOWN, bool PAIR, class PRM>
+S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                              const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_)
 {
@@ -843,7 +892,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
         else { out2.cls = cls_m; out2.r = r_m; out2.P = P_m; if (WANT_STATE) out2.dP = dP_m; }
     }
     // ---------------- g-factor and flux of the accepted crossings ----------------
-    bool cf0 = false, cf1 = false;               // the flux of the ray is owed by the closed form (below)
+    const auto& pd = param_reload(p);            // (constant-address-space parameters: the disk's are loaded from here on)
 #pragma unroll
     for (int member = 0; member < MEMBERS; ++member) {
         ThinRay& o = (member == 0) ? out : out2;
@@ -853,7 +902,7 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
             double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
             sqrt_rsqrt_pos(o.r, x, rx);                   // r >= rms > 0
             o.g = gfactor_kepler_x(o.r, x, a_in, l);
-            o.flux = disk_flux_table(p.disk, o.r, x, rx, cf);
+            o.flux = disk_flux_table(pd.disk, o.r, x, rx, cf);
 #else
 #ifdef S5_KO_G
             o.g = 0.5 + 1e-3 * o.r;
@@ -866,19 +915,9 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
             o.flux = disk_flux(p.disk, o.r);
 #endif
 #endif
-            if (member == 0) cf0 = cf; else cf1 = cf;
+            if (cf) o.flux = FLUX_OWED;          // the closed form, once, at the end of trace_thin_disk_impl (thin_disk_owed_flux)
         }
     }
-#if !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
-    // the closed form of the flux for the few rays the table does not serve (s5_disk.hpp), outside the loop above
-    if (wave_any(cf0 || cf1)) {
-        // constants from the disk model's device block, not from the kernel arguments: referenced here they would sit in
-        // ~30 SGPRs of every wave from the first instruction (the launchers always attach the block: capi_core.hip)
-        const double* cold_block = p.disk.cold;
-        if (cf0) { double x, rx; sqrt_rsqrt_pos(out.r, x, rx); out.flux = cold_block ? disk_flux_closed_form_mem(cold_block, out.r, x) : NAN; }
-        if (PAIR && cf1) { double x, rx; sqrt_rsqrt_pos(out2.r, x, rx); out2.flux = cold_block ? disk_flux_closed_form_mem(cold_block, out2.r, x) : NAN; }
-    }
-#endif
     // ---------------- the rays left to the direct evaluation ----------------
     // marked for the caller (trace_thin_disk_impl), which runs the direct routine for them from the pixel's coordinates:
     // nothing of this routine's state has to stay alive for it
@@ -892,7 +931,8 @@ S5_DEV void thin_disk_finish(const s5abi::ImageParams& p, ThinRay& out, ThinRay&
 // other's negatives bit for bit: that is what lets the mirrored kernel give the very image of the plain one.  For image sizes
 // that are powers of two the fast variant's products with the reciprocals are the reference's numbers exactly; for other
 // sizes see the two routines.
-S5_DEV double pixel_alpha(const s5abi::ImageParams& p, int ix)
+template <class PRM>
+S5_DEV double pixel_alpha(const PRM& p, int ix)
 {
 #if S5_FAST
     // the product with 1/nx is the reference's quotient bit for bit when nx is a power of two (every BASELINE size); for the
@@ -904,7 +944,8 @@ S5_DEV double pixel_alpha(const s5abi::ImageParams& p, int ix)
 #endif
 }
 
-S5_DEV double pixel_beta(const s5abi::ImageParams& p, int iy)
+template <class PRM>
+S5_DEV double pixel_beta(const PRM& p, int iy)
 {
 #if S5_FAST
     // ny a power of two (every BASELINE size): the product below IS the reference's expression, bit for bit, and antisymmetric.

@@ -556,6 +556,47 @@ def test_in_place_rows_and_share_placement(capi):
         assert np.array_equal(got, want), (nx, ny, world, dealt, int((got != want).sum()))
 
 
+def test_job_list_launch_gives_the_single_launch_images(capi):
+    """sim5gpu_disk_image_jobs: a list of jobs of different sizes, spins and inclinations -- whole images, a centred band, an
+    in-place mirrored share (rank 1 of 3 into a whole-image buffer), odd heights, two crossing orders, plus jobs the job-list
+    kernel does not serve (strict variant, an asymmetric row range: launched by themselves, in order) -- every image bit for
+    bit what sim5gpu_disk_image gives for the job; 16 + 3 jobs exercise a full group and the wrap to a second launch."""
+    from sim5_amd import sharding
+    rad = math.radians
+    jobs = []      # (desc, rows, nx)
+    def add(d, rows=None):
+        jobs.append((d, capi.image_rows(d) if rows is None else rows, d.nx))
+    add(capi.image_desc(256, 256, 0.998, rad(70)))
+    add(capi.image_desc(301, 203, 0.9, rad(60)))
+    add(capi.image_desc(200, 128, 0.5, rad(30), max_order=1))
+    add(capi.image_desc(320, 512, 0.9, rad(65), y0=128, y1=384))                    # centred band
+    add(capi.image_desc(256, 512, 0.9, rad(65), **sharding.job_rows(512, 1, 3)))     # packed mirrored share
+    add(capi.image_desc(256, 512, 0.9, rad(65), inplace=True, **sharding.job_rows(512, 0, 3)), rows=512)   # in place
+    add(capi.image_desc(128, 128, 0.7, rad(50), strict=True))                       # not served: strict
+    add(capi.image_desc(160, 200, 0.7, rad(50), y0=10, y1=90))                      # not served: asymmetric
+    add(capi.image_desc(64, 3, 0.7, rad(50)))
+    add(capi.image_desc(192, 1001, 0.3, rad(80)))
+    for k in range(9):
+        add(capi.image_desc(96 + 16 * k, 64 + 8 * k, 0.1 * k, rad(10 + 9 * k)))
+    assert len(jobs) == 19
+    A = [(capi.DeviceBuffer(r * nx * 4), capi.DeviceBuffer(r * nx * 4)) for (_, r, nx) in jobs]
+    B = [(capi.DeviceBuffer(r * nx * 4), capi.DeviceBuffer(r * nx * 4)) for (_, r, nx) in jobs]
+    for (f, g) in A + B:
+        f.fill(0xff); g.fill(0xff)
+    for (d, _, _), (f, g) in zip(jobs, A):
+        capi.disk_image_device(d, f.ptr, g.ptr)
+    capi.disk_image_jobs([d for (d, _, _) in jobs], [f.ptr for (f, _) in B], [g.ptr for (_, g) in B])
+    capi.synchronize()
+    for k, ((d, r, nx), (fa, ga), (fb, gb)) in enumerate(zip(jobs, A, B)):
+        assert capi.words_differ(fa.ptr, fb.ptr, r * nx) == 0 and capi.words_differ(ga.ptr, gb.ptr, r * nx) == 0, k
+    lit = A[0][1].to_numpy(np.float32, (256, 256))
+    assert (lit > 0).sum() > 1000
+    # an empty list is fine; a NULL plane, a bad description are refused before anything is launched
+    capi.disk_image_jobs([], [], [])
+    with pytest.raises(capi.Sim5GpuError):
+        capi.disk_image_jobs([jobs[0][0], capi.image_desc(0, 10, 0.5, 1.0)], [A[0][0].ptr, A[1][0].ptr], [A[0][1].ptr, A[1][1].ptr])
+
+
 def test_words_differ_utility(capi):
     """sim5gpu_words_differ counts differing 32-bit words (NaN patterns included), aligned and unaligned lengths"""
     rng = np.random.default_rng(5)
