@@ -59,7 +59,8 @@ sys.path.insert(0, ROOT)
 
 SPIN, INCL_DEG = 0.998, 70.0
 W_ELL = 1.3e3                     # algorithmic FP64 ops per elliptic thin-disk ray (an estimate)
-IMAGE_KERNEL = "disk_image_mirror_kernel"   # whole images and mirrored stripe shares (k_disk_image.hip); other row sets: disk_image_grid_kernel
+IMAGE_KERNEL = "disk_image_jobs_kernel"     # whole images, centred bands and mirrored stripe shares (k_disk_image.hip: the pairing kernel reading its
+                                            # job from the argument segment, a list of one); other row sets: disk_image_grid_kernel
 # the same quantity counted exactly on the reference binary (oracle/opcount.c, profiles/r01_opcount_image.json):
 # 363 add + 207 sub + 419 mul + 165 div + 152 sqrt + 308 compare + 11 x87 + 139 library calls per ray
 W_ELL_MEASURED = 1764.8

@@ -19,10 +19,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 # the headline image is traced by the mirror kernel since round 2 (a lane takes a ray and its mirror image in beta);
 # `tag`s collected before that hold the grid kernel
-KERNEL = "disk_image_mirror_kernel"
+# ... and since round 4 by the same routine reading its job from the argument segment (disk_image_jobs_kernel)
+KERNEL = "disk_image_jobs_kernel"
 for _d in glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")):
-    if "disk_image_mirror_kernel" not in open(_d).read():
-        KERNEL = "disk_image_grid_kernel"
+    _txt = open(_d).read()
+    if "disk_image_jobs_kernel" not in _txt:
+        KERNEL = "disk_image_mirror_kernel" if "disk_image_mirror_kernel" in _txt else "disk_image_grid_kernel"
 
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 if stats:

@@ -28,11 +28,12 @@ SOURCES = [("capi_core.hip", "capi_core.o", "strict"), ("capi_batch.hip", "capi_
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
-# Both variants round products and sums separately (-ffp-contract=off), as the reference build does
-# (x86-64 baseline, no FMA).  Measured on MI355X (tests/tools/ablate.sh, 4096^2 headline image): letting
-# the compiler contract changed neither the kernel time (1.74 vs 1.71 ms) nor the class map, but raised
-# the worst-pixel error of r from 6e-13 to 2.6e-7 and of g to 1.5e-6 (a cancellation near the horizon
-# that only agrees with the reference when rounded the reference's way), so contraction stays off.
+# The translation units are compiled with -ffp-contract=off (the reference build is x86-64 baseline, no FMA).  The STRICT
+# variant keeps it that way everywhere; the FAST variant lets the compiler fuse a*b+c region by region through
+# `#pragma clang fp contract(on)` at the head of its routines (s5_config.hpp: S5_FPC_MASK = 62: every region but the
+# closed-form quartic, whose discriminant X = F^2 - 4E^3 agrees with the reference only when F^2 is rounded before the
+# subtraction -- bisected on MI355X in round 3: fusing the quartic alone takes the worst pixel from r 6e-13 to 1.4e-7), and
+# the march kernel's fast build is compiled with -ffp-contract=fast (below).
 VARIANT = {"strict": ["-DS5_FAST=0", "-ffp-contract=off"], "fast": ["-DS5_FAST=1", "-ffp-contract=off"]}
 
 
@@ -130,9 +131,29 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
     build_rccl(hipcc, force=force or bool(cmds), verbose=verbose)
+    check_no_scratch(LIB)
     with open(stamp, "w") as fh:
         fh.write(fp + "\n")
     return LIB
+
+
+def check_no_scratch(lib):
+    """Refuse a library whose fast image kernels spill a vector register or use a private segment (a build of
+    the pairing kernel with ONE spilled double gave wrong pixels in one launch mode; the cause was never pinned below the
+    compiler, so such a build is an error HERE, for the in-tree library and for every experiment variant, not only in the
+    test suite).  S5_ALLOW_SCRATCH=1 lets a timing experiment through."""
+    if os.environ.get("S5_ALLOW_SCRATCH") == "1":
+        return
+    try:
+        from sim5_amd.codeobj import kernel_metadata
+    except ImportError:
+        sys.path.insert(0, os.path.dirname(HERE))
+        from sim5_amd.codeobj import kernel_metadata
+    bad = {k: v for k, v in kernel_metadata(lib).items()
+           if "s5f" in k and "disk_image" in k and (v.get("vgpr_spill_count", 0) or v.get("private_segment_fixed_size", 0))}
+    if bad:
+        os.remove(lib)
+        raise RuntimeError("build refused: fast image kernels with spilled VGPRs / scratch: %r" % bad)
 
 
 def build_rccl(hipcc, force=False, verbose=False):

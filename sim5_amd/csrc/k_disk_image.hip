@@ -154,16 +154,24 @@ void disk_image_mirror_kernel(ImageParams p)
 // cost.  The jobs' parameters are read from the kernel-argument segment through the constant address space (kernels.hpp:
 // JobList): scalar loads at the point of use, the late ones (flux table, output pointers) behind param_reload().  A lane's
 // arithmetic is that of disk_image_mirror_kernel<false>, value for value: images are the same bits.
+// SINGLE: the list holds one job (sim5gpu_disk_image of a symmetric row set): no search, the job at a constant offset
+template <bool SINGLE>
 __global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
 void disk_image_jobs_kernel(JobList list_arg)
 {
     const S5_AS4 JobList* L = (const S5_AS4 JobList*)__builtin_amdgcn_kernarg_segment_ptr();
     const int t = (int)blockIdx.x;
-    int j = 0;
-    const int nj = L->njobs;
-    while (j + 1 < nj && t >= L->tile_end[j]) ++j;                       // scalar: <= 15 steps
-    const int t0 = (j > 0) ? L->tile_end[j - 1] : 0;
-    const S5_AS4 FastJob& p = L->job[j];
+    int j = 0, t0 = 0;
+    if (!SINGLE) {
+        // the job of this tile: all prefix sums in one scalar load, compared in registers (a search with a load per step is a
+        // chain of dependent memory round trips at the head of every workgroup).  Entries past the last job hold the total.
+#pragma unroll
+        for (int k = 0; k < JOBS_MAX - 1; ++k) {
+            const int te = L->tile_end[k];
+            if (t >= te) { j = k + 1; t0 = te; }
+        }
+    }
+    const S5_AS4 FastJob& p = L->job[SINGLE ? 0 : j];
     const int nx = p.nx, nrows = p.nrows;
     const int half = (nrows + 1) / 2;
     const int tiles_x = (nx + TILE_W - 1) / TILE_W;
@@ -237,7 +245,8 @@ int s5_launch_disk_image_jobs_fast(const s5abi::ImageParams* jobs, int n, hipStr
         L.tile_end[j] = (int)total;
     }
     for (int j = n; j < JOBS_MAX; ++j) L.tile_end[j] = (int)total;
-    hipLaunchKernelGGL(disk_image_jobs_kernel, dim3((unsigned)total), dim3(256), 0, stream, L);
+    if (n == 1) hipLaunchKernelGGL(disk_image_jobs_kernel<true>, dim3((unsigned)total), dim3(256), 0, stream, L);
+    else hipLaunchKernelGGL(disk_image_jobs_kernel<false>, dim3((unsigned)total), dim3(256), 0, stream, L);
     return (int)hipGetLastError();
 }
 
@@ -254,6 +263,12 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
     } else {
 #if S5_FAST && !defined(S5_NO_MIRROR)
         if ((p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny)) && p.nrows >= 2) {
+            // production jobs (two f32 planes): the job-list kernel with a list of one -- same time as the by-value kernel
+            // (measured: 0.3123 against 0.3125 ms at 4096^2, 0.0257 / 0.0259 at 1024^2), and its hot path holds no spilled
+            // scalar register (parameters are read where they are used); the by-value kernel serves the full-precision planes
+#ifndef S5_SINGLE_BY_VALUE
+            if (!aux) return s5_launch_disk_image_jobs_fast(&p, 1, stream);
+#endif
             const dim3 grid((p.nx + TILE_W - 1) / TILE_W, ((p.nrows + 1) / 2 + TILE_H - 1) / TILE_H);
             if (aux) hipLaunchKernelGGL(disk_image_mirror_kernel<true>, grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL(disk_image_mirror_kernel<false>, grid, dim3(256), 0, stream, p);

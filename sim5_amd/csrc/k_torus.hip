@@ -8,9 +8,9 @@
 //      src/sim5raytrace.c:44).  The state goes to HBM as a structure of arrays (one 8-B column
 //      per quantity, so every load/store below is a coalesced 512-B wave access).
 //  (B) torus_pool_kernel: persistent waves advance rays with raytrace() (ref src/sim5raytrace.c:109-245),
-//      accumulating the transfer integral after each accepted step; each wave keeps a pool of 128 rays in
-//      LDS and runs the Verlet half and the RK4 half of raytrace() as separate full-width batches (see
-//      the comment at the kernel).
+//      accumulating the transfer integral after each accepted step; each workgroup keeps a pool of 320 rays in
+//      LDS from which its waves run the Verlet half and the RK4 half of raytrace() as separate full-width
+//      batches (see the comment at the kernel).
 //
 // Transfer model (the reference has no transfer integrator nor torus; this is
 // this project's definition, stated in DESIGN.md): fluid on circular orbits with constant specific
@@ -260,7 +260,7 @@ S5_DEV void write_ray_end(const TorusAux& aux, sim5gpu_stokes* __restrict__ out,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// torus_pool_kernel: persistent waves, each with a private pool of 128 rays in LDS.
+// torus_pool_kernel: persistent workgroups of four waves, each workgroup with a pool of rays in LDS.
 //
 // What occupancy counters showed when 64 image neighbours march in lock-step (C4, 1024^2): at precision 1,
 // 76 % of the wave-steps contain a lane whose Verlet attempt fails, 27 of 64 lanes on average; at precision 0.01, 29 % of
@@ -272,29 +272,58 @@ S5_DEV void write_ray_end(const TorusAux& aux, sim5gpu_stokes* __restrict__ out,
 //            restores x, k; ref :221-222), the ray is tagged R.
 //   R batch: up to 64 rays tagged R: recompute the step size (same expression, same operands as the failed
 //            attempt), RK4 step, finish the step, back to V.
-// With 128 rays in the pool one of the two batches always has >= 64 rays while the pool is full, so both bodies
+// With 128 rays to choose from one of the two kinds always has >= 64 rays while the pool is full, so both bodies
 // run with (nearly) all lanes.  A ray's arithmetic is unchanged: same calls, same operands, same order.
-// Finished rays are replaced from the global cursor (one atomic per wave and refill pass).  No inter-wave
-// communication: the pool, its tags and the batch list are private to the wave (LDS, 18 KB per wave).
+// Finished rays are replaced from the global cursor (one atomic per wave and refill pass).  The waves of a workgroup
+// share the pool through the slots' tags only (LDS compare-and-swap; no locks, no barriers after the first).
 // ---------------------------------------------------------------------------------------------------------
-#ifndef S5_POOL_SLOTS
-#define S5_POOL_SLOTS 128                // rays per wave pool, 65..128 (lane l owns slots l and l + 64)
+// ONE POOL PER WORKGROUP, THREE QUEUES (round 4).  Until round 3 every wave had a private pool of 128 rays (512 per
+// workgroup), scanned its slots' tags for work, and the four pools were shared only in the drain phase.  What a wave needs
+// is 64 rays of one kind when it comes back from a batch; while the other three waves each hold at most 64 rays in their
+// batches, a pool of 4 x 64 + 64 = 320 rays leaves the returning wave the same 128 to choose from (its own 64 + 64 idle
+// ones) as the private pools did -- with 320 rays in flight per workgroup instead of 512.  Rays in flight are what the job
+// pays for at its end: when the cursor runs out every pooled ray still has half its steps to make, with batches that thin
+// out (T = 7 ms + steps / 2.65e10 at 512 per workgroup).  Sharing by SCANNING the tags of the whole pool costs what the
+// smaller pool gains (measured: 28.4 ms at 512 shared slots against 25.9 with private pools, 25.7 at 320), so the slots now
+// travel through three ring queues in LDS -- empty slots (E), rays whose next action is a Verlet attempt (V), rays that owe
+// the RK4 half of a call (R): a wave takes up to 64 entries of a queue with ONE compare-and-swap on its head and returns
+// them with one atomic add on a tail per kind; nothing is scanned, the order is first in first out (no ray waits while
+// others are stepped twice), and a wave with nothing to take sleeps until the workgroup's last ray is done instead of
+// retiring early.
+// Workgroup width.  Fast variant: ONE workgroup of eight waves per CU (two per SIMD, the VGPR-bound occupancy) with a pool
+// of 8 x 64 + 64 = 576 rays -- one pool per CU instead of two of 320: fewer rays in flight still, and the drain phase shares
+// the rays of the whole CU.  Measured, C4, one call: 4 waves x 256 slots 25.9 ms, x 320 24.1-24.4, x 384 24.2; 8 waves x 576
+// 23.6, x 640 23.6-23.8 (private 128-ray pools of round 3: 25.7).  Strict variant: its bodies need one wave per SIMD, four
+// waves per workgroup keep every CU busy.
+#ifndef S5_POOL_WG_WAVES
+#define S5_POOL_WG_WAVES (S5_FAST ? 8 : 4)
 #endif
-constexpr int POOL_SLOTS = S5_POOL_SLOTS;
-static_assert(POOL_SLOTS > 64 && POOL_SLOTS <= 128 && POOL_SLOTS % 4 == 0, "pool size");
+#ifndef S5_POOL_WG_SLOTS
+#define S5_POOL_WG_SLOTS (64 * S5_POOL_WG_WAVES + 64)     // rays per workgroup pool: every wave's batch + 64
+#endif
+#ifndef S5_POOL_REFILL_MIN
+#define S5_POOL_REFILL_MIN 32            // empty slots that make a refill worth its global atomic and loads
+#endif
+constexpr int WG_WAVES = S5_POOL_WG_WAVES;
+constexpr int WG_THREADS = 64 * WG_WAVES;
+constexpr int WG_SLOTS = S5_POOL_WG_SLOTS;
+constexpr int RING = (WG_SLOTS <= 512) ? 512 : 1024;         // entries of a queue: a power of two >= WG_SLOTS (a slot is in one queue at most)
+static_assert(WG_SLOTS % 64 == 0 && WG_SLOTS >= 128 && WG_SLOTS <= RING, "pool size");
 #ifndef POOL_KEEP_NUM
 #define POOL_KEEP_NUM 7                   // ... while at least NUM/DEN of its lanes are still stepping
 #define POOL_KEEP_DEN 8
 #endif
 #ifndef POOL_RUN
-#define POOL_RUN 4                       // Verlet attempts a batch may take before it returns to the pool
-#endif
+#define POOL_RUN 6                       // Verlet attempts a batch may take before it returns to the pool (measured with the queues
+#endif                                   // of round 4, C4, one call: 4 -> 23.7-23.9 ms, 6 -> 23.4-23.5, 8 -> 23.3-23.5)
 enum : int { PC_X0 = 0, PC_X1, PC_X2, PC_X3, PC_K0, PC_K1, PC_K2, PC_K3, PC_DK0, PC_DK1, PC_DK2, PC_DK3,
              PC_KT, PC_E, PC_I, PC_TAU, NPC };
-enum : int { TAG_EMPTY = 0, TAG_V = 1, TAG_R = 2, TAG_BUSY = 3 };
-constexpr int WG_WAVES = 4;                                  // 256-thread workgroups
-constexpr int WG_SLOTS = WG_WAVES * POOL_SLOTS;              // the pools of a workgroup lie side by side in LDS
-constexpr int POOL_WG_BYTES = ((NPC * WG_SLOTS * 8 + 4 * WG_SLOTS * 4 + WG_WAVES * 64 * 2) + 15) / 16 * 16;
+enum : int { TAG_EMPTY = 0, TAG_V = 1, TAG_R = 2 };            // what a ray owes next = the queue its slot goes back to
+enum : int { Q_E = 0, Q_V = 1, Q_R = 2, NQ = 3 };
+// control words of a workgroup (LDS): head and tail of the three queues, rays alive in the pool, "the cursor is exhausted"
+enum : int { CW_HEAD = 0, CW_TAIL = NQ, CW_LIVE = 2 * NQ, CW_DRAINED = 2 * NQ + 1, NCW = 8 };
+constexpr unsigned short RING_VOID = 0xffffu;                 // a queue entry that has been reserved but not written yet
+constexpr int POOL_WG_BYTES = ((NPC * WG_SLOTS * 8 + 3 * WG_SLOTS * 4 + NQ * RING * 2 + NCW * 4) + 15) / 16 * 16;
 
 S5_DEV void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 S5_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
@@ -306,19 +335,18 @@ S5_DEV void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256, S5_MARCH_WAVES)
+__global__ __launch_bounds__(WG_THREADS, S5_MARCH_WAVES)
 void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__ ok, const int* __restrict__ order,
                        unsigned long long* __restrict__ cursor, sim5gpu_stokes* __restrict__ out, TorusAux aux)
 {
     extern __shared__ char pool_raw[];
-    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int lane = (int)(threadIdx.x & 63);
     double* pd = (double*)pool_raw;                                  // [NPC][WG_SLOTS]
     int* pray = (int*)(pool_raw + NPC * WG_SLOTS * 8);               // [WG_SLOTS]
     int* ppass = pray + WG_SLOTS;
     float* pworst = (float*)(ppass + WG_SLOTS);
-    int* ptag = (int*)(pworst + WG_SLOTS);                           // [WG_SLOTS], claimed with LDS compare-and-swap
-    unsigned short* plist = (unsigned short*)(ptag + WG_SLOTS) + wave * 64;   // [64] slots of this wave's current batch
-    const int own = wave * POOL_SLOTS;                               // this wave's quarter: the slots it refills
+    unsigned short* ring = (unsigned short*)(pworst + WG_SLOTS);     // [NQ][RING]
+    unsigned* cw = (unsigned*)(ring + NQ * RING);                    // [NCW]
 
     const size_t n = p_arg.nrays;
 #if S5_FAST && !defined(S5_TORUS_UNIFORMS_IN_SGPRS)
@@ -347,12 +375,13 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
     const double* __restrict__ sc = start.d;
     const size_t scap = start.cap;
 
-    ptag[own + lane] = TAG_EMPTY;
-    if (lane + 64 < POOL_SLOTS) ptag[own + lane + 64] = TAG_EMPTY;
-    __syncthreads();                                                 // the only workgroup barrier: all quarters exist
-    bool drained = false;                                            // wave-uniform: the cursor ran past the last ray
+    // the pool: every slot in the queue of empty slots, the other two queues void
+    for (int i = (int)threadIdx.x; i < NQ * RING; i += WG_THREADS) ring[i] = (i < WG_SLOTS) ? (unsigned short)i : RING_VOID;
+    if (threadIdx.x < NCW) cw[threadIdx.x] = (threadIdx.x == CW_TAIL + Q_E) ? (unsigned)WG_SLOTS : 0u;
+    __syncthreads();                                                 // the only workgroup barrier: the pool exists
 #ifdef S5_TORUS_DEBUG
     // timeline of the wave (100 MHz clock): start, first time the cursor was found exhausted, exit
+    const int wave = (int)(threadIdx.x >> 6);
     unsigned long long* tl = (unsigned long long*)aux.k_end + 16 + 3 * ((size_t)blockIdx.x * WG_WAVES + wave);
     if (lane == 0) { tl[0] = wall_clock64(); tl[1] = 0; tl[2] = 0; }
 #endif
@@ -368,36 +397,105 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
     asm volatile("" : "+v"(s.bh_spin));
 #endif
 
-    // every pass either consumes cursor positions or advances at least one pooled ray by half a raytrace() call
-    const unsigned long long guard = 8ull * (unsigned long long)(p.max_steps + 2) * ((n + 63) / 64 + 2);
+    // Every wait in this kernel is bounded: the spins of the queue primitives by SPIN_CAP (~50 ms; they normally last a few
+    // cycles), the main loop by `guard` passes AND by a wall-clock budget far above any job's need (5 s + 1 ns per ray and
+    // permitted step): a wave that runs into either leaves the loop, so the grid always drains -- the rays it abandons are
+    // never written, which the step counts and hit checks of every caller and test catch.
+    constexpr int SPIN_CAP = 1 << 20;
+    bool broken = false;
+    const unsigned long long t_begin = wall_clock64();
+    const unsigned long long t_budget = 100000000ull * 5ull + (unsigned long long)n * (unsigned long long)(p_arg.max_steps > 0 ? p_arg.max_steps : 1) / 10ull;
+    // Queue primitives (wave-uniform calls).  take: up to `want` entries from queue q -- one lane snapshots head and tail and
+    // moves the head by compare-and-swap (retried while other waves move it); lane i < count then owns entry head + i: it waits
+    // for the entry to be written (a producer reserves its positions before it fills them), reads the slot and voids the entry.
+    // give: the lanes with `mine` append their slot to queue q -- one atomic add on the tail, then each lane writes its entry.
+    auto q_take = [&](const int q, const int want, int& slot) -> int {
+        unsigned h = 0, cnt = 0;
+        if (lane == 0) {
+            for (;;) {
+                h = __hip_atomic_load(&cw[CW_HEAD + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned t = __hip_atomic_load(&cw[CW_TAIL + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned avail = t - h;
+                cnt = avail < (unsigned)want ? avail : (unsigned)want;
+                if ((int)avail <= 0) { cnt = 0; break; }
+                if (atomicCAS(&cw[CW_HEAD + q], h, h + cnt) == h) break;
+            }
+        }
+        h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+        cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)cnt);
+        slot = 0;
+        if ((unsigned)lane < cnt) {
+            unsigned short* e = &ring[q * RING + ((h + (unsigned)lane) & (unsigned)(RING - 1))];
+            unsigned v;
+            int spins = 0;
+            while ((v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == RING_VOID && ++spins < SPIN_CAP) __builtin_amdgcn_s_sleep(1);
+            if (v == RING_VOID) { broken = true; v = 0; }             // (never seen: the writer is a few instructions behind its reservation)
+            __hip_atomic_store(e, RING_VOID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            slot = (int)v;
+        }
+        wg_acquire();                                               // the state of the taken slots, written by the wave that gave them
+        return (int)cnt;
+    };
+    auto q_give = [&](const int q, const bool mine, const int slot) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+        if (!m) return;
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        unsigned base = 0;
+        if (mine && rank == 0u) base = atomicAdd(&cw[CW_TAIL + q], (unsigned)__builtin_popcountll(m));
+        base = (unsigned)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (mine) {
+            // the entry is void unless a taker that reserved it a whole ring ago has not read it yet (it would have to sleep
+            // through seven batches of the other waves): wait for that read rather than overwrite it
+            unsigned short* e = &ring[q * RING + ((base + rank) & (unsigned)(RING - 1))];
+            int spins = 0;
+            while (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != RING_VOID && ++spins < SPIN_CAP) __builtin_amdgcn_s_sleep(1);
+            if (spins >= SPIN_CAP) broken = true;
+            __hip_atomic_store(e, (unsigned short)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+
+    // every pass consumes cursor positions, advances at least one pooled ray by half a raytrace() call, or waits for the other
+    // waves of the workgroup (bounded like the rest: a waiting pass is a sleep of ~1 us, the bound allows for it)
+    const unsigned long long guard = 64ull * (unsigned long long)(p.max_steps + 2) * ((n + 63) / 64 + 2);
     for (unsigned long long it = 0; it < guard; ++it) {
-        wave_lds_fence();
-        // ---- 1. refill the empty slots of the own quarter from the cursor: lane l looks after slots l and l + 64.
-        //         Only the owner ever turns an EMPTY slot into something else, so no claim is needed here.
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            const int slot = own + lane + 64 * half;
-            const bool inq = (lane + 64 * half) < POOL_SLOTS;
-            const bool want = !drained && inq && (ptag[inq ? slot : own] == TAG_EMPTY);
-            const unsigned long long idle = __builtin_amdgcn_ballot_w64(want);
-            if (idle) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
-                                          __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                const int leader = __builtin_ctzll(idle);
-                const unsigned cnt = (unsigned)__builtin_popcountll(idle);
+        if (__builtin_amdgcn_ballot_w64(broken)) break;
+        if ((it & 255ull) == 255ull && wall_clock64() - t_begin > t_budget) break;
+        // ---- 1. new rays into empty slots, as long as the cursor has any: when a batch's worth of slots is empty, or the
+        //         queues could not fill a batch otherwise
+        const bool drained = __hip_atomic_load(&cw[CW_DRAINED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+        unsigned nE = 0, nV = 0, nR = 0;
+        {
+            unsigned hv = 0;
+            if (lane < 2 * NQ) hv = __hip_atomic_load(&cw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned h = (unsigned)__shfl((int)hv, lane % NQ, 64), t = (unsigned)__shfl((int)hv, NQ + lane % NQ, 64);
+            const int d = (int)(t - h);
+            const unsigned dd = d > 0 ? (unsigned)d : 0u;
+            nE = (unsigned)__shfl((int)dd, Q_E, 64); nV = (unsigned)__shfl((int)dd, Q_V, 64); nR = (unsigned)__shfl((int)dd, Q_R, 64);
+        }
+        if (!drained && nE > 0u && (nE >= (unsigned)S5_POOL_REFILL_MIN || nV + nR < 64u)) {
+            int slot;
+            const int got = q_take(Q_E, 64, slot);
+            if (got > 0) {
+                const bool have = lane < got;
                 unsigned long long base = 0;
-                if (want && rank == 0u) base = atomicAdd(cursor, (unsigned long long)cnt);
-                base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader, 64) << 32) |
-                       (unsigned long long)(unsigned)__shfl((int)(unsigned)base, leader, 64);
+                if (lane == 0) {
+                    atomicAdd(&cw[CW_LIVE], (unsigned)got);                 // counted alive BEFORE the cursor is asked (see the exit test)
+                    base = atomicAdd(cursor, (unsigned long long)got);
+                }
+                base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+                if (base + (unsigned long long)got >= n) {
 #ifdef S5_TORUS_DEBUG
-                if (base + cnt >= n && !drained && lane == 0) tl[1] = wall_clock64();
+                    if (lane == 0 && tl[1] == 0) tl[1] = wall_clock64();
 #endif
-                if (base + cnt >= n) drained = true;
-                const unsigned long long mine = base + rank;
-                if (want && mine < n) {
+                    if (lane == 0) __hip_atomic_store(&cw[CW_DRAINED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const unsigned long long mine = base + (unsigned long long)lane;
+                bool started = false;
+                if (have && mine < n) {
                     const size_t ray = (size_t)order[mine];         // (torus_start_kernel: the long rays first)
                     if (!ok[ray]) {
-                        // rejected at start-up: an empty record, the slot stays empty
+                        // rejected at start-up: an empty record, the slot goes back to the empty ones
                         sim5gpu_stokes z = { 0.0, 0.0, 0.0, 0.0, 0.0 };
                         out[ray] = z;
                         if (aux.steps) aux.steps[ray] = 0;
@@ -414,63 +512,40 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
                         pd[PC_I * WG_SLOTS + slot] = 0.0;
                         pd[PC_TAU * WG_SLOTS + slot] = 0.0;
                         pray[slot] = (int)ray; ppass[slot] = 0; pworst[slot] = 0.0f;
-                        wg_release();                                  // the state before the tag, for a wave that steals it
-                        ptag[slot] = TAG_V;
+                        started = true;
                     }
                 }
+                wg_release();                                          // the state before the queue entry
+                const unsigned long long sm = __builtin_amdgcn_ballot_w64(started);
+                const int unused = got - __builtin_popcountll(sm);
+                if (unused > 0 && lane == 0) atomicSub(&cw[CW_LIVE], (unsigned)unused);
+                q_give(Q_V, started, slot);
+                q_give(Q_E, have && !started, slot);                   // rejected rays and positions past the end
+                continue;                                              // look at the queues again
             }
         }
-        wave_lds_fence();
 
-        // ---- 2. what is there to do: the own quarter, and -- once the cursor is exhausted and no refill keeps the own
-        //         pool full -- the quarters of the other waves of the workgroup as well (work stealing: in the drain phase
-        //         the four pools act as one, so the batches stay full until the WORKGROUP runs out of rays; measured
-        //         before: 40 % of the job's time was spent in drain-phase batches of ~32 lanes)
-        const int ngroups = drained ? 2 * WG_WAVES : 2;               // groups of 64 slots, own quarter first
-        int nV = 0, nR = 0;
-#pragma unroll 1
-        for (int gi = 0; gi < ngroups; ++gi) {
-            const int q = (wave + (gi >> 1)) % WG_WAVES, off = lane + 64 * (gi & 1);
-            const int t = (off < POOL_SLOTS) ? ptag[q * POOL_SLOTS + off] : TAG_EMPTY;
-            nV += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t == TAG_V));
-            nR += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t == TAG_R));
+        // ---- 2. what is there to do
+        if (nV + nR == 0u) {
+            // nothing to take: the rays of the workgroup are all in other waves' batches (or finished).  Leave when the cursor
+            // is exhausted and no ray of the pool is alive; wait otherwise.
+            if (drained && __hip_atomic_load(&cw[CW_LIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+            __builtin_amdgcn_s_sleep(32);
+            continue;
         }
-        if (nV + nR == 0) {
-            if (drained) break;                      // nothing to claim anywhere, nothing left to start: the wave retires
-            continue;                                // only rejected rays came in: refill again
-        }
-        const bool do_rk4 = (nR >= 64) || (nV == 0) || (nV < 64 && nR > nV);
-        const int kind = do_rk4 ? TAG_R : TAG_V;
+        const bool do_rk4 = (nR >= 64u) || (nV == 0u) || (nV < 64u && nR > nV);
 
-        // ---- 3. claim up to 64 slots of the chosen kind (compare-and-swap kind -> BUSY: a slot belongs to the wave that
-        //         wins it until that wave writes its next tag) and list them
-        int take = 0;
-#pragma unroll 1
-        for (int gi = 0; gi < ngroups && take < 64; ++gi) {
-            const int q = (wave + (gi >> 1)) % WG_WAVES, off = lane + 64 * (gi & 1);
-            const int slot_c = q * POOL_SLOTS + off;
-            const bool cand = (off < POOL_SLOTS) && (ptag[(off < POOL_SLOTS) ? slot_c : own] == kind);
-            const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
-            if (!cm) continue;
-            const int crank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
-            bool got = false;
-            if (cand && (take + crank < 64)) got = (atomicCAS(&ptag[slot_c], kind, (int)TAG_BUSY) == kind);
-            const unsigned long long gm = __builtin_amdgcn_ballot_w64(got);
-            if (got) {
-                const int r = take + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(gm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gm, 0u));
-                plist[r] = (unsigned short)slot_c;
-            }
-            take += __builtin_popcountll(gm);
-        }
+        // ---- 3. take up to 64 rays of the chosen kind
+        int slot;
+        const int take = q_take(do_rk4 ? Q_R : Q_V, 64, slot);
         if (take == 0) continue;                     // another wave was faster: look again
-        wg_acquire();
-        wave_lds_fence();
         const bool active = lane < take;
-        const int slot = active ? (int)plist[lane] : 0;
 
         // ---- 4. the batch: [RK4 half of the pending call for an R batch], then up to POOL_RUN Verlet attempts;
-        //         a lane whose attempt is rejected stops (tag R), the wave goes back to the pool when a quarter
+        //         a lane whose attempt is rejected stops (tag R), the wave goes back to the pool when an eighth
         //         of the batch has stopped.  Consecutive accepted steps stay in registers.
+        int tag = TAG_EMPTY;
+        bool finished = false;
         if (active) {
             double x[4], k[4];
 #pragma unroll
@@ -486,7 +561,7 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
             const size_t ray = (size_t)pray[slot];
             double I = pd[PC_I * WG_SLOTS + slot], tau = pd[PC_TAU * WG_SLOTS + slot];
             float worst = pworst[slot];
-            int tag = do_rk4 ? TAG_R : TAG_V;
+            tag = do_rk4 ? TAG_R : TAG_V;
             bool on = true;
 #pragma unroll 1
             for (int run = 0; run <= POOL_RUN; ++run) {
@@ -536,7 +611,7 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
 #ifndef S5_KO_END
                             write_ray_end(aux, out, ray, x, k, s, I, tau, worst);
 #endif
-                            tag = TAG_EMPTY; on = false;
+                            tag = TAG_EMPTY; on = false; finished = true;
                         }
                     }
                 }
@@ -555,8 +630,15 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
                 ppass[slot] = s.pass;
                 pworst[slot] = worst;
             }
-            wg_release();                                              // the state before the tag
-            ptag[slot] = tag;
+        }
+        // ---- 5. the slots back into their queues (the state before the entries)
+        wg_release();
+        q_give(Q_V, active && tag == TAG_V, slot);
+        q_give(Q_R, active && tag == TAG_R, slot);
+        q_give(Q_E, active && tag == TAG_EMPTY, slot);
+        {
+            const int nf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished));
+            if (nf > 0 && lane == 0) atomicSub(&cw[CW_LIVE], (unsigned)nf);
         }
     }
 #ifdef S5_TORUS_DEBUG
@@ -624,19 +706,19 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
     hipLaunchKernelGGL(torus_order_kernel, dim3(blocks_a), dim3(256), 0, stream, n, ranks, cursor + 1, order);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
 
-    // persistent grid: 2 workgroups of 4 waves per CU (VGPR-bound occupancy 2 waves/SIMD; 2 x 71 KB of LDS),
-    // never more waves than 128-ray pools to fill
+    // persistent grid: S5_MARCH_WAVES workgroups of 4 waves per CU (VGPR-bound occupancy; 46 KB of LDS each at 320 slots),
+    // never more workgroups than pools to fill
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    size_t blocks_b = (size_t)cus * S5_MARCH_WAVES;
-    const size_t needed = (n + 4 * POOL_SLOTS - 1) / (4 * POOL_SLOTS);
+    size_t blocks_b = (size_t)cus * S5_MARCH_WAVES * 4 / WG_WAVES;
+    const size_t needed = (n + WG_SLOTS - 1) / WG_SLOTS;
     if (blocks_b > needed) blocks_b = needed;
     const size_t lds = (size_t)POOL_WG_BYTES;
     if (!g_ws.attr_set) {
         if ((e = hipFuncSetAttribute((const void*)torus_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
         g_ws.attr_set = true;
     }
-    hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(256), lds, stream, p, start, ok, order, cursor, out, aux);
+    hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(WG_THREADS), lds, stream, p, start, ok, order, cursor, out, aux);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     return 0;
 }

@@ -251,9 +251,16 @@ def test_no_register_spills_in_the_image_kernels():
     from sim5_amd.codeobj import kernel_metadata
     meta = kernel_metadata(capi.LIB_PATH)
     image = {k: v for k, v in meta.items() if "s5f" in k and "disk_image" in k}
-    assert len(image) >= 9, sorted(meta)
+    assert len(image) >= 11, sorted(meta)
     for k, v in image.items():
         assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+    # the production kernel (every job without full-precision planes: bench.py, the sharded path): its parameters are read from
+    # the argument segment where they are used, so its hot path keeps no scalar register in a vector lane; what the compiler
+    # still spills (<= 12 SGPRs) sits in the cold re-trace a few rays per million take (tests/tools/isa_spill_sites.py shows where)
+    jobs = {k: v for k, v in image.items() if "disk_image_jobs_kernel" in k}
+    assert len(jobs) == 2, sorted(image)
+    for k, v in jobs.items():
+        assert v["sgpr_spill_count"] <= 12, (k, v)
     march = [v for k, v in meta.items() if "torus_pool_kernel" in k]
     assert len(march) == 2 and all(v["vgpr_spill_count"] == 0 for v in march), march          # both variants
     # nothing else of the library spills a register either, but for the set-up kernel of the surface search in its strict
