@@ -386,6 +386,27 @@ def extra_configs(torch, capi, dev, stream):
     out["c2_1024_thin_disk"] = {"kernel": IMAGE_KERNEL, "kernel_ms": ms, "rays": n * n, "rays_per_s": n * n / ms * 1e3,
                                 "roofline_frac": n * n * W_ELL / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                 "disk_hits": int((img[1] > 0).sum().item()), "disk_hits_reference": 991579}
+    # the same image as one of EIGHT jobs of one job-list launch (sim5gpu_disk_image_jobs: the jobs stream through the GPU back
+    # to back -- what a caller with several small images, or a rank with several shares, should use): ms per image
+    imgs = torch.zeros((8, 2, n, n), dtype=torch.float32, device=dev)
+    fp, gp = [imgs[k, 0].data_ptr() for k in range(8)], [imgs[k, 1].data_ptr() for k in range(8)]
+    ms8 = timed_kernel(capi, stream, lambda: capi.disk_image_jobs([d] * 8, fp, gp, stream=stream), 60, 200) / 8
+    out["c2_1024_thin_disk"]["job_list_of_8"] = {
+        "kernel_ms_per_image": ms8, "rays_per_s": n * n / ms8 * 1e3,
+        "roofline_frac": n * n * W_ELL / (ms8 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+        "same_bits_as_single_launch": bool(all(torch.equal(imgs[k].view(torch.int32), img.view(torch.int32)) for k in range(8))),
+        "what": "8 x C2 in ONE launch of disk_image_jobs_kernel; a single launch pays ~6 us of launch gap, ramp and ragged last round"}
+    del imgs
+    # the share of one of 8 ranks of the 4096^2 headline image (512 rows: mirrored 64-row stripes), one launch: the regime of
+    # the multi-GPU value_kernel_only at N = 8
+    from sim5_amd import sharding
+    dsh = capi.image_desc(4096, 4096, SPIN, INCL_DEG * rad, **sharding.job_rows(4096, 1, 8))
+    rows = capi.image_rows(dsh)
+    sh = torch.zeros((2, rows, 4096), dtype=torch.float32, device=dev)
+    mss = timed_kernel(capi, stream, lambda: capi.disk_image_device(dsh, sh[0].data_ptr(), sh[1].data_ptr(), stream=stream), 300, 1000)
+    out["share_512_rows_of_4096"] = {"kernel": IMAGE_KERNEL, "kernel_ms": mss, "rays": rows * 4096, "rays_per_s": rows * 4096 / mss * 1e3,
+                                     "roofline_frac": rows * 4096 * W_ELL / (mss * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS}
+    del sh
     # C3: 2048^2, a = 0.9, i = 70, Stokes I, Q, U in f64
     n = 2048
     st = torch.zeros((3, n, n), dtype=torch.float64, device=dev)
@@ -416,6 +437,52 @@ def extra_configs(torch, capi, dev, stream):
                                    "roofline_frac_with_counted_flops": tot * W_STEP_MEASURED / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                    "stokes_I_sum": float(stokes[:, 0].sum().item())}
     del stokes, steps
+    # the spectrum of the C2 image on 128 energies, fused into the image kernel (k_spectrum.hip).
+    # Algorithmic work: the ray (W_ELL + the local frame ~ W_POL) per pixel + 5 FP64 operations and one exp per (pixel, energy)
+    import ctypes as C
+    import numpy as np
+    n, ne = 1024, 128
+    d = capi.image_desc(n, n, 0.998, 70.0 * rad)
+    E = torch.tensor(10.0 ** np.linspace(-1, 1.5, ne), dtype=torch.float64, device=dev)
+    S = torch.zeros(ne, dtype=torch.float64, device=dev)
+    capi._lib.sim5gpu_disk_spectrum_workspace.restype = capi.SZ
+    wsb = capi._lib.sim5gpu_disk_spectrum_workspace(C.byref(d), capi.I(ne))
+    ws = torch.zeros(max(int(wsb), 8), dtype=torch.uint8, device=dev)
+    spec = lambda: capi._check(capi._lib.sim5gpu_disk_spectrum(C.byref(d), capi.I(ne), capi.VP(E.data_ptr()), capi.D(1.7), capi.I(1),
+                                                                capi.VP(S.data_ptr()), capi.VP(ws.data_ptr()), capi.VP(stream)), "sim5gpu_disk_spectrum")
+    ms = timed_kernel(capi, stream, spec, 40, 60)
+    w_spec = n * n * (W_ELL + W_POL) + n * n * ne * 6.0
+    out["f3_spectrum_1024_x128"] = {"kernel": "disk_spectrum_kernel + spectrum_reduce_kernel", "job_ms": ms, "pixels": n * n, "energies": ne,
+                                    "pixel_energy_pairs_per_s": n * n * ne / ms * 1e3, "algorithmic_flops": w_spec,
+                                    "roofline_frac": w_spec / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                    "spectrum_sum": float(S.sum().item()),
+                                    "note": "roofline: (W_ell + 3e2) per pixel + 6 FP64 operations (1 exp) per (pixel, energy) pair over the job time"}
+    del E, S, ws
+    # the surface search of the reference's Python DiskRaytrace for a thick disk H(R) = 0.25 (R - 2), 1024^2
+    # rays (k_surface.hip).  Algorithmic work per ray: ~550 sub-steps of geodesic_follow (ref src/sim5kerr-geod.c:891-925), each
+    # r(P) + mu(P) = two jacobi_sncndn (~4 AGM levels, a sincos, the back recurrence) ~ 3.6e2 FP64 operations by SURVEY 8(d)'s
+    # counting convention -> W_SURF ~ 2.0e5 per ray that walks (an estimate, stated in DESIGN.md)
+    n = 1024
+    ax = ((np.arange(n) + .5) / n - .5) * 2 * 20.0
+    al, be = np.meshgrid(ax, ax)
+    tR = np.linspace(2.0, 60.0, 256); tH = 0.25 * (tR - 2.0)
+    tb = {k: torch.tensor(np.ascontiguousarray(v).ravel(), dtype=torch.float64, device=dev) for k, v in (("tR", tR), ("tH", tH), ("al", al), ("be", be))}
+    N = n * n
+    ob = {k: torch.zeros(N * w, dtype=torch.float64, device=dev) for k, w in (("P", 1), ("r", 1), ("m", 1), ("k", 4))}
+    stt = torch.zeros(N, dtype=torch.int32, device=dev)
+    surf = lambda: capi._check(capi._lib.sim5gpu_disk_surface_rays(
+        capi.D(0.9), capi.D(70.0 * rad), capi.I(tR.size), capi.VP(tb["tR"].data_ptr()), capi.VP(tb["tH"].data_ptr()), capi.SZ(N),
+        capi.VP(tb["al"].data_ptr()), capi.VP(tb["be"].data_ptr()), capi.VP(ob["P"].data_ptr()), capi.VP(ob["r"].data_ptr()),
+        capi.VP(ob["m"].data_ptr()), capi.VP(ob["k"].data_ptr()), capi.VP(stt.data_ptr()), capi.I(capi.SURFACE_TABLE_CHECKED), capi.VP(stream)),
+        "sim5gpu_disk_surface_rays")
+    ms = timed_kernel(capi, stream, surf, 10, 10)
+    W_SURF = 2.0e5
+    out["f1_surface_search_1024"] = {"kernel": "surface_setup / walk / slow / finish kernels", "job_ms": ms, "rays": N, "rays_per_s": N / ms * 1e3,
+                                     "surface_hits": int((stt == 1).sum().item()), "algorithmic_flops_per_ray_estimate": W_SURF,
+                                     "roofline_frac": N * W_SURF / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                     "note": "thick disk H(R) = 0.25 (R - 2), a = 0.9, i = 70 deg, field of view +-20; W_SURF = 550 "
+                                             "sub-steps x 3.6e2 operations is an estimate (no entry in SURVEY 8(d))"}
+    del tb, ob, stt
     return out
 
 

@@ -128,6 +128,21 @@ int sim5gpu_geodesic_init_inf(size_t n, const double *incl, const double *a,
                               const double *alpha, const double *beta,
                               sim5gpu_geodesic *g, int *error, int *ok);
 
+/* geodesic_init_inf plus the values the caller loop of ref examples/04-disk-image-eqplane/disk-image.c:62-100 asks for
+ * next -- one launch and one round trip per ray instead of five.  For the orders k = 0, 1:
+ *   P[k] = geodesic_find_midplane_crossing(g, k);  r[k] = geodesic_position_rad(g, P[k]) if P[k] is a number (have_r[k]);
+ *   g[k] = gfactorK(r[k], a, g->l) and flux[k] = disk_nt_flux(r[k]) if r[k] is a number (flux only when the disk model has
+ *   been set up: flux_valid).  Every value comes from the device routine of the single entry point, same arguments. */
+typedef struct sim5gpu_geodesic_chain {
+    double P[2], r[2], g[2], flux[2];
+    double a, l;               /* the arguments g[] was computed with: the caller's spin and the geodesic's l          */
+    int    have_r[2];          /* position_rad was evaluated for this order                                           */
+    int    valid;              /* geodesic_init_inf returned TRUE                                                     */
+    int    flux_valid;         /* sim5gpu_disk_nt_setup had been called: flux[] holds disk_nt_flux of the model then set */
+} sim5gpu_geodesic_chain;
+int sim5gpu_geodesic_init_inf_chain(size_t n, const double *incl, const double *a, const double *alpha, const double *beta,
+                                    sim5gpu_geodesic *g, int *error, int *ok, sim5gpu_geodesic_chain *chain);
+
 /* geodesic_init_src (ref src/sim5kerr-geod.c:106-173); k is n x 4 */
 int sim5gpu_geodesic_init_src(size_t n, const double *a, const double *r, const double *m,
                               const double *k, const int *ppc,

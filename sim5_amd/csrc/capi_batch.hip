@@ -128,6 +128,64 @@ int sim5gpu_geodesic_init_inf(size_t n, const double* incl, const double* a, con
     return SIM5GPU_OK;
 }
 
+/* geodesic_init_inf AND what the caller loop of ref examples/04-disk-image-eqplane/disk-image.c:62-100 asks of the geodesic
+ * next, in the same launch: the equatorial crossings of orders 0 and 1, the radii there, gfactorK(r, a, g.l) and -- when the
+ * disk model has been set up -- disk_nt_flux(r).  Each value is produced by the very device routine the single entry point
+ * calls with the same arguments, so a host that answers the follow-up calls from this record (sim5_amd/host/sim5lib.c does,
+ * after checking that the arguments are the ones the record was made for, bit for bit) returns the same numbers with one
+ * round trip to the GPU per ray instead of five. */
+int sim5gpu_geodesic_init_inf_chain(size_t n, const double* incl, const double* a, const double* alpha, const double* beta,
+                                    sim5gpu_geodesic* g, int* error, int* ok, sim5gpu_geodesic_chain* chain)
+{
+    S5_NEED("geodesic_init_inf_chain", incl && a && alpha && beta && g && chain);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> di(incl, n), da(a, n), dal(alpha, n), dbe(beta, n);
+    DevBuf<Geod> dg((const Geod*)g, n);            // keep caller's bytes in fields we never write
+    DevBuf<int> derr(n), dok(n);
+    DevBuf<sim5gpu_geodesic_chain> dch(n);
+    S5_BUFS_OK("geodesic_init_inf_chain", di.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok() && dch.ok());
+    const double *pi = di.ptr, *pa = da.ptr, *pal = dal.ptr, *pbe = dbe.ptr;
+    Geod* pg = dg.ptr; int *pe = derr.ptr, *po = dok.ptr;
+    sim5gpu_geodesic_chain* pc = dch.ptr;
+    const bool have_disk = g_disk.ready != 0;
+    const DiskConsts d = g_disk;
+    S5_RUN(n, "geodesic_init_inf_chain", [=] __device__(size_t i) {
+        Geod gd = pg[i];
+        GeodCache cache;
+        int err = 0;
+        const double inc = pi[i];
+        const bool ok_ = init_inf(inc, sin(inc), cos(inc), pa[i], pal[i], pbe[i], gd, err, cache);
+        pg[i] = gd;
+        pe[i] = err;
+        po[i] = ok_ ? 1 : 0;
+        sim5gpu_geodesic_chain c;
+        c.flux_valid = have_disk ? 1 : 0; c.valid = ok_ ? 1 : 0;
+        c.a = pa[i]; c.l = gd.l;
+        for (int k = 0; k < 2; ++k) { c.P[k] = NAN; c.r[k] = NAN; c.g[k] = NAN; c.flux[k] = NAN; c.have_r[k] = 0; }
+        if (ok_) {
+            for (int k = 0; k < 2; ++k) {
+                GeodCache none; none.valid = false; none.K = none.icn_i = none.u_i = 0.0;      // as the single entry point
+                c.P[k] = midplane_crossing(gd, k, none);
+                if (!isnan(c.P[k])) {
+                    c.r[k] = position_rad(gd, c.P[k]);
+                    c.have_r[k] = 1;
+                    if (!isnan(c.r[k])) {
+                        c.g[k] = gfactor_kepler(c.r[k], pa[i], gd.l);
+                        if (have_disk) c.flux[k] = disk_flux(d, c.r[k]);
+                    }
+                }
+            }
+        }
+        pc[i] = c;
+    });
+    S5_HIP(dg.to_host((Geod*)g));
+    if (error) S5_HIP(derr.to_host(error));
+    if (ok) S5_HIP(dok.to_host(ok));
+    S5_HIP(dch.to_host(chain));
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_geodesic_init_src(size_t n, const double* a, const double* r, const double* m,
                               const double* k, const int* ppc, sim5gpu_geodesic* g, int* error, int* ok)
 {

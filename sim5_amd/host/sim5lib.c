@@ -76,11 +76,40 @@ typedef int (*fn_d1)(size_t, const double *, double *);
 typedef int (*fn_d2)(size_t, const double *, const double *, double *);
 typedef int (*fn_d3)(size_t, const double *, const double *, const double *, double *);
 
+/* One round trip per ray for the caller loop of ref examples/04-disk-image-eqplane/disk-image.c:62-100.  geodesic_init_inf
+ * asks the GPU for the geodesic AND for what that loop asks next (sim5gpu_geodesic_init_inf_chain: crossings of orders 0 and
+ * 1, the radii there, gfactorK and disk_nt_flux at those radii -- each by the device routine of the single call).  The record
+ * is kept per thread next to a copy of the geodesic; geodesic_find_midplane_crossing, geodesic_position_rad, gfactorK and
+ * disk_nt_flux answer from it when -- and only when -- their arguments are bit for bit the ones the record was made for (the
+ * whole 240-byte struct, P, r, a, l, and the same disk set-up); any other call goes to the GPU as before.  SIM5_SHIM_NO_CHAIN=1
+ * switches the record off (every call a round trip: the tests compare the two). */
+typedef struct {
+    double P[2], r[2], g[2], flux[2];
+    double a, l;
+    int have_r[2];
+    int valid, flux_valid;
+} s5_chain;
+typedef int (*fn_geod_chain)(size_t, const double *, const double *, const double *, const double *, geodesic *, int *, int *, s5_chain *);
+static __thread struct { int live; unsigned long disk_gen; geodesic g; s5_chain c; } s5_last;
+static unsigned long s5_disk_gen = 1;             /* bumped by every disk set-up of this process */
+static int s5_chain_mode = -1;                    /* -1 unknown, 0 off, 1 on */
+
+static int s5_same_bits(double x, double y) { return memcmp(&x, &y, sizeof x) == 0; }
+static int s5_record_for(const geodesic *g) { return s5_last.live && memcmp(g, &s5_last.g, sizeof *g) == 0; }
+
 int geodesic_init_inf(double i, double a, double alpha, double beta, geodesic *g, int *error)
 {
-    S5_FN(fn_geod_init_inf, f, "sim5gpu_geodesic_init_inf");
     int err = 0, ok = 0;
-    s5_check(f(1, &i, &a, &alpha, &beta, g, &err, &ok), "geodesic_init_inf");
+    if (s5_chain_mode < 0) { const char *e = getenv("SIM5_SHIM_NO_CHAIN"); s5_chain_mode = (e && *e && *e != '0') ? 0 : 1; }
+    if (s5_chain_mode) {
+        S5_FN(fn_geod_chain, fc, "sim5gpu_geodesic_init_inf_chain");
+        s5_last.live = 0;
+        s5_check(fc(1, &i, &a, &alpha, &beta, g, &err, &ok, &s5_last.c), "geodesic_init_inf");
+        if (ok) { memcpy(&s5_last.g, g, sizeof *g); s5_last.disk_gen = s5_disk_gen; s5_last.live = 1; }
+    } else {
+        S5_FN(fn_geod_init_inf, f, "sim5gpu_geodesic_init_inf");
+        s5_check(f(1, &i, &a, &alpha, &beta, g, &err, &ok), "geodesic_init_inf");
+    }
     if (error) *error = err;
     return ok ? TRUE : FALSE;
 }
@@ -104,6 +133,9 @@ double geodesic_P_int(geodesic *g, double r, int ppc)
 
 double geodesic_position_rad(geodesic *g, double P)
 {
+    if (s5_record_for(g)) {
+        for (int k = 0; k < 2; k++) if (s5_last.c.have_r[k] && s5_same_bits(P, s5_last.c.P[k])) return s5_last.c.r[k];
+    }
     S5_FN(fn_geod_P, f, "sim5gpu_geodesic_position_rad");
     double r = NAN;
     s5_check(f(1, g, &P, &r), "geodesic_position_rad");
@@ -152,6 +184,7 @@ double geodesic_timedelay(geodesic *g, double P1, double r1, double m1, double P
 
 double geodesic_find_midplane_crossing(geodesic *g, int order)
 {
+    if ((order == 0 || order == 1) && s5_record_for(g)) return s5_last.c.P[order];
     S5_FN(fn_geod_order, f, "sim5gpu_geodesic_find_midplane_crossing");
     double P = NAN;
     s5_check(f(1, g, &order, &P), "geodesic_find_midplane_crossing");
@@ -242,6 +275,9 @@ double Omega_from_ell(double ell, sim5metric *m)
 
 double gfactorK(double r, double a, double l)
 {
+    if (s5_last.live && s5_same_bits(a, s5_last.c.a) && s5_same_bits(l, s5_last.c.l)) {
+        for (int k = 0; k < 2; k++) if (s5_last.c.have_r[k] && !isnan(r) && s5_same_bits(r, s5_last.c.r[k])) return s5_last.c.g[k];
+    }
     S5_FN(fn_d3, f, "sim5gpu_gfactorK");
     double g = NAN;
     s5_check(f(1, &r, &a, &l, &g), "gfactorK");
@@ -305,6 +341,7 @@ int disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int option
     S5_FN(fn, f, "sim5gpu_disk_nt_setup");
     s5_check(f(M, a, mdot_or_L, alpha, options), "disk_nt_setup");
     s5_disk_M = M; s5_disk_a = a; s5_disk_alpha = alpha; s5_disk_options = options;
+    s5_disk_gen++;                                    /* records made for the previous model no longer answer disk_nt_flux */
     return 0;
 }
 
@@ -324,7 +361,13 @@ double disk_nt_vr(double r) { (void)r; return 0.0; }                          /*
 double disk_nt_h(double r) { (void)r; return 0.0; }
 double disk_nt_dhdr(double r) { (void)r; return 0.0; }
 
-double disk_nt_flux(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_flux"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_flux"); return o; }
+double disk_nt_flux(double r)
+{
+    if (s5_last.live && s5_last.c.flux_valid && s5_last.disk_gen == s5_disk_gen) {
+        for (int k = 0; k < 2; k++) if (s5_last.c.have_r[k] && !isnan(r) && s5_same_bits(r, s5_last.c.r[k])) return s5_last.c.flux[k];
+    }
+    S5_FN(fn_d1, f, "sim5gpu_disk_nt_flux"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_flux"); return o;
+}
 double disk_nt_ell(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_ell"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_ell"); return o; }
 double disk_nt_sigma(double r) { S5_FN(fn_d1, f, "sim5gpu_disk_nt_sigma"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_sigma"); return o; }
 

@@ -39,6 +39,12 @@ def test_single_gpu_line_carries_every_config():
     assert x["c2_1024_thin_disk"]["disk_hits"] == x["c2_1024_thin_disk"]["disk_hits_reference"]
     assert x["c3_2048_polarized"]["disk_hits"] == x["c3_2048_polarized"]["disk_hits_reference"]
     assert 500 < x["c4_1024_torus_verlet"]["steps_per_ray"] < 540 and x["c4_1024_torus_verlet"]["stokes_I_sum"] > 0
+    jl = x["c2_1024_thin_disk"]["job_list_of_8"]
+    assert jl["same_bits_as_single_launch"] is True and 0 < jl["kernel_ms_per_image"] < x["c2_1024_thin_disk"]["kernel_ms"]
+    assert x["share_512_rows_of_4096"]["rays"] == 512 * 4096 and x["share_512_rows_of_4096"]["roofline_frac"] > 0.3
+    # SURVEY 8(f) ranks 1 and 3 are driver-timed too
+    assert x["f1_surface_search_1024"]["surface_hits"] > 100000 and x["f1_surface_search_1024"]["job_ms"] > 0
+    assert x["f3_spectrum_1024_x128"]["spectrum_sum"] > 0 and x["f3_spectrum_1024_x128"]["pixel_energy_pairs_per_s"] > 1e10
     c5 = x["c5_8192_x8_inclinations"]
     assert c5["hits_ok"] and len(c5["per_inclination"]) == 8
     assert all(v["disk_hits"] == v["disk_hits_reference"] for v in c5["per_inclination"].values())

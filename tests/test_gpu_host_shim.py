@@ -56,6 +56,44 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     assert abs(float(tail[4]) / orc.geodesic_timedelay(C.byref(gd), P1, 0.0, 0.0, P2, 0.0, 0.0) - 1) < 1e-9
 
 
+def test_c1_through_the_scalar_api_one_round_trip_per_ray(tmp_path, capi, golden):
+    """BASELINE.json configs[0] -- 64 x 64, a = 0, i = 60 deg, the loop of ref examples/04-disk-image-eqplane/disk-image.c:
+    53-105 -- through the SIM5 SCALAR API on the GPU (tests/c/shim_probe.c is that loop, call for call), against the golden
+    image of the unmodified reference (img_c1_64_a0_i60.npz: hit / miss exact, r, g, flux within 1e-6).  Run twice: with
+    the shim's record of the ray (geodesic_init_inf brings the crossings, radii, g-factors and fluxes of the ray in the same
+    launch; the follow-up calls are answered from it after a bit-for-bit check of their arguments) and with it switched off
+    (SIM5_SHIM_NO_CHAIN=1: five round trips per ray) -- the two outputs must be the same text, and the rates are printed."""
+    import time
+    exe = str(tmp_path / "probe")
+    subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", "shim_probe.c"), os.path.join(HOST, "sim5lib.c"),
+                    "-I", HOST, "-o", exe, "-lm", "-O3", "-w", "-fgnu89-inline"], check=True)
+    n, a, inc = 64, 0.0, 60.0
+    outs, secs = [], []
+    for chain in (True, False):
+        env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+        if not chain:
+            env["SIM5_SHIM_NO_CHAIN"] = "1"
+        t0 = time.time()
+        p = subprocess.run([exe, str(a), str(inc), str(n)], env=env, capture_output=True, text=True, timeout=900)
+        secs.append(time.time() - t0)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p.stdout)
+    assert outs[0] == outs[1], "the record-served run differs from the call-by-call run"
+    print("scalar API, %d rays: %.3e rays/s with one round trip per ray, %.3e call by call (process start-up included)" % (
+        n * n, n * n / secs[0], n * n / secs[1]))
+    g = golden("img_c1_64_a0_i60.npz")
+    rec = np.array([[float(v) for v in ln.split()] for ln in outs[0].strip().splitlines()[1:1 + n * n]])
+    hit = np.where(g["cls"] == 2, 1, np.where(g["cls"] == 4, 2, 0)).ravel()
+    assert np.array_equal(rec[:, 3].astype(int), hit), "hit / miss differs from the reference on %d pixels" % int((rec[:, 3].astype(int) != hit).sum())
+    assert hit.astype(bool).sum() == 3544
+    m = hit > 0
+    assert_close(rec[m, 4], g["r"].ravel()[m], what="r"); assert_close(rec[m, 5], g["g"].ravel()[m], what="g")
+    assert_close(rec[m, 6], g["flux"].ravel()[m], floor=1e-9 * g["flux"].max(), what="flux")
+    # pixels the reference rejects (error from geodesic_init_inf) are rejected here with the same code
+    err_ref = (g["cls"] == 0).ravel()
+    assert np.array_equal(rec[:, 2] != 0, err_ref)
+
+
 def test_boundary_prototypes_program(tmp_path, capi):
     """tests/c/boundary_probe.c: the public prototypes that are not on the inner path, called from C through
     sim5_amd/host/sim5lib.c (n = 1 batch calls on the GPU), every printed number against the UNMODIFIED reference
