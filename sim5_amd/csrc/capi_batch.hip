@@ -27,7 +27,12 @@ static int run_map(size_t n, F body, const char* what)
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(map_rays<F>, dim3(blocks), dim3(256), 0, 0, n, body);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) {
+        // a handful of rays (the n = 1 calls of the SIM5 scalar API): poll for the end of the launch instead of the blocking
+        // wait, whose wake-up costs more than the kernel (measured through tests/tools/shim_rate.sh)
+        if (n <= 64) { while ((e = hipStreamQuery(nullptr)) == hipErrorNotReady) { } }
+        else e = hipDeviceSynchronize();
+    }
     if (e != hipSuccess) { set_error(what, e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;
 }
@@ -150,34 +155,40 @@ int sim5gpu_geodesic_init_inf_chain(size_t n, const double* incl, const double* 
     sim5gpu_geodesic_chain* pc = dch.ptr;
     const bool have_disk = g_disk.ready != 0;
     const DiskConsts d = g_disk;
-    S5_RUN(n, "geodesic_init_inf_chain", [=] __device__(size_t i) {
+    // two lanes per ray, one per crossing order (both set the geodesic up: a single ray is a chain of dependent FP64
+    // operations, and its latency -- not the launch -- is what a caller of the scalar API waits for)
+    S5_RUN(2 * n, "geodesic_init_inf_chain", [=] __device__(size_t j) {
+        const size_t i = j >> 1;
+        const int k = (int)(j & 1);
         Geod gd = pg[i];
         GeodCache cache;
         int err = 0;
         const double inc = pi[i];
         const bool ok_ = init_inf(inc, sin(inc), cos(inc), pa[i], pal[i], pbe[i], gd, err, cache);
-        pg[i] = gd;
-        pe[i] = err;
-        po[i] = ok_ ? 1 : 0;
-        sim5gpu_geodesic_chain c;
-        c.flux_valid = have_disk ? 1 : 0; c.valid = ok_ ? 1 : 0;
-        c.a = pa[i]; c.l = gd.l;
-        for (int k = 0; k < 2; ++k) { c.P[k] = NAN; c.r[k] = NAN; c.g[k] = NAN; c.flux[k] = NAN; c.have_r[k] = 0; }
+        sim5gpu_geodesic_chain* c = &pc[i];
+        c->P[k] = NAN; c->r[k] = NAN; c->g[k] = NAN; c->flux[k] = NAN; c->have_r[k] = 0;
         if (ok_) {
-            for (int k = 0; k < 2; ++k) {
-                GeodCache none; none.valid = false; none.K = none.icn_i = none.u_i = 0.0;      // as the single entry point
-                c.P[k] = midplane_crossing(gd, k, none);
-                if (!isnan(c.P[k])) {
-                    c.r[k] = position_rad(gd, c.P[k]);
-                    c.have_r[k] = 1;
-                    if (!isnan(c.r[k])) {
-                        c.g[k] = gfactor_kepler(c.r[k], pa[i], gd.l);
-                        if (have_disk) c.flux[k] = disk_flux(d, c.r[k]);
-                    }
+            // K(mm) and the inverse cn of the observer's position come from init_inf (GeodCache): the very values the
+            // crossing search would form again from the same expressions (the image kernels rely on the same identity)
+            c->P[k] = midplane_crossing(gd, k, cache);
+            if (!isnan(c->P[k])) {
+                c->r[k] = position_rad(gd, c->P[k]);
+                c->have_r[k] = 1;
+                if (!isnan(c->r[k])) {
+                    c->g[k] = gfactor_kepler(c->r[k], pa[i], gd.l);
+                    if (have_disk) c->flux[k] = disk_flux(d, c->r[k]);
                 }
             }
         }
-        pc[i] = c;
+        if (k == 0) {
+            c->flux_valid = have_disk ? 1 : 0; c->valid = ok_ ? 1 : 0;
+            c->a = pa[i]; c->l = gd.l;
+            pe[i] = err;
+            po[i] = ok_ ? 1 : 0;
+        }
+        // both lanes read pg[i] above; the geodesic is written back by lane 0 after its partner has read it too: the two
+        // lanes of a ray sit in one wave (j even/odd), which executes the read before the write in program order
+        if (k == 0) pg[i] = gd;
     });
     S5_HIP(dg.to_host((Geod*)g));
     if (error) S5_HIP(derr.to_host(error));

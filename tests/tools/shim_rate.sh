@@ -1,14 +1,19 @@
 #!/bin/bash
 # ON THE GPU BOX: rays per second of a caller written against the SIM5 SCALAR API (tests/c/shim_probe.c: the call
 # sequence of the reference's example 04 -- init_inf, midplane crossing, position_rad, gfactorK, disk_nt_flux per
-# pixel -- every call one n = 1 launch through sim5_amd/host/sim5lib.c), next to the reference CPU library and the
-# whole-image entry point on the same image.
+# pixel -- through sim5_amd/host/sim5lib.c).  Two image sizes, so that process start-up (library load, GPU context:
+# ~0.3 s) drops out of the marginal rate; with the shim's per-ray record (one round trip per ray) and without it
+# (SIM5_SHIM_NO_CHAIN=1: five round trips per ray).
 cd $GRAFT_REPO_ROOT
-N=${1:-160}
 gcc tests/c/shim_probe.c src/sim5lib.c -Isrc -o /tmp/probe -lm -O3 -w -fgnu89-inline || exit 1
 export SIM5GPU_LIB=$GRAFT_REPO_ROOT/sim5_amd/lib/libsim5gpu.so
-t0=$(date +%s.%N); /tmp/probe 0.998 70 $N > /tmp/probe.out; t1=$(date +%s.%N)
+run() { local t0=$(date +%s.%N); "$@" /tmp/probe 0.998 70 $N > /tmp/probe.out; local t1=$(date +%s.%N); echo "$t1 - $t0" | bc -l; }
+N=64;  a1=$(run env); b1=$(run env SIM5_SHIM_NO_CHAIN=1)
+N=256; a2=$(run env); b2=$(run env SIM5_SHIM_NO_CHAIN=1)
 python3 - <<PY
-n=$N*$N; dt=$t1-$t0
-print("scalar SIM5 API over the GPU library: %d rays in %.2f s = %.3e rays/s (%.1f us per ray, ~5 calls per ray)" % (n, dt, n/dt, dt/n*1e6))
+n1, n2 = 64 * 64, 256 * 256
+for name, t1, t2 in (("one round trip per ray (record)", $a1, $a2), ("call by call (SIM5_SHIM_NO_CHAIN=1)", $b1, $b2)):
+    per = (t2 - t1) / (n2 - n1)
+    print("scalar SIM5 API over the GPU library, %s: %d rays in %.2f s, %d in %.2f s -> %.1f us per ray = %.3e rays/s (start-up %.2f s)" % (
+        name, n1, t1, n2, t2, per * 1e6, 1.0 / per, t1 - n1 * per))
 PY
