@@ -549,8 +549,10 @@ typedef struct sim5gpu_torus_aux {
 } sim5gpu_torus_aux;
 
 /* The surface-search and torus jobs keep a per-device workspace that grows to the largest job seen (surface search:
- * ~0.5 GB per million rays; torus: 120 B per ray).  This gives them back (waits for the devices that own them); the next
- * job allocates again.  *bytes, if not NULL, receives the number of bytes freed. */
+ * ~0.5 GB per million rays; torus: 120 B per ray), and the image jobs of the default variant keep one 8 KB block per disk
+ * model (spin, mdot / M) and device -- the Novikov-Thorne flux table -- for up to 1024 models per device (least recently
+ * used first out).  This gives all of it back (waits for the devices that own it); the next job allocates again.
+ * *bytes, if not NULL, receives the number of bytes freed. */
 int sim5gpu_release_workspaces(size_t *bytes);
 
 /* d_stokes: (y1-y0) x nx records of sim5gpu_stokes */

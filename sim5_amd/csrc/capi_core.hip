@@ -4,7 +4,9 @@
 #include "capi_util.hpp"
 #include <math.h>
 #include <string.h>
+#include <algorithm>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace s5 {
@@ -97,13 +99,48 @@ DiskConsts make_disk_consts(double M, double a_in, double mdot, double alpha)
 namespace {
 // One device block per (device, disk model): the COLD_N constants of the closed form (read from memory by the image
 // kernels' rare closed-form lanes, so that they do not occupy ~30 SGPRs of every wave for the whole kernel), then the
-// table.  One block per (spin, scale) and device, kept for the life of the process (8 KB each: a sweep over a thousand disk
-// models is 8 MB) -- a block is never freed, so a kernel that another thread is about to launch with its pointer cannot
-// lose it, and no entry point ever has to wait for the device to recycle one.
+// table; 8 KB each.  Found through a hash of (spin, scale) -- a fitting sweep over 1e5 disk models costs a look-up per
+// launch, not a scan -- and BOUNDED: beyond FT_CACHE_MAX models per device the least recently used half is retired.
+// A retired block is not freed at once (a thread that has just been handed its pointer may be about to launch with it):
+// it rests until the NEXT retirement, FT_CACHE_MAX / 2 new models later, and is freed then, after the device has been
+// waited for.  sim5gpu_release_workspaces frees everything (it waits for the device first).
 constexpr int FT_DEVICES = 64;
-struct FluxTable { double a, scale; double* ptr; bool usable; };
-std::vector<FluxTable> g_ftab[FT_DEVICES];
+constexpr size_t FT_CACHE_MAX = 1024;
+struct FluxTable { double a, scale; double* ptr; bool usable; unsigned long long stamp; };
+struct FluxKey { unsigned long long a, s; bool operator==(const FluxKey& o) const { return a == o.a && s == o.s; } };
+struct FluxKeyHash { size_t operator()(const FluxKey& k) const { return (size_t)(k.a * 0x9e3779b97f4a7c15ull ^ (k.s + (k.a << 7))); } };
+struct FluxCache {
+    std::unordered_map<FluxKey, FluxTable, FluxKeyHash> live;
+    std::vector<double*> resting;                   // retired at the last round: freed at the next
+    unsigned long long clock = 0;
+};
+FluxCache g_ftab[FT_DEVICES];
 std::mutex g_ftab_lock;
+
+static FluxKey flux_key(double a, double scale)
+{
+    FluxKey k;
+    memcpy(&k.a, &a, sizeof a); memcpy(&k.s, &scale, sizeof scale);
+    return k;
+}
+
+// called under the lock, on the device that owns the cache
+static void flux_cache_retire(FluxCache& Cc)
+{
+    if (Cc.live.size() < FT_CACHE_MAX) return;
+    (void)hipDeviceSynchronize();                   // every launch that was handed a resting block has long been issued
+    for (double* p : Cc.resting) (void)hipFree(p);
+    Cc.resting.clear();
+    std::vector<unsigned long long> stamps;
+    stamps.reserve(Cc.live.size());
+    for (auto& kv : Cc.live) stamps.push_back(kv.second.stamp);
+    std::nth_element(stamps.begin(), stamps.begin() + stamps.size() / 2, stamps.end());
+    const unsigned long long cut = stamps[stamps.size() / 2];
+    for (auto it = Cc.live.begin(); it != Cc.live.end();) {
+        if (it->second.stamp < cut) { Cc.resting.push_back(it->second.ptr); it = Cc.live.erase(it); }
+        else ++it;
+    }
+}
 
 // f on [lo, hi] as N polynomials of degree DEG in the local coordinate tau in [-1, 1] of N equal intervals: Chebyshev
 // interpolation (DEG + 1 interior nodes per interval, long double), converted to monomials for a Horner evaluation on
@@ -219,13 +256,18 @@ int attach_flux_table(DiskConsts& d)
     const double wmin = d.x0 / 16.0;
     d.ft_wmin = wmin;
     d.ft_inv_dw = (double)s5abi::FT_N / (1.0 - wmin);
-    std::vector<FluxTable>& T = g_ftab[dev];
-    for (size_t i = T.size(); i-- > 0;)                                  // the newest models first
-        if (T[i].a == d.a && T[i].scale == d.scale) {
-            d.cold = T[i].ptr;
-            d.ftab = T[i].usable ? T[i].ptr + s5abi::COLD_N : nullptr;
+    FluxCache& Cc = g_ftab[dev];
+    const FluxKey key = flux_key(d.a, d.scale);
+    {
+        auto it = Cc.live.find(key);
+        if (it != Cc.live.end()) {
+            it->second.stamp = ++Cc.clock;
+            d.cold = it->second.ptr;
+            d.ftab = it->second.usable ? it->second.ptr + s5abi::COLD_N : nullptr;
             return SIM5GPU_OK;
         }
+    }
+    flux_cache_retire(Cc);
     std::vector<double> tab;
     const double fit_error = build_flux_table(d, wmin, tab);
     // towards a = 1 the inner edge approaches the logarithmic singularity at x1 and the uniform grid stops resolving
@@ -240,10 +282,30 @@ int attach_flux_table(DiskConsts& d)
     hipError_t e = hipMalloc((void**)&ptr, block.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(ptr, block.data(), block.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) { if (ptr) (void)hipFree(ptr); set_error("flux table", e); return SIM5GPU_E_HIP; }
-    T.push_back(FluxTable{ d.a, d.scale, ptr, usable });
+    Cc.live.emplace(key, FluxTable{ d.a, d.scale, ptr, usable, ++Cc.clock });
     d.cold = ptr;
     d.ftab = usable ? ptr + s5abi::COLD_N : nullptr;
     return SIM5GPU_OK;
+}
+
+// every flux-table block of every device given back (sim5gpu_release_workspaces); returns the bytes freed
+size_t release_flux_tables()
+{
+    std::lock_guard<std::mutex> hold(g_ftab_lock);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    size_t freed = 0;
+    for (int dev = 0; dev < FT_DEVICES; ++dev) {
+        FluxCache& Cc = g_ftab[dev];
+        if (Cc.live.empty() && Cc.resting.empty()) continue;
+        (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        for (auto& kv : Cc.live) { (void)hipFree(kv.second.ptr); freed += (size_t)(s5abi::COLD_N + (kv.second.usable ? s5abi::FT_N * (s5abi::FT_DEG + 1) : 0)) * sizeof(double); }
+        for (double* p : Cc.resting) { (void)hipFree(p); freed += (size_t)s5abi::COLD_N * sizeof(double); }
+        Cc.live.clear(); Cc.resting.clear();
+    }
+    (void)hipSetDevice(cur);
+    return freed;
 }
 
 // validate a job description and turn it into the kernel argument block

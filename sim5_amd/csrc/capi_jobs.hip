@@ -202,7 +202,7 @@ int sim5gpu_release_workspaces(size_t* bytes)
 {
     if (!have_device()) { if (bytes) *bytes = 0; return SIM5GPU_OK; }
     const size_t freed = s5_release_surface_workspace_fast() + s5_release_surface_workspace_strict() +
-                         s5f::release_torus_workspace_fast() + s5::release_torus_workspace_strict();
+                         s5f::release_torus_workspace_fast() + s5::release_torus_workspace_strict() + release_flux_tables();
     if (bytes) *bytes = freed;
     return SIM5GPU_OK;
 }

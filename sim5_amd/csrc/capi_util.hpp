@@ -19,6 +19,7 @@ int  have_device();
 DiskConsts make_disk_consts(double M, double a, double mdot, double alpha = 0.1);
 int  attach_flux_table(DiskConsts& d);
 int  attach_K_table(ImageParams& p);                     // capi_core.hip: universal K(m) table of the fast image kernels (device)                    // capi_core.hip: radial profile table of the fast variant (device)
+size_t release_flux_tables();                              // capi_core.hip: every cached flux-table block of every device
 void disk_set_mdot(DiskConsts& d, double mdot);
 int  disk_lumi(const DiskConsts& d, double* lumi);          // capi_batch.hip: Simpson rule, integrand on the device
 int  fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_disk = true);

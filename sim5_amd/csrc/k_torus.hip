@@ -102,8 +102,9 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
     // turning point nearly a double root, (r1 - r2)/r1 < 0.2, or the complex pair of a plunging ray nearly real, |Im r3| <
     // 0.2 |Re r3| -- and those that pass the polar axis (1 - m2p < 0.01: the step size follows sin theta).  On the C4 job
     // that rule marks 7.7 % of the rays, among them every ray above 1 000 calls and 89 % of those above 800 (median 506;
-    // tests/tools/torus_long_predict.py).  They go FIRST, everything else after them from the last ray backwards; a ray
-    // wrongly taken for long costs nothing.
+    // tests/tools/torus_long_predict.py).  They are dealt into the head of the order, every second position (torus_order_kernel), the
+    // other rays fill the gaps and follow in the order of their ranks (which come from atomics: the order within a class
+    // differs from run to run, a ray's result does not); a ray wrongly taken for long costs nothing.
     // (A third class -- the SHORTEST rays last: those that fall into the hole, 250 - 450 calls -- is built and measured,
     // -DS5_SHORT_CLASS: 25.85 against 25.55 ms without it; not used.)
     int cls = 0;                                                         // 0 ordinary, 1 long, 2 short

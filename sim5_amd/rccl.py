@@ -6,7 +6,11 @@ import os
 
 from . import capi as _c
 
-LIB_PATH = os.environ.get("SIM5GPU_RCCL_LIB") or os.path.join(os.path.dirname(_c.LIB_PATH), "libsim5gpu_rccl.so")
+# the multi-GPU library that was linked against the base library in use: an experiment variant sim5_amd/lib/ab_<name>.so
+# (SIM5GPU_LIB, tests/tools/ab_build.sh) has its own ab_<name>_rccl.so next to it -- the in-tree pair is never mixed with it
+_base = os.path.basename(_c.LIB_PATH)
+_pair = (_base[:-3] + "_rccl.so") if (_base.startswith("ab_") and _base.endswith(".so")) else "libsim5gpu_rccl.so"
+LIB_PATH = os.environ.get("SIM5GPU_RCCL_LIB") or os.path.join(os.path.dirname(_c.LIB_PATH), _pair)
 if not os.path.exists(LIB_PATH):
     raise ImportError("sim5_amd: %s is missing -- build it with `python -m sim5_amd.build`" % LIB_PATH)
 _lib = C.CDLL(LIB_PATH)

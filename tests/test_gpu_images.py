@@ -700,3 +700,20 @@ def test_direct_flag_runs_the_direct_routine_everywhere(capi, a, inc, n, order):
     assert lit.sum() > 100
     for k in range(3):
         assert (np.abs(S1[k][lit] - S0[k][lit]) / S0[0][lit]).max() < 1e-6, k
+
+
+def test_flux_table_cache_is_bounded_and_released(capi):
+    """the per-model flux tables (8 KB each) were kept for ever.  Now: a hash look-up, at most 1024 models per
+    device (the least recently used half is retired, and freed one retirement later), and sim5gpu_release_workspaces gives
+    everything back.  1300 models through 16 x 16 images (the same pixels for every model: results must not depend on what
+    the cache holds), the first model again after it has been retired, then the release."""
+    d0 = capi.image_desc(16, 16, 0.5, math.radians(60.0), mdot=0.1)
+    first = capi.disk_image(d0)
+    for k in range(1300):
+        capi.disk_image(capi.image_desc(16, 16, 0.5, math.radians(60.0), mdot=0.1 + 1e-4 * (k + 1)))
+    again = capi.disk_image(d0)
+    assert np.array_equal(first["image_f"], again["image_f"]) and np.array_equal(first["image_g"], again["image_g"])
+    freed = capi.release_workspaces()
+    assert freed >= 200 * 8 * 1024, freed                      # at least the live half of the cache came back
+    after = capi.disk_image(d0)
+    assert np.array_equal(first["image_f"], after["image_f"])
