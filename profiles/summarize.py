@@ -76,7 +76,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     json.dump(tj, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 # the default bench command (headline + the other configurations): per-kernel statistics as rocprofv3 prints them, and the
 # headline launches picked out of its kernel trace by their grid (256 x 256 workgroups of 256 threads: X = 65536, Y = 256;
-# the mirror kernel covers the upper half: Y = 128)
+# the mirror kernel covers the upper half: Y = 128; the job-list kernel has a one-dimensional grid of 256 x 128 tiles of 256
+# threads = 8388608, and the headline runs its single-job instantiation)
 dstats = glob.glob(os.path.join(src, "stats_default_cmd", "*", "*kernel_stats.csv"))
 if dstats:
     rows = list(csv.reader(open(dstats[0])))
@@ -87,8 +88,9 @@ if dstats:
 dtrace = glob.glob(os.path.join(src, "stats_default_cmd", "*", "*kernel_trace.csv"))
 if dtrace:
     hd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(dtrace[0]))
-          if KERNEL in r["Kernel_Name"] and r.get("Grid_Size_X") == "65536" and
-          r.get("Grid_Size_Y") == ("128" if "mirror" in KERNEL else "256")]
+          if KERNEL in r["Kernel_Name"] and (
+              (r.get("Grid_Size_X") == "8388608" and "ILb1E" in r["Kernel_Name"] + "ILb1E" * ("<true>" in r["Kernel_Name"])) if "jobs" in KERNEL else
+              (r.get("Grid_Size_X") == "65536" and r.get("Grid_Size_Y") == ("128" if "mirror" in KERNEL else "256")))]
     out["default_cmd_headline_launches"] = {"launches": len(hd), "kernel_ns_avg": sum(hd) / len(hd) if hd else None}
 dl = os.path.join(src, "stats_default_cmd.log")
 if os.path.exists(dl):
