@@ -183,7 +183,8 @@ void torus_order_kernel(size_t n, const int* __restrict__ ranks, const unsigned 
     order[pos] = (int)i;
 }
 
-S5_DEV double torus_density(const TorusParams& p, double r, double m)
+template <class PRM>
+S5_DEV double torus_density(const PRM& p, double r, double m)
 {
     if (p.shape == 1) return (r <= p.torus_w) ? 1.0 : 0.0;
     const double R = r * sqrt(1. - m * m), z = r * m;
@@ -193,11 +194,12 @@ S5_DEV double torus_density(const TorusParams& p, double r, double m)
 }
 
 #ifndef S5_MARCH_WAVES
-#define S5_MARCH_WAVES (S5_FAST ? 2 : 1)   // strict: its bodies need ~261 registers -- one wave per SIMD and no scratch rather than two with
-#endif                                     // six registers spilled (a spilled register in an image kernel went wrong in round 3: DESIGN.md 4)
+#define S5_MARCH_WAVES (S5_FAST ? 3 : 1)   // fast: THREE waves per SIMD since round 4 (168 VGPRs, nothing spilled: the lean form of the
+#endif                                     // kernel below); strict: its bodies need ~261 registers -- one wave per SIMD and no scratch
 // Emission and absorption picked up over one accepted step (see the header comment for the model).  `g` is the
 // metric at the end point of the step, which both halves of raytrace() have just evaluated there.
-S5_DEV void accumulate_transfer(const TorusParams& p, const bool no_absorption, const RayState& s, const Metric& g, const double x[4],
+template <class PRM>
+S5_DEV void accumulate_transfer(const PRM& p, const bool no_absorption, const RayState& s, const Metric& g, const double x[4],
                                 const double k[4], double dl_taken, double& I, double& tau)
 {
 #if S5_FAST
@@ -220,14 +222,19 @@ S5_DEV void accumulate_transfer(const TorusParams& p, const bool no_absorption, 
     const double k_f = k[3] * g.g33 + k[0] * g.g03;
     const double sQ = sqrt_pos(Q);
     const double gfac = mdiv((B >= 0.0 ? s.E : -s.E) * sQ, k_t * B + A * k_f);
+    // (the two sums through local increments: with `I += ..` in one branch and `I += ..; tau += ..` in the other the compiler
+    // kept I and tau in a 16-byte stack slot indexed by the branch -- the kernel's only scratch use, inside the step loop)
+    double add_I, add_tau = 0.0;
     if (no_absorption) {
-        I += (gfac * gfac * gfac) * (p.emis0 * rho) * dl_taken;
+        add_I = (gfac * gfac * gfac) * (p.emis0 * rho) * dl_taken;
     } else {
         const double ds = mdiv(dl_taken, gfac);
         const double g2 = gfac * gfac;
-        I += (g2 * g2) * p.emis0 * rho * mexp(-tau) * ds;
-        tau += p.absorb0 * rho * ds;
+        add_I = (g2 * g2) * p.emis0 * rho * mexp(-tau) * ds;
+        add_tau = p.absorb0 * rho * ds;
     }
+    I += add_I;
+    if (!no_absorption) tau += add_tau;
 #else
     const double rho = torus_density(p, x[1], x[2]);
     if (!(rho > 0.0)) return;
@@ -246,7 +253,8 @@ S5_DEV void accumulate_transfer(const TorusParams& p, const bool no_absorption, 
 #endif
 }
 
-S5_DEV void write_ray_end(const TorusAux& aux, sim5gpu_stokes* __restrict__ out, size_t ray,
+template <class AUX>
+S5_DEV void write_ray_end(const AUX& aux, sim5gpu_stokes* __restrict__ out, size_t ray,
                           const double x[4], const double k[4], const RayState& s, double I, double tau, float worst)
 {
     sim5gpu_stokes rec = { I, 0.0, 0.0, 0.0, tau };
@@ -254,9 +262,9 @@ S5_DEV void write_ray_end(const TorusAux& aux, sim5gpu_stokes* __restrict__ out,
     if (aux.steps) aux.steps[ray] = s.pass;
     if (aux.max_step_error) aux.max_step_error[ray] = worst;
     if (aux.carter_error) aux.carter_error[ray] = raytrace_error(x, k, s);
-    if (aux.x_end) { for (int c = 0; c < 4; ++c) aux.x_end[4 * ray + c] = x[c]; }
+    if (aux.x_end) { double* __restrict__ o = aux.x_end + 4 * ray; o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3]; }
 #ifndef S5_TORUS_DEBUG
-    if (aux.k_end) { for (int c = 0; c < 4; ++c) aux.k_end[4 * ray + c] = k[c]; }
+    if (aux.k_end) { double* __restrict__ o = aux.k_end + 4 * ray; o[0] = k[0]; o[1] = k[1]; o[2] = k[2]; o[3] = k[3]; }
 #endif
 }
 
@@ -297,7 +305,7 @@ S5_DEV void write_ray_end(const TorusAux& aux, sim5gpu_stokes* __restrict__ out,
 // 23.6, x 640 23.6-23.8 (private 128-ray pools of round 3: 25.7).  Strict variant: its bodies need one wave per SIMD, four
 // waves per workgroup keep every CU busy.
 #ifndef S5_POOL_WG_WAVES
-#define S5_POOL_WG_WAVES (S5_FAST ? 8 : 4)
+#define S5_POOL_WG_WAVES (S5_FAST ? 4 * S5_MARCH_WAVES : 4)      // fast: the twelve waves a CU holds are ONE workgroup
 #endif
 #ifndef S5_POOL_WG_SLOTS
 #define S5_POOL_WG_SLOTS (64 * S5_POOL_WG_WAVES + 64)     // rays per workgroup pool: every wave's batch + 64
@@ -324,7 +332,13 @@ enum : int { Q_E = 0, Q_V = 1, Q_R = 2, NQ = 3 };
 // control words of a workgroup (LDS): head and tail of the three queues, rays alive in the pool, "the cursor is exhausted"
 enum : int { CW_HEAD = 0, CW_TAIL = NQ, CW_LIVE = 2 * NQ, CW_DRAINED = 2 * NQ + 1, NCW = 8 };
 constexpr unsigned short RING_VOID = 0xffffu;                 // a queue entry that has been reserved but not written yet
-constexpr int POOL_WG_BYTES = ((NPC * WG_SLOTS * 8 + 3 * WG_SLOTS * 4 + NQ * RING * 2 + NCW * 4) + 15) / 16 * 16;
+// A ray's sixteen doubles lie together, slots PD_STRIDE doubles apart (one double of padding: a stride of 16 doubles would put
+// every lane of a batch on the same LDS banks): one address register per ray and small immediate offsets for its columns,
+// whatever the size of the pool (column-major, the offsets of the last columns of an 832-slot pool no longer fit the
+// instruction's 16-bit offset field and cost address registers the three-wave build does not have).
+constexpr int PD_STRIDE = NPC + 1;
+#define PD_AT(c, slot) ((slot) * PD_STRIDE + (c))
+constexpr int POOL_WG_BYTES = ((PD_STRIDE * WG_SLOTS * 8 + 3 * WG_SLOTS * 4 + NQ * RING * 2 + NCW * 4 + 4 * 8) + 15) / 16 * 16;
 
 S5_DEV void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 S5_DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
@@ -336,46 +350,52 @@ S5_DEV void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// All arguments of the march kernel in ONE block.  LEAN (fast variant): the kernel reads it through the constant address space
+// where a value is used (param_reload at the head of every phase: nothing of it is held -- or spilled into vector lanes --
+// across the step bodies); otherwise (strict) it is an ordinary by-value argument block.
+struct PoolArgs {
+    TorusParams p;
+    RayCols start;
+    const int* ok;
+    const int* order;
+    unsigned long long* cursor;
+    sim5gpu_stokes* out;
+    TorusAux aux;
+};
+#ifndef S5_MARCH_LEAN
+#define S5_MARCH_LEAN (S5_FAST ? 1 : 0)
+#endif
+
 __global__ __launch_bounds__(WG_THREADS, S5_MARCH_WAVES)
-void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__ ok, const int* __restrict__ order,
-                       unsigned long long* __restrict__ cursor, sim5gpu_stokes* __restrict__ out, TorusAux aux)
+void torus_pool_kernel(PoolArgs args)
 {
     extern __shared__ char pool_raw[];
     const int lane = (int)(threadIdx.x & 63);
-    double* pd = (double*)pool_raw;                                  // [NPC][WG_SLOTS]
-    int* pray = (int*)(pool_raw + NPC * WG_SLOTS * 8);               // [WG_SLOTS]
+    double* pd = (double*)pool_raw;                                  // [WG_SLOTS][PD_STRIDE]
+    int* pray = (int*)(pool_raw + PD_STRIDE * WG_SLOTS * 8);         // [WG_SLOTS]
     int* ppass = pray + WG_SLOTS;
     float* pworst = (float*)(ppass + WG_SLOTS);
     unsigned short* ring = (unsigned short*)(pworst + WG_SLOTS);     // [NQ][RING]
     unsigned* cw = (unsigned*)(ring + NQ * RING);                    // [NCW]
+    double* cwd = (double*)(cw + NCW);                               // [4]: step_epsilon, r_in, r_out (formed once, below)
 
-    const size_t n = p_arg.nrays;
-#if S5_FAST && !defined(S5_TORUS_UNIFORMS_IN_SGPRS)
-    // The wave-uniform doubles the step loop reads every pass -- torus geometry, emissivity, stop radii, step cap -- are
-    // kept in VGPRs (a copy per lane, 2 registers each), not in SGPRs.  The kernel's argument block and pointers alone
-    // are ~70 SGPRs; with the exec masks of the nested per-lane branches the scalar file overflows (110 SGPRs spilled to
-    // VGPR lanes) and every use of a parameter in the loop was a v_readlane pair on the VALU, ~140 per accepted step in
-    // the transfer and stop-test blocks.  The kernel has VGPRs to spare (211 of the 256 its two waves per SIMD allow): 230
-    // now, SGPR spills 110 -> 66, VALU instructions in the code -7 %, the C4 job 31.0 -> 29.4 ms (same call, same results).
-    // Not in the strict variant: its bodies already use 255 registers, and the copies would go to scratch.
-    TorusParams p = p_arg;
-#define S5_TO_VGPR(x) asm volatile("" : "+v"(x))
-    const bool no_absorption = (p_arg.absorb0 == 0.0);             // the wave-uniform branch on it stays scalar
-    S5_TO_VGPR(p.torus_r); S5_TO_VGPR(p.torus_w); S5_TO_VGPR(p.torus_l); S5_TO_VGPR(p.inv_2w2); S5_TO_VGPR(p.cut_d2);
-    S5_TO_VGPR(p.emis0); S5_TO_VGPR(p.absorb0); S5_TO_VGPR(p.max_error); S5_TO_VGPR(p.dl_max);
-    double r_in = p_arg.r_stop_in * r_horizon(p_arg.a);
-    double r_out = p_arg.r_stop_out * p_arg.r0;
-    S5_TO_VGPR(r_in); S5_TO_VGPR(r_out);
-#undef S5_TO_VGPR
+#if S5_MARCH_LEAN
+    // LEAN: between two attempts a ray lives in its LDS slot, not in registers -- an attempt loads what it needs when it needs
+    // it (position and momentum at its head, kt at the precision check, the transfer integrals and the ray's identity after an
+    // accepted step) and stores the new state when the step is accepted; a rejected attempt stores nothing.  With the job's
+    // parameters read where they are used, the registers a wave carries THROUGH the two step bodies are the slot number and a
+    // few flags: the bodies themselves are what is left (round 3: 230 VGPRs, ~66 of them state and uniform parameters).
+    const S5_AS4 PoolArgs& A = *(const S5_AS4 PoolArgs*)__builtin_amdgcn_kernarg_segment_ptr();
 #else
-    const TorusParams& p = p_arg;
-    const bool no_absorption = (p_arg.absorb0 == 0.0);
-    const double r_in = p.r_stop_in * r_horizon(p.a);
-    const double r_out = p.r_stop_out * p.r0;
+    const PoolArgs& A = args;
 #endif
-    const double* __restrict__ sc = start.d;
-    const size_t scap = start.cap;
-
+    const size_t n = A.p.nrays;
+    const bool no_absorption = (A.p.absorb0 == 0.0);               // the wave-uniform branch on it stays scalar
+    if (threadIdx.x == 0) {
+        cwd[0] = S5_DIVC(msqrt(A.p.precision), 10.);
+        cwd[1] = A.p.r_stop_in * r_horizon(A.p.a);
+        cwd[2] = A.p.r_stop_out * A.p.r0;
+    }
     // the pool: every slot in the queue of empty slots, the other two queues void
     for (int i = (int)threadIdx.x; i < NQ * RING; i += WG_THREADS) ring[i] = (i < WG_SLOTS) ? (unsigned short)i : RING_VOID;
     if (threadIdx.x < NCW) cw[threadIdx.x] = (threadIdx.x == CW_TAIL + Q_E) ? (unsigned)WG_SLOTS : 0u;
@@ -387,17 +407,6 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
     if (lane == 0) { tl[0] = wall_clock64(); tl[1] = 0; tl[2] = 0; }
 #endif
 
-    RayState s;
-    s.opt_gr = !((p.options & 1) == 1);
-    s.opt_pol = 0;
-    s.step_epsilon = S5_DIVC(msqrt(p.precision), 10.);
-    s.bh_spin = p.a;
-    s.refines = 0; s.Q = 0.0;
-#if S5_FAST && !defined(S5_TORUS_UNIFORMS_IN_SGPRS)
-    asm volatile("" : "+v"(s.step_epsilon));                    // as above: read every pass, kept in VGPRs
-    asm volatile("" : "+v"(s.bh_spin));
-#endif
-
     // Every wait in this kernel is bounded: the spins of the queue primitives by SPIN_CAP (~50 ms; they normally last a few
     // cycles), the main loop by `guard` passes AND by a wall-clock budget far above any job's need (5 s + 1 ns per ray and
     // permitted step): a wave that runs into either leaves the loop, so the grid always drains -- the rays it abandons are
@@ -405,7 +414,7 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
     constexpr int SPIN_CAP = 1 << 20;
     bool broken = false;
     const unsigned long long t_begin = wall_clock64();
-    const unsigned long long t_budget = 100000000ull * 5ull + (unsigned long long)n * (unsigned long long)(p_arg.max_steps > 0 ? p_arg.max_steps : 1) / 10ull;
+    const unsigned long long t_budget = 100000000ull * 5ull + (unsigned long long)n * (unsigned long long)(A.p.max_steps > 0 ? A.p.max_steps : 1) / 10ull;
     // Queue primitives (wave-uniform calls).  take: up to `want` entries from queue q -- one lane snapshots head and tail and
     // moves the head by compare-and-swap (retried while other waves move it); lane i < count then owns entry head + i: it waits
     // for the entry to be written (a producer reserves its positions before it fills them), reads the slot and voids the entry.
@@ -457,7 +466,7 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
 
     // every pass consumes cursor positions, advances at least one pooled ray by half a raytrace() call, or waits for the other
     // waves of the workgroup (bounded like the rest: a waiting pass is a sleep of ~1 us, the bound allows for it)
-    const unsigned long long guard = 64ull * (unsigned long long)(p.max_steps + 2) * ((n + 63) / 64 + 2);
+    const unsigned long long guard = 64ull * (unsigned long long)(A.p.max_steps + 2) * ((n + 63) / 64 + 2);
     for (unsigned long long it = 0; it < guard; ++it) {
         if (__builtin_amdgcn_ballot_w64(broken)) break;
         if ((it & 255ull) == 255ull && wall_clock64() - t_begin > t_budget) break;
@@ -479,9 +488,12 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
             if (got > 0) {
                 const bool have = lane < got;
                 unsigned long long base = 0;
+                const auto& R = param_reload(A);                       // (pointers of the refill: loaded here)
+                const double* __restrict__ sc = R.start.d;
+                const size_t scap = R.start.cap;
                 if (lane == 0) {
                     atomicAdd(&cw[CW_LIVE], (unsigned)got);                 // counted alive BEFORE the cursor is asked (see the exit test)
-                    base = atomicAdd(cursor, (unsigned long long)got);
+                    base = atomicAdd(R.cursor, (unsigned long long)got);
                 }
                 base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
@@ -494,24 +506,31 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
                 const unsigned long long mine = base + (unsigned long long)lane;
                 bool started = false;
                 if (have && mine < n) {
-                    const size_t ray = (size_t)order[mine];         // (torus_start_kernel: the long rays first)
-                    if (!ok[ray]) {
+                    const size_t ray = (size_t)R.order[mine];       // (torus_start_kernel: the long rays first)
+                    if (!R.ok[ray]) {
                         // rejected at start-up: an empty record, the slot goes back to the empty ones
                         sim5gpu_stokes z = { 0.0, 0.0, 0.0, 0.0, 0.0 };
-                        out[ray] = z;
-                        if (aux.steps) aux.steps[ray] = 0;
-                        if (aux.max_step_error) aux.max_step_error[ray] = 0.0f;
-                        if (aux.carter_error) aux.carter_error[ray] = NAN;
-                        if (aux.x_end) { for (int c = 0; c < 4; ++c) aux.x_end[4 * ray + c] = sc[(COL_X0 + c) * scap + ray]; }
+                        R.out[ray] = z;
+                        if (R.aux.steps) R.aux.steps[ray] = 0;
+                        if (R.aux.max_step_error) R.aux.max_step_error[ray] = 0.0f;
+                        if (R.aux.carter_error) {
+                            // NaN made HERE (an opaque zero added to its high word): as a literal the compiler hoists it out of the
+                            // main loop and carries it, two registers, through both step bodies -- at three waves per SIMD the one
+                            // value it then spilled
+                            int z = 0;
+                            asm volatile("" : "+v"(z));
+                            R.aux.carter_error[ray] = __hiloint2double(0x7ff80000 + z, z);
+                        }
+                        if (R.aux.x_end) { for (int c = 0; c < 4; ++c) R.aux.x_end[4 * ray + c] = sc[(COL_X0 + c) * scap + ray]; }
 #ifndef S5_TORUS_DEBUG
-                        if (aux.k_end) { for (int c = 0; c < 4; ++c) aux.k_end[4 * ray + c] = sc[(COL_K0 + c) * scap + ray]; }
+                        if (R.aux.k_end) { for (int c = 0; c < 4; ++c) R.aux.k_end[4 * ray + c] = sc[(COL_K0 + c) * scap + ray]; }
 #endif
                     } else {
 #pragma unroll
-                        for (int c = 0; c < 13; ++c) pd[c * WG_SLOTS + slot] = sc[c * scap + ray];   // x, k, dk, kt
-                        pd[PC_E * WG_SLOTS + slot] = sc[COL_KT * scap + ray];
-                        pd[PC_I * WG_SLOTS + slot] = 0.0;
-                        pd[PC_TAU * WG_SLOTS + slot] = 0.0;
+                        for (int c = 0; c < 13; ++c) pd[PD_AT(c, slot)] = sc[c * scap + ray];   // x, k, dk, kt
+                        pd[PD_AT(PC_E, slot)] = sc[COL_KT * scap + ray];
+                        pd[PD_AT(PC_I, slot)] = 0.0;
+                        pd[PD_AT(PC_TAU, slot)] = 0.0;
                         pray[slot] = (int)ray; ppass[slot] = 0; pworst[slot] = 0.0f;
                         started = true;
                     }
@@ -548,35 +567,84 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
         int tag = TAG_EMPTY;
         bool finished = false;
         if (active) {
+            tag = do_rk4 ? TAG_R : TAG_V;
+            bool on = true;
+#if !S5_MARCH_LEAN
+            // by-value parameters (strict variant): the state of the ray in registers through the batch, as in round 3
+            const TorusParams& p = A.p;
+            const double* __restrict__ sc = A.start.d;
+            const size_t scap = A.start.cap;
+            const double r_in = cwd[1], r_out = cwd[2];
+            RayState s;
+            s.opt_gr = !((p.options & 1) == 1);
+            s.opt_pol = 0;
+            s.step_epsilon = cwd[0];
+            s.bh_spin = p.a;
+            s.refines = 0; s.Q = 0.0;
             double x[4], k[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                x[c] = pd[(PC_X0 + c) * WG_SLOTS + slot];
-                k[c] = pd[(PC_K0 + c) * WG_SLOTS + slot];
-                s.dk[c] = pd[(PC_DK0 + c) * WG_SLOTS + slot];
+                x[c] = pd[PD_AT(PC_X0 + c, slot)];
+                k[c] = pd[PD_AT(PC_K0 + c, slot)];
+                s.dk[c] = pd[PD_AT(PC_DK0 + c, slot)];
             }
-            s.kt = pd[PC_KT * WG_SLOTS + slot];
-            s.E = pd[PC_E * WG_SLOTS + slot];
+            s.kt = pd[PD_AT(PC_KT, slot)];
+            s.E = pd[PD_AT(PC_E, slot)];
             s.pass = ppass[slot];
             s.error = 0.0f;
             const size_t ray = (size_t)pray[slot];
-            double I = pd[PC_I * WG_SLOTS + slot], tau = pd[PC_TAU * WG_SLOTS + slot];
+            double I = pd[PD_AT(PC_I, slot)], tau = pd[PD_AT(PC_TAU, slot)];
             float worst = pworst[slot];
-            tag = do_rk4 ? TAG_R : TAG_V;
-            bool on = true;
+#endif
 #pragma unroll 1
             for (int run = 0; run <= POOL_RUN; ++run) {
                 if (on) {
                     double dl;
                     bool advanced;
                     Metric g;                                      // metric at the end point of the step
+#if S5_MARCH_LEAN
+                    // ---- the ray's dynamical state from its slot; the job's parameters from the argument segment, from here
+                    const auto& P = param_reload(A);
+                    RayState s;
+                    s.opt_gr = !((P.p.options & 1) == 1);
+                    s.opt_pol = 0;
+                    s.step_epsilon = cwd[0];
+                    s.bh_spin = P.p.a;
+                    s.refines = 0; s.Q = 0.0; s.E = 0.0;
+                    double x[4], k[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        x[c] = pd[PD_AT(PC_X0 + c, slot)];
+                        k[c] = pd[PD_AT(PC_K0 + c, slot)];
+                        s.dk[c] = pd[PD_AT(PC_DK0 + c, slot)];
+                    }
+                    s.kt = (run == 0 && do_rk4) ? 0.0 : pd[PD_AT(PC_KT, slot)];      // (RK4: read after the step, below)
+                    s.pass = ppass[slot];
+                    s.error = 0.0f;
+                    const double dl_max = P.p.dl_max;
+#else
+                    const double dl_max = p.dl_max;
+#endif
 #ifdef S5_KO_RK4                 // diagnostic builds only (register budget of the two bodies)
                     if (false) {
                         dl = 0.0;
 #else
                     if (run == 0 && do_rk4) {
-                        dl = next_step_size(k, p.dl_max, s);      // the value the rejected attempt used
+                        dl = next_step_size(k, dl_max, s);        // the value the rejected attempt used
+#if S5_MARCH_LEAN
+                        {
+                            auto late = [&](int c) -> double { return pd[PD_AT(PC_X0 + c, slot)]; };
+                            x[0] = 0.0; x[3] = 0.0;               // (t and phi are read from the slot at the end of the step)
+                            rk4_step<true>(x, k, dl, s, g, late);
+                        }
+#else
                         rk4_step(x, k, dl, s, g);
+#endif
+#if S5_MARCH_LEAN
+                        // the step's error measures k_t against its value before the step (ref :306-308): read from the slot
+                        // HERE (same expression, same operands as inside rk4_step) rather than carried through the four stages
+                        s.error = (float)rel_diff(k[0] * g.g00 + k[3] * g.g03, pd[PD_AT(PC_KT, slot)]);
+#endif
 #endif
                         if (!s.opt_gr) flat_metric(x[1], x[2], g); // RK4 leaves the Kerr metric (ref :305); the fluid lives in the flat one
                         advanced = true;
@@ -584,12 +652,12 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
 #ifdef S5_KO_VERLET
                         advanced = false; dl = 0.0;
 #else
-                        advanced = verlet_attempt(x, k, p.dl_max, dl, s, g);
+                        advanced = verlet_attempt(x, k, dl_max, dl, s, g);
 #endif
                     }
 #ifdef S5_TORUS_DEBUG
                     {
-                        unsigned long long* dbg = (unsigned long long*)aux.k_end;
+                        unsigned long long* dbg = (unsigned long long*)A.aux.k_end;
                         const unsigned long long mA = __builtin_amdgcn_ballot_w64(true);
                         const int w = (run == 0 && do_rk4) ? 2 : 0;
                         if (__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u)) == 0u) {
@@ -597,10 +665,43 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
                         }
                     }
 #endif
+#if S5_MARCH_LEAN
+                    ppass[slot] = s.pass;                          // the attempt counts as a pass either way (ref :168)
+#endif
                     if (!advanced) {
-                        tag = TAG_R; on = false;                  // x, k, dk untouched; the attempt counts as a pass (ref :168)
+                        tag = TAG_R; on = false;                  // x, k, dk untouched
                     } else {
                         tag = TAG_V;
+#if S5_MARCH_LEAN
+                        // ---- accepted: the new state into the slot, then the transfer step and the end tests with what they need
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            pd[PD_AT(PC_X0 + c, slot)] = x[c];
+                            pd[PD_AT(PC_K0 + c, slot)] = k[c];
+                            pd[PD_AT(PC_DK0 + c, slot)] = s.dk[c];
+                        }
+                        if (!(run == 0 && do_rk4)) pd[PD_AT(PC_KT, slot)] = s.kt;      // (an RK4 step leaves kt as it was)
+                        const auto& T = param_reload(A);
+                        const float worst = fmaxf(pworst[slot], s.error);
+                        pworst[slot] = worst;
+                        double I = pd[PD_AT(PC_I, slot)], tau = pd[PD_AT(PC_TAU, slot)];
+                        s.E = pd[PD_AT(PC_E, slot)];
+#ifndef S5_KO_TRANSFER
+                        accumulate_transfer(T.p, no_absorption, s, g, x, k, dl, I, tau);
+#endif
+                        pd[PD_AT(PC_I, slot)] = I;
+                        pd[PD_AT(PC_TAU, slot)] = tau;
+                        const bool done = !(x[1] > cwd[1]) || !(x[1] < cwd[2]) || ((double)s.error > T.p.max_error) ||
+                                          (s.pass >= T.p.max_steps);
+                        if (done) {
+                            const size_t ray = (size_t)pray[slot];
+                            s.Q = T.start.d[COL_Q * T.start.cap + ray];
+#ifndef S5_KO_END
+                            write_ray_end(T.aux, T.out, ray, x, k, s, I, tau, worst);
+#endif
+                            tag = TAG_EMPTY; on = false; finished = true;
+                        }
+#else
                         worst = fmaxf(worst, s.error);
 #ifndef S5_KO_TRANSFER
                         accumulate_transfer(p, no_absorption, s, g, x, k, dl, I, tau);
@@ -610,27 +711,30 @@ void torus_pool_kernel(TorusParams p_arg, RayCols start, const int* __restrict__
                         if (done) {
                             s.Q = sc[COL_Q * scap + ray];
 #ifndef S5_KO_END
-                            write_ray_end(aux, out, ray, x, k, s, I, tau, worst);
+                            write_ray_end(A.aux, A.out, ray, x, k, s, I, tau, worst);
 #endif
                             tag = TAG_EMPTY; on = false; finished = true;
                         }
+#endif
                     }
                 }
                 if (POOL_KEEP_DEN * __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)) < POOL_KEEP_NUM * take) break;
             }
+#if !S5_MARCH_LEAN
             if (tag != TAG_EMPTY) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    pd[(PC_X0 + c) * WG_SLOTS + slot] = x[c];
-                    pd[(PC_K0 + c) * WG_SLOTS + slot] = k[c];
-                    pd[(PC_DK0 + c) * WG_SLOTS + slot] = s.dk[c];
+                    pd[PD_AT(PC_X0 + c, slot)] = x[c];
+                    pd[PD_AT(PC_K0 + c, slot)] = k[c];
+                    pd[PD_AT(PC_DK0 + c, slot)] = s.dk[c];
                 }
-                pd[PC_KT * WG_SLOTS + slot] = s.kt;
-                pd[PC_I * WG_SLOTS + slot] = I;
-                pd[PC_TAU * WG_SLOTS + slot] = tau;
+                pd[PD_AT(PC_KT, slot)] = s.kt;
+                pd[PD_AT(PC_I, slot)] = I;
+                pd[PD_AT(PC_TAU, slot)] = tau;
                 ppass[slot] = s.pass;
                 pworst[slot] = worst;
             }
+#endif
         }
         // ---- 5. the slots back into their queues (the state before the entries)
         wg_release();
@@ -719,7 +823,9 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
         if ((e = hipFuncSetAttribute((const void*)torus_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
         g_ws.attr_set = true;
     }
-    hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(WG_THREADS), lds, stream, p, start, ok, order, cursor, out, aux);
+    PoolArgs pa;
+    pa.p = p; pa.start = start; pa.ok = ok; pa.order = order; pa.cursor = cursor; pa.out = out; pa.aux = aux;
+    hipLaunchKernelGGL(torus_pool_kernel, dim3((unsigned)blocks_b), dim3(WG_THREADS), lds, stream, pa);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     return 0;
 }

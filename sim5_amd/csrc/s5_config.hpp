@@ -111,3 +111,14 @@
 #endif
 // constant address space (kernel-argument segment, read-only tables): loads through such a pointer are scalar loads
 #define S5_AS4 __attribute__((address_space(4)))
+
+// Parameters behind a constant-address-space reference: the same object through a pointer the optimiser cannot see through,
+// so the loads that follow are issued from here on (not hoisted to the kernel's head and held -- spilled -- in SGPRs).  A
+// by-value argument block passes through unchanged.
+template <class T> S5_DEV const T& param_reload(const T& p) { return p; }
+template <class T> S5_DEV const S5_AS4 T& param_reload(const S5_AS4 T& p)
+{
+    const S5_AS4 T* q = &p;
+    asm volatile("" : "+s"(q));
+    return *q;
+}

@@ -67,10 +67,15 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
 // the connection code, and only the latest stage plus the running sums are live -- 8+8 doubles instead of
 // 32.  The sums are accumulated in the reference's order ((k1 + 2 k2) + 2 k3) + k4 and the stage-0
 // operations with a zero offset / unit weight are exact, so every rounding is the reference's.
+// LATE_TPHI (march kernel, fast variant): t and phi do not enter the connection, so a caller that keeps the ray's state in
+// memory passes a functor that returns x[0] / x[3] when asked and the routine asks only at the very end (x[0], x[3] on entry are
+// ignored): four registers less through the three stages.  Same expressions, same operands: the same numbers.
+struct NoLateFetch { S5_DEV double operator()(int) const { return 0.0; } };
+template <bool LATE_TPHI = false, class Fetch = NoLateFetch>
 #ifdef S5_RK4_NOINLINE
-static __device__ __noinline__ void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g)
+static __device__ __noinline__ void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g, const Fetch& late = Fetch())
 #else
-S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g)
+S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g, const Fetch& late = Fetch())
 #endif
 {
     Conn G;
@@ -87,6 +92,37 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
 #else
     x[2] = macos(x[2]);
 #endif
+#if S5_FAST
+    // Stage 0 apart from the loop: its offsets are zero and its acceleration is the one the previous step left in s.dk, so
+    // it is four additions of zero and two sums -- written out with the operations the rolled loop performed for stage == 0
+    // (x + 0 * 0, k + 0 * 0, 0 + 1 * k: every rounding as before), and s.dk is dead from here on instead of being carried,
+    // eight registers, through the three stages that evaluate a connection.  The position offsets of t and phi are never
+    // formed: the connection does not depend on them.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ki[i] = k[i] + 0.0 * 0.0;
+        di[i] = s.dk[i];
+        sx[i] = 0.0 + 1.0 * ki[i];
+        sk[i] = 0.0 + 1.0 * di[i];
+    }
+    xp[0] = xp[3] = 0.0;
+#pragma unroll 1
+    for (int stage = 1; stage < 4; ++stage) {
+        const double off = (stage == 3) ? dl : 0.5 * dl;           // (0.5 dl is exact: formed here, not carried)
+        const double wgt = (stage == 3) ? 1.0 : 2.0;
+        xp[1] = x[1] + ki[1] * off; xp[2] = x[2] + ki[2] * off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ki[i] = k[i] + di[i] * off;
+        {
+            double sd, cd;
+            msincos_small(xp[2], sd, cd);
+            rt_connection(s, xp[1], m0 * cd - sn0 * sd, G);
+            transport_self(G, ki, di);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + wgt * ki[i]; sk[i] = sk[i] + wgt * di[i]; }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ki[i] = 0.0; di[i] = 0.0; sx[i] = 0.0; sk[i] = 0.0; }
 #ifdef S5_RK4_UNROLL
@@ -99,26 +135,13 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
         const double wgt = (stage == 1 || stage == 2) ? 2.0 : 1.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xp[i] = x[i] + ki[i] * off; ki[i] = k[i] + di[i] * off; }
-#if S5_FAST
-        // stage 0 is the acceleration at the current point with the current momentum: the value every step
-        // leaves in s.dk (Verlet :232, RK4 :299, prepare :90).  The reference recomputes it through
-        // cos(acos(m)) and the other summation order; the fast variant reuses it (one connection less).
-        if (stage == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) di[i] = s.dk[i];
-        } else {
-            double sd, cd;
-            msincos_small(xp[2], sd, cd);
-            rt_connection(s, xp[1], m0 * cd - sn0 * sd, G);
-            transport_self(G, ki, di);
-        }
-#else
         rt_connection(s, xp[1], mcos(xp[2]), G);
         transport_self(G, ki, di);
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + wgt * ki[i]; sk[i] = sk[i] + wgt * di[i]; }
     }
+#endif
+    if (LATE_TPHI) { x[0] = late(0); x[3] = late(3); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         x[i] += S5_DIVC(dl, 6.) * sx[i];

@@ -70,16 +70,7 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
                                     const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                                     const double ra, const double rb, const double rc_, const double rd_);
 
-// Parameters behind a constant-address-space reference: the same object through a pointer the optimiser cannot see through,
-// so the loads that follow are issued from here on (not hoisted to the kernel's head and held -- spilled -- in SGPRs).  The
-// by-value argument block of the other kernels passes through unchanged.
-template <class T> S5_DEV const T& param_reload(const T& p) { return p; }
-template <class T> S5_DEV const S5_AS4 T& param_reload(const S5_AS4 T& p)
-{
-    const S5_AS4 T* q = &p;
-    asm volatile("" : "+s"(q));
-    return *q;
-}
+// (param_reload(): s5_config.hpp)
 #ifndef S5_COLD_UNPAIRED
 #define S5_COLD_UNPAIRED 0      // measured by the compiler: 21 spilled SGPRs against 9 with the paired copy; kept for the record
 #endif
