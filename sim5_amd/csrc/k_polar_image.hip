@@ -23,8 +23,8 @@ using namespace s5abi;
 // the polarization chain of one traced ray (header comment): Stokes I, Q, U and the angle
 // AUX = false: the instantiation for jobs that take the Stokes planes only (no chi plane, no full-precision planes): six
 // pointers fewer held in SGPRs through the kernel, no atan2, no tests around the stores (as k_disk_image.hip)
-template <bool AUX>
-S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const ThinRay& t, double& I, double& Q, double& U,
+template <bool AUX, class PRM>
+S5_DEV void polarize_ray(const PRM& p, double alpha, double beta, const ThinRay& t, double& I, double& Q, double& U,
                          double& chi)
 {
     I = 0.0; Q = 0.0; U = 0.0; chi = NAN;
@@ -116,8 +116,8 @@ S5_DEV void polarize_ray(const ImageParams& p, double alpha, double beta, const 
 #endif
 }
 
-template <bool AUX>
-S5_DEV void store_polarized(const ImageParams& p, size_t o, const ThinRay& t, double I, double Q, double U, double chi)
+template <bool AUX, class PRM>
+S5_DEV void store_polarized(const PRM& p, size_t o, const ThinRay& t, double I, double Q, double U, double chi)
 {
     const size_t npix = (size_t)p.nrows * (size_t)p.nx;
     p.stokes[o] = I;
@@ -162,8 +162,15 @@ void disk_image_polarized_kernel(ImageParams p)
 #endif
 template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)
-void disk_image_polarized_mirror_kernel(ImageParams p)
+void disk_image_polarized_mirror_kernel(ImageParams p_arg)
 {
+#ifndef S5_POLAR_BY_VALUE
+    // the job read through the constant address space where its values are used (as the job-list kernel of k_disk_image.hip):
+    // the argument block is this kernel's only parameter, at the head of the argument segment
+    const S5_AS4 ImageParams& p = *(const S5_AS4 ImageParams*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const ImageParams& p = p_arg;
+#endif
     const int lane_x = threadIdx.x & 15;
     const int lane_y = threadIdx.x >> 4;
     const int ix = blockIdx.x * 16 + lane_x;
@@ -187,9 +194,10 @@ void disk_image_polarized_mirror_kernel(ImageParams p)
         if (member == 1) m = t2;
         const double b = (member == 0) ? beta : -beta;
         double I, Q, U, chi;
-        polarize_ray<AUX>(p, alpha, b, m, I, Q, U, chi);
+        const auto& pp = param_reload(p);                  // (the chain's few parameters and the output pointers: loaded here)
+        polarize_ray<AUX>(pp, alpha, b, m, I, Q, U, chi);
         if (member == 0 || lr2 != lr)
-            store_polarized<AUX>(p, (size_t)(member == 0 ? lr : lr2) * (size_t)p.nx + (size_t)ix, m, I, Q, U, chi);
+            store_polarized<AUX>(pp, (size_t)(member == 0 ? lr : lr2) * (size_t)pp.nx + (size_t)ix, m, I, Q, U, chi);
     }
 }
 #endif
