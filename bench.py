@@ -189,6 +189,18 @@ class ImageJob:
         else:
             self._launch(self.desc, buf)
 
+    def trace_both(self, buf, view):
+        """rank 0 with a band: its in-place share and the band as ONE job-list launch (two jobs streaming back to back)"""
+        a = b = None
+        if self.events is not None and self.used < len(self.events):
+            a, b = self.events[self.used]
+            self.used += 1
+            a.record(self.stream)
+        self.capi.disk_image_jobs([self.desc, self.band_desc], [buf[0].data_ptr(), view[0].data_ptr()],
+                                  [buf[1].data_ptr(), view[1].data_ptr()], stream=self.stream)
+        if b is not None:
+            b.record(self.stream)
+
     def trace_band(self, view):
         if self.band_events is not None and self.band_used < len(self.band_events):
             a, b = self.band_events[self.band_used]
@@ -622,7 +634,8 @@ def main():
 
     def step(i):
         for job in jobs:                    # one image per inclination: trace my share, gather (overlapped), rank 0: its band,
-            pipe.step(job.trace, job.trace_band if job.band_desc is not None else None)      # then the previous image's rows in place
+            pipe.step(job.trace, job.trace_band if job.band_desc is not None else None,      # then the previous image's rows in place
+                      job.trace_both if (job.band_desc is not None and job.desc is not None) else None)
             if check_every_step and rank == 0 and pipe.count > 1:
                 # the image of the previous step is complete on this stream from here on (no drain: that is the claim tested)
                 prev = pipe.full[(pipe.count - 2) % pipe.nbuf]
@@ -846,7 +859,8 @@ def run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one
 
     def scan(check):
         for job, inc in zip(jobs, C5_INCLINATIONS):
-            pipe.step(job.trace, job.trace_band if job.band_desc is not None else None)
+            pipe.step(job.trace, job.trace_band if job.band_desc is not None else None,
+                      job.trace_both if (job.band_desc is not None and job.desc is not None) else None)
             if check and rank == 0:
                 pipe.drain()
                 torch.cuda.synchronize()         # the band is traced by this rank, after the gather was issued

@@ -206,18 +206,19 @@ int sim5gpu_shard_image_begin(sim5gpu_shard* s, const sim5gpu_image_desc* image,
     // ---- from here on the rank ALWAYS joins the gather: a launch that fails now (a HIP error) poisons the shard and is
     //      reported, but the peers are not left waiting in a collective
     int bad = 0;
-    if (s->rank == 0) {
-        if (have_rows && (rc = sim5gpu_disk_image(&d, d_image_f, d_image_g, nullptr, stream)) != 0) bad = fail_base("sim5gpu_disk_image (share of rank 0, in place)", rc);
-        s->image_f[b] = d_image_f; s->image_g[b] = d_image_g;
-    } else {
+    if (s->rank != 0) {
         float* pf = s->payload[b];
         if (have_rows && (rc = sim5gpu_disk_image(&d, pf, pf + (size_t)s->rows_max * (size_t)s->nx, nullptr, stream)) != 0) bad = fail_base("sim5gpu_disk_image (share)", rc);
+    } else {
+        s->image_f[b] = d_image_f; s->image_g[b] = d_image_g;
     }
     if (s->comm) {                                            // also with a world of one: the collective degenerates, the path is the same
+        // peers: the gather after their share has been traced.  The root only RECEIVES (in place: sendbuff == recvbuff + rank *
+        // sendcount, its own block is never read), so its gather does not depend on its tracing and is issued BEFORE it: the
+        // event orders it after what `stream` held so far (the placement that last read this payload slot).
         hipError_t e = hipEventRecord(s->traced[b], st);
         if (e == hipSuccess) e = hipStreamWaitEvent(s->comm_stream, s->traced[b], 0);
         if (e != hipSuccess && !bad) bad = fail_hip("shard_image_begin: event before the gather", e);
-        // in place on the root (sendbuff == recvbuff + rank * sendcount): its block is never read
         const ncclResult_t r = ncclGather(s->payload[b], s->rank == 0 ? s->payload[b] : nullptr, s->block, ncclFloat, 0, s->comm, s->comm_stream);
         if (r != ncclSuccess) { s->poisoned = 1; return fail_nccl("ncclGather", r); }      // not enqueued: the slot is not in flight
         s->begun++;                                           // the gather is in flight: the slot is tracked from here, whatever follows
@@ -226,9 +227,14 @@ int sim5gpu_shard_image_begin(sim5gpu_shard* s, const sim5gpu_image_desc* image,
     } else {
         s->begun++;
     }
-    if (have_band && !bad) {                                  // the band, while the gather is in flight
-        const size_t off = (size_t)b0 * (size_t)s->nx;
-        if ((rc = sim5gpu_disk_image(&band, d_image_f + off, d_image_g + off, nullptr, stream)) != 0) bad = fail_base("sim5gpu_disk_image (band)", rc);
+    if (s->rank == 0 && !bad) {
+        // the root's own rows while the gather is in flight: its share in place and its band, ONE job-list launch
+        sim5gpu_image_desc jobs[2];
+        float* jf[2]; float* jg[2];
+        int nj = 0;
+        if (have_rows) { jobs[nj] = d; jf[nj] = d_image_f; jg[nj] = d_image_g; ++nj; }
+        if (have_band) { const size_t off = (size_t)b0 * (size_t)s->nx; jobs[nj] = band; jf[nj] = d_image_f + off; jg[nj] = d_image_g + off; ++nj; }
+        if (nj > 0 && (rc = sim5gpu_disk_image_jobs(nj, jobs, jf, jg, stream)) != 0) bad = fail_base("sim5gpu_disk_image_jobs (share of rank 0 in place + band)", rc);
     }
     if (bad) { s->poisoned = 1; return bad; }                 // the image in this slot is not valid; shard_image_end still has to be called for it
     return SIM5GPU_OK;

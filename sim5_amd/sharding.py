@@ -153,8 +153,9 @@ class TilePipeline:
                    payload of the gather, rows packed (inplace False).  Rank 0: `buffer` is its [2, ny, nx] IMAGE and the
                    share is written at its image rows (inplace True: SIM5GPU_IMG_INPLACE) -- rank 0's rows never move.
       every rank   ONE gather per image (both planes of a rank's stripes are one contiguous payload), asynchronous.
-      rank 0       trace_band(view) traces the centred band root_band(ny, dealt) into the same image while the gather is
-                   in flight (dealt < upper_half(ny) only).
+      rank 0       issues the gather BEFORE it traces (it only receives), then traces its share in place and the centred band
+                   root_band(ny, dealt) into the same image while the gather is in flight: trace_both(image, band_view) in
+                   one launch if given, else trace() then trace_band(view).
       rank 0       when the gather of an image has completed, place(shares, image) copies the peers' rows to their image
                    rows -- so every step ends with a complete row-major [2, ny, nx] image on rank 0.  The placement of
                    image i is issued after the tracing of image i+1 has been enqueued, so gather i overlaps tracing i+1;
@@ -188,18 +189,25 @@ class TilePipeline:
         self.gathers = 0
         self.placed = 0
 
-    def step(self, trace, trace_band=None):
-        if self.band and trace_band is None:
+    def step(self, trace, trace_band=None, trace_both=None):
+        if self.band and trace_band is None and trace_both is None:
             raise ValueError("TilePipeline.step: rank 0 keeps the band %r of the image: trace_band is required" % (self.band,))
         b = self.count % self.nbuf
         self.finish(b)                          # buffer b is free: its gather has completed and its rows are placed
         if self.world == 1:
             trace(self.full[b], True)
         elif self.rank == 0:
-            trace(self.full[b], True)           # in place: rank 0's rows are final
+            # The root RECEIVES only (its block of the gather is never read: its rows are traced in place), so its part of
+            # the collective does not depend on its own tracing: the gather is issued FIRST and runs while rank 0 traces its
+            # share and its band -- with `trace_both`, in ONE job-list launch (sim5gpu_disk_image_jobs: the two jobs stream
+            # through the GPU back to back instead of paying a launch gap and a ragged last round each).
             self.gather(b)
-            if self.band:                       # its band, while the gather is in flight
-                trace_band(self.full[b][:, self.band[0]:self.band[1]])
+            if trace_both is not None and self.band:
+                trace_both(self.full[b], self.full[b][:, self.band[0]:self.band[1]])
+            else:
+                trace(self.full[b], True)       # in place: rank 0's rows are final
+                if self.band:
+                    trace_band(self.full[b][:, self.band[0]:self.band[1]])
             if self.count > 0:
                 self.finish((self.count - 1) % self.nbuf)      # the previous image is complete from here on
         else:
