@@ -299,11 +299,11 @@ S5_DEV void write_ray_end(const AUX& aux, sim5gpu_stokes* __restrict__ out, size
 // them with one atomic add on a tail per kind; nothing is scanned, the order is first in first out (no ray waits while
 // others are stepped twice), and a wave with nothing to take sleeps until the workgroup's last ray is done instead of
 // retiring early.
-// Workgroup width.  Fast variant: ONE workgroup of eight waves per CU (two per SIMD, the VGPR-bound occupancy) with a pool
-// of 8 x 64 + 64 = 576 rays -- one pool per CU instead of two of 320: fewer rays in flight still, and the drain phase shares
-// the rays of the whole CU.  Measured, C4, one call: 4 waves x 256 slots 25.9 ms, x 320 24.1-24.4, x 384 24.2; 8 waves x 576
-// 23.6, x 640 23.6-23.8 (private 128-ray pools of round 3: 25.7).  Strict variant: its bodies need one wave per SIMD, four
-// waves per workgroup keep every CU busy.
+// Workgroup width.  Fast variant: ALL waves of a CU are one workgroup with one pool of (waves x 64 + 64) rays -- fewer rays in
+// flight than with several pools per CU, and the drain phase shares the rays of the whole CU.  Measured, C4, one call each, at
+// two waves per SIMD: 4 waves x 256 slots 25.9 ms, x 320 24.1-24.4, x 384 24.2; 8 waves x 576 23.6, x 640 23.6-23.8 (private
+// 128-ray pools of round 3: 25.7); at three waves per SIMD (the lean form below): 4-wave workgroups 22.4-22.7, twelve waves x 832
+// slots 21.2-21.6, x 896 21.4.  Strict variant: its bodies need one wave per SIMD; four waves per workgroup keep every CU busy.
 #ifndef S5_POOL_WG_WAVES
 #define S5_POOL_WG_WAVES (S5_FAST ? 4 * S5_MARCH_WAVES : 4)      // fast: the twelve waves a CU holds are ONE workgroup
 #endif
@@ -324,7 +324,7 @@ static_assert(WG_SLOTS % 64 == 0 && WG_SLOTS >= 128 && WG_SLOTS <= RING, "pool s
 #endif
 #ifndef POOL_RUN
 #define POOL_RUN 6                       // Verlet attempts a batch may take before it returns to the pool (measured with the queues
-#endif                                   // of round 4, C4, one call: 4 -> 23.7-23.9 ms, 6 -> 23.4-23.5, 8 -> 23.3-23.5)
+#endif                                   // of round 4, C4, one call: 4 / 6 / 8 -> 23.8 / 23.4 / 23.4 ms at two waves, 21.3-21.4 at three)
 enum : int { PC_X0 = 0, PC_X1, PC_X2, PC_X3, PC_K0, PC_K1, PC_K2, PC_K3, PC_DK0, PC_DK1, PC_DK2, PC_DK3,
              PC_KT, PC_E, PC_I, PC_TAU, NPC };
 enum : int { TAG_EMPTY = 0, TAG_V = 1, TAG_R = 2 };            // what a ray owes next = the queue its slot goes back to
@@ -811,8 +811,8 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
     hipLaunchKernelGGL(torus_order_kernel, dim3(blocks_a), dim3(256), 0, stream, n, ranks, cursor + 1, order);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
 
-    // persistent grid: S5_MARCH_WAVES workgroups of 4 waves per CU (VGPR-bound occupancy; 46 KB of LDS each at 320 slots),
-    // never more workgroups than pools to fill
+    // persistent grid: the waves a CU holds (4 SIMDs x S5_MARCH_WAVES) in workgroups of WG_WAVES -- fast: one 12-wave workgroup
+    // per CU, 129 KB of LDS; never more workgroups than pools to fill
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     size_t blocks_b = (size_t)cus * S5_MARCH_WAVES * 4 / WG_WAVES;
