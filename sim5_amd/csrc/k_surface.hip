@@ -84,11 +84,27 @@ struct WalkState {
     int state, purpose, iteration, grow, sub_it, found, deep, pad;
 };
 
+// counters[]: how many rays the walk kernels of a round will find to do -- [0..3] rays with short ladders that walk in round r,
+// [4..7] rays with deep ladders.  Counted (one atomic per wave) by the kernel that puts a ray into that state (set-up: round
+// 0; slow steps of round r: round r + 1); a walk kernel reads ONE word and leaves at once when it is zero, instead of every
+// workgroup reading the state of its 256 rays to find that out (rounds 2-4 are empty for almost every job: six full-grid
+// launches with 64 KB of LDS each that swept the whole workspace).
+constexpr int SURF_ROUNDS = 4;
+enum : int { CNT_WALK = 0, CNT_DEEP = SURF_ROUNDS, CNT_SLOW = 2 * SURF_ROUNDS, N_SURF_COUNTERS = 3 * SURF_ROUNDS + 4 };
 struct SurfaceWork {                 // the job's workspace (device): one record of each per ray
     Geod* gd;
     GeodCache* cache;
     WalkState* ws;
+    unsigned* counters;
 };
+
+// count the lanes with `mine` into *counter: one atomic per wave
+S5_DEV void count_lanes(unsigned* __restrict__ counter, bool mine)
+{
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+    if (m && (__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) == 0u) && mine)
+        atomicAdd(counter, (unsigned)__builtin_popcountll(m));
+}
 
 S5_DEV double first_r0(const Geod& gd, int iteration, double alpha_beta, double cos_view)          // ref py :265
 {
@@ -249,6 +265,8 @@ void surface_setup_kernel(SurfaceParams p, SurfaceWork wk, const double* __restr
         gd.type = -1;
     }
     wk.gd[i] = gd; wk.cache[i] = cache; wk.ws[i] = w;
+    count_lanes(&wk.counters[CNT_WALK + 0], w.state == ST_FOLLOW && !w.deep);
+    count_lanes(&wk.counters[CNT_DEEP + 0], w.state == ST_FOLLOW && w.deep);
 }
 
 #ifndef S5_SURF_WAVES
@@ -261,8 +279,9 @@ void surface_setup_kernel(SurfaceParams p, SurfaceWork wk, const double* __restr
 // few that need the full ladders (64 KB of LDS per workgroup; launched beside the other on a second stream)
 template <int NST, bool DEEP>
 __global__ __launch_bounds__(SURF_BLOCK, DEEP ? 2 : (S5_FAST ? S5_SURF_WAVES_FAST_PLAIN : S5_SURF_WAVES))
-void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH)
+void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH, const int round)
 {
+    if (wk.counters[(DEEP ? CNT_DEEP : CNT_WALK) + round] == 0u) return;      // no ray of this kind walks in this round
     extern __shared__ double lds[];
     double* sLad = lds;                                              // [2 ladders][2 * NST][SURF_BLOCK]
     double* sR = lds + (size_t)2 * 2 * NST * SURF_BLOCK;
@@ -292,12 +311,14 @@ void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restri
     follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, trk.rp, alpha_beta, cos_view, sR, sH, p.n_table);
 #endif
     wk.ws[i] = w;
+    // (the rays this walk hands to the slow steps are NOT counted here: the walk sits at its register bound -- 168 for three waves
+    // per SIMD -- and a ballot at its end spilled four registers and cost 7 % of the job; the slow kernel still sweeps)
 }
 
 // the rare steps: equatorial crossing (ref py :317-320) and a new search for the starting radius after the ray
 // escaped (:325 -> :265-280), through the generic per-ray routines (same values as the tracked ones, s5_geod.hpp)
 __global__ __launch_bounds__(SURF_BLOCK)
-void surface_slow_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH)
+void surface_slow_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH, const int round)
 {
     extern __shared__ double lds[];
     double* sR = lds;
@@ -325,6 +346,10 @@ void surface_slow_kernel(SurfaceParams p, SurfaceWork wk, const double* __restri
         if (w.state == ST_GROW) w.state = ST_DONE;
     }
     wk.ws[i] = w;
+    if (round + 1 < SURF_ROUNDS) {
+        count_lanes(&wk.counters[CNT_WALK + round + 1], w.state == ST_FOLLOW && !w.deep);
+        count_lanes(&wk.counters[CNT_DEEP + round + 1], w.state == ST_FOLLOW && w.deep);
+    }
 }
 
 __global__ __launch_bounds__(SURF_BLOCK)
@@ -450,7 +475,7 @@ int s5_launch_disk_surface_strict(const s5abi::SurfaceParams& p, const double* t
     const size_t n = p.n;
     const size_t b_gd = (sizeof(Geod) * n + 255) & ~size_t(255), b_ca = (sizeof(GeodCache) * n + 255) & ~size_t(255);
     const size_t b_ws = (sizeof(WalkState) * n + 255) & ~size_t(255);
-    const size_t need = b_gd + b_ca + b_ws;
+    const size_t need = b_gd + b_ca + b_ws + 256;
     if (W.used && W.last != stream) { if ((e = hipStreamSynchronize(W.last)) != hipSuccess) return (int)e; }
     if (need > W.cap) {
         if (W.base) { if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e; (void)hipFree(W.base); W.base = nullptr; W.cap = 0; }
@@ -460,6 +485,9 @@ int s5_launch_disk_surface_strict(const s5abi::SurfaceParams& p, const double* t
     W.last = stream; W.used = true;
     SurfaceWork wk;
     wk.gd = (Geod*)W.base; wk.cache = (GeodCache*)(W.base + b_gd); wk.ws = (WalkState*)(W.base + b_gd + b_ca);
+    wk.counters = (unsigned*)(W.base + b_gd + b_ca + b_ws);
+    static_assert(N_SURF_COUNTERS * sizeof(unsigned) <= 256, "counter block");
+    if ((e = hipMemsetAsync(wk.counters, 0, 256, stream)) != hipSuccess) return (int)e;
 
     const unsigned blocks = (unsigned)((n + SURF_BLOCK - 1) / SURF_BLOCK);
     const size_t tab_bytes = 2 * sizeof(double) * (size_t)p.n_table;
@@ -477,16 +505,16 @@ int s5_launch_disk_surface_strict(const s5abi::SurfaceParams& p, const double* t
         W.attr_set = true;
     }
     hipLaunchKernelGGL(surface_setup_kernel, dim3(blocks), dim3(SURF_BLOCK), lds_lad, stream, p, wk, tabR, tabH, alpha, beta);
-    for (int round = 0; round < 4; ++round) {                       // a ray retries at most three times (ref py :258)
+    for (int round = 0; round < SURF_ROUNDS; ++round) {             // a ray retries at most three times (ref py :258)
         // fork: the few rays with deep ladders walk on the side stream (a handful of waves, latency bound) while the
         // rest walk here; join before the slow steps
         if ((e = hipEventRecord(W.fork, stream)) != hipSuccess) return (int)e;
         if ((e = hipStreamWaitEvent(W.side, W.fork, 0)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(walk_deep, dim3(blocks), dim3(SURF_BLOCK), lds_lad, W.side, p, wk, tabR, tabH);
+        hipLaunchKernelGGL(walk_deep, dim3(blocks), dim3(SURF_BLOCK), lds_lad, W.side, p, wk, tabR, tabH, round);
         if ((e = hipEventRecord(W.join, W.side)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(walk, dim3(blocks), dim3(SURF_BLOCK), lds_walk, stream, p, wk, tabR, tabH);
+        hipLaunchKernelGGL(walk, dim3(blocks), dim3(SURF_BLOCK), lds_walk, stream, p, wk, tabR, tabH, round);
         if ((e = hipStreamWaitEvent(stream, W.join, 0)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(surface_slow_kernel, dim3(blocks), dim3(SURF_BLOCK), tab_bytes, stream, p, wk, tabR, tabH);
+        hipLaunchKernelGGL(surface_slow_kernel, dim3(blocks), dim3(SURF_BLOCK), tab_bytes, stream, p, wk, tabR, tabH, round);
     }
     hipLaunchKernelGGL(surface_finish_kernel, dim3(blocks), dim3(SURF_BLOCK), tab_bytes, stream, p, wk, tabR, tabH, P, r, m, k, status);
     return (int)hipGetLastError();
