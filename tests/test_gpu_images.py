@@ -193,13 +193,15 @@ def test_random_image_shapes_and_parameters(capi):
       * a symmetric row range (the pairing kernel) gives the plain kernel's image bit for bit;
       * fast and strict variants: identical classes, r and g within 1e-7, flux within 1e-6 of max(F, 1e-9 F_peak);
       * strict variant and CPU oracle: identical classes, r within 1e-9.
-    Left out of the class comparisons, and counted: the central column of an odd-width image.  There alpha = 0 exactly, so
-    l = 0 and the radial quartic is degenerate: the LIVE reference changes its own class on 10 - 55 % of that column when its
-    spin or inclination moves by one unit in the last place, and on no other pixel (test_degenerate_sets_against_the_live_
-    reference, profiles/r04_degenerate_sets_vs_live_reference.json).  The central ROW of an odd height (beta = 0, which the
-    reference replaces by 1e-6) was left out as well until round 4; against the live reference both variants have the
-    reference's class on every pixel of it, so it is compared like any other row (values there: r within 1e-5 only -- the
-    inverse cn is evaluated at its square-root singularity -- so the VALUE comparisons below leave that row out)."""
+    Left out of the class comparisons, and counted: the central column of an odd-width image and the central row of an
+    odd-height one.  On the column alpha = 0 exactly, so l = 0 and the radial quartic is degenerate: the LIVE reference changes
+    its own class on 10 - 55 % of that column when its spin or inclination moves by one to three units in the last place, and
+    on no pixel off the two sets (test_degenerate_sets_against_the_live_reference, profiles/r04_degenerate_sets_vs_live_
+    reference.json).  On the row beta = 0 (the reference replaces it by 1e-6): the observer sits on the polar turning point and
+    the test |cos i| > sqrt(m2p) is decided by rounding.  At moderate inclinations both variants have the reference's class on
+    every pixel of that row (9 of the 10 jobs of that record); at 7.7 deg (the tenth job, found by the randomised campaign) six
+    pixels of 85 differ from it and the reference flips one of them under one ulp of its own inputs -- so the row stays out of
+    the class comparison too."""
     rng = np.random.default_rng(2026)
     col_px = col_diff = 0
     for case in range(40):
@@ -220,6 +222,8 @@ def test_random_image_shapes_and_parameters(capi):
         col = np.ones((ny, nx), bool)
         if nx % 2 == 1:
             col[:, nx // 2] = False
+        if ny % 2 == 1:
+            col[ny // 2, :] = False
         col_px += int((~col).sum()); col_diff += int((st["cls"] != sym["cls"])[~col].sum())
         assert np.array_equal(st["cls"][col], sym["cls"][col]), what
         val = col.copy()
@@ -240,7 +244,8 @@ def test_random_image_shapes_and_parameters(capi):
 
 
 DEGENERATE_JOBS = [(0.9, 60.0, 201, 128), (0.998, 70.0, 301, 200), (0.5, 30.0, 151, 100), (0.0, 45.0, 99, 64),
-                   (0.9, 60.0, 128, 201), (0.998, 70.0, 200, 301), (0.5, 30.0, 100, 151), (0.0, 45.0, 64, 99), (0.7, 80.0, 255, 255)]
+                   (0.9, 60.0, 128, 201), (0.998, 70.0, 200, 301), (0.5, 30.0, 100, 151), (0.0, 45.0, 64, 99), (0.7, 80.0, 255, 255),
+                   (0.2610441040764561, 7.6689822933994, 85, 253)]      # (found by tests/tools/fuzz_images.py 1500 5001, case 89)
 
 
 def degenerate_sets_report(capi):

@@ -40,9 +40,9 @@ for case in range(ncases):
     col = np.ones((ny, nx), bool)
     if nx % 2 == 1:
         col[:, nx // 2] = False
-    val = col.copy()                     # values: the central row (beta = 0 -> 1e-6, cn^-1 at its square-root singularity) only to 1e-5
     if ny % 2 == 1:
-        val[ny // 2, :] = False
+        col[ny // 2, :] = False          # beta = 0 (-> 1e-6): the observer sits on the polar turning point, |cos i| > sqrt(m2p) is noise
+    val = col
     note = ""
     note_in = ""
     if (st["cls"] != sym["cls"])[~col].any():
