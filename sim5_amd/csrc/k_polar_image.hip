@@ -32,10 +32,26 @@ S5_DEV void polarize_ray(const PRM& p, double alpha, double beta, const ThinRay&
     const double g2 = t.g * t.g;
     I = t.flux * (g2 * g2);
     // geodesic_momentum(gd, P, r, m = 0): sign of dm/dP from the polar phase, radial sign from P vs Rpc
+    double wp[2];
+#if S5_FAST
+    // The polar phase at an EQUATORIAL crossing needs no bookkeeping.  The reference counts the polar turning points passed
+    // by stepping T in units of Tpp until P <= T + Tpp (ref src/sim5kerr-geod.c:385-389); with P = mK ((2n+1) K +- cn^-1(u))
+    // for the crossing of order n, Tpp = 2 mK K and Tip = mK cn^-1(u) that is n + 1 steps for beta > 0 and n for beta < 0 --
+    // each test decided by a margin of mK K, no rounding can move it -- so sign(dm/dP) = -(-1)^n for either sign of beta.
+    // With it the chain needs NOTHING of the geodesic but r, the crossing's order and the radial direction: l and q are formed
+    // here from the pixel's coordinates (the expressions of ref :76-77, as trace_thin_disk_impl forms them), and the kernel no
+    // longer carries Tpp, Tip, P, l, q, a, beta of both rays of a pair through the trace (148 -> see k_polar_image.hip's bounds).
+    const double sdm = (t.cls == PX_HIT1) ? +1.0 : -1.0;
+    const double a_in_ = p.a;
+    const double t_a = fmax(1e-4, a_in_);
+    const double beta_e = (beta == 0.0) ? +1e-6 : beta;
+    const double t_l = -alpha * p.sin_i;
+    const double t_q = sq(beta_e) + sq(p.cos_i) * (sq(alpha) - sq(a_in_));
+#else
     double sdm = (t.beta >= 0.0) ? +1.0 : -1.0;
     double T = (sdm > 0.0) ? -(t.Tpp - t.Tip) : -(t.Tip);
     for (int it = 0; it < 4096 && (t.P > T + t.Tpp); ++it) { T += t.Tpp; sdm = -sdm; }
-    double wp[2];
+#endif
 #if S5_FAST
     // The chain photon_momentum -> kerr_metric -> tetrad_azimuthal -> bl2on -> on2bl -> normalise -> polarization_constant of
     // the strict branch below, WRITTEN OUT for its one use: an emitter in the equatorial plane (m = 0) on a Keplerian orbit.
@@ -48,18 +64,18 @@ S5_DEV void polarize_ray(const PRM& p, double alpha, double beta, const ThinRay&
     // imaginary, orbit not time-like).
     {
         const double r = t.r, r2 = r * r;
-        const double ak = t.a, am = p.a;                   // the geodesic's spin (clamped at 1e-4) and the job's, as below
+        const double ak = t_a, am = p.a;                   // the geodesic's spin (clamped at 1e-4) and the job's, as below
         // r^2 k^mu  (ref src/sim5kerr.c:1151-1213 at m = 0)
         const double Dk = r2 - 2. * r + ak * ak;
-        const double Tk = r2 + ak * ak - ak * t.l;
-        double Rk = Tk * Tk - Dk * (sq(t.l - ak) + t.q);
-        double Mk = t.q;
+        const double Tk = r2 + ak * ak - ak * t_l;
+        double Rk = Tk * Tk - Dk * (sq(t_l - ak) + t_q);
+        double Mk = t_q;
         if ((Mk < 0.0) && (-Mk < 1e-8)) Mk = 0.0;
         if ((Rk < 0.0) && (-Rk < 1e-8)) Rk = 0.0;
         const double iDk = mrcp(Dk);
         const double TD = Tk * iDk;
-        const double K0 = (r2 + ak * ak) * TD - ak * (ak - t.l);
-        const double K3 = ak * TD - (ak - t.l);
+        const double K0 = (r2 + ak * ak) * TD - ak * (ak - t_l);
+        const double K3 = ak * TD - (ak - t_l);
         const double K1 = (t.dP > 0.0) ? -msqrt(Rk) : msqrt(Rk);
         const double K2 = (sdm < 0.0) ? -msqrt(Mk) : msqrt(Mk);           // NaN for Mk < 0, as there
         // metric of the equatorial plane (ref :75-101 at m = 0)
@@ -154,11 +170,10 @@ void disk_image_polarized_kernel(ImageParams p)
 // symmetric row sets (k_disk_image.hip: disk_image_mirror_kernel): the pixel and its mirror image in beta share the geodesic;
 // the polarization chain runs for each of the two, as a loop of two passes over ONE inlined copy
 #ifndef S5_LB_POLAR_MIRROR
-#define S5_LB_POLAR_MIRROR 3                // ~150 VGPRs by itself with the addition-theorem r(P) (s5_thindisk.hpp): three waves per SIMD,
-                                            // NO SCRATCH.  Capped at 128 for a fourth wave it spilled 20-30 registers and measured 5 % faster
-                                            // (0.137 against 0.145 ms at C3) -- not taken: a register spill in the image kernel (same
-                                            // routine, same toolchain) gave wrong pixels and a memory fault; spills are
-                                            // refused in these kernels by tests/test_capi_boundary.py
+#define S5_LB_POLAR_MIRROR 4                // FOUR waves per SIMD since round 4: 120 VGPRs, no scratch -- the polarization chain takes
+                                            // nothing of the geodesic but r, the crossing's order and the radial direction (polarize_ray),
+                                            // so the trace no longer keeps Tpp, Tip, P, l, q, a, beta of both rays alive (round 3: 148
+                                            // VGPRs, three waves; capped at 128 it spilled 20-30 registers, and spills are refused here)
 #endif
 template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)
