@@ -226,6 +226,7 @@ double build_K_table(std::vector<double>& tab)
 
 // universal K(m) table, one per device (never freed: 8 KB)
 static const double* g_ktab[64];
+static const double* g_sctab[64];
 
 int attach_K_table(ImageParams& p)
 {
@@ -244,6 +245,18 @@ int attach_K_table(ImageParams& p)
         g_ktab[dev] = ptr;
     }
     p.ktab = g_ktab[dev];
+    // sin / cos nodes of msincos_tab (s5_trig.hpp), one block per device like the K table: SC_N nodes per turn, long double
+    if (!g_sctab[dev]) {
+        std::vector<double> tab(2 * 256);
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (int i = 0; i < 256; i++) { tab[2 * i] = (double)sinl(two_pi * i / 256); tab[2 * i + 1] = (double)cosl(two_pi * i / 256); }
+        double* ptr = nullptr;
+        hipError_t e = hipMalloc((void**)&ptr, tab.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(ptr, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (ptr) (void)hipFree(ptr); set_error("sincos table", e); return SIM5GPU_E_HIP; }
+        g_sctab[dev] = ptr;
+    }
+    p.sctab = g_sctab[dev];
     return SIM5GPU_OK;
 }
 

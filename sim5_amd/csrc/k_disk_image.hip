@@ -236,7 +236,7 @@ int s5_launch_disk_image_jobs_fast(const s5abi::ImageParams* jobs, int n, hipStr
         f.nx = p.nx; f.ny = p.ny; f.y0 = p.y0; f.y1 = p.y1; f.nrows = p.nrows; f.stripe_rows = p.stripe_rows; f.stripe_step = p.stripe_step;
         f.mirror = p.mirror; f.nrows_top = p.nrows_top; f.max_order = p.max_order; f.inplace = p.inplace; f.direct = p.direct;
         f.a = p.a; f.incl = p.incl; f.sin_i = p.sin_i; f.cos_i = p.cos_i; f.rmax = p.rmax; f.rms = p.rms;
-        f.inv_nx = p.inv_nx; f.inv_ny = p.inv_ny; f.ny_over_nx = p.ny_over_nx; f.inv_2a2 = p.inv_2a2; f.ktab = p.ktab;
+        f.inv_nx = p.inv_nx; f.inv_ny = p.inv_ny; f.ny_over_nx = p.ny_over_nx; f.inv_2a2 = p.inv_2a2; f.ktab = p.ktab; f.sctab = p.sctab;
         f.disk.rms = p.disk.rms; f.disk.x0 = p.disk.x0; f.disk.scale = p.disk.scale; f.disk.ft_wmin = p.disk.ft_wmin;
         f.disk.ft_inv_dw = p.disk.ft_inv_dw; f.disk.ftab = p.disk.ftab; f.disk.cold = p.disk.cold;
         f.img_f = p.img_f; f.img_g = p.img_g;

@@ -56,6 +56,7 @@ struct ImageParams {
     double inv_2a2;                    // 1 / (2 max(a, 1e-4)^2)              (fast variant)
     double pol_degree;
     const double* ktab;                // K(m) table of the fast variant (DEVICE memory, capi_core.hip) or NULL
+    const double* sctab;               // sin / cos table of the fast variant (s5_trig.hpp: msincos_tab; DEVICE memory) or NULL
     DiskConsts disk;
     // outputs (tile-local, row-major)
     float*   img_f;
@@ -74,8 +75,8 @@ struct ImageParams {
 };
 
 // ---- job list of the fast pairing kernel (k_disk_image.hip: disk_image_jobs_kernel) ----------------------------------------
-// What that kernel reads of a job, 208 bytes, same member names as ImageParams so that the ray routines take either.  Up to
-// JOBS_MAX of them travel BY VALUE in the kernel-argument segment (3.4 KB of its 4 KB): no device allocation, no copy, and the
+// What that kernel reads of a job, 216 bytes, same member names as ImageParams so that the ray routines take either.  Up to
+// JOBS_MAX of them travel BY VALUE in the kernel-argument segment (3.5 KB of its 4 KB): no device allocation, no copy, and the
 // kernel reads them through the constant address space -- scalar loads where a value is used, instead of ~80 scalar registers
 // of argument block held (and spilled) from the first instruction.
 struct FastDisk {
@@ -90,6 +91,7 @@ struct FastJob {
     double rmax, rms;
     double inv_nx, inv_ny, ny_over_nx, inv_2a2;
     const double* ktab;
+    const double* sctab;
     FastDisk disk;
     float* img_f;
     float* img_g;
@@ -100,7 +102,7 @@ struct JobList {
     int tile_end[JOBS_MAX];           // prefix sums of the jobs' workgroup tiles: job j owns blocks [tile_end[j-1], tile_end[j])
     FastJob job[JOBS_MAX];
 };
-static_assert(sizeof(FastJob) == 208 && sizeof(JobList) <= 4096, "the job list must fit the kernel-argument segment");
+static_assert(sizeof(FastJob) == 216 && sizeof(JobList) <= 4096, "the job list must fit the kernel-argument segment");
 
 // image row of packed (local) output row lr: the rows named by y0, y1 and the striping first, then -- with mirror -- their
 // mirror images ny - 1 - y, so that the packed rows are in increasing image-row order

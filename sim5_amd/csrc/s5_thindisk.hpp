@@ -826,7 +826,13 @@ S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const do
 #else
                     {
                         double s0, c0, C, ga, N, D;
+#ifdef S5_NO_SINCOS_TABLE
                         msincos(wc, s0, c0);                               // RR: 0 < w c < pi, RC: < 2 pi
+#else
+                        // (from the node table where the launcher attached one -- every launcher of the fast variant does, so all
+                        // its image kernels form the same numbers: s5_trig.hpp msincos_tab; a wave-uniform test)
+                        if (p.sctab) msincos_tab(p.sctab, wc, s0, c0); else msincos(wc, s0, c0);
+#endif
                         ladder_descend_fractions(lad, lst, s0, c0, C, ga, N, D);
                         // numerators of sn(w) and cn(w) over rho (the signs as ladder_descend assigns them)
                         const double S = (s0 >= 0.0) ? fabs(ga) : -fabs(ga);

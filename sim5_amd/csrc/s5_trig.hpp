@@ -68,6 +68,33 @@ S5_DEV void msincos(double x, double& s, double& c)
 S5_DEV double mcos(double x) { double s, c; msincos(x, s, c); return c; }
 S5_DEV double msin(double x) { double s, c; msincos(x, s, c); return s; }
 
+// sin and cos from a table of SC_N nodes per turn (host-made in long double, capi_core.hip: tab[2 i] = sin(2 pi i / SC_N),
+// tab[2 i + 1] = cos): the angle is split into the nearest node and a remainder |d| <= pi / SC_N = 0.0123, for which three
+// series terms each are exact to rounding (next terms: d^8 / 9! = 1e-21, d^8 / 8! = 1e-20 relative), and the two are joined
+// by the angle-addition formulas -- ~21 instructions and one 16-byte load where the minimax kernels with their Cody-Waite
+// reduction and quadrant selects take ~40.  Any finite |x| < 2^20 (the node index wraps; the remainder is formed with the
+// SIGNED node number against a two-part pi / 128 whose head has 13 trailing zero bits, so n * head is exact).  The image
+// kernels' fast variant uses it for the one sincos a crossing needs (s5_thindisk.hpp); accuracy 1-2 ulp.
+constexpr int SC_N = 256;
+S5_DEV void msincos_tab(const double* __restrict__ tab, double x, double& s, double& c)
+{
+    const double inv_step = 40.74366543152521;               // SC_N / (2 pi)
+    const double step_hi = 0.02454369260615863, step_lo = 1.1630542938260349e-14;
+    const double fn = __builtin_rint(x * inv_step);
+    const int i = ((int)fn) & (SC_N - 1);
+    double d = __builtin_fma(-fn, step_hi, x);
+    d = __builtin_fma(-fn, step_lo, d);
+    const double z = d * d;
+    const double ps = __builtin_fma(z, __builtin_fma(z, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0);      // (sin d / d - 1) / z
+    const double pc = __builtin_fma(z, __builtin_fma(z, -1.0 / 720.0, 1.0 / 24.0), -0.5);             // (cos d - 1) / z
+    const double sd = __builtin_fma(d * z, ps, d);
+    const double cm = z * pc;                                                                            // cos d - 1
+    const double S = tab[2 * i], C = tab[2 * i + 1];          // (one 16-byte load)
+    // sin(a + d) = S + (S (cos d - 1) + C sin d),  cos(a + d) = C + (C (cos d - 1) - S sin d)
+    s = S + __builtin_fma(S, cm, C * sd);
+    c = C + __builtin_fma(C, cm, -(S * sd));
+}
+
 // The same for an angle that is almost always small (the change of the polar angle over one integrator step): for
 // |x| <= pi/4 the reduction above gives n = 0 and a zero tail, so the two kernels are evaluated on x directly -- the values
 // msincos returns, without the reduction, the tail terms and the quadrant selects (18 instructions instead of ~40); the
