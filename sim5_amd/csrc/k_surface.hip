@@ -31,6 +31,9 @@
 // A ray retries at most three times (ref py :258), so four walk/slow rounds finish every ray; later rounds find almost
 // nothing to do and return at once.
 #include <mutex>
+// (this file keeps the explicit wave votes around skippable work, s5_math.hpp S5_ANY: as plain divergent branches the walk
+// kernel of the fast variant needs 170 registers against its cap of 168 for three waves per SIMD, and spills)
+#define S5_WAVE_VOTES 1
 #include "s5_disk.hpp"
 #include "kernels.hpp"
 

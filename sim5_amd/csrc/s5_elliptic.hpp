@@ -54,7 +54,7 @@ S5_DEV double carlson_rf_impl(double x, double y, double z, double sqrt_x = 0.0)
     double A = A0, pw = 1.0;                        // pw = 2^n
     bool live = dev >= tol * A;
     if (ROOT_X) {
-        if (wave_any(live)) {
+        if (S5_ANY(live)) {
             if (live) {
                 const double sy = sqrt_pos(y);
                 const double lam = sqrt_x * (sy + 1.0) + sy;
@@ -68,8 +68,12 @@ S5_DEV double carlson_rf_impl(double x, double y, double z, double sqrt_x = 0.0)
         }
     }
     for (int pass = 0; pass < 32; ++pass) {
+        // the wave's vote on a flag compared HERE costs nothing beyond the comparison (s5_math.hpp S5_ANY); a lane that
+        // stopped keeps its A, so asking again gives its answer again.  (Without a vote, as a plain divergent loop, the
+        // kernels need 8 more vector registers -- the polarized pair kernel then spills -- for the same time.)
+        live = dev >= tol * A;
         if (!wave_any(live)) break;
-        if (live) {                              // a lane's result depends on its own arguments only
+        if (live) {
             const double sx = sqrt_pos(x), sy = sqrt_pos(y), sz = sqrt_pos(z);
             const double lam = sx * (sy + sz) + sy * sz;
             x += lam;
@@ -77,7 +81,6 @@ S5_DEV double carlson_rf_impl(double x, double y, double z, double sqrt_x = 0.0)
             z += lam;
             A += lam;
             pw += pw;
-            live = dev >= tol * A;
         }
     }
     // 1/(4^n A_n) and its square root from one reciprocal square root
@@ -384,7 +387,7 @@ S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
             if (fabs(a - emc) <= conv * a) { climbing = false; top = i; }
             else { emc *= a; a = c; }
         }
-        if (!wave_any(climbing)) break;        // rungs above are never read (i <= top below)
+        if (!S5_ANY(climbing)) break;          // rungs above are never read (i <= top below)
     }
     st.c = c; st.top = top; st.incomplete = climbing;
 }
@@ -409,7 +412,7 @@ S5_DEV void ladder_descend_fractions(const Ladder& lad, const LadderState& st, c
     C = c * c0; ga = s0; N = 1.0; D = 1.0;
 #pragma unroll
     for (int i = NR - 1; i >= 0; --i) {
-        if (wave_any(i <= top)) {          // rungs no lane of the wave reached are skipped
+        if (S5_ANY(i <= top)) {             // rungs no lane of the wave reached are skipped (s5_math.hpp S5_ANY)
             if (i <= top) {
                 const double b = lad.get_a(i), g = lad.get_g(i);
                 const double t1 = C * A, t2 = ga * al;

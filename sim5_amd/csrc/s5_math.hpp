@@ -16,6 +16,26 @@
 namespace S5NS {
 
 S5_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// "if (S5_ANY(c)) { if (c) ... }" and "if (!S5_ANY(live)) break;": where a wave may skip work none of its lanes needs.  The
+// plain divergent branch does that already -- s_and_saveexec sets the execution mask and s_cbranch_execz skips the block --
+// on scalar instructions alone, while the vote of a flag that was not compared in the same basic block goes through a
+// vector register and back (v_cndmask 0/1, v_cmp_ne: two vector instructions each; 180 of them in the pair kernel of
+// rounds 1-3).  wave_any stays where a wave-uniform DECISION is needed (which instantiation a wave takes).
+#ifdef S5_WAVE_VOTES                 // A/B builds: the explicit votes of rounds 1-3
+#define S5_ANY(c) wave_any(c)
+#else
+#define S5_ANY(c) (c)
+#endif
+#ifdef S5_VOTE_ORDER
+#define S5_ANY_ORDER(c) wave_any(c)
+#else
+#define S5_ANY_ORDER(c) S5_ANY(c)
+#endif
+#ifdef S5_VOTE_MISC
+#define S5_ANY_MISC(c) wave_any(c)
+#else
+#define S5_ANY_MISC(c) S5_ANY(c)
+#endif
 
 S5_DEV double sq(double x) { return x * x; }
 S5_DEV double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), fabs(b)), fabs(c)); }

@@ -89,14 +89,14 @@ S5_DEV void thin_disk_owed_flux(const PRM& p, ThinRay& out, ThinRay& out2)
 #if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
     const bool f0 = (out.flux < 0.0), f1 = PAIR && (out2.flux < 0.0);
     S5_MARK("owed flux begin");
-    if (wave_any(f0 || f1)) {
+    if (S5_ANY(f0 || f1)) {
         // constants from the disk model's device block, not from the kernel arguments: referenced here they would sit in
         // ~30 SGPRs of every wave from the first instruction (the launchers always attach the block: capi_core.hip)
         const double* cold = param_reload(p).disk.cold;
 #pragma unroll 1
         for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
             const bool f = member ? f1 : f0;
-            if (!wave_any(f)) continue;
+            if (!S5_ANY(f)) continue;
             const double r = member ? out2.r : out.r;
             double F = 0.0;
             if (f) { double x, rx; sqrt_rsqrt_pos(r, x, rx); F = cold ? disk_flux_closed_form_mem(cold, r, x) : NAN; }
@@ -227,7 +227,7 @@ S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, Thi
     // the routine's end with the roots kept alive for it: 6 %).  It redoes both rays of the lane's pair; the wave waits.
     const bool c0 = (out.cls == PX_COLD_MARK), c1 = PAIR && (out2.cls == PX_COLD_MARK);
     S5_MARK("cold retrace begin");
-    if (wave_any(c0 || c1)) {
+    if (S5_ANY(c0 || c1)) {
         if (c0 || c1) {
             ThinRay d0, d1;
             if constexpr (P_FIRST) {
@@ -616,11 +616,18 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
 enum : int { CROSS_FORMULA = 0, CROSS_BEYOND = 1, CROSS_NONE = 2 };
 
 template <bool WANT_STATE, int KNOWN, bool PAIR, class PRM>
-S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
+S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                              const double l, const double q, const double alpha, const double beta, int err, const int type_in,
                              const double ra, const double rb, const double rc_, const double rd_)
 {
     S5_FPC_FINISH
+#ifdef S5_NO_FINISH_RELOAD
+    const auto& p = p_in;
+#else
+    // constant-address-space parameters are loaded from HERE: each class instantiation issues its own scalar loads of the few
+    // it reads instead of holding them -- spilled to vector lanes -- from the kernel's first instruction
+    const auto& p = param_reload(p_in);
+#endif
     using namespace s5abi;
     constexpr double S5_PI = 3.14159265358979323846;
     const int type = (KNOWN >= 0) ? KNOWN : type_in;
@@ -739,12 +746,12 @@ S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const do
             K = acc;
         }
 #ifndef S5_KO_KAGM
-        if (wave_any(!tab)) {
+        if (S5_ANY_MISC(!tab)) {
             if (!tab) K = ell_K(mmT);
         }
 #endif
     }
-    if (wave_any(ok && !plain2)) {
+    if (S5_ANY_MISC(ok && !plain2)) {
         if (ok && !plain2) icn_i = inv_cn_cold(u_i, mmT);
     }
     if (WANT_STATE) {
@@ -763,7 +770,7 @@ S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const do
 
     // ---------------- equatorial crossings and r(P) (ref :846-885, :291-357) ----------------
     double icn_u = icn_i;
-    if (wave_any(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
+    if (S5_ANY_MISC(uu != u_i && !u_bad && q_pos)) {              // clamped by the slack rule: re-evaluate
         if (uu != u_i && !u_bad && q_pos) icn_u = inv_cn_cold(uu, mmT);
     }
     // mK distributed over the sum in P (two products formed once per ray, not three factors kept per crossing)
@@ -771,7 +778,7 @@ S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const do
     // constants of the addition theorem: sn, cn, dn of F0 as products.  Few, and the cheap ones are re-formed where they
     // are used: every double kept across the crossing loop is two of the kernel's 128 registers.
     double add_s = 0.0, add_d = 0.0;             // RC: sn(F0), dn(F0);  RR: add_s = cn(F0) dn(F0)
-    if (wave_any(by_add)) {
+    if (S5_ANY_MISC(by_add)) {
         if (type == T_RC) {
             const double s2 = 1. - zR * zR;                     // sn^2(F0)
             add_s = sqrt_pos(s2); add_d = sqrt_pos(1. - mR * s2);
@@ -804,7 +811,7 @@ S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const do
         bool done = cold[member];
 #pragma unroll 1
         for (int order = 0; order < p.max_order; ++order) {
-            if (!wave_any(!done)) break;
+            if (!S5_ANY_ORDER(!done)) break;
             if (!done) {
                 double P;
                 if (!may_cross) P = NAN;

@@ -255,12 +255,19 @@ def test_no_register_spills_in_the_image_kernels():
     for k, v in image.items():
         assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
     # the production kernel (every job without full-precision planes: bench.py, the sharded path): its parameters are read from
-    # the argument segment where they are used, so its hot path keeps no scalar register in a vector lane; what the compiler
-    # still spills (<= 12 SGPRs) sits in the cold re-trace a few rays per million take (tests/tools/isa_spill_sites.py shows where)
+    # the argument segment where they are used.  What a spilled scalar register COSTS is the lane moves (v_writelane /
+    # v_readlane) on the executed path; the metadata's sgpr_spill_count counts reserved slots.  Of the ~70 lane moves of the
+    # kernel all but a handful sit in the cold re-trace a few rays per million take: the hot path -- three class instantiations
+    # -- holds at most 12 (tests/tools/isa_spill_sites.py compiles the kernel with region marks and says where they are)
+    from sim5_amd.codeobj import lane_moves
     jobs = {k: v for k, v in image.items() if "disk_image_jobs_kernel" in k}
     assert len(jobs) == 2, sorted(image)
-    for k, v in jobs.items():
-        assert v["sgpr_spill_count"] <= 12, (k, v)
+    moves = lane_moves(capi.LIB_PATH, "disk_image_jobs_kernel")
+    assert len(moves) == 2 and all(w + r <= 90 for (w, r) in moves.values()), moves
+    import os, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "isa_spill_sites.py")
+    res = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
     march = [v for k, v in meta.items() if "torus_pool_kernel" in k]
     assert len(march) == 2 and all(v["vgpr_spill_count"] == 0 for v in march), march          # both variants
     # nothing else of the library spills a register either, but for the set-up kernel of the surface search in its strict
