@@ -342,6 +342,7 @@ struct LadderRegs {
 struct LadderLds {
     double* base;                               // this lane's column of the workgroup's ladder block
     S5_DEV void put(int i, double av, double gv) { base[(2 * i) * 256] = av; base[(2 * i + 1) * 256] = gv; }
+    S5_DEV void put_a(int i, double av) { base[(2 * i) * 256] = av; }         // (i = LADDER_RUNGS: the block's extra row)
     S5_DEV double get_a(int i) const { return base[(2 * i) * 256]; }
     S5_DEV double get_g(int i) const { return base[(2 * i + 1) * 256]; }
 };
@@ -359,7 +360,9 @@ struct LadderState {
     bool incomplete; // the AGM had not converged when the NR rungs were used up (a caller with a short ladder checks)
 };
 
-template <class Ladder, int NR = LADDER_RUNGS>
+// STORE_NEXT: the arithmetic mean ABOVE the last rung, a_{top+1} = (a_top + g_top) / 2 = st.c, is stored as well (slot
+// top + 1 of the a column; the storage must have NR + 1 of them): ladder_descend_squares reads a_{i+1} at every rung
+template <class Ladder, int NR = LADDER_RUNGS, bool STORE_NEXT = false>
 S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
 {
     S5_FPC_LADDER
@@ -384,7 +387,7 @@ S5_DEV void ladder_climb(Ladder& lad, double m, LadderState& st)
             emc = sqrt_pos(emc);                // 0 < 1 - m <= 1, and products of positive means after that
             lad.put(i, a, emc);
             c = 0.5 * (a + emc);
-            if (fabs(a - emc) <= conv * a) { climbing = false; top = i; }
+            if (fabs(a - emc) <= conv * a) { climbing = false; top = i; if constexpr (STORE_NEXT) lad.put_a(i + 1, c); }
             else { emc *= a; a = c; }
         }
         if (!S5_ANY(climbing)) break;          // rungs above are never read (i <= top below)
@@ -427,6 +430,44 @@ S5_DEV void ladder_descend_fractions(const Ladder& lad, const LadderState& st, c
                 A = C;
                 al = ga * b;
                 N = Nn; D = Dn;
+            }
+        }
+    }
+}
+
+
+// The same descent with the carried pair (A, al) eliminated.  After a rung A = C and al = ga b_i, so the next rung's products
+// are t1 = C^2 and t2 = ga^2 a_i -- and the FIRST rung a lane takes fits the same form with a_{top+1} = c, the mean the climb
+// ended on: t1 / t2 = (c c0)^2 / (s0^2 c) = c cot^2, the reference's a <- c a.  Every rung then reads a_{i+1} beside its own
+// (a_i, g_i) (ladder_climb<..., STORE_NEXT = true> stored the extra one) and updates C, ga, N, D in place: seven
+// multiplications, no register copies at the join of the predicated block (the form above: seven and three copies of a
+// double per rung).  The pair (C, ga) is rescaled by a power of two at rungs 4 and 0 only: with (e_C, e_N) the binary
+// exponents of the pairs (C, ga) and (N, D), a rung maps (e_C, e_N) to (e_C + e_N, 2 e_C) -- they roughly double -- and the
+// start is (<= 4, 0) (C^2 + ga^2 lies between c^2 and 1, and the last mean c = pi / 2K(m) >= 0.08 for a double-precision
+// modulus), so four rungs reach 2^-44 and the squares of the next four 2^-400 at the worst.
+template <class Ladder, int NR = LADDER_RUNGS>
+S5_DEV void ladder_descend_squares(const Ladder& lad, const LadderState& st, const double s0, const double c0,
+                                   double& C, double& ga, double& N, double& D)      // (s0, c0) = sincos(u st.c)
+{
+    S5_FPC_LADDER
+    static_assert(NR <= 8, "rescaling points are laid out for at most 8 rungs");
+    const int top = st.top;
+    C = st.c * c0; ga = s0; N = 1.0; D = 1.0;
+#pragma unroll
+    for (int i = NR - 1; i >= 0; --i) {
+        if (S5_ANY(i <= top)) {             // rungs no lane of the wave reached are skipped (s5_math.hpp S5_ANY)
+            if (i <= top) {
+                const double an = lad.get_a(i + 1), b = lad.get_a(i), g = lad.get_g(i);
+                const double t1 = C * C, t2 = (ga * ga) * an;
+                C = N * C;
+                ga = D * ga;
+                N = g * t2 + t1;
+                D = b * t2 + t1;
+                if (i == 4 || i == 0) {
+                    const int e = -__builtin_amdgcn_frexp_exp(fabs(C) + fabs(ga));
+                    C = __builtin_amdgcn_ldexp(C, e);
+                    ga = __builtin_amdgcn_ldexp(ga, e);
+                }
             }
         }
     }

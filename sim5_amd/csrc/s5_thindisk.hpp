@@ -263,7 +263,7 @@ S5_DEV void trace_thin_disk(const PRM& p, double alpha, double beta_in, ThinRay&
 // this lane's column of the workgroup's ladder block (256-thread one-dimensional workgroups: all callers)
 S5_DEV double* thin_disk_ladder_column()
 {
-    __shared__ double s_ladder[2 * LADDER_RUNGS * 256];
+    __shared__ double s_ladder[(2 * LADDER_RUNGS + 1) * 256];      // (the extra row: a_{top+1} of ladder_descend_squares)
     return &s_ladder[threadIdx.x];
 }
 
@@ -710,7 +710,7 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
     LadderLds lad{thin_disk_ladder_column()};
     LadderState lst{};
 #ifndef S5_KO_RAD
-    if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
+    if (wave_any(ladder_class && may_cross)) ladder_climb<LadderLds, LADDER_RUNGS, true>(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
 #endif
     const bool by_add = ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
 
@@ -840,7 +840,11 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
                         // its image kernels form the same numbers: s5_trig.hpp msincos_tab; a wave-uniform test)
                         if (p.sctab) msincos_tab(p.sctab, wc, s0, c0); else msincos(wc, s0, c0);
 #endif
+#ifdef S5_DESCEND_FRACTIONS          // A/B builds: the descent of rounds 2-3
                         ladder_descend_fractions(lad, lst, s0, c0, C, ga, N, D);
+#else
+                        ladder_descend_squares(lad, lst, s0, c0, C, ga, N, D);
+#endif
                         // numerators of sn(w) and cn(w) over rho (the signs as ladder_descend assigns them)
                         const double S = (s0 >= 0.0) ? fabs(ga) : -fabs(ga);
                         const double Cc = ((ga >= 0.0) == (s0 >= 0.0)) ? C : -C;
