@@ -185,7 +185,17 @@ void disk_image_jobs_kernel(JobList list_arg)
     if (ix >= nx || lr >= half) return;
     const int lr2 = nrows - 1 - lr;
     ThinRay t1, t2;
-    const int iy = image_row_top(p, lr);
+    // image row of packed row lr (kernels.hpp image_row_top).  A striped job (a rank's share of a split image) divides by
+    // the stripe height: per lane that is ~25 vector instructions of integer division; a tile's 16 rows lie in ONE stripe
+    // when the stripe height is a multiple of 16 (the dealt stripes are 64 rows), so the tile's first row is divided once,
+    // on a wave-uniform value, and the lanes add their row
+    int iy;
+    const int sr = p.stripe_rows;
+    if (sr > 0 && (sr % TILE_H) == 0) {
+        const int lr0 = (tiles_y - 1 - by) * TILE_H;
+        const int q = __builtin_amdgcn_readfirstlane(lr0 / sr);
+        iy = p.y0 + q * p.stripe_step + (lr0 - q * sr) + lane_y;
+    } else iy = image_row_top(p, lr);
     trace_thin_disk_impl<false, true, false, false>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t1, t2);
     const RayResult r1 = ray_result(t1), r2 = ray_result(t2);
     const S5_AS4 FastJob& po = param_reload(p);                          // the output side: loaded here, not carried through the trace

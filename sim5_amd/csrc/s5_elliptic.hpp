@@ -63,7 +63,6 @@ S5_DEV double carlson_rf_impl(double x, double y, double z, double sqrt_x = 0.0)
                 z += lam;
                 A += lam;
                 pw += pw;
-                live = dev >= tol * A;
             }
         }
     }
