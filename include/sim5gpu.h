@@ -142,6 +142,10 @@ typedef struct sim5gpu_geodesic_chain {
 } sim5gpu_geodesic_chain;
 int sim5gpu_geodesic_init_inf_chain(size_t n, const double *incl, const double *a, const double *alpha, const double *beta,
                                     sim5gpu_geodesic *g, int *error, int *ok, sim5gpu_geodesic_chain *chain);
+/* the same record in the library's FAST arithmetic (the whole-image kernels' default: sim5_amd/csrc/k_chain.hip): agrees with
+ * the entry point above to ~1e-12 relative, in a third of its latency -- which is what a caller of the scalar API waits for */
+int sim5gpu_geodesic_init_inf_chain_fast(size_t n, const double *incl, const double *a, const double *alpha, const double *beta,
+                                         sim5gpu_geodesic *g, int *error, int *ok, sim5gpu_geodesic_chain *chain);
 
 /* geodesic_init_src (ref src/sim5kerr-geod.c:106-173); k is n x 4 */
 int sim5gpu_geodesic_init_src(size_t n, const double *a, const double *r, const double *m,

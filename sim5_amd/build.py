@@ -24,7 +24,8 @@ SOURCES = [("capi_core.hip", "capi_core.o", "strict"), ("capi_batch.hip", "capi_
            ("k_disk_image.hip", "k_disk_image_strict.o", "strict"), ("k_disk_image.hip", "k_disk_image_fast.o", "fast"),
            ("k_polar_image.hip", "k_polar_image_strict.o", "strict"), ("k_polar_image.hip", "k_polar_image_fast.o", "fast"),
            ("k_spectrum.hip", "k_spectrum_strict.o", "strict"), ("k_spectrum.hip", "k_spectrum_fast.o", "fast"),
-           ("k_surface.hip", "k_surface_strict.o", "strict"), ("k_surface.hip", "k_surface_fast.o", "fast")]
+           ("k_surface.hip", "k_surface_strict.o", "strict"), ("k_surface.hip", "k_surface_fast.o", "fast"),
+           ("k_chain.hip", "k_chain_fast.o", "fast")]
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]

@@ -228,6 +228,26 @@ def geodesic_init_inf(incl, a, alpha, beta):
     return g, err, ok
 
 
+CHAIN_DTYPE = np.dtype([("P", "f8", 2), ("r", "f8", 2), ("g", "f8", 2), ("flux", "f8", 2), ("a", "f8"), ("l", "f8"),
+                        ("have_r", "i4", 2), ("valid", "i4"), ("flux_valid", "i4")])
+
+
+def geodesic_init_inf_chain(incl, a, alpha, beta, fast=False):
+    """geodesic_init_inf and the example-04 chain of every ray in one launch (sim5gpu_geodesic_init_inf_chain; fast=True:
+    the record in the library's fast arithmetic, sim5gpu_geodesic_init_inf_chain_fast).  Returns (geodesics, err, ok, chain)."""
+    alpha = _f64(alpha).ravel()
+    n = alpha.size
+    incl, a, beta = _f64(incl, n), _f64(a, n), _f64(beta, n)
+    g = np.zeros(n, dtype=GEODESIC_DTYPE)
+    err = np.zeros(n, dtype=np.int32)
+    ok = np.zeros(n, dtype=np.int32)
+    ch = np.zeros(n, dtype=CHAIN_DTYPE)
+    assert CHAIN_DTYPE.itemsize == 96
+    fn = _lib.sim5gpu_geodesic_init_inf_chain_fast if fast else _lib.sim5gpu_geodesic_init_inf_chain
+    _check(fn(SZ(n), _p(incl), _p(a), _p(alpha), _p(beta), _p(g), _p(err), _p(ok), _p(ch)), "sim5gpu_geodesic_init_inf_chain")
+    return g, err, ok, ch
+
+
 def geodesic_init_src(a, r, m, k, ppc):
     k = _f64(k).reshape(-1, 4)
     n = k.shape[0]

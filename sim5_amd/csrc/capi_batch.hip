@@ -13,29 +13,9 @@
 
 namespace s5 {
 
+// (the batch runner -- one lane per element, small batches announcing their own end -- is run_batch of capi_util.hpp)
 template <typename F>
-__global__ __launch_bounds__(256) void map_rays(size_t n, F body)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) body(i);
-}
-
-template <typename F>
-static int run_map(size_t n, F body, const char* what)
-{
-    if (n == 0) return SIM5GPU_OK;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(map_rays<F>, dim3(blocks), dim3(256), 0, 0, n, body);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) {
-        // a handful of rays (the n = 1 calls of the SIM5 scalar API): poll for the end of the launch instead of the blocking
-        // wait, whose wake-up costs more than the kernel (measured through tests/tools/shim_rate.sh)
-        if (n <= 64) { while ((e = hipStreamQuery(nullptr)) == hipErrorNotReady) { } }
-        else e = hipDeviceSynchronize();
-    }
-    if (e != hipSuccess) { set_error(what, e); return SIM5GPU_E_HIP; }
-    return SIM5GPU_OK;
-}
+static int run_map(size_t n, F body, const char* what) { return run_batch(n, body, what); }
 
 static int arg_error(const char* fn)
 {
@@ -190,6 +170,33 @@ int sim5gpu_geodesic_init_inf_chain(size_t n, const double* incl, const double* 
         // lanes of a ray sit in one wave (j even/odd), which executes the read before the write in program order
         if (k == 0) pg[i] = gd;
     });
+    S5_HIP(dg.to_host((Geod*)g));
+    if (error) S5_HIP(derr.to_host(error));
+    if (ok) S5_HIP(dok.to_host(ok));
+    S5_HIP(dch.to_host(chain));
+    return SIM5GPU_OK;
+}
+
+/* The same record in the arithmetic of the FAST variant (k_chain.hip): what a caller of the scalar API waits for is the latency
+ * of one ray's dependent FP64 chain, and the fast routines make it three to four times shorter.  Values agree with the strict
+ * entry point's to ~1e-12 relative; the host shim uses this one unless SIM5_SHIM_STRICT is set. */
+int sim5gpu_geodesic_init_inf_chain_fast(size_t n, const double* incl, const double* a, const double* alpha, const double* beta,
+                                         sim5gpu_geodesic* g, int* error, int* ok, sim5gpu_geodesic_chain* chain)
+{
+    S5_NEED("geodesic_init_inf_chain_fast", incl && a && alpha && beta && g && chain);
+    if (n == 0) return SIM5GPU_OK;
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> di(incl, n), da(a, n), dal(alpha, n), dbe(beta, n);
+    DevBuf<Geod> dg((const Geod*)g, n);            // keep caller's bytes in fields we never write
+    DevBuf<int> derr(n), dok(n);
+    DevBuf<sim5gpu_geodesic_chain> dch(n);
+    S5_BUFS_OK("geodesic_init_inf_chain_fast", di.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok() && dch.ok());
+    int* done = (2 * n <= 256) ? take_done_word() : nullptr;
+    hipError_t e = (hipError_t)s5_launch_geodesic_chain_fast(n, di.ptr, da.ptr, dal.ptr, dbe.ptr, dg.ptr, derr.ptr, dok.ptr, dch.ptr,
+                                                             &g_disk, sizeof g_disk, g_disk.ready != 0, done, nullptr);
+    if (e == hipSuccess) e = done ? wait_done_word(done) : hipDeviceSynchronize();
+    if (done) arena().give_pinned();
+    if (e != hipSuccess) { set_error("geodesic_init_inf_chain_fast", e); return SIM5GPU_E_HIP; }
     S5_HIP(dg.to_host((Geod*)g));
     if (error) S5_HIP(derr.to_host(error));
     if (ok) S5_HIP(dok.to_host(ok));

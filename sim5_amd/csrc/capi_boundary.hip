@@ -10,23 +10,7 @@
 namespace s5 {
 
 template <typename F>
-__global__ __launch_bounds__(256) void map_elems(size_t n, F body)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) body(i);
-}
-
-template <typename F>
-static int run_elems(size_t n, F body, const char* what)
-{
-    if (n == 0) return SIM5GPU_OK;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(map_elems<F>, dim3(blocks), dim3(256), 0, 0, n, body);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { set_error(what, e); return SIM5GPU_E_HIP; }
-    return SIM5GPU_OK;
-}
+static int run_elems(size_t n, F body, const char* what) { return run_batch(n, body, what); }
 
 static int null_arg(const char* fn)
 {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/sim5gpu.h"
 #include "kernels.hpp"
 #include "s5_config.hpp"
@@ -136,5 +137,78 @@ struct DevBuf {
         return hipMemcpy(host, ptr, n * sizeof(T), hipMemcpyDeviceToHost);
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// the batch entry points' kernel runner: one lane per element
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename F>
+__global__ __launch_bounds__(256) void map_rays(size_t n, F body)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) body(i);
+}
+
+// the same for ONE workgroup's worth of rays, announcing its end itself: every thread makes its stores visible to the host,
+// the workgroup meets, thread 0 raises a word in page-locked host memory.  The host watches that word instead of asking the
+// runtime for the stream's state: the end-of-kernel signal, its interrupt-less polling through the runtime and the
+// queue's bookkeeping are off the caller's critical path (they complete behind the next call's set-up)
+template <typename F>
+__global__ __launch_bounds__(256) void map_rays_flag(size_t n, F body, int* done)
+{
+    const size_t i = threadIdx.x;
+    if (i < n) body(i);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// wait for the word a small launch raises at its end (map_rays_flag below, k_chain.hip); every 256 looks ask the runtime too, so
+// that a launch that died -- it will never raise the word -- ends the wait with its error
+inline hipError_t wait_done_word(int* done)
+{
+    hipError_t e = hipSuccess;
+    for (unsigned spin = 1; !__atomic_load_n(done, __ATOMIC_ACQUIRE); ++spin) {
+        if ((spin & 255u) == 0u) {
+            e = hipStreamQuery(nullptr);
+            if (e == hipErrorNotReady) { e = hipSuccess; continue; }
+            if (e != hipSuccess) break;
+            if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+        }
+    }
+    return e;
+}
+inline int* take_done_word()
+{
+    if (getenv("SIM5GPU_NO_DONE_FLAG")) return nullptr;
+    int* done = (int*)arena().take_pinned(64);
+    if (done) __atomic_store_n(done, 0, __ATOMIC_RELEASE);
+    return done;
+}
+
+template <typename F>
+int run_batch(size_t n, F body, const char* what)
+{
+    if (n == 0) return SIM5GPU_OK;
+    hipError_t e;
+    // a handful of rays (the n = 1 calls of the SIM5 scalar API): the caller waits for ONE short kernel, and the blocking
+    // wait's wake-up costs more than the kernel (measured through tests/tools/shim_rate.sh, shim_latency.py)
+    int* done = (n <= 256) ? take_done_word() : nullptr;
+    if (done) {
+        hipLaunchKernelGGL(map_rays_flag<F>, dim3(1), dim3(256), 0, 0, n, body, done);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = wait_done_word(done);
+        arena().give_pinned();
+    } else {
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(map_rays<F>, dim3(blocks), dim3(256), 0, 0, n, body);
+        e = hipGetLastError();
+        if (e == hipSuccess) {
+            if (n <= 64) { while ((e = hipStreamQuery(nullptr)) == hipErrorNotReady) { } }
+            else e = hipDeviceSynchronize();
+        }
+    }
+    if (e != hipSuccess) { set_error(what, e); return SIM5GPU_E_HIP; }
+    return SIM5GPU_OK;
+}
 
 } // namespace s5

@@ -82,7 +82,11 @@ typedef int (*fn_d3)(size_t, const double *, const double *, const double *, dou
  * is kept per thread next to a copy of the geodesic; geodesic_find_midplane_crossing, geodesic_position_rad, gfactorK and
  * disk_nt_flux answer from it when -- and only when -- their arguments are bit for bit the ones the record was made for (the
  * whole 240-byte struct, P, r, a, l, and the same disk set-up); any other call goes to the GPU as before.  SIM5_SHIM_NO_CHAIN=1
- * switches the record off (every call a round trip: the tests compare the two). */
+ * switches the record off (every call a round trip: the tests compare the two).
+ * The record -- geodesic included -- is made in the library's FAST arithmetic (sim5gpu_geodesic_init_inf_chain_fast: the
+ * whole-image kernels' default; what the caller waits for is the latency of one ray's dependent FP64 chain, three to four
+ * times shorter there) and agrees with the strict routines of the single calls to ~1e-12 relative; SIM5_SHIM_STRICT=1 makes
+ * it with the strict routines (sim5gpu_geodesic_init_inf_chain), value for value what the single calls return. */
 typedef struct {
     double P[2], r[2], g[2], flux[2];
     double a, l;
@@ -92,7 +96,7 @@ typedef struct {
 typedef int (*fn_geod_chain)(size_t, const double *, const double *, const double *, const double *, geodesic *, int *, int *, s5_chain *);
 static __thread struct { int live; unsigned long disk_gen; geodesic g; s5_chain c; } s5_last;
 static unsigned long s5_disk_gen = 1;             /* bumped by every disk set-up of this process */
-static int s5_chain_mode = -1;                    /* -1 unknown, 0 off, 1 on */
+static int s5_chain_mode = -1;                    /* -1 unknown, 0 off, 1 on (fast arithmetic), 2 on (strict) */
 
 static int s5_same_bits(double x, double y) { return memcmp(&x, &y, sizeof x) == 0; }
 static int s5_record_for(const geodesic *g) { return s5_last.live && memcmp(g, &s5_last.g, sizeof *g) == 0; }
@@ -100,9 +104,14 @@ static int s5_record_for(const geodesic *g) { return s5_last.live && memcmp(g, &
 int geodesic_init_inf(double i, double a, double alpha, double beta, geodesic *g, int *error)
 {
     int err = 0, ok = 0;
-    if (s5_chain_mode < 0) { const char *e = getenv("SIM5_SHIM_NO_CHAIN"); s5_chain_mode = (e && *e && *e != '0') ? 0 : 1; }
+    if (s5_chain_mode < 0) {
+        const char *e = getenv("SIM5_SHIM_NO_CHAIN"), *st = getenv("SIM5_SHIM_STRICT");
+        s5_chain_mode = (e && *e && *e != '0') ? 0 : ((st && *st && *st != '0') ? 2 : 1);
+    }
     if (s5_chain_mode) {
-        S5_FN(fn_geod_chain, fc, "sim5gpu_geodesic_init_inf_chain");
+        S5_FN(fn_geod_chain, fc_fast, "sim5gpu_geodesic_init_inf_chain_fast");
+        S5_FN(fn_geod_chain, fc_strict, "sim5gpu_geodesic_init_inf_chain");
+        fn_geod_chain fc = (s5_chain_mode == 2) ? fc_strict : fc_fast;
         s5_last.live = 0;
         s5_check(fc(1, &i, &a, &alpha, &beta, g, &err, &ok, &s5_last.c), "geodesic_init_inf");
         if (ok) { memcpy(&s5_last.g, g, sizeof *g); s5_last.disk_gen = s5_disk_gen; s5_last.live = 1; }

@@ -62,25 +62,34 @@ def test_c1_through_the_scalar_api_one_round_trip_per_ray(tmp_path, capi, golden
     image of the unmodified reference (img_c1_64_a0_i60.npz: hit / miss exact, r, g, flux within 1e-6).  Run twice: with
     the shim's record of the ray (geodesic_init_inf brings the crossings, radii, g-factors and fluxes of the ray in the same
     launch; the follow-up calls are answered from it after a bit-for-bit check of their arguments) and with it switched off
-    (SIM5_SHIM_NO_CHAIN=1: five round trips per ray) -- the two outputs must be the same text, and the rates are printed."""
+    (SIM5_SHIM_NO_CHAIN=1: five round trips per ray).  The record made with the strict routines (SIM5_SHIM_STRICT=1) must
+    give the call-by-call run's text, digit for digit; the default record, made in the library's fast arithmetic, the same
+    hits and errors and every number within 1e-10 of it.  All three against the golden image; the rates are printed."""
     import time
     exe = str(tmp_path / "probe")
     subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", "shim_probe.c"), os.path.join(HOST, "sim5lib.c"),
                     "-I", HOST, "-o", exe, "-lm", "-O3", "-w", "-fgnu89-inline"], check=True)
     n, a, inc = 64, 0.0, 60.0
     outs, secs = [], []
-    for chain in (True, False):
-        env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
-        if not chain:
-            env["SIM5_SHIM_NO_CHAIN"] = "1"
+    for extra in ({}, {"SIM5_SHIM_STRICT": "1"}, {"SIM5_SHIM_NO_CHAIN": "1"}):
+        env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH, **extra)
         t0 = time.time()
         p = subprocess.run([exe, str(a), str(inc), str(n)], env=env, capture_output=True, text=True, timeout=900)
         secs.append(time.time() - t0)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(p.stdout)
-    assert outs[0] == outs[1], "the record-served run differs from the call-by-call run"
-    print("scalar API, %d rays: %.3e rays/s with one round trip per ray, %.3e call by call (process start-up included)" % (
-        n * n, n * n / secs[0], n * n / secs[1]))
+    assert outs[1] == outs[2], "the record-served run (strict arithmetic) differs from the call-by-call run"
+    table = lambda txt: np.array([[float(v) for v in ln.split()] for ln in txt.strip().splitlines()[1:1 + n * n]])
+    fast, strict = table(outs[0]), table(outs[1])
+    assert np.array_equal(fast[:, :4], strict[:, :4]), "pixel indices, error codes or hit orders differ between the two records"
+    lit = strict[:, 3] > 0
+    assert np.array_equal(np.isfinite(fast[:, 4:7]), np.isfinite(strict[:, 4:7]))
+    worst = float(np.max(np.abs(fast[lit, 4:6] / strict[lit, 4:6] - 1.0)))                 # r, g
+    worst_f = float(np.max(np.abs(fast[lit, 6] - strict[lit, 6])) / strict[lit, 6].max())    # flux, against the brightest pixel
+    assert worst < 1e-10 and worst_f < 1e-10, (worst, worst_f)
+    print("scalar API, %d rays: %.3e rays/s with one round trip per ray (fast record; worst difference from the strict one %.1e), "
+          "%.3e with the strict record, %.3e call by call (process start-up included)" % (
+              n * n, n * n / secs[0], worst, n * n / secs[1], n * n / secs[2]))
     g = golden("img_c1_64_a0_i60.npz")
     rec = np.array([[float(v) for v in ln.split()] for ln in outs[0].strip().splitlines()[1:1 + n * n]])
     hit = np.where(g["cls"] == 2, 1, np.where(g["cls"] == 4, 2, 0)).ravel()

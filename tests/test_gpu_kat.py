@@ -60,6 +60,44 @@ def test_geodesic_init_inf_records(capi, golden):
     assert_close(k, g["kmom"][m], floor=1e-9, what="geodesic_momentum")
 
 
+def test_geodesic_chain_records_both_arithmetics(capi, golden):
+    """sim5gpu_geodesic_init_inf_chain and _chain_fast on the 4 000 golden rays of the reference (kat_geodesic.npz: records,
+    crossings P0 / P1 and the radii there captured from the unmodified reference): the same ok / error flags and classes as the
+    reference in both arithmetics; the geodesic, P and r against the reference's values; g and flux of the record against the
+    single entry points called with the record's own r (strict: the same bits; fast: within 1e-10)."""
+    g = golden("kat_geodesic.npz")
+    inp = g["inp"]
+    ref = np.frombuffer(g["dump"].tobytes(), dtype=capi.GEODESIC_DTYPE)
+    capi.disk_nt_setup(10.0, 0.9, 0.1, 0.1)
+    for fast in (False, True):
+        rec, err, ok, ch = capi.geodesic_init_inf_chain(inp[:, 0], inp[:, 1], inp[:, 2], inp[:, 3], fast=fast)
+        assert np.array_equal(ok, g["ok"]) and np.array_equal(err, g["err"])
+        good = ok == 1
+        assert np.array_equal(ch["valid"], ok) and np.all(ch["flux_valid"] == 1)
+        assert np.array_equal(rec["nrr"][good], ref["nrr"][good]) and np.array_equal(rec["type"][good], ref["type"][good])
+        for f in ("l", "q", "m2p", "m2m", "mm", "mK", "Rpc", "Tpp", "Tip"):
+            assert_close(rec[f][good], ref[f][good], what="chain geodesic." + f)
+        for k, (Pk, rk) in enumerate((("P0", "r0"), ("P1", "r1"))):
+            P = ch["P"][:, k]
+            assert np.array_equal(np.isnan(P[good]), np.isnan(g[Pk][good])), "crossing of order %d exists / does not exist" % k
+            m = good & ~np.isnan(g[Pk])
+            assert_close(P[m], g[Pk][m], what=Pk)
+            assert np.all(ch["have_r"][m, k] == 1)
+            assert_close(ch["r"][m, k], g[rk][m], what=rk)
+            mm = m & ~np.isnan(ch["r"][:, k])
+            gg = capi.gfactorK(ch["r"][mm, k], inp[mm, 1], rec["l"][mm])
+            ff = capi.disk_nt_flux(ch["r"][mm, k])
+            if fast:
+                fin = np.isfinite(gg)
+                assert np.array_equal(np.isfinite(ch["g"][mm, k]), fin)
+                assert_close(ch["g"][mm, k][fin], gg[fin], what="g of the fast record")
+                finf = np.isfinite(ff)
+                assert np.array_equal(np.isfinite(ch["flux"][mm, k]), finf)
+                assert np.max(np.abs(ch["flux"][mm, k][finf] - ff[finf])) <= 1e-10 * np.max(ff[finf])
+            else:
+                assert np.array_equal(ch["g"][mm, k], gg, equal_nan=True) and np.array_equal(ch["flux"][mm, k], ff, equal_nan=True)
+
+
 def test_geodesic_init_src_records(capi, golden):
     """geodesic_init_src (ref src/sim5kerr-geod.c:106-173) through sim5gpu_geodesic_init_src against the 2 000 records
     captured from the reference (oracle/gen_golden.py:kat_init_src): return value and error code identical, geodesic

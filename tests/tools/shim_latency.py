@@ -20,5 +20,7 @@ class Chain(C.Structure):
 ch = Chain()
 capi.disk_nt_setup(10.0, 0.998, 0.1, 0.1)
 chain = lambda: lib.sim5gpu_geodesic_init_inf_chain(capi.SZ(1), capi._p(inc), capi._p(sp), capi._p(al), capi._p(be), capi._p(g), capi._p(err), capi._p(ok), C.byref(ch))
+chain_fast = lambda: lib.sim5gpu_geodesic_init_inf_chain_fast(capi.SZ(1), capi._p(inc), capi._p(sp), capi._p(al), capi._p(be), capi._p(g), capi._p(err), capi._p(ok), C.byref(ch))
 plain = lambda: lib.sim5gpu_geodesic_init_inf(capi.SZ(1), capi._p(inc), capi._p(sp), capi._p(al), capi._p(be), capi._p(g), capi._p(err), capi._p(ok))
-print("trivial call %.1f us | geodesic_init_inf %.1f us | chain (init_inf + crossings + radii + g + flux) %.1f us | r0 %.6f" % (t(triv), t(plain), t(chain), ch.r[0]))
+print("trivial call %.1f us | geodesic_init_inf %.1f us | chain (init_inf + crossings + radii + g + flux) %.1f us | r0 %.15g" % (t(triv), t(plain), t(chain), ch.r[0]))
+print("the chain in the fast arithmetic %.1f us | r0 %.15g flux0 %.15g" % (t(chain_fast), ch.r[0], ch.flux[0]))
