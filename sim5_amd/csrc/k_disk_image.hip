@@ -99,12 +99,18 @@ void disk_image_grid_kernel(ImageParams p)
 // takes the pixel (ix, iy) of the upper half AND its mirror image (ix, ny - 1 - iy).  The two rays differ in the sign of
 // beta only and share the geodesic (trace_thin_disk_impl<.., PAIR>) -- about two thirds of a ray's arithmetic.  The image
 // is the plain kernel's bit for bit (pixel_beta above); an odd middle row is its own mirror and is written once.
+// spill experiments only (tests/tools/spill_repro.sh): a register budget below what the pairing kernels need
+#ifdef S5_FORCE_NUM_VGPR
+#define S5_NUM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(S5_FORCE_NUM_VGPR)))
+#else
+#define S5_NUM_VGPR_ATTR
+#endif
 #ifndef S5_LB_WAVES_MIRROR
 #define S5_LB_WAVES_MIRROR 4             // four waves per SIMD (the kernel needs 112 VGPRs, no scratch).  Measured, 4096^2, same
                                          // call: 0.527 ms at three -> 0.478 ms
 #endif
 template <bool AUX>
-__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
+__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR) S5_NUM_VGPR_ATTR
 void disk_image_mirror_kernel(ImageParams p)
 {
     const int lane_x = threadIdx.x % TILE_W;
@@ -156,7 +162,7 @@ void disk_image_mirror_kernel(ImageParams p)
 // arithmetic is that of disk_image_mirror_kernel<false>, value for value: images are the same bits.
 // SINGLE: the list holds one job (sim5gpu_disk_image of a symmetric row set): no search, the job at a constant offset
 template <bool SINGLE>
-__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
+__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR) S5_NUM_VGPR_ATTR
 void disk_image_jobs_kernel(JobList list_arg)
 {
     const S5_AS4 JobList* L = (const S5_AS4 JobList*)__builtin_amdgcn_kernarg_segment_ptr();
