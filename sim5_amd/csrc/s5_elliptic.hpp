@@ -440,10 +440,12 @@ S5_DEV void ladder_descend_fractions(const Ladder& lad, const LadderState& st, c
 // ended on: t1 / t2 = (c c0)^2 / (s0^2 c) = c cot^2, the reference's a <- c a.  Every rung then reads a_{i+1} beside its own
 // (a_i, g_i) (ladder_climb<..., STORE_NEXT = true> stored the extra one) and updates C, ga, N, D in place: seven
 // multiplications, no register copies at the join of the predicated block (the form above: seven and three copies of a
-// double per rung).  The pair (C, ga) is rescaled by a power of two at rungs 4 and 0 only: with (e_C, e_N) the binary
-// exponents of the pairs (C, ga) and (N, D), a rung maps (e_C, e_N) to (e_C + e_N, 2 e_C) -- they roughly double -- and the
-// start is (<= 4, 0) (C^2 + ga^2 lies between c^2 and 1, and the last mean c = pi / 2K(m) >= 0.08 for a double-precision
-// modulus), so four rungs reach 2^-44 and the squares of the next four 2^-400 at the worst.
+// double per rung).  The pair (C, ga) is rescaled by a power of two after rung 5 (lanes that entered at rungs 5-7: moduli
+// within ~1e-3 of 1) and after the LAST rung: with (e_C, e_N) the binary exponents of the pairs (C, ga) and (N, D), a rung
+// maps (e_C, e_N) to (e_C + e_N, 2 e_C) -- they roughly double -- and the start is (<= 4, 0) (C^2 + ga^2 lies between c^2
+// and 1, and the last mean c = pi / 2K(m) >= 0.08 for a double-precision modulus).  Five rungs without rescaling (top = 4,
+// the common case) end at (84, 88); three rungs, a rescaling and five more (top = 7) at (264, 240) with squares of 2^-240
+// inside the last rung: the products the addition theorem forms from the rescaled pair and (N, D) stay above 2^-600.
 template <class Ladder, int NR = LADDER_RUNGS>
 S5_DEV void ladder_descend_squares(const Ladder& lad, const LadderState& st, const double s0, const double c0,
                                    double& C, double& ga, double& N, double& D)      // (s0, c0) = sincos(u st.c)
@@ -462,7 +464,7 @@ S5_DEV void ladder_descend_squares(const Ladder& lad, const LadderState& st, con
                 ga = D * ga;
                 N = g * t2 + t1;
                 D = b * t2 + t1;
-                if (i == 4 || i == 0) {
+                if (i == 5 || i == 0) {
                     const int e = -__builtin_amdgcn_frexp_exp(fabs(C) + fabs(ga));
                     C = __builtin_amdgcn_ldexp(C, e);
                     ga = __builtin_amdgcn_ldexp(ga, e);
