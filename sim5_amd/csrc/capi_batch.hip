@@ -7,6 +7,7 @@
 #include <vector>
 #include "capi_util.hpp"
 #include "s5_disk.hpp"
+#include "s5_chain.hpp"
 #include "s5_raytrace.hpp"
 #include "s5_polar.hpp"
 #include "s5_azimuth.hpp"
@@ -135,40 +136,8 @@ int sim5gpu_geodesic_init_inf_chain(size_t n, const double* incl, const double* 
     sim5gpu_geodesic_chain* pc = dch.ptr;
     const bool have_disk = g_disk.ready != 0;
     const DiskConsts d = g_disk;
-    // two lanes per ray, one per crossing order (both set the geodesic up: a single ray is a chain of dependent FP64
-    // operations, and its latency -- not the launch -- is what a caller of the scalar API waits for)
     S5_RUN(2 * n, "geodesic_init_inf_chain", [=] __device__(size_t j) {
-        const size_t i = j >> 1;
-        const int k = (int)(j & 1);
-        Geod gd = pg[i];
-        GeodCache cache;
-        int err = 0;
-        const double inc = pi[i];
-        const bool ok_ = init_inf(inc, sin(inc), cos(inc), pa[i], pal[i], pbe[i], gd, err, cache);
-        sim5gpu_geodesic_chain* c = &pc[i];
-        c->P[k] = NAN; c->r[k] = NAN; c->g[k] = NAN; c->flux[k] = NAN; c->have_r[k] = 0;
-        if (ok_) {
-            // K(mm) and the inverse cn of the observer's position come from init_inf (GeodCache): the very values the
-            // crossing search would form again from the same expressions (the image kernels rely on the same identity)
-            c->P[k] = midplane_crossing(gd, k, cache);
-            if (!isnan(c->P[k])) {
-                c->r[k] = position_rad(gd, c->P[k]);
-                c->have_r[k] = 1;
-                if (!isnan(c->r[k])) {
-                    c->g[k] = gfactor_kepler(c->r[k], pa[i], gd.l);
-                    if (have_disk) c->flux[k] = disk_flux(d, c->r[k]);
-                }
-            }
-        }
-        if (k == 0) {
-            c->flux_valid = have_disk ? 1 : 0; c->valid = ok_ ? 1 : 0;
-            c->a = pa[i]; c->l = gd.l;
-            pe[i] = err;
-            po[i] = ok_ ? 1 : 0;
-        }
-        // both lanes read pg[i] above; the geodesic is written back by lane 0 after its partner has read it too: the two
-        // lanes of a ray sit in one wave (j even/odd), which executes the read before the write in program order
-        if (k == 0) pg[i] = gd;
+        geodesic_chain_lane(j, pi, pa, pal, pbe, pg, pe, po, pc, d, have_disk);          // s5_chain.hpp
     });
     S5_HIP(dg.to_host((Geod*)g));
     if (error) S5_HIP(derr.to_host(error));

@@ -179,7 +179,8 @@ inline hipError_t wait_done_word(int* done)
 }
 inline int* take_done_word()
 {
-    if (getenv("SIM5GPU_NO_DONE_FLAG")) return nullptr;
+    static const bool off = getenv("SIM5GPU_NO_DONE_FLAG") != nullptr;       // (debugging: the stream is polled instead)
+    if (off) return nullptr;
     int* done = (int*)arena().take_pinned(64);
     if (done) __atomic_store_n(done, 0, __ATOMIC_RELEASE);
     return done;

@@ -8,9 +8,8 @@
 // FP64 chain in a lane or two, and that chain is three to four times shorter here; the values agree with the strict ones to
 // ~1e-12 relative (tests/test_gpu_host_shim.py).  Compiled for the fast variant only.
 #include <string.h>
-#include "s5_disk.hpp"
+#include "s5_chain.hpp"
 #include "kernels.hpp"
-#include "../../include/sim5gpu.h"
 
 #if S5_FAST
 namespace S5NS {
@@ -23,35 +22,7 @@ void geodesic_chain_kernel(size_t n, const double* __restrict__ pi, const double
                            DiskConsts d, int have_disk, int* done)
 {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j < 2 * n) {
-        const size_t i = j >> 1;
-        const int k = (int)(j & 1);
-        Geod gd = pg[i];
-        GeodCache cache;
-        int err = 0;
-        const double inc = pi[i];
-        const bool ok_ = init_inf(inc, sin(inc), cos(inc), pa[i], pal[i], pbe[i], gd, err, cache);
-        sim5gpu_geodesic_chain* c = &pc[i];
-        c->P[k] = NAN; c->r[k] = NAN; c->g[k] = NAN; c->flux[k] = NAN; c->have_r[k] = 0;
-        if (ok_) {
-            c->P[k] = midplane_crossing(gd, k, cache);
-            if (!isnan(c->P[k])) {
-                c->r[k] = position_rad(gd, c->P[k]);
-                c->have_r[k] = 1;
-                if (!isnan(c->r[k])) {
-                    c->g[k] = gfactor_kepler(c->r[k], pa[i], gd.l);
-                    if (have_disk) c->flux[k] = disk_flux(d, c->r[k]);
-                }
-            }
-        }
-        if (k == 0) {
-            c->flux_valid = have_disk ? 1 : 0; c->valid = ok_ ? 1 : 0;
-            c->a = pa[i]; c->l = gd.l;
-            pe[i] = err;
-            po[i] = ok_ ? 1 : 0;
-            pg[i] = gd;                  // (its partner lane, in the same wave, has read pg[i] above: program order)
-        }
-    }
+    if (j < 2 * n) geodesic_chain_lane(j, pi, pa, pal, pbe, pg, pe, po, pc, d, have_disk != 0);      // s5_chain.hpp
     if (done) {
         __threadfence_system();
         __syncthreads();
