@@ -167,12 +167,16 @@ __global__ __launch_bounds__(256) void map_rays_flag(size_t n, F body, int* done
 inline hipError_t wait_done_word(int* done)
 {
     hipError_t e = hipSuccess;
+    int idle_seen = 0;
     for (unsigned spin = 1; !__atomic_load_n(done, __ATOMIC_ACQUIRE); ++spin) {
         if ((spin & 255u) == 0u) {
             e = hipStreamQuery(nullptr);
-            if (e == hipErrorNotReady) { e = hipSuccess; continue; }
+            if (e == hipErrorNotReady) { e = hipSuccess; idle_seen = 0; continue; }
             if (e != hipSuccess) break;
             if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
+            // the stream is idle and the word is still down: the store is on its way -- or the kernel never ran.  Bounded:
+            // a thousand such looks (milliseconds) and the call fails instead of spinning for ever
+            if (++idle_seen > 1000) { e = hipErrorLaunchFailure; break; }
         }
     }
     return e;
