@@ -403,7 +403,7 @@ void torus_pool_kernel(PoolArgs args)
 #ifdef S5_TORUS_DEBUG
     // timeline of the wave (100 MHz clock): start, first time the cursor was found exhausted, exit
     const int wave = (int)(threadIdx.x >> 6);
-    unsigned long long* tl = (unsigned long long*)aux.k_end + 16 + 3 * ((size_t)blockIdx.x * WG_WAVES + wave);
+    unsigned long long* tl = (unsigned long long*)A.aux.k_end + 16 + 3 * ((size_t)blockIdx.x * WG_WAVES + wave);
     if (lane == 0) { tl[0] = wall_clock64(); tl[1] = 0; tl[2] = 0; }
 #endif
 

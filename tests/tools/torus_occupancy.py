@@ -9,7 +9,7 @@ dbg.from_numpy(np.zeros(N*4,dtype=np.float64))
 capi.torus_image_device(dd, sb.ptr, aux={"steps":steps.ptr,"k_end":dbg.ptr}); capi.synchronize()
 c=dbg.to_numpy(np.uint64,(N*4,))[:6]
 print("V batches %d avg lanes %.1f | R batches %d avg lanes %.1f"%(c[0], c[1]/max(c[0],1), c[2], c[3]/max(c[2],1)))
-t=dbg.to_numpy(np.uint64,(N*4,))[16:16+3*2048].reshape(-1,3).astype(np.float64)
+t=dbg.to_numpy(np.uint64,(N*4,))[16:16+3*3072].reshape(-1,3).astype(np.float64)
 t=t[t[:,0]>0]; t0=t[:,0].min()
 dr=t[:,1][t[:,1]>0]
 print("waves %d | cursor exhausted (first wave) at %.2f ms, (median wave) %.2f ms | exits: first %.2f median %.2f p90 %.2f last %.2f ms"%(
