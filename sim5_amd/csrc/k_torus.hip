@@ -107,7 +107,10 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
     // differs from run to run, a ray's result does not); a ray wrongly taken for long costs nothing.
     // (A third class -- the SHORTEST rays last: those that fall into the hole, 250 - 450 calls -- is built and measured,
     // -DS5_SHORT_CLASS: 25.85 against 25.55 ms without it; not used.)
-    int cls = 0;                                                         // 0 ordinary, 1 long, 2 short
+#ifndef S5_FAR_CLASS
+#define S5_FAR_CLASS 8
+#endif
+    int cls = 0;                                                         // 0 ordinary, 1 long, 2 last (far rays; -DS5_SHORT_CLASS: the short ones too)
     if (good && !(p.options & 1)) {
         const double crit = (gd.nrr == 4) ? (gd.r1[0] - gd.r2[0]) / gd.r1[0]
                           : (gd.nrr == 2) ? fabs(gd.r3[1]) / fmax(fabs(gd.r3[0]), 1e-9) : 9.0;
@@ -118,6 +121,14 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
         if ((crit < S5_LONG_CRIT) || (1.0 - gd.m2p < S5_LONG_POLE)) cls = 1;
 #ifdef S5_SHORT_CLASS
         else if (gd.nrr != 4) cls = 2;
+#endif
+#if S5_FAR_CLASS > 0
+        // THE RAYS HANDED OUT LAST decide when a CU ends (its pool drains alone: the CUs of the C4 job ended between 90 % and
+        // 100 % of the run, half of them before 95 %).  The rays that pass far from the hole -- impact parameter above
+        // S5_FAR_CLASS gravitational radii -- are the most uniform in length (472 - 520 calls beyond b = 10 on the C4 job,
+        // where the others spread from 220 to 1 900), so they close the order: C4 21.4 -> 20.65 ms in one call (thresholds
+        // 6 / 8 / 10 / 12: 20.9 / 20.65 / 20.85 / 20.95; a fourth class for b > 12 behind them: 20.55, not kept).
+        else if (alpha * alpha + beta * beta > (double)(S5_FAR_CLASS) * (double)(S5_FAR_CLASS)) cls = 2;
 #endif
     }
 #ifdef S5_SHORT_CLASS
@@ -155,8 +166,8 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
 }
 
 // The order of the march from the ranks.  The long rays are DEALT into the head of the order, every M-th position (M = 2
-// when they are under half of the job), the ordinary ones fill the gaps in their own order and follow, the short ones
-// close.  Dealt rather than put in front: a pool needs rays of both kinds -- Verlet attempts and RK4 fallbacks -- to fill its
+// when they are under half of the job), the ordinary ones fill the gaps in their own order and follow, the last class
+// (the far rays, torus_start_kernel) closes.  Dealt rather than put in front: a pool needs rays of both kinds -- Verlet attempts and RK4 fallbacks -- to fill its
 // batches, and the long rays are the ones that fall back at almost every step.  Measured on MI355X, one call, 1024^2 / 2048^2
 // rays: row-major 29.1 / 90.6 ms; all long rays first 26.5 / 95.4 (-8 % asymptotic rate); dealt 1:2 25.9 / 89.8; 1:3 29.2 /
 // 92.7; 1:4 27.4 / 89.8.
