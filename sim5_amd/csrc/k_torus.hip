@@ -274,6 +274,9 @@ S5_DEV void write_ray_end(const AUX& aux, sim5gpu_stokes* __restrict__ out, size
     if (aux.max_step_error) aux.max_step_error[ray] = worst;
     if (aux.carter_error) aux.carter_error[ray] = raytrace_error(x, k, s);
     if (aux.x_end) { double* __restrict__ o = aux.x_end + 4 * ray; o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3]; }
+#ifdef S5_TORUS_DEBUG
+    if (aux.x_end) aux.x_end[4 * ray] = (double)wall_clock64();      // debug builds: WHEN the ray ended, in place of its t
+#endif
 #ifndef S5_TORUS_DEBUG
     if (aux.k_end) { double* __restrict__ o = aux.k_end + 4 * ray; o[0] = k[0]; o[1] = k[1]; o[2] = k[2]; o[3] = k[3]; }
 #endif
