@@ -495,7 +495,41 @@ def extra_configs(torch, capi, dev, stream):
                                      "note": "thick disk H(R) = 0.25 (R - 2), a = 0.9, i = 70 deg, field of view +-20; W_SURF = 550 "
                                              "sub-steps x 3.6e2 operations is an estimate (no entry in SURVEY 8(d))"}
     del tb, ob, stt
+    out["scalar_api_example04_loop"] = scalar_api_rate(capi)
     return out
+
+
+def scalar_api_rate(capi):
+    """The SIM5 SCALAR API over the GPU library, the way an unmodified caller uses it: tests/c/shim_probe.c is the loop of ref
+    examples/04-disk-image-eqplane/disk-image.c:53-105 (geodesic_init_inf, midplane crossing, position_rad, gfactorK,
+    disk_nt_flux per pixel) compiled against sim5_amd/host/sim5lib.c.  Two image sizes in child processes, so that process
+    start-up drops out of the marginal rate.  A host-side figure (one round trip to the GPU per ray); skipped, with the reason,
+    where no C compiler is at hand."""
+    import shutil
+    import subprocess
+    import tempfile
+    try:
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if not cc:
+            return {"skipped": "no C compiler on this box"}
+        tmp = tempfile.mkdtemp(prefix="s5shim_")
+        exe = os.path.join(tmp, "probe")
+        host = os.path.join(ROOT, "sim5_amd", "host")
+        subprocess.run([cc, os.path.join(ROOT, "tests", "c", "shim_probe.c"), os.path.join(host, "sim5lib.c"), "-I", host, "-o", exe,
+                        "-lm", "-O3", "-w", "-fgnu89-inline"], check=True, capture_output=True, timeout=120)
+        env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+        secs = {}
+        for n in (48, 144):
+            t0 = time.perf_counter()
+            subprocess.run([exe, "0.998", "70", str(n)], env=env, check=True, capture_output=True, timeout=300)
+            secs[n] = time.perf_counter() - t0
+        per = (secs[144] - secs[48]) / (144 * 144 - 48 * 48)
+        shutil.rmtree(tmp, ignore_errors=True)
+        return {"what": "tests/c/shim_probe.c (the example-04 loop, ~5 SIM5 calls per ray) through sim5_amd/host/sim5lib.c: one launch per "
+                        "ray, the per-ray record in the library's fast arithmetic", "rays_per_s": 1.0 / per, "us_per_ray": per * 1e6,
+                "runs_s": {str(k): v for k, v in secs.items()}, "a": 0.998, "incl_deg": 70.0}
+    except Exception as e:                      # a host-side extra must never take the bench line with it
+        return {"skipped": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 def c5_on_one_gpu(torch, capi, dev, stream):
