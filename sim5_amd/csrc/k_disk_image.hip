@@ -71,7 +71,7 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
                                          // 64x1 0.909
 #endif
 #ifndef S5_LB_WAVES
-#define S5_LB_WAVES 2                    // a floor only: the kernel needs 105 VGPRs and 32 KB of LDS per workgroup
+#define S5_LB_WAVES 2                    // a floor only: the kernel needs ~110 VGPRs and 34 KB of LDS per workgroup
                                          // (ladder rungs), so 4 waves/SIMD are resident.  Occupancy is not a lever:
                                          // 4 -> 6 waves/SIMD (shorter ladder) 0.922 -> 0.915 ms; forcing 8 spills.
 #endif

@@ -322,7 +322,7 @@ S5_DEV double inv_tn(double z, double m)
 //               kernels use this one: the register arrays cost 40 VGPRs and, worse, whole-array v_mov chains
 //               at every control-flow join around the inlined call; in LDS a rung is two ds_write_b64 and two
 //               ds_read_b64 with immediate offsets, lanes 8 B apart (conflict-free), 2 x LADDER_RUNGS x 2 KB per workgroup
-//               (32 KB fast, 52 KB strict).
+//               (32 KB fast -- 34 KB in the image kernels, which keep one more row: ladder_descend_squares -- 52 KB strict).
 // 13 rungs as in the reference; the AGM of a double-precision modulus (1 - m >= 1.1e-16, the m == 1 clamp included)
 // reaches 1e-8 at rung index 7 at the latest (scanned over 1e5 moduli up to 1 - 2^-53), so the fast variant keeps 8.
 #ifdef S5_LADDER_RUNGS_OVERRIDE          // timing experiments only
