@@ -41,10 +41,10 @@ S5_DEV RayResult ray_result(const ThinRay& t)
     return out;
 }
 
-S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta)
+S5_DEV RayResult trace_disk_ray(const ImageParams& p, double alpha, double beta, const int iy = -1)
 {
     ThinRay t;
-    trace_thin_disk<false>(p, alpha, beta, t);
+    trace_thin_disk<false>(p, alpha, beta, t, iy);
     return ray_result(t);
 }
 
@@ -88,7 +88,7 @@ void disk_image_grid_kernel(ImageParams p)
     const int lr = blockIdx.y * TILE_H + lane_y;                 // packed (local) row
     if (ix >= p.nx || lr >= p.nrows) return;
     const int iy = image_row(p, lr);
-    const RayResult res = trace_disk_ray(p, pixel_alpha(p, ix), pixel_beta(p, iy));
+    const RayResult res = trace_disk_ray(p, pixel_alpha(p, ix), pixel_beta(p, iy), iy);
     store_ray<AUX>(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, res);     // packed rows, or in place in the whole image
 }
 
@@ -142,9 +142,9 @@ void disk_image_mirror_kernel(ImageParams p)
         pl.disk.ftab = s_ftab;
     }
     __syncthreads();
-    trace_thin_disk_impl<false, true>(pl, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);
+    trace_thin_disk_impl<false, true>(pl, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2, iy);
 #else
-    trace_thin_disk_impl<false, true, false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2);   // (p is this kernel's first parameter)
+    trace_thin_disk_impl<false, true, false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2, iy);   // (p is this kernel's first parameter)
 #endif
 #ifdef S5_FLUX_TABLE_LDS
     if (ix >= p.nx || lr >= half) return;                        // after the barrier of the table copy (tiles of the bench sizes are full)
@@ -202,7 +202,7 @@ void disk_image_jobs_kernel(JobList list_arg)
         const int q = __builtin_amdgcn_readfirstlane(lr0 / sr);
         iy = p.y0 + q * p.stripe_step + (lr0 - q * sr) + lane_y;
     } else iy = image_row_top(p, lr);
-    trace_thin_disk_impl<false, true, false, false>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t1, t2);
+    trace_thin_disk_impl<false, true, false, false>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t1, t2, iy);
     const RayResult r1 = ray_result(t1), r2 = ray_result(t2);
     const S5_AS4 FastJob& po = param_reload(p);                          // the output side: loaded here, not carried through the trace
     const int inplace = po.inplace, ny = po.ny;

@@ -158,9 +158,10 @@ void disk_image_polarized_kernel(ImageParams p)
     const int ix = blockIdx.x * 16 + lane_x;
     const int lr = blockIdx.y * 16 + lane_y;                     // packed (local) row
     if (ix >= p.nx || lr >= p.nrows) return;
-    const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, image_row(p, lr));       // as the unpolarized kernel
+    const int iy = image_row(p, lr);
+    const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, iy);       // as the unpolarized kernel
     ThinRay t;
-    trace_thin_disk<true>(p, alpha, beta, t);
+    trace_thin_disk<true>(p, alpha, beta, t, iy);
     double I, Q, U, chi;
     polarize_ray<AUX>(p, alpha, beta, t, I, Q, U, chi);
     store_polarized<AUX>(p, (size_t)lr * (size_t)p.nx + (size_t)ix, t, I, Q, U, chi);
@@ -194,9 +195,10 @@ void disk_image_polarized_mirror_kernel(ImageParams p_arg)
     const int half = (p.nrows + 1) / 2;
     if (ix >= p.nx || lr >= half) return;
     const int lr2 = p.nrows - 1 - lr;
-    const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, image_row_top(p, lr));
+    const int iy = image_row_top(p, lr);
+    const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, iy);
     ThinRay t, t2;
-    trace_thin_disk_impl<true, true>(p, alpha, beta, t, t2);
+    trace_thin_disk_impl<true, true>(p, alpha, beta, t, t2, iy);
 #ifdef S5_POLAR_ROLLED
 #pragma unroll 1
 #else

@@ -11,10 +11,13 @@
 //    geodesic_find_midplane_crossing (twice for two crossings).  Same inputs, same routine, same
 //    bits -- 3 Carlson R_F evaluations per ray instead of 6.3;
 //  * the record lives in registers; fields nobody reads are removed by the compiler per kernel.
-//  * the polar roots use double throughout, as the reference's own device branch does
-//    (:1133-1138); its host branch carries one intermediate in x87 long double (:1126-1131).
+//  * the polar roots m2m, m2p follow the reference's HOST branch (:1125-1131: x87 long double, each result rounded to 64
+//    bits and again to 53) through an integer restatement of those operations (s5_x87.hpp): the strict variant for every
+//    ray, the fast variant for the rays whose range tests (:1140, :1153) that rounding decides (l = 0: m2p = 1 in real
+//    arithmetic; beta = 0 -> 1e-6: the observer on the polar turning point).
 #pragma once
 #include "s5_kerr.hpp"
+#include "s5_x87.hpp"
 
 namespace S5NS {
 
@@ -153,24 +156,74 @@ S5_DEV bool radial_roots(Geod& g, double r0, int& err)
 // ---------------------------------------------------------------------------------------
 // roots of the polar potential  (ref :1110-1184, device branch)
 // ---------------------------------------------------------------------------------------
+// m2m = X / 2a^2, m2p = 2q / X, X = sqrt(qla^2 + 4 q a^2) + qla (ref :1125-1131), with the reference's host roundings
+S5_DEV void polar_m2_host_rounding(double q, double l2, double a2, double& m2m, double& m2p)
+{
+    const double qla = q + l2 - a2;
+    const double c4 = 4. * q * a2;
+    if (s5x87::polar_roots_x87(qla, c4, a2 + a2, q + q, m2m, m2p)) return;
+    const double X = sqrt(sq(qla) + c4) + qla;             // (operands outside the emulation's range: NaN / infinity as in double)
+    m2m = X / (a2 + a2);
+    m2p = (q + q) / X;
+}
+
+// the two range tests on m2p that the last bit can decide: m2p against 1 (ref :1140) and |m| against sqrt(m2p) (ref :1153)
+S5_DEV bool polar_tests_marginal(double m2p, double s_m2p, double m)
+{
+    return (fabs(m2p - 1.0) < 1e-12) || (fabs(s_m2p - fabs(m)) < 1e-12);
+}
+
+// Carter's constant of a ray from infinity (ref :77; the caller's spin, not the clamped one), in the reference's roundings
+S5_DEV double constant_q(double beta, double cos_i, double alpha, double a_in)
+{
+    const double b2 = rounded_product(sq(beta)), al2 = rounded_product(sq(alpha)), as2 = rounded_product(sq(a_in));
+    return b2 + rounded_product(rounded_product(sq(cos_i)) * (al2 - as2));
+}
+
+// the range tests of the polar roots alone (ref :1140-1176), in the reference's order
+S5_DEV int polar_range_error(double q, double a2, double m2m, double m2p, double s_m2p, double m)
+{
+    if ((m2p <= 0.0) || (m2p >= 1.0)) return GD_E_MUPLUS;
+    if (q > 0.0) {
+        const double mm = m2p / (m2p + m2m);
+        if ((mm < 0.0) || (mm >= 1.0)) return GD_E_MM;
+        if (fabs(m) > s_m2p) return GD_E_MU0;
+    } else if (q < 0.0) {
+        const double mm = (m2p + m2m) / m2p;
+        if ((mm < 0.0) || (mm >= 1.0)) return GD_E_MM;
+        if ((fabs(m) > s_m2p) || (fabs(m) < sqrt(-m2m))) return GD_E_MU0;
+    } else return GD_E_Q_RANGE;
+    return GD_OK;
+}
+
 S5_DEV bool polar_roots(Geod& g, double m, int& err)
 {
     const double a = g.a, l = g.l, q = g.q;
-    const double a2 = a * a, l2 = l * l;
+    const double a2 = rounded_product(a * a), l2 = rounded_product(l * l);
+#if S5_FAST
     const double qla = q + l2 - a2;
     const double X = msqrt(sq(qla) + 4. * q * a2) + qla;
     g.m2m = mdiv(X, a2 + a2);
     g.m2p = mdiv(q + q, X);
+    double s_m2p = msqrt(g.m2p);
+    if (polar_tests_marginal(g.m2p, s_m2p, m)) {             // the last bit decides: the reference's roundings, an IEEE root
+        polar_m2_host_rounding(q, l2, a2, g.m2m, g.m2p);
+        s_m2p = sqrt(g.m2p);
+    }
+#else
+    polar_m2_host_rounding(q, l2, a2, g.m2m, g.m2p);
+    const double s_m2p = msqrt(g.m2p);
+#endif
     if ((g.m2p <= 0.0) || (g.m2p >= 1.0)) { err = GD_E_MUPLUS; return false; }
     if (q > 0.0) {
         g.mm = mdiv(g.m2p, g.m2p + g.m2m);
         if ((g.mm < 0.0) || (g.mm >= 1.0)) { err = GD_E_MM; return false; }
-        if (fabs(m) > msqrt(g.m2p)) { err = GD_E_MU0; return false; }
+        if (fabs(m) > s_m2p) { err = GD_E_MU0; return false; }
         g.mK = mdiv(1., msqrt(a2 * (g.m2p + g.m2m)));
     } else if (q < 0.0) {
         g.mm = mdiv(g.m2p + g.m2m, g.m2p);
         if ((g.mm < 0.0) || (g.mm >= 1.0)) { err = GD_E_MM; return false; }
-        if ((fabs(m) > msqrt(g.m2p)) || (fabs(m) < msqrt(-g.m2m))) { err = GD_E_MU0; return false; }
+        if ((fabs(m) > s_m2p) || (fabs(m) < msqrt(-g.m2m))) { err = GD_E_MU0; return false; }
         g.mK = mdiv(1., msqrt(a2 * g.m2p));
     } else {
         err = GD_E_Q_RANGE;
@@ -198,7 +251,7 @@ S5_DEV bool init_inf(double incl, double sin_i, double cos_i, double a, double a
     g.alpha = alpha;
     g.beta = beta;
     g.l = -alpha * sin_i;
-    g.q = sq(beta) + sq(cos_i) * (sq(alpha) - sq(a));       // caller's a, not the clamped one
+    g.q = constant_q(beta, cos_i, alpha, a);                // caller's a, not the clamped one
     if (g.q == 0.0) { err = GD_E_Q_RANGE; return false; }
 
     if (!radial_roots(g, DBL_MAX, err)) return false;

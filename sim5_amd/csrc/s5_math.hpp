@@ -38,6 +38,11 @@ S5_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 #endif
 
 S5_DEV double sq(double x) { return x * x; }
+// A product the back end must not fuse into the sum that follows (no instruction is emitted).  The march kernel's fast build
+// is compiled with -ffp-contract=fast, which lets the back end fuse any a*b+c of the translation unit whatever a pragma says;
+// the constants of motion and the operands of the polar range tests must carry the reference's own roundings in EVERY build
+// (the last bit of q decides the class of a ray with l = 0: s5_geod.hpp).
+S5_DEV double rounded_product(double x) { asm("" : "+v"(x)); return x; }
 S5_DEV double max3abs(double a, double b, double c) { return fmax(fmax(fabs(a), fabs(b)), fabs(c)); }
 
 // Horner step a*b + c as one instruction (the build runs with -ffp-contract=off; the approximation kernels

@@ -68,7 +68,8 @@ S5_DEV void thin_disk_finish(const PRM& p, ThinRay& out, ThinRay& out2, const do
 template <bool WANT_STATE, int KNOWN, bool PAIR, class PRM>
 S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                                     const double l, const double q, const double alpha, const double beta, int err, const int type_in,
-                                    const double ra, const double rb, const double rc_, const double rd_);
+                                    const double ra, const double rb, const double rc_, const double rd_,
+                                    const double beta_test0 = NAN, const double beta_test1 = NAN);
 
 // (param_reload(): s5_config.hpp)
 #ifndef S5_COLD_UNPAIRED
@@ -115,8 +116,17 @@ S5_DEV void thin_disk_owed_flux(const PRM& p, ThinRay& out, ThinRay& out2)
 // behind the fast one then reads the parameters from the kernel's argument segment, where it runs, instead of out of the
 // scalar registers that would have to carry them -- spilled to vector lanes -- through the whole fast path (measured on the
 // pair kernel: SGPR spills 44 -> 28, -1.2 % time; the same pointer made in the kernel and handed down: +3 %).
+// iy: the image row of (alpha, beta_in) when the caller made them with pixel_alpha / pixel_beta, -1 for a caller's own ray.
+// Used by the fast variant's cold re-trace alone.  For a height that is not a power of two pixel_beta gives a row of the LOWER
+// half minus its mirror row's value -- within an ulp of the reference's own quotient, and that ulp decides the polar range
+// tests of the rays for which they are marginal (the central column of an odd width: polar_tests_marginal).  So the direct
+// routine is handed the reference's own beta of such a row -- beta_test0 for this ray, beta_test1 for the mirror ray of a pair,
+// NaN where the ray's beta is the reference's already -- and forms the q of THOSE TESTS from it, per ray; everything else of
+// the ray (and of the pair's shared geodesic) keeps beta_in, so paired and plain kernels still give the same bits.
+template <class PRM> S5_DEV double pixel_beta_reference(const PRM& p, int iy);
 template <bool WANT_STATE, bool PAIR, bool DIRECT = false, bool P_FIRST = false, class PRM>
-S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, ThinRay& out, ThinRay& out2)
+S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, ThinRay& out, ThinRay& out2, const int iy = -1,
+                                 const double beta_test0 = NAN, const double beta_test1 = NAN)
 {
     S5_FPC_QUARTIC
     using namespace s5abi;
@@ -208,7 +218,7 @@ S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, Thi
     if constexpr (DIRECT || !S5_RPC_ADD) {
         // one instantiation per uniform class (78 % of the rays of the headline image are RR, 22 % RC, and image
         // neighbours share the class), the generic one for mixed waves
-        if constexpr (DIRECT) thin_disk_finish_direct<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
+        if constexpr (DIRECT) thin_disk_finish_direct<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_, beta_test0, beta_test1);
         else if (!wave_any(type != T_RR)) thin_disk_finish_direct<WANT_STATE, T_RR, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
         else if (!wave_any(type != T_RC)) thin_disk_finish_direct<WANT_STATE, T_RC, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
         else thin_disk_finish_direct<WANT_STATE, -1, PAIR>(p, out, out2, a_in, a, l, q, alpha, beta, err, type, ra, rb, rc_, rd_);
@@ -230,19 +240,29 @@ S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, Thi
     if (S5_ANY(c0 || c1)) {
         if (c0 || c1) {
             ThinRay d0, d1;
+            // the reference's own beta where pixel_beta's is not it bit for bit (see the routine's head): t0 for this ray (a row of
+            // the lower half), t1 for the mirror ray of a pair; NaN = the ray's beta is the reference's
+            double t0 = NAN, t1 = NAN;
+            {
+                const int ny = param_reload(p).ny;
+                if (iy >= 0 && (ny & (ny - 1)) != 0) {
+                    if (2 * iy + 1 > ny) { t0 = pixel_beta_reference(param_reload(p), iy); if (t0 == beta_in) t0 = NAN; }
+                    if (PAIR && 2 * iy + 1 < ny) { t1 = pixel_beta_reference(param_reload(p), ny - 1 - iy); if (t1 == -beta_in) t1 = NAN; }
+                }
+            }
             if constexpr (P_FIRST) {
                 const s5abi::ImageParams* pk = (const s5abi::ImageParams*)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(pk));                    // opaque: its reads are not merged with the kernel's own
-                trace_thin_disk_impl<WANT_STATE, PAIR, true>(*pk, alpha, beta_in, d0, PAIR ? d1 : d0);
+                trace_thin_disk_impl<WANT_STATE, PAIR, true>(*pk, alpha, beta_in, d0, PAIR ? d1 : d0, -1, t0, t1);
             } else if constexpr (PAIR && S5_COLD_UNPAIRED) {
                 // constant-address-space parameters (job-list kernel): the two rays of the pair one after the other through
                 // ONE copy of the UNPAIRED direct routine (a ray of a pair is the unpaired routine's ray, value for value:
                 // tests/test_gpu_images.py::test_mirrored_pairs_give_the_plain_image) -- half the code of the paired copy and
                 // well under its scalar-register need, which was the peak of the whole kernel
-                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, beta_in, d0, d0);
-                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, -beta_in, d1, d1);
+                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, beta_in, d0, d0, -1, t0);
+                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, -beta_in, d1, d1, -1, t1);
             } else {
-                trace_thin_disk_impl<WANT_STATE, PAIR, true>(param_reload(p), alpha, beta_in, d0, PAIR ? d1 : d0);
+                trace_thin_disk_impl<WANT_STATE, PAIR, true>(param_reload(p), alpha, beta_in, d0, PAIR ? d1 : d0, -1, t0, t1);
             }
             // (the marks are read again here rather than kept: a per-lane flag alive across the routine is a scalar register pair)
             if (out.cls == PX_COLD_MARK) out = d0;
@@ -255,9 +275,9 @@ S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, Thi
 }
 
 template <bool WANT_STATE, bool P_FIRST = false, class PRM>
-S5_DEV void trace_thin_disk(const PRM& p, double alpha, double beta_in, ThinRay& out)
+S5_DEV void trace_thin_disk(const PRM& p, double alpha, double beta_in, ThinRay& out, const int iy = -1)
 {
-    trace_thin_disk_impl<WANT_STATE, false, false, P_FIRST>(p, alpha, beta_in, out, out);
+    trace_thin_disk_impl<WANT_STATE, false, false, P_FIRST>(p, alpha, beta_in, out, out, iy);
 }
 
 // this lane's column of the workgroup's ladder block (256-thread one-dimensional workgroups: all callers)
@@ -275,7 +295,7 @@ S5_DEV double* thin_disk_ladder_column()
 template <bool WANT_STATE, int KNOWN, bool PAIR, class PRM>
 S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, const double a_in, const double a,
                              const double l, const double q, const double alpha, const double beta, int err, const int type_in,
-                             const double ra, const double rb, const double rc_, const double rd_)
+                             const double ra, const double rb, const double rc_, const double rd_, const double beta_test0, const double beta_test1)
 {
     S5_FPC_FINISH
     using namespace s5abi;
@@ -325,19 +345,46 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
         rp = b1 - a1 * g1;
     }
 
-    // ---------------- roots of the polar potential (ref :1110-1184, device branch) ----------------
+    // ---------------- roots of the polar potential (ref :1110-1184, host branch: s5_geod.hpp polar_m2_host_rounding) --------
+#if S5_FAST
     const double qla = q + l2 - a2;
     const double XT = msqrt(sq(qla) + 4. * q * a2) + qla;
-#if S5_FAST
-    const double m2m = XT * p.inv_2a2;
-#else
-    const double m2m = mdiv(XT, a2 + a2);
-#endif
-    const double m2p = mdiv(q + q, XT);
-#if S5_FAST
+    double m2m = XT * p.inv_2a2;
+    double m2p = mdiv(q + q, XT);
     double s_m2p, rs_m2p;                                   // sqrt(m2p) and its reciprocal, used three times
     sqrt_rsqrt_pos(m2p, s_m2p, rs_m2p);
+    // the rays whose range tests below are decided by the last bit of m2p (central column: l = 0, m2p = 1 in real arithmetic;
+    // central row: beta = 0 -> 1e-6) get the reference's own roundings: its x87 sequence and an IEEE square root
+    // (a ray whose reference beta is not the beta it was given bit for bit -- beta_test0 / beta_test1, heights that are not a
+    // power of two -- has its OWN q in those tests: err_m[]; where the given beta's roots fail them and a ray's own pass, the
+    // shared polar roots are the passing ray's, an ulp away)
+    int err_m[2] = {-1, -1};                                // >= 0: this member's own verdict of the polar range tests
+    if (S5_ANY(polar_tests_marginal(m2p, s_m2p, p.cos_i))) {
+        if (polar_tests_marginal(m2p, s_m2p, p.cos_i)) {
+            polar_m2_host_rounding(q, l2, a2, m2m, m2p);
+            s_m2p = sqrt(m2p);
+            const bool own0 = (beta_test0 == beta_test0), own1 = PAIR && (beta_test1 == beta_test1);
+            if ((own0 || own1) && err == GD_OK) {
+                const int e_sh = polar_range_error(q, a2, m2m, m2p, s_m2p, p.cos_i);
+                err_m[0] = err_m[1] = e_sh;
+                double mm_own = m2m, mp_own = m2p;
+#pragma unroll
+                for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
+                    if (!(member ? own1 : own0)) continue;
+                    const double q_own = constant_q(member ? beta_test1 : beta_test0, p.cos_i, alpha, a_in);
+                    double mm2, mp2;
+                    polar_m2_host_rounding(q_own, l2, a2, mm2, mp2);
+                    err_m[member] = polar_range_error(q_own, a2, mm2, mp2, sqrt(mp2), p.cos_i);
+                    if (err_m[member] == GD_OK) { mm_own = mm2; mp_own = mp2; }
+                }
+                if (e_sh != GD_OK) { m2m = mm_own; m2p = mp_own; s_m2p = sqrt(m2p); }
+            }
+            rs_m2p = 1.0 / s_m2p;
+        }
+    }
 #else
+    double m2m, m2p;
+    polar_m2_host_rounding(q, l2, a2, m2m, m2p);
     const double s_m2p = msqrt(m2p);
 #endif
     double mmT = 0.0, mK = 0.0;
@@ -369,6 +416,7 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
     out.err = err;
     const bool ok = (err == GD_OK);
 #if S5_FAST
+    const bool ok_m0 = ok && !(err_m[0] > GD_OK), ok_m1 = ok && !(err_m[1] > GD_OK);       // (a member failing its own range tests)
     const double u_i = p.cos_i * rs_m2p;
 #else
     const double u_i = mdiv(p.cos_i, s_m2p);
@@ -473,6 +521,10 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
     out.gtype = type;
     out.cls = PX_MISS;
     if (PAIR) { out2.gtype = type; out2.cls = PX_MISS; }
+#if S5_FAST
+    if (!ok_m0) { out.err = err_m[0]; out.gtype = -1; out.cls = PX_ERROR; }
+    if (PAIR && !ok_m1) { out2.err = err_m[1]; out2.gtype = -1; out2.cls = PX_ERROR; }
+#endif
 
     // ---------------- equatorial crossings and r(P) (ref :846-885, :291-357) ----------------
     const bool q_pos = (q > 0.0);
@@ -513,6 +565,9 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
         int cls_m = PX_MISS;
         double r_m = NAN, P_m = NAN, g_m = 0.0, flux_m = 0.0, dP_m = NAN;
         bool cf_m = false;                      // fast variant: the flux of this ray is owed by the closed form (below)
+#if S5_FAST
+        if (!((member == 0) ? ok_m0 : ok_m1)) continue;              // this member failed its own range tests: PX_ERROR stands
+#endif
         bool done = false;
 #pragma unroll 1
         for (int order = 0; order < p.max_order; ++order) {
@@ -691,6 +746,9 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
     out.err = err;
     const bool ok = (err == GD_OK);
     const double u_i = p.cos_i * rs_m2p;
+    // a range test decided by the last bit of m2p (central column / row of an odd-sized image): the direct routine, which
+    // forms m2p with the reference's own roundings, has the say (both rays of the pair: they share the polar roots)
+    const bool marginal = polar_tests_marginal(m2p, s_m2p, p.cos_i);
 
     // ---------------- what the crossing search needs to know about the ray ----------------
     // "no special case of the inverse function": CONSERVATIVE forms of isn_plain / icn_plain (a handful of comparisons
@@ -763,7 +821,10 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
         }
     }
     if (PAIR) out2.err = err;
-    if (!ok) return;
+    if (!ok) {
+        if (marginal) { out.cls = PX_COLD_MARK; if (PAIR) out2.cls = PX_COLD_MARK; }      // (the error may be the last bit's)
+        return;
+    }
     out.gtype = type;
     out.cls = PX_MISS;
     if (PAIR) { out2.gtype = type; out2.cls = PX_MISS; }
@@ -796,7 +857,7 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
 #endif
     constexpr int MEMBERS = PAIR ? S5_PAIR_MEMBERS : 1;
     // a ray that may cross but is not served by the addition theorem goes the reference's way, after the loops
-    bool cold[2] = {may_cross && !by_add, may_cross && !by_add};
+    bool cold[2] = {(may_cross && !by_add) || marginal, (may_cross && !by_add) || marginal};
     // two inlined passes rather than a run-time loop: as a loop the compiler predicates the pass on per-lane state and the
     // lanes used fall from 97 % to 91 % (measured: +6.5 % VALU instructions, +4.5 % time)
 #ifdef S5_PAIR_ROLLED
@@ -952,6 +1013,13 @@ S5_DEV double pixel_alpha(const PRM& p, int ix)
 #endif
 }
 
+// the reference's expression for every row (ref disk-image.c:58)
+template <class PRM>
+S5_DEV double pixel_beta_reference(const PRM& p, int iy)
+{
+    return (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax * ((double)p.ny / (double)p.nx);
+}
+
 template <class PRM>
 S5_DEV double pixel_beta(const PRM& p, int iy)
 {
@@ -967,7 +1035,7 @@ S5_DEV double pixel_beta(const PRM& p, int iy)
     const double b = (((double)(jy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax * p.ny_over_nx;
     return lower ? -b : b;
 #else
-    return (((double)(iy) + .5) / (double)(p.ny) - 0.5) * 2.0 * p.rmax * ((double)p.ny / (double)p.nx);
+    return pixel_beta_reference(p, iy);
 #endif
 }
 

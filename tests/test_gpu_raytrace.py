@@ -252,11 +252,18 @@ def test_random_torus_jobs(capi):
     ... 27^2 rays, torus size, with and without absorption; tests/tools/fuzz_torus.py runs the open-ended version): the step
     count of EVERY ray equals the CPU checker's raytrace() loop in both variants; end point, end momentum, Stokes I and tau
     within 1e-6 in both variants (compare_rays: a ray may exceed it only if the checker's own result moves as much under a
-    +-1 ulp change of its start state).  Left out and counted: rays with alpha = 0 exactly (central column of an odd-sized
-    image), whose start-up is degenerate in the reference itself (l = 0: it returns garbage states or rejects the ray,
-    depending on rounding)."""
+    +-1 ulp change of its start state).
+    Rays with alpha = 0 exactly (central column of an odd-sized image; left out of everything until round 5): l = 0, and whether
+    the reference starts such a ray at all is decided by the roundings of its x87 polar roots, which the device now reproduces
+    (s5_x87.hpp) -- so they are IN the step-count comparison of both variants.  Their VALUES are not asserted, only counted and
+    printed (how many above 1e-6, the worst): an l = 0 ray runs INTO the polar axis, the step control hits its floor dl = 1e-3 (ref
+    src/sim5raytrace.c:166) and creeps up to sin(theta) ~ 1e-5, where one ulp of m = cos(theta) is 1e-6 of sin^2(theta):
+    last-bit differences of the state grow by 1e2 - 1e4 per step (tests/tools/torus_diverge.py: k^phi 6e-12 -> 2e-5 over the
+    last ten steps before the axis).  The strict variant stays within 2e-8 on most of them (its operations are the
+    reference's; acos / cos of the device's libm differ from glibc's in the last bit now and then -- one ray of the 25 jobs
+    then ends elsewhere altogether), the fast one within 2e-4."""
     rng = np.random.default_rng(2027)
-    left_out = 0
+    axis_rays, axis_over, axis_worst = {True: 0, False: 0}, {True: 0, False: 0}, {True: 0.0, False: 0.0}
     for case in range(25):
         a = float(rng.choice([0.1, 0.3, 0.9, 0.998, rng.uniform(0.01, 0.99)]))
         inc = float(rng.uniform(10.0, 85.0))
@@ -271,22 +278,30 @@ def test_random_torus_jobs(capi):
         al, be = np.tile(c, n), np.repeat(c, n)
         job = dict(r0=r0, precision=prec, absorb0=absorb0, torus_r=tr, torus_w=tw)
         ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, **job)
-        regular = np.nonzero(al != 0.0)[0]
-        sub = {k: v[regular] for k, v in ref.items()}
-
-        def probe(idx):
-            return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al[regular][idx], be[regular][idx],
-                                      {k: v[idx] for k, v in sub.items()}, **job)
+        off_axis = np.nonzero(al != 0.0)[0]
         for strict in (True, False):
+            regular = off_axis
+            sub = {k: v[regular] for k, v in ref.items()}
+
+            def probe(idx):
+                return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al[regular][idx], be[regular][idx],
+                                          {k: v[idx] for k, v in sub.items()}, **job)
             d = torus_desc(capi, n, a, inc, **job)
             if strict:
                 d.img.flags = 1
             S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
-            left_out += int((steps != ref["steps"]).sum() - (steps[regular] != ref["steps"][regular]).sum())
-            assert np.array_equal(steps[regular], ref["steps"][regular]), what + (strict,)
+            assert np.array_equal(steps, ref["steps"]), what + (strict,)             # every ray, alpha = 0 included
             compare_rays("random job %d %s" % (case, "strict" if strict else "fast"), S[regular], steps[regular], xe[regular],
                          ke[regular], sub, 1.0, probe)
-    print("alpha = 0 rays with another step count than the CPU loop (left out): %d" % left_out)
+            on_axis = np.nonzero((al == 0.0) & (steps > 0))[0]
+            if on_axis.size:
+                e = ray_errors({"x_end": xe[on_axis], "k_end": ke[on_axis], "I": S[on_axis, 0], "tau": S[on_axis, 4]},
+                               {k: v[on_axis] for k, v in ref.items()})
+                w = np.max(np.stack(list(e.values())), axis=0)
+                axis_rays[strict] += on_axis.size; axis_over[strict] += int((w > REL).sum()); axis_worst[strict] = max(axis_worst[strict], float(w.max()))
+    for strict in (True, False):
+        print("%s variant, rays into the polar axis (alpha = 0): %d, of them above 1e-6: %d, worst difference %.1e (not asserted)" % (
+            "strict" if strict else "fast", axis_rays[strict], axis_over[strict], axis_worst[strict]))
 
 
 @pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
