@@ -77,6 +77,8 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
 #endif
 // internal class value: the fast routine leaves this ray to the direct one (never stored)
 constexpr int PX_COLD_MARK = 100;
+// internal error value of the fast routine: the ray's polar range tests are marginal, the direct routine decides (never stored)
+constexpr int GD_E_LAST_BIT = 99;
 // internal flux value (a flux is never negative): the table of the fast variant does not serve this hit -- within 2e-4 of the
 // inner edge in x, beyond x = 16, or no table for this spin (s5_disk.hpp) -- and the closed form is owed.  It is evaluated
 // ONCE, by thin_disk_owed_flux at the end of trace_thin_disk_impl, for both rays of a pair and whichever routine found the
@@ -724,20 +726,29 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
     const double m2p = mdiv(q + q, XT);
     double s_m2p, rs_m2p;                                   // sqrt(m2p) and its reciprocal, used three times
     sqrt_rsqrt_pos(m2p, s_m2p, rs_m2p);
+    // The two range tests on m2p (ref :1140, :1153) can only fail by rounding: in real arithmetic m2p <= 1 (equal for l = 0:
+    // the central column of an odd width) and |cos i| <= sqrt(m2p) (equal for beta = 0: the observer on the polar turning
+    // point; the central row of an odd height, where the reference sets beta = 1e-6).  So whoever comes within 1e-12 of
+    // either threshold is left to the direct routine, which forms m2p with the reference's own roundings (s5_geod.hpp
+    // polar_m2_host_rounding) -- as an error code of its own: the lane idles through this routine like any rejected ray, both
+    // rays of a pair (they share the polar roots).  One subtraction more than the exact tests.
     double mmT = 0.0, mK = 0.0;
     if (err == GD_OK) {
-        if ((m2p <= 0.0) || (m2p >= 1.0)) err = GD_E_MUPLUS;
+        const double s_near = s_m2p - 1e-12;
+        if (m2p <= 0.0) err = GD_E_MUPLUS;
+        else if (m2p >= 1.0 - 1e-12) err = GD_E_LAST_BIT;
         else if (q > 0.0) {
             // mK = 1/sqrt(a^2 (m2p + m2m)) first; the modulus m2p/(m2p + m2m) is then m2p a^2 mK^2
             const double rk = rsqrt_pos(a2 * (m2p + m2m));
             mmT = (m2p * a2) * (rk * rk);
             if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
-            else if (fabs(p.cos_i) > s_m2p) err = GD_E_MU0;
+            else if (fabs(p.cos_i) > s_near) err = GD_E_LAST_BIT;
             else mK = rk;
         } else if (q < 0.0) {
             mmT = mdiv(m2p + m2m, m2p);
             if ((mmT < 0.0) || (mmT >= 1.0)) err = GD_E_MM;
-            else if ((fabs(p.cos_i) > s_m2p) || (fabs(p.cos_i) < msqrt(-m2m))) err = GD_E_MU0;
+            else if (fabs(p.cos_i) > s_near) err = GD_E_LAST_BIT;
+            else if (fabs(p.cos_i) < msqrt(-m2m)) err = GD_E_MU0;
             else mK = mdiv(1., msqrt(a2 * m2p));
         } else {
             err = GD_E_Q_RANGE;
@@ -746,9 +757,6 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
     out.err = err;
     const bool ok = (err == GD_OK);
     const double u_i = p.cos_i * rs_m2p;
-    // a range test decided by the last bit of m2p (central column / row of an odd-sized image): the direct routine, which
-    // forms m2p with the reference's own roundings, has the say (both rays of the pair: they share the polar roots)
-    const bool marginal = polar_tests_marginal(m2p, s_m2p, p.cos_i);
 
     // ---------------- what the crossing search needs to know about the ray ----------------
     // "no special case of the inverse function": CONSERVATIVE forms of isn_plain / icn_plain (a handful of comparisons
@@ -822,7 +830,7 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
     }
     if (PAIR) out2.err = err;
     if (!ok) {
-        if (marginal) { out.cls = PX_COLD_MARK; if (PAIR) out2.cls = PX_COLD_MARK; }      // (the error may be the last bit's)
+        if (err == GD_E_LAST_BIT) { out.cls = PX_COLD_MARK; if (PAIR) out2.cls = PX_COLD_MARK; }
         return;
     }
     out.gtype = type;
@@ -857,7 +865,7 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
 #endif
     constexpr int MEMBERS = PAIR ? S5_PAIR_MEMBERS : 1;
     // a ray that may cross but is not served by the addition theorem goes the reference's way, after the loops
-    bool cold[2] = {(may_cross && !by_add) || marginal, (may_cross && !by_add) || marginal};
+    bool cold[2] = {may_cross && !by_add, may_cross && !by_add};
     // two inlined passes rather than a run-time loop: as a loop the compiler predicates the pass on per-lane state and the
     // lanes used fall from 97 % to 91 % (measured: +6.5 % VALU instructions, +4.5 % time)
 #ifdef S5_PAIR_ROLLED

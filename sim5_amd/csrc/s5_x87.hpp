@@ -7,7 +7,7 @@
 // those very roundings; for beta = 0 -> 1e-6 (central row) `|cos i| > sqrt(m2p)` (ref :1153) is.  A double-only evaluation
 // (the reference's own CUDA branch, ref :1133-1138) lands on the other side for a quarter of such pixels.  So the sequence is
 // reproduced here in integer arithmetic: products, sums and quotients of 64-bit significands with one rounding to 64 bits,
-// then one to 53.  What gcc 11 -O3 emits for the statement group (checked in the disassembly of oracle/_ref/libsim5ref.so:
+// then one to 53.  What gcc 11 -O3 emits for the statement group (checked in the disassembly of the reference library built here:
 // fmul / faddl / fstpl / sqrtsd / faddl / fdivl / fdivrl) is restated in `polar_roots_x87` below.
 //
 // No device float instruction takes part, so host (g++: tests/c/x87_check.cpp compares every operation with the CPU's real
@@ -162,17 +162,36 @@ S5X_FN double to_double(const X80& x)
 //     X / dbla -> fstpl m2m;   dblq / X -> fstpl m2p
 // Returns false (nothing written) when an operand is zero, not finite, or the radicand negative: the caller's plain double
 // sequence then gives the reference's NaN / infinity behaviour.
-S5X_FN bool polar_roots_x87(double qla, double c4, double dbla, double dblq, double& m2m, double& m2p)
+struct PolarM2 { double m2m, m2p; int ok; };
+#if defined(__HIP_DEVICE_COMPILE__)
+// ONE copy per code object, called: the routine is ~1 300 instructions and sits on cold paths only (three inlined copies in
+// the image kernels' direct routine cost the production kernel 0.6 % through code size alone).  Arguments and result by
+// value, in registers: a result through references would put the caller's variables on a stack.
+__device__ __attribute__((noinline))
+#else
+inline
+#endif
+PolarM2 polar_roots_x87_value(double qla, double c4, double dbla, double dblq)
 {
-    if (!(fabs(qla) < 1e150 && fabs(c4) < 1e300 && fabs(dbla) < 1e300 && fabs(dblq) < 1e300)) return false;
-    if (dbla == 0.0 || dblq == 0.0 || (qla != 0.0 && fabs(qla) < 1e-150) || fabs(dbla) < 1e-300 || fabs(dblq) < 1e-300) return false;
+    PolarM2 out = {0.0, 0.0, 0};
+    if (!(fabs(qla) < 1e150 && fabs(c4) < 1e300 && fabs(dbla) < 1e300 && fabs(dblq) < 1e300)) return out;
+    if (dbla == 0.0 || dblq == 0.0 || (qla != 0.0 && fabs(qla) < 1e-150) || fabs(dbla) < 1e-300 || fabs(dblq) < 1e-300) return out;
     const X80 xq = from_double(qla);
     const double rad = to_double(add(mul(xq, xq), from_double(c4)));
-    if (!(rad >= 0.0)) return false;
+    if (!(rad >= 0.0)) return out;
     const X80 X = add(xq, from_double(sqrt(rad)));
-    if (X.m == 0) return false;
-    m2m = to_double(div(X, from_double(dbla)));
-    m2p = to_double(div(from_double(dblq), X));
+    if (X.m == 0) return out;
+    out.m2m = to_double(div(X, from_double(dbla)));
+    out.m2p = to_double(div(from_double(dblq), X));
+    out.ok = 1;
+    return out;
+}
+
+S5X_FN bool polar_roots_x87(double qla, double c4, double dbla, double dblq, double& m2m, double& m2p)
+{
+    const PolarM2 r = polar_roots_x87_value(qla, c4, dbla, dblq);
+    if (!r.ok) return false;
+    m2m = r.m2m; m2p = r.m2p;
     return true;
 }
 
