@@ -5,6 +5,7 @@
 // host program written against the SIM5 scalar API (and the parity tests) can reach each routine
 // through the C-ABI; throughput work goes through the whole-job kernels instead.
 #include <vector>
+#include <math.h>
 #include "capi_util.hpp"
 #include "s5_disk.hpp"
 #include "s5_chain.hpp"
@@ -28,6 +29,21 @@ static int arg_error(const char* fn)
 #define S5_DEVICE_OR_FAIL() do { if (!have_device()) return SIM5GPU_E_NO_DEVICE; } while (0)
 #define S5_BUFS_OK(fn, cond) do { if (!(cond)) { snprintf(g_err, sizeof g_err, "%s: device allocation/copy failed", fn); return SIM5GPU_E_HIP; } } while (0)
 #define S5_RUN(n, what, ...) do { int rc_ = run_map(n, __VA_ARGS__, what); if (rc_) return rc_; } while (0)
+
+// sin and cos of the inclinations from the HOST's libm -- the numbers the reference itself forms (ref src/sim5kerr-geod.c:
+// 73-77: cos(i), sin(i) by glibc): the last bit of cos(i) enters q and, for a ray with l = 0, decides its class (s5_geod.hpp).
+// The whole-job kernels have always taken them from the host (one inclination per job); the batch entry points now do too.
+// A caller's rays nearly always share one inclination: consecutive equal values cost a comparison, not two libm calls.
+static void host_sincos(size_t n, const double* incl, std::vector<double>& s, std::vector<double>& c)
+{
+    s.resize(n); c.resize(n);
+    double last = 0.0, ls = 0.0, lc = 1.0;
+    bool have = false;
+    for (size_t i = 0; i < n; ++i) {
+        if (!have || memcmp(&incl[i], &last, sizeof last) != 0) { last = incl[i]; ls = sin(last); lc = cos(last); have = true; }
+        s[i] = ls; c[i] = lc;
+    }
+}
 
 // Total disk luminosity in Eddington units (ref src/sim5disk-nt.c:151-188): the reference's Simpson rule on the
 // refined trapezoid rule (src/sim5integration.c:26-52 stage rule with its running abscissa x += del, :96-133:
@@ -92,18 +108,19 @@ int sim5gpu_geodesic_init_inf(size_t n, const double* incl, const double* a, con
     S5_NEED("geodesic_init_inf", incl && a && alpha && beta && g);
     if (n == 0) return SIM5GPU_OK;
     S5_DEVICE_OR_FAIL();
-    DevBuf<double> di(incl, n), da(a, n), dal(alpha, n), dbe(beta, n);
+    std::vector<double> hs, hc;
+    host_sincos(n, incl, hs, hc);
+    DevBuf<double> di(incl, n), dsi(hs.data(), n), dci(hc.data(), n), da(a, n), dal(alpha, n), dbe(beta, n);
     DevBuf<Geod> dg((const Geod*)g, n);            // keep caller's bytes in fields we never write
     DevBuf<int> derr(n), dok(n);
-    S5_BUFS_OK("geodesic_init_inf", di.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok());
-    const double *pi = di.ptr, *pa = da.ptr, *pal = dal.ptr, *pbe = dbe.ptr;
+    S5_BUFS_OK("geodesic_init_inf", di.ok() && dsi.ok() && dci.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok());
+    const double *pi = di.ptr, *psi = dsi.ptr, *pci = dci.ptr, *pa = da.ptr, *pal = dal.ptr, *pbe = dbe.ptr;
     Geod* pg = dg.ptr; int *pe = derr.ptr, *po = dok.ptr;
     S5_RUN(n, "geodesic_init_inf", [=] __device__(size_t i) {
         Geod gd = pg[i];
         GeodCache cache;
         int err = 0;                                // on failure *error receives the GD_* code
-        const double inc = pi[i];
-        const bool ok_ = init_inf(inc, sin(inc), cos(inc), pa[i], pal[i], pbe[i], gd, err, cache);
+        const bool ok_ = init_inf(pi[i], psi[i], pci[i], pa[i], pal[i], pbe[i], gd, err, cache);
         pg[i] = gd;
         pe[i] = err;
         po[i] = ok_ ? 1 : 0;
@@ -126,18 +143,20 @@ int sim5gpu_geodesic_init_inf_chain(size_t n, const double* incl, const double* 
     S5_NEED("geodesic_init_inf_chain", incl && a && alpha && beta && g && chain);
     if (n == 0) return SIM5GPU_OK;
     S5_DEVICE_OR_FAIL();
-    DevBuf<double> di(incl, n), da(a, n), dal(alpha, n), dbe(beta, n);
+    std::vector<double> hs, hc;
+    host_sincos(n, incl, hs, hc);
+    DevBuf<double> di(incl, n), dsi(hs.data(), n), dci(hc.data(), n), da(a, n), dal(alpha, n), dbe(beta, n);
     DevBuf<Geod> dg((const Geod*)g, n);            // keep caller's bytes in fields we never write
     DevBuf<int> derr(n), dok(n);
     DevBuf<sim5gpu_geodesic_chain> dch(n);
-    S5_BUFS_OK("geodesic_init_inf_chain", di.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok() && dch.ok());
-    const double *pi = di.ptr, *pa = da.ptr, *pal = dal.ptr, *pbe = dbe.ptr;
+    S5_BUFS_OK("geodesic_init_inf_chain", di.ok() && dsi.ok() && dci.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok() && dch.ok());
+    const double *pi = di.ptr, *psi = dsi.ptr, *pci = dci.ptr, *pa = da.ptr, *pal = dal.ptr, *pbe = dbe.ptr;
     Geod* pg = dg.ptr; int *pe = derr.ptr, *po = dok.ptr;
     sim5gpu_geodesic_chain* pc = dch.ptr;
     const bool have_disk = g_disk.ready != 0;
     const DiskConsts d = g_disk;
     S5_RUN(2 * n, "geodesic_init_inf_chain", [=] __device__(size_t j) {
-        geodesic_chain_lane(j, pi, pa, pal, pbe, pg, pe, po, pc, d, have_disk);          // s5_chain.hpp
+        geodesic_chain_lane(j, pi, psi, pci, pa, pal, pbe, pg, pe, po, pc, d, have_disk);          // s5_chain.hpp
     });
     S5_HIP(dg.to_host((Geod*)g));
     if (error) S5_HIP(derr.to_host(error));
@@ -155,15 +174,18 @@ int sim5gpu_geodesic_init_inf_chain_fast(size_t n, const double* incl, const dou
     S5_NEED("geodesic_init_inf_chain_fast", incl && a && alpha && beta && g && chain);
     if (n == 0) return SIM5GPU_OK;
     S5_DEVICE_OR_FAIL();
-    DevBuf<double> di(incl, n), da(a, n), dal(alpha, n), dbe(beta, n);
+    std::vector<double> hs, hc;
+    host_sincos(n, incl, hs, hc);
+    DevBuf<double> di(incl, n), dsi(hs.data(), n), dci(hc.data(), n), da(a, n), dal(alpha, n), dbe(beta, n);
     DevBuf<Geod> dg((const Geod*)g, n);            // keep caller's bytes in fields we never write
     DevBuf<int> derr(n), dok(n);
     DevBuf<sim5gpu_geodesic_chain> dch(n);
-    S5_BUFS_OK("geodesic_init_inf_chain_fast", di.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok() && dch.ok());
+    S5_BUFS_OK("geodesic_init_inf_chain_fast", di.ok() && dsi.ok() && dci.ok() && da.ok() && dal.ok() && dbe.ok() && dg.ok() && derr.ok() && dok.ok() && dch.ok());
     int* done = (2 * n <= 256) ? take_done_word() : nullptr;
-    hipError_t e = (hipError_t)s5_launch_geodesic_chain_fast(n, di.ptr, da.ptr, dal.ptr, dbe.ptr, dg.ptr, derr.ptr, dok.ptr, dch.ptr,
-                                                             &g_disk, sizeof g_disk, g_disk.ready != 0, done, nullptr);
-    if (e == hipSuccess) e = done ? wait_done_word(done) : hipDeviceSynchronize();
+    hipStream_t stream = thread_stream();
+    hipError_t e = (hipError_t)s5_launch_geodesic_chain_fast(n, di.ptr, dsi.ptr, dci.ptr, da.ptr, dal.ptr, dbe.ptr, dg.ptr, derr.ptr, dok.ptr, dch.ptr,
+                                                             &g_disk, sizeof g_disk, g_disk.ready != 0, done, stream);
+    if (e == hipSuccess) e = done ? wait_done_word(done, stream) : hipStreamSynchronize(stream);
     if (done) arena().give_pinned();
     if (e != hipSuccess) { set_error("geodesic_init_inf_chain_fast", e); return SIM5GPU_E_HIP; }
     S5_HIP(dg.to_host((Geod*)g));

@@ -20,6 +20,26 @@ Arena& arena()
     return a;
 }
 
+namespace {
+struct ThreadStream {
+    hipStream_t s = nullptr;
+    int dev = -1;
+    ~ThreadStream() { if (s) (void)hipStreamDestroy(s); }
+};
+}
+
+hipStream_t thread_stream()
+{
+    static thread_local ThreadStream t;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    if (t.s && t.dev == cur) return t.s;
+    if (t.s) { (void)hipStreamSynchronize(t.s); (void)hipStreamDestroy(t.s); t.s = nullptr; }
+    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) { t.s = nullptr; t.dev = -1; return nullptr; }   // (falls back to the null stream)
+    t.dev = cur;
+    return t.s;
+}
+
 void set_error(const char* what, hipError_t e)
 {
     snprintf(g_err, sizeof g_err, "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <time.h>
 #include "../../include/sim5gpu.h"
 #include "kernels.hpp"
 #include "s5_config.hpp"
@@ -77,7 +78,8 @@ struct Arena {
     char* pin = nullptr;
     size_t pin_cap = 0, pin_used = 0;
     int pin_live = 0;
-    static constexpr size_t PIN_BLOCK = 256 << 10, PIN_LIMIT = 16 << 10;
+    // (a look-ahead batch of the scalar shim -- a row of rays with their 240-byte records -- is staged here too)
+    static constexpr size_t PIN_BLOCK = 4 << 20, PIN_LIMIT = 512 << 10;
     void* take_pinned(size_t bytes)
     {
         if (bytes > PIN_LIMIT) return nullptr;
@@ -96,6 +98,12 @@ struct Arena {
     ~Arena() { release(); if (pin) (void)hipHostFree(pin); }   // thread exit: the blocks go back
 };
 Arena& arena();
+
+// The stream of the calling HOST THREAD (capi_core.hip): every batch entry point launches on it and waits for it alone, so
+// host threads that call the per-ray functions concurrently (ref README.md:16,202: "thread-safe", the OpenMP'd caller of
+// SURVEY 8(d)) neither serialise on the legacy null stream nor wait for each other's kernels in a device-wide
+// synchronisation.  Non-blocking (no implicit ordering with the null stream), one per thread and device, made on first use.
+hipStream_t thread_stream();
 
 // RAII device buffer for the host-array (batch) entry points
 template <typename T>
@@ -162,21 +170,37 @@ __global__ __launch_bounds__(256) void map_rays_flag(size_t n, F body, int* done
     if (threadIdx.x == 0) __hip_atomic_store(done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// wait for the word a small launch raises at its end (map_rays_flag below, k_chain.hip); every 256 looks ask the runtime too, so
-// that a launch that died -- it will never raise the word -- ends the wait with its error
-inline hipError_t wait_done_word(int* done)
+// wait for the word a small launch raises at its end (map_rays_flag below, k_chain.hip); now and then the runtime is asked
+// too, so that a launch that died -- it will never raise the word -- ends the wait with its error.  The wait is bounded in
+// WALL-CLOCK time (S5_DONE_TIMEOUT_S with the stream idle and the word still down) and its expiry has an error of its own.
+constexpr double S5_DONE_TIMEOUT_S = 2.0;
+inline double wall_seconds()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+inline hipError_t wait_done_word(int* done, hipStream_t stream)
 {
     hipError_t e = hipSuccess;
-    int idle_seen = 0;
+    double idle_since = -1.0;
     for (unsigned spin = 1; !__atomic_load_n(done, __ATOMIC_ACQUIRE); ++spin) {
+        cpu_relax();
         if ((spin & 255u) == 0u) {
-            e = hipStreamQuery(nullptr);
-            if (e == hipErrorNotReady) { e = hipSuccess; idle_seen = 0; continue; }
+            e = hipStreamQuery(stream);
+            if (e == hipErrorNotReady) { e = hipSuccess; idle_since = -1.0; continue; }
             if (e != hipSuccess) break;
             if (__atomic_load_n(done, __ATOMIC_ACQUIRE)) break;
-            // the stream is idle and the word is still down: the store is on its way -- or the kernel never ran.  Bounded:
-            // a thousand such looks (milliseconds) and the call fails instead of spinning for ever
-            if (++idle_seen > 1000) { e = hipErrorLaunchFailure; break; }
+            // the stream is idle and the word is still down: the store is on its way -- or the kernel never ran
+            const double now = wall_seconds();
+            if (idle_since < 0.0) idle_since = now;
+            else if (now - idle_since > S5_DONE_TIMEOUT_S) { e = hipErrorLaunchTimeOut; break; }
         }
     }
     return e;
@@ -195,22 +219,20 @@ int run_batch(size_t n, F body, const char* what)
 {
     if (n == 0) return SIM5GPU_OK;
     hipError_t e;
+    hipStream_t stream = thread_stream();
     // a handful of rays (the n = 1 calls of the SIM5 scalar API): the caller waits for ONE short kernel, and the blocking
     // wait's wake-up costs more than the kernel (measured through tests/tools/shim_rate.sh, shim_latency.py)
     int* done = (n <= 256) ? take_done_word() : nullptr;
     if (done) {
-        hipLaunchKernelGGL(map_rays_flag<F>, dim3(1), dim3(256), 0, 0, n, body, done);
+        hipLaunchKernelGGL(map_rays_flag<F>, dim3(1), dim3(256), 0, stream, n, body, done);
         e = hipGetLastError();
-        if (e == hipSuccess) e = wait_done_word(done);
+        if (e == hipSuccess) e = wait_done_word(done, stream);
         arena().give_pinned();
     } else {
         const unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(map_rays<F>, dim3(blocks), dim3(256), 0, 0, n, body);
+        hipLaunchKernelGGL(map_rays<F>, dim3(blocks), dim3(256), 0, stream, n, body);
         e = hipGetLastError();
-        if (e == hipSuccess) {
-            if (n <= 64) { while ((e = hipStreamQuery(nullptr)) == hipErrorNotReady) { } }
-            else e = hipDeviceSynchronize();
-        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
     }
     if (e != hipSuccess) { set_error(what, e); return SIM5GPU_E_HIP; }
     return SIM5GPU_OK;

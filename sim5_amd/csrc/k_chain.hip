@@ -17,12 +17,13 @@ namespace S5NS {
 // one workgroup; lane pair (2 i, 2 i + 1) = ray i, crossing orders 0 and 1; announces its end in `done` (page-locked host
 // memory, capi_batch.hip run_map) when that is given
 __global__ __launch_bounds__(256)
-void geodesic_chain_kernel(size_t n, const double* __restrict__ pi, const double* __restrict__ pa, const double* __restrict__ pal,
+void geodesic_chain_kernel(size_t n, const double* __restrict__ pi, const double* __restrict__ psi, const double* __restrict__ pci,
+                           const double* __restrict__ pa, const double* __restrict__ pal,
                            const double* __restrict__ pbe, Geod* pg, int* pe, int* po, sim5gpu_geodesic_chain* pc,
                            DiskConsts d, int have_disk, int* done)
 {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j < 2 * n) geodesic_chain_lane(j, pi, pa, pal, pbe, pg, pe, po, pc, d, have_disk != 0);      // s5_chain.hpp
+    if (j < 2 * n) geodesic_chain_lane(j, pi, psi, pci, pa, pal, pbe, pg, pe, po, pc, d, have_disk != 0);      // s5_chain.hpp
     if (done) {
         __threadfence_system();
         __syncthreads();
@@ -34,7 +35,7 @@ void geodesic_chain_kernel(size_t n, const double* __restrict__ pi, const double
 
 // `disk`: the process's disk constants (s5::DiskConsts of capi_core.hip; the two namespaces' structs are the same bytes).
 // `done` != nullptr: n <= 128 rays, one workgroup, the kernel raises *done at its end.
-int s5_launch_geodesic_chain_fast(size_t n, const double* incl, const double* a, const double* alpha, const double* beta,
+int s5_launch_geodesic_chain_fast(size_t n, const double* incl, const double* sin_i, const double* cos_i, const double* a, const double* alpha, const double* beta,
                                   void* geod, int* err, int* ok, sim5gpu_geodesic_chain* chain,
                                   const void* disk, size_t disk_bytes, int have_disk, int* done, hipStream_t stream)
 {
@@ -45,7 +46,7 @@ int s5_launch_geodesic_chain_fast(size_t n, const double* incl, const double* a,
     memcpy(&d, disk, sizeof d);
     if (done && 2 * n > 256) return (int)hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((2 * n + 255) / 256);
-    hipLaunchKernelGGL(geodesic_chain_kernel, dim3(blocks), dim3(256), 0, stream, n, incl, a, alpha, beta, (Geod*)geod, err, ok, chain,
+    hipLaunchKernelGGL(geodesic_chain_kernel, dim3(blocks), dim3(256), 0, stream, n, incl, sin_i, cos_i, a, alpha, beta, (Geod*)geod, err, ok, chain,
                        d, have_disk, done);
     return (int)hipGetLastError();
 }

@@ -162,7 +162,7 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
 int s5_launch_place_shares(int n_shares, const s5abi::RowMap* maps, const float* shares, size_t share_rows, int nx,
                            float* image_f, float* image_g, hipStream_t stream);
 // k_assemble.hip: *d_count += number of 32-bit words in which the two device buffers differ
-int s5_launch_geodesic_chain_fast(size_t n, const double* incl, const double* a, const double* alpha, const double* beta,
+int s5_launch_geodesic_chain_fast(size_t n, const double* incl, const double* sin_i, const double* cos_i, const double* a, const double* alpha, const double* beta,
                                   void* geod, int* err, int* ok, struct sim5gpu_geodesic_chain* chain,
                                   const void* disk, size_t disk_bytes, int have_disk, int* done, hipStream_t stream);
 int s5_launch_words_differ(const void* a, const void* b, size_t n_words, unsigned long long* d_count, hipStream_t stream);

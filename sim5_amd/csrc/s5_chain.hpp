@@ -10,39 +10,44 @@
 
 namespace S5NS {
 
-S5_DEV void geodesic_chain_lane(size_t j, const double* __restrict__ pi, const double* __restrict__ pa,
-                                const double* __restrict__ pal, const double* __restrict__ pbe, Geod* pg, int* pe, int* po,
-                                sim5gpu_geodesic_chain* pc, const DiskConsts& d, bool have_disk)
+S5_DEV void geodesic_chain_lane(size_t j, const double* __restrict__ pi, const double* __restrict__ psi, const double* __restrict__ pci,
+                                const double* __restrict__ pa, const double* __restrict__ pal, const double* __restrict__ pbe,
+                                Geod* pg, int* pe, int* po, sim5gpu_geodesic_chain* pc, const DiskConsts& d, bool have_disk)
 {
     const size_t i = j >> 1;
     const int k = (int)(j & 1);
     Geod gd = pg[i];
     GeodCache cache;
     int err = 0;
-    const double inc = pi[i];
-    const bool ok_ = init_inf(inc, sin(inc), cos(inc), pa[i], pal[i], pbe[i], gd, err, cache);
-    sim5gpu_geodesic_chain* c = &pc[i];
-    c->P[k] = NAN; c->r[k] = NAN; c->g[k] = NAN; c->flux[k] = NAN; c->have_r[k] = 0;
+    // (psi, pci: sin and cos of the inclination from the host's libm, capi_batch.hip host_sincos)
+    const bool ok_ = init_inf(pi[i], psi[i], pci[i], pa[i], pal[i], pbe[i], gd, err, cache);
+    // the record's values in registers, stored ONCE at the end: the record may be page-locked host memory the kernel writes
+    // over the bus (capi_util.hpp DevBuf), and nothing is read back through that pointer
+    double P = NAN, r = NAN, gf = NAN, flux = NAN;
+    int have_r = 0;
     if (ok_) {
         // K(mm) and the inverse cn of the observer's position come from init_inf (GeodCache): the very values the
         // crossing search would form again from the same expressions (the image kernels rely on the same identity)
-        c->P[k] = midplane_crossing(gd, k, cache);
-        if (!isnan(c->P[k])) {
-            c->r[k] = position_rad(gd, c->P[k]);
-            c->have_r[k] = 1;
-            if (!isnan(c->r[k])) {
-                c->g[k] = gfactor_kepler(c->r[k], pa[i], gd.l);
-                if (have_disk) c->flux[k] = disk_flux(d, c->r[k]);
+        P = midplane_crossing(gd, k, cache);
+        if (!isnan(P)) {
+            r = position_rad(gd, P);
+            have_r = 1;
+            if (!isnan(r)) {
+                gf = gfactor_kepler(r, pa[i], gd.l);
+                if (have_disk) flux = disk_flux(d, r);
             }
         }
     }
+    sim5gpu_geodesic_chain* c = &pc[i];
+    c->P[k] = P; c->r[k] = r; c->g[k] = gf; c->flux[k] = flux; c->have_r[k] = have_r;
+    // both lanes of a ray (j even / odd: one wave) have read pg[i] above; lane 0 writes the geodesic back after the wave has
+    // passed this point together
+    __builtin_amdgcn_wave_barrier();
     if (k == 0) {
         c->flux_valid = have_disk ? 1 : 0; c->valid = ok_ ? 1 : 0;
         c->a = pa[i]; c->l = gd.l;
         pe[i] = err;
         po[i] = ok_ ? 1 : 0;
-        // both lanes read pg[i] above; the geodesic is written back by lane 0 after its partner has read it too: the two
-        // lanes of a ray sit in one wave (j even / odd), which executes the read before the write in program order
         pg[i] = gd;
     }
 }

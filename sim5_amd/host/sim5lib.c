@@ -51,12 +51,15 @@ static void *s5_sym(const char *name)
     return p;
 }
 
+/* A failed call: the reference's convention is error() -- print "ERROR: ..." to stderr and return (ref src/sim5utils.c:41-54);
+ * nothing exits, the caller gets the NaN / FALSE the wrapper initialised its result with.  Only a machine without a usable
+ * GPU ends the program: there is no CPU path behind this API, and every later call would fail the same way. */
 static void s5_check(int rc, const char *fn)
 {
     if (rc != 0) {
         const char *(*last)(void) = (const char *(*)(void))s5_sym("sim5gpu_last_error");
         fprintf(stderr, "ERROR: sim5lib (MI355X): %s failed (%d): %s\n", fn, rc, last());
-        exit(EXIT_FAILURE);
+        if (rc == -1) exit(EXIT_FAILURE);               /* SIM5GPU_E_NO_DEVICE */
     }
 }
 
@@ -81,12 +84,20 @@ typedef int (*fn_d3)(size_t, const double *, const double *, const double *, dou
  * 1, the radii there, gfactorK and disk_nt_flux at those radii -- each by the device routine of the single call).  The record
  * is kept per thread next to a copy of the geodesic; geodesic_find_midplane_crossing, geodesic_position_rad, gfactorK and
  * disk_nt_flux answer from it when -- and only when -- their arguments are bit for bit the ones the record was made for (the
- * whole 240-byte struct, P, r, a, l, and the same disk set-up); any other call goes to the GPU as before.  SIM5_SHIM_NO_CHAIN=1
- * switches the record off (every call a round trip: the tests compare the two).
- * The record -- geodesic included -- is made in the library's FAST arithmetic (sim5gpu_geodesic_init_inf_chain_fast: the
- * whole-image kernels' default; what the caller waits for is the latency of one ray's dependent FP64 chain, three to four
- * times shorter there) and agrees with the strict routines of the single calls to ~1e-12 relative; SIM5_SHIM_STRICT=1 makes
- * it with the strict routines (sim5gpu_geodesic_init_inf_chain), value for value what the single calls return. */
+ * whole 240-byte struct, P, r, a, l, and the same disk set-up); any other call goes to the GPU as before.  The record is made
+ * by the STRICT routines -- the ones the single calls run -- so a function's value never depends on whether a record
+ * answered it (round 4 made it in the fast arithmetic by default).  SIM5_SHIM_NO_CHAIN=1 switches the record off
+ * (every call a round trip: the tests compare the two).
+ *
+ * LOOK-AHEAD (round 5).  Both callers of the reference walk an image in raster order (disk-image.c:53-58,
+ * python/sim5diskraytrace.py:163-165): a row is one (i, a, beta) with the SAME sequence of alpha values as the row before.
+ * So the shim remembers the alphas of the row it is being shown; when a new row starts with the first alpha of the previous
+ * one, it asks for the records of the WHOLE row -- the remembered alphas, bit for bit, with the new beta -- in ONE batch call,
+ * and answers the following geodesic_init_inf calls from them: each only after its four arguments have been compared, bit for
+ * bit, with the ones its record was made for.  The first call that does not match (another order, another image) drops the
+ * remaining records and goes to the GPU on its own, as before; nothing is ever answered from a record made for other
+ * arguments, so a caller in any order gets the values of the single calls.  One launch per row instead of one per ray.
+ * SIM5_SHIM_NO_LOOKAHEAD=1 switches it off. */
 typedef struct {
     double P[2], r[2], g[2], flux[2];
     double a, l;
@@ -96,25 +107,241 @@ typedef struct {
 typedef int (*fn_geod_chain)(size_t, const double *, const double *, const double *, const double *, geodesic *, int *, int *, s5_chain *);
 static __thread struct { int live; unsigned long disk_gen; geodesic g; s5_chain c; } s5_last;
 static unsigned long s5_disk_gen = 1;             /* bumped by every disk set-up of this process */
-static int s5_chain_mode = -1;                    /* -1 unknown, 0 off, 1 on (fast arithmetic), 2 on (strict) */
+static int s5_chain_mode = -1;                    /* -1 unknown, 0 off, 2 on (strict routines) */
+static int s5_lookahead = -1;                     /* -1 unknown, 0 off, 1 on */
 
 static int s5_same_bits(double x, double y) { return memcmp(&x, &y, sizeof x) == 0; }
 static int s5_record_for(const geodesic *g) { return s5_last.live && memcmp(g, &s5_last.g, sizeof *g) == 0; }
+
+#define S5_ROW_MAX 16384                          /* longest row remembered */
+#define S5_AHEAD_MAX 32768                        /* rays asked for in one look-ahead call (11 MB of records) */
+typedef struct {
+    /* the row being shown */
+    double i, a, beta;
+    double *alpha; int n, cap;
+    /* the row before it, complete */
+    double *tmpl; int tmpl_n, tmpl_cap;
+    double tmpl_i, tmpl_a, tmpl_beta;
+    int rows_seen;                 /* complete rows of this (i, a) with this alpha sequence, the template's included */
+    /* the callers' pixel formula, once its parameters reproduce what was shown bit for bit (s5_fit_*): alpha_x =
+     * ((x + .5) / nx - .5) * 2 * R and beta_y = ((y + .5) / ny - .5) * 2 * R [* (ny / nx)]  (ref disk-image.c:57-58,
+     * python/sim5diskraytrace.py:163-164); 0 = not known */
+    int fit_nx, fit_ny, fit_scaled, fit_tried;
+    double fit_R;
+    /* records made ahead: entry k was made for (spec_i, spec_a, spec_alpha[k], spec_beta[k]); `cursor` = the entry the next
+     * call should ask for */
+    int spec_n, cursor, spec_cap;
+    double spec_i, spec_a;
+    double *spec_alpha, *spec_beta, *arg_i, *arg_a;
+    geodesic *g; int *err, *ok; s5_chain *c;
+    unsigned long disk_gen;
+} s5_ahead;
+static __thread s5_ahead s5_la;
+
+static int s5_grow(double **p, int *cap, int need)
+{
+    if (need <= *cap) return 1;
+    int nc = *cap ? *cap : 256;
+    while (nc < need) nc *= 2;
+    double *q = (double *)realloc(*p, (size_t)nc * sizeof(double));
+    if (!q) return 0;
+    *p = q; *cap = nc;
+    return 1;
+}
+
+/* the callers' expression for a pixel coordinate, operation for operation (volatile: no contraction, no excess precision) */
+static double s5_pixel(int x, int n, double R, double scale)
+{
+    volatile double t = ((double)x + .5) / (double)n;
+    t = t - 0.5;
+    t = t * 2.0;
+    t = t * R;
+    if (scale != 1.0) t = t * scale;
+    return t;
+}
+
+/* n and R of the formula from its first two values v0, v1 (pixels 0 and 1), or 0: tried with R a few units in the last
+ * place around v0 / t0, accepted only if BOTH values come out bit for bit */
+static int s5_fit_axis(double v0, double v1, double scale, double R_hint, double *R_out)
+{
+    const double d = v1 - v0;
+    if (!(d > 0.0) || !(v0 < 0.0)) return 0;
+    const double nf = 1.0 - 2.0 * v0 / d;
+    if (!(nf >= 2.0 && nf <= 1e6)) return 0;
+    const int n = (int)(nf + 0.5);
+    if (fabs(nf - (double)n) > 1e-6 * nf) return 0;
+    double R0 = R_hint;
+    if (!(R0 > 0.0)) R0 = v0 / ((((double)0 + .5) / (double)n - 0.5) * 2.0 * scale);
+    double R = R0;
+    for (int k = 0; k < 9; k++) {                    /* R0, then its neighbours alternately up and down */
+        if (R > 0.0 && s5_same_bits(s5_pixel(0, n, R, scale), v0) && s5_same_bits(s5_pixel(1, n, R, scale), v1)) { *R_out = R; return n; }
+        if (R_hint > 0.0) break;                      /* the other axis fixed R already */
+        R = R0;
+        for (int j = 0; j <= k / 2; j++) R = nextafter(R, (k & 1) ? 0.0 : INFINITY);
+    }
+    return 0;
+}
+
+static void s5_forget_fit(void) { s5_la.fit_nx = s5_la.fit_ny = s5_la.fit_scaled = s5_la.fit_tried = 0; s5_la.fit_R = 0.0; }
+
+/* The caller shows (i, a, alpha, beta): keep the book of rows.  Returns what could be made ahead now:
+ *   1  this call opens a row that repeats the remembered one (same i, a, first alpha)
+ *   2  this is the second call of the FIRST row of an image and the pixel formula reproduces both alphas: the rest of the row
+ *   0  nothing */
+static int s5_row_note(double i, double a, double alpha, double beta)
+{
+    s5_ahead *L = &s5_la;
+    if (L->n > 0 && s5_same_bits(i, L->i) && s5_same_bits(a, L->a) && s5_same_bits(beta, L->beta)) {
+        if (L->n < S5_ROW_MAX && s5_grow(&L->alpha, &L->cap, L->n + 1)) L->alpha[L->n++] = alpha;
+        else L->n = S5_ROW_MAX + 1;                           /* too long to remember: never becomes a template */
+        if (L->n == 2 && L->tmpl_n == 0 && !L->fit_tried) {
+            L->fit_tried = 1;
+            L->fit_nx = s5_fit_axis(L->alpha[0], L->alpha[1], 1.0, 0.0, &L->fit_R);
+            if (L->fit_nx > 2 && L->fit_nx <= S5_ROW_MAX) return 2;
+            L->fit_nx = 0;
+        }
+        return 0;
+    }
+    /* a new row: the finished one becomes the template if it was a row at all */
+    const int same_image = L->n >= 2 && L->n <= S5_ROW_MAX && s5_same_bits(i, L->i) && s5_same_bits(a, L->a);
+    const int repeats = same_image && L->tmpl_n == L->n && memcmp(L->tmpl, L->alpha, (size_t)L->n * sizeof(double)) == 0;
+    if (same_image) {
+        const double beta_prev = L->beta;
+        double *t = L->tmpl; int tc = L->tmpl_cap;
+        L->tmpl = L->alpha; L->tmpl_cap = L->cap; L->tmpl_n = L->n; L->tmpl_i = L->i; L->tmpl_a = L->a;
+        L->alpha = t; L->cap = tc;
+        L->rows_seen = repeats ? L->rows_seen + 1 : 1;
+        /* two complete-or-begun rows: the vertical axis of the formula (needs the horizontal one: R and nx) */
+        if (L->rows_seen == 1 && L->fit_nx == L->tmpl_n && L->fit_ny == 0) {
+            double R = 0.0;
+            int ny = s5_fit_axis(beta_prev, beta, 1.0, L->fit_R, &R);                       /* python caller: square image */
+            if (ny > 1) { L->fit_ny = ny; L->fit_scaled = 0; }
+            else {
+                /* ref disk-image.c:58: ... * 2 * rmax * ((double)ny / (double)nx) */
+                const double d = beta - beta_prev;
+                const double nf = (d > 0.0) ? 1.0 - 2.0 * beta_prev / d : 0.0;
+                const int nyc = (nf >= 2.0 && nf <= 1e6) ? (int)(nf + 0.5) : 0;
+                if (nyc > 1) {
+                    const double sc = (double)nyc / (double)L->fit_nx;
+                    if (s5_same_bits(s5_pixel(0, nyc, L->fit_R, sc), beta_prev) && s5_same_bits(s5_pixel(1, nyc, L->fit_R, sc), beta)) { L->fit_ny = nyc; L->fit_scaled = 1; }
+                }
+            }
+        }
+        L->tmpl_beta = beta_prev;
+    } else { L->tmpl_n = 0; L->rows_seen = 0; s5_forget_fit(); }
+    L->i = i; L->a = a; L->beta = beta; L->n = 0;
+    if (s5_grow(&L->alpha, &L->cap, 1)) L->alpha[L->n++] = alpha;
+    return (L->tmpl_n >= 2 && s5_same_bits(alpha, L->tmpl[0])) ? 1 : 0;
+}
+
+static int s5_spec_room(int n)
+{
+    s5_ahead *L = &s5_la;
+    if (n <= L->spec_cap) return 1;
+    int nc = L->spec_cap ? L->spec_cap : 256;
+    while (nc < n) nc *= 2;
+    double *sa = (double *)realloc(L->spec_alpha, (size_t)nc * sizeof(double));
+    if (sa) L->spec_alpha = sa;
+    double *sb = (double *)realloc(L->spec_beta, (size_t)nc * sizeof(double));
+    if (sb) L->spec_beta = sb;
+    double *ai = (double *)realloc(L->arg_i, (size_t)nc * sizeof(double));
+    if (ai) L->arg_i = ai;
+    double *aa = (double *)realloc(L->arg_a, (size_t)nc * sizeof(double));
+    if (aa) L->arg_a = aa;
+    geodesic *g = (geodesic *)realloc(L->g, (size_t)nc * sizeof(geodesic));
+    if (g) L->g = g;
+    int *e = (int *)realloc(L->err, (size_t)nc * sizeof(int));
+    if (e) L->err = e;
+    int *o = (int *)realloc(L->ok, (size_t)nc * sizeof(int));
+    if (o) L->ok = o;
+    s5_chain *c = (s5_chain *)realloc(L->c, (size_t)nc * sizeof(s5_chain));
+    if (c) L->c = c;
+    if (!sa || !sb || !ai || !aa || !g || !e || !o || !c) { L->spec_cap = 0; return 0; }
+    memset(L->g, 0, (size_t)nc * sizeof(geodesic));
+    L->spec_cap = nc;
+    return 1;
+}
+
+/* Records made ahead in ONE batch call; 0 if that was not possible (the caller goes on alone).
+ *   what = 1: the template row with this call's beta -- and, where the vertical axis of the formula is known and reproduces
+ *             this beta, the rows after it too, up to S5_AHEAD_MAX rays
+ *   what = 2: pixels 2 .. nx-1 of the first row by the formula (this call is pixel 1: it is answered on its own) */
+static int s5_make_ahead(fn_geod_chain fc, int what, double i, double a, double beta)
+{
+    s5_ahead *L = &s5_la;
+    int n = 0;
+    L->spec_n = 0;
+    if (what == 2) {
+        n = L->fit_nx - 2;
+        if (n < 1 || !s5_spec_room(n)) return 0;
+        for (int k = 0; k < n; k++) { L->spec_alpha[k] = s5_pixel(k + 2, L->fit_nx, L->fit_R, 1.0); L->spec_beta[k] = beta; }
+    } else {
+        const int nx = L->tmpl_n;
+        int rows = 1;
+        int y = L->rows_seen;                                  /* this row's index if the image started with the first template */
+        const double sc = L->fit_scaled ? (double)L->fit_ny / (double)L->fit_nx : 1.0;
+        /* (the next image of the same size and view starts over at row 0) */
+        if (L->fit_ny > 0 && L->fit_nx == nx && s5_same_bits(s5_pixel(0, L->fit_ny, L->fit_R, sc), beta)) { y = 0; L->rows_seen = 0; }
+        if (L->fit_ny > 0 && L->fit_nx == nx && y < L->fit_ny && s5_same_bits(s5_pixel(y, L->fit_ny, L->fit_R, sc), beta)) {
+            rows = L->fit_ny - y;
+            if (rows > S5_AHEAD_MAX / nx) rows = S5_AHEAD_MAX / nx;
+            if (rows < 1) rows = 1;
+        }
+        n = rows * nx;
+        if (!s5_spec_room(n)) return 0;
+        for (int r = 0; r < rows; r++) {
+            const double b = (r == 0) ? beta : s5_pixel(y + r, L->fit_ny, L->fit_R, sc);
+            for (int k = 0; k < nx; k++) { L->spec_alpha[r * nx + k] = L->tmpl[k]; L->spec_beta[r * nx + k] = b; }
+        }
+    }
+    for (int k = 0; k < n; k++) { L->arg_i[k] = i; L->arg_a[k] = a; }
+    const int rc = fc((size_t)n, L->arg_i, L->arg_a, L->spec_alpha, L->spec_beta, L->g, L->err, L->ok, L->c);
+    if (rc != 0) { s5_check(rc, "geodesic_init_inf (look-ahead)"); return 0; }
+    L->spec_n = n; L->cursor = 0;
+    L->spec_i = i; L->spec_a = a;
+    L->disk_gen = s5_disk_gen;
+    return 1;
+}
+
+/* the record made ahead for exactly these arguments, if it is the next one; -1 otherwise (what was made ahead is dropped) */
+static int s5_row_take(double i, double a, double alpha, double beta)
+{
+    s5_ahead *L = &s5_la;
+    if (!L->spec_n) return -1;
+    if (L->cursor < L->spec_n && s5_same_bits(alpha, L->spec_alpha[L->cursor]) && s5_same_bits(beta, L->spec_beta[L->cursor]) &&
+        s5_same_bits(i, L->spec_i) && s5_same_bits(a, L->spec_a)) return L->cursor++;
+    if (L->cursor < L->spec_n) s5_forget_fit();               /* the caller left the predicted order: no formula any more */
+    L->spec_n = 0;
+    return -1;
+}
 
 int geodesic_init_inf(double i, double a, double alpha, double beta, geodesic *g, int *error)
 {
     int err = 0, ok = 0;
     if (s5_chain_mode < 0) {
-        const char *e = getenv("SIM5_SHIM_NO_CHAIN"), *st = getenv("SIM5_SHIM_STRICT");
-        s5_chain_mode = (e && *e && *e != '0') ? 0 : ((st && *st && *st != '0') ? 2 : 1);
+        const char *e = getenv("SIM5_SHIM_NO_CHAIN"), *la = getenv("SIM5_SHIM_NO_LOOKAHEAD");
+        s5_chain_mode = (e && *e && *e != '0') ? 0 : 2;
+        s5_lookahead = (s5_chain_mode && !(la && *la && *la != '0')) ? 1 : 0;
     }
     if (s5_chain_mode) {
-        S5_FN(fn_geod_chain, fc_fast, "sim5gpu_geodesic_init_inf_chain_fast");
-        S5_FN(fn_geod_chain, fc_strict, "sim5gpu_geodesic_init_inf_chain");
-        fn_geod_chain fc = (s5_chain_mode == 2) ? fc_strict : fc_fast;
+        S5_FN(fn_geod_chain, fc, "sim5gpu_geodesic_init_inf_chain");
         s5_last.live = 0;
-        s5_check(fc(1, &i, &a, &alpha, &beta, g, &err, &ok, &s5_last.c), "geodesic_init_inf");
-        if (ok) { memcpy(&s5_last.g, g, sizeof *g); s5_last.disk_gen = s5_disk_gen; s5_last.live = 1; }
+        int k = -1;
+        if (s5_lookahead) {
+            k = s5_row_take(i, a, alpha, beta);
+            const int what = s5_row_note(i, a, alpha, beta);
+            if (k < 0 && what == 1 && s5_make_ahead(fc, 1, i, a, beta)) k = s5_row_take(i, a, alpha, beta);
+            else if (k < 0 && what == 2) (void)s5_make_ahead(fc, 2, i, a, beta);         /* (this call itself goes alone) */
+        }
+        if (k >= 0) {
+            const s5_ahead *L = &s5_la;
+            memcpy(g, &L->g[k], sizeof *g);
+            err = L->err[k]; ok = L->ok[k];
+            if (ok) { memcpy(&s5_last.g, g, sizeof *g); s5_last.c = L->c[k]; s5_last.disk_gen = L->disk_gen; s5_last.live = 1; }
+        } else {
+            s5_check(fc(1, &i, &a, &alpha, &beta, g, &err, &ok, &s5_last.c), "geodesic_init_inf");
+            if (ok) { memcpy(&s5_last.g, g, sizeof *g); s5_last.disk_gen = s5_disk_gen; s5_last.live = 1; }
+        }
     } else {
         S5_FN(fn_geod_init_inf, f, "sim5gpu_geodesic_init_inf");
         s5_check(f(1, &i, &a, &alpha, &beta, g, &err, &ok), "geodesic_init_inf");

@@ -45,7 +45,8 @@ def test_single_gpu_line_carries_every_config():
     # SURVEY 8(f) ranks 1 and 3 are driver-timed too
     assert x["f1_surface_search_1024"]["surface_hits"] > 100000 and x["f1_surface_search_1024"]["job_ms"] > 0
     sa = x["scalar_api_example04_loop"]              # the example-04 loop through the scalar API (host-side; skipped without gcc)
-    assert ("skipped" in sa) or (sa["rays_per_s"] > 1.5e4 and sa["us_per_ray"] < 70.0), sa
+    # round 5: faster than the reference on one core of this box (1.2e6 rays/s) -- floor 2e6 (measured 1.4e7), same hits
+    assert ("skipped" in sa) or (sa["rays_per_s"] > 2e6 and sa["disk_hits"] == sa["disk_hits_reference"]), sa
     assert x["f3_spectrum_1024_x128"]["spectrum_sum"] > 0 and x["f3_spectrum_1024_x128"]["pixel_energy_pairs_per_s"] > 1e10
     c5 = x["c5_8192_x8_inclinations"]
     assert c5["hits_ok"] and len(c5["per_inclination"]) == 8

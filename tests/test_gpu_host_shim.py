@@ -56,40 +56,37 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     assert abs(float(tail[4]) / orc.geodesic_timedelay(C.byref(gd), P1, 0.0, 0.0, P2, 0.0, 0.0) - 1) < 1e-9
 
 
+def _cc(tmp_path, src, name, extra=()):
+    exe = str(tmp_path / name)
+    subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", src), os.path.join(HOST, "sim5lib.c"), "-I", HOST, "-o", exe, "-lm",
+                    "-O3", "-w", "-fgnu89-inline"] + list(extra), check=True)
+    return exe
+
+
 def test_c1_through_the_scalar_api_one_round_trip_per_ray(tmp_path, capi, golden):
     """BASELINE.json configs[0] -- 64 x 64, a = 0, i = 60 deg, the loop of ref examples/04-disk-image-eqplane/disk-image.c:
     53-105 -- through the SIM5 SCALAR API on the GPU (tests/c/shim_probe.c is that loop, call for call), against the golden
-    image of the unmodified reference (img_c1_64_a0_i60.npz: hit / miss exact, r, g, flux within 1e-6).  Run twice: with
-    the shim's record of the ray (geodesic_init_inf brings the crossings, radii, g-factors and fluxes of the ray in the same
-    launch; the follow-up calls are answered from it after a bit-for-bit check of their arguments) and with it switched off
-    (SIM5_SHIM_NO_CHAIN=1: five round trips per ray).  The record made with the strict routines (SIM5_SHIM_STRICT=1) must
-    give the call-by-call run's text, digit for digit; the default record, made in the library's fast arithmetic, the same
-    hits and errors and every number within 1e-10 of it.  All three against the golden image; the rates are printed."""
+    image of the unmodified reference (img_c1_64_a0_i60.npz: hit / miss exact, r, g, flux within 1e-6).  Run three ways: with
+    the shim's look-ahead (records of whole rows asked for in one batch call, every call answered after a bit-for-bit check of
+    its arguments: the default), with the per-ray record alone (SIM5_SHIM_NO_LOOKAHEAD=1: geodesic_init_inf brings the
+    crossings, radii, g-factors and fluxes of its ray in the same launch) and call by call (SIM5_SHIM_NO_CHAIN=1: five round
+    trips per ray).  All records are made by the strict routines the single calls run, so the three outputs must be the same
+    TEXT, digit for digit.  The rates are printed."""
     import time
-    exe = str(tmp_path / "probe")
-    subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", "shim_probe.c"), os.path.join(HOST, "sim5lib.c"),
-                    "-I", HOST, "-o", exe, "-lm", "-O3", "-w", "-fgnu89-inline"], check=True)
+    exe = _cc(tmp_path, "shim_probe.c", "probe")
     n, a, inc = 64, 0.0, 60.0
     outs, secs = [], []
-    for extra in ({}, {"SIM5_SHIM_STRICT": "1"}, {"SIM5_SHIM_NO_CHAIN": "1"}):
+    for extra in ({}, {"SIM5_SHIM_NO_LOOKAHEAD": "1"}, {"SIM5_SHIM_NO_CHAIN": "1"}):
         env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH, **extra)
         t0 = time.time()
         p = subprocess.run([exe, str(a), str(inc), str(n)], env=env, capture_output=True, text=True, timeout=900)
         secs.append(time.time() - t0)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(p.stdout)
-    assert outs[1] == outs[2], "the record-served run (strict arithmetic) differs from the call-by-call run"
-    table = lambda txt: np.array([[float(v) for v in ln.split()] for ln in txt.strip().splitlines()[1:1 + n * n]])
-    fast, strict = table(outs[0]), table(outs[1])
-    assert np.array_equal(fast[:, :4], strict[:, :4]), "pixel indices, error codes or hit orders differ between the two records"
-    lit = strict[:, 3] > 0
-    assert np.array_equal(np.isfinite(fast[:, 4:7]), np.isfinite(strict[:, 4:7]))
-    worst = float(np.max(np.abs(fast[lit, 4:6] / strict[lit, 4:6] - 1.0)))                 # r, g
-    worst_f = float(np.max(np.abs(fast[lit, 6] - strict[lit, 6])) / strict[lit, 6].max())    # flux, against the brightest pixel
-    assert worst < 1e-10 and worst_f < 1e-10, (worst, worst_f)
-    print("scalar API, %d rays: %.3e rays/s with one round trip per ray (fast record; worst difference from the strict one %.1e), "
-          "%.3e with the strict record, %.3e call by call (process start-up included)" % (
-              n * n, n * n / secs[0], worst, n * n / secs[1], n * n / secs[2]))
+    assert outs[0] == outs[2], "the look-ahead run differs from the call-by-call run"
+    assert outs[1] == outs[2], "the record-served run differs from the call-by-call run"
+    print("scalar API, %d rays (process start-up included): %.3e rays/s with the look-ahead, %.3e with one round trip per ray, "
+          "%.3e call by call" % (n * n, n * n / secs[0], n * n / secs[1], n * n / secs[2]))
     g = golden("img_c1_64_a0_i60.npz")
     rec = np.array([[float(v) for v in ln.split()] for ln in outs[0].strip().splitlines()[1:1 + n * n]])
     hit = np.where(g["cls"] == 2, 1, np.where(g["cls"] == 4, 2, 0)).ravel()
@@ -101,6 +98,50 @@ def test_c1_through_the_scalar_api_one_round_trip_per_ray(tmp_path, capi, golden
     # pixels the reference rejects (error from geodesic_init_inf) are rejected here with the same code
     err_ref = (g["cls"] == 0).ravel()
     assert np.array_equal(rec[:, 2] != 0, err_ref)
+
+
+def test_lookahead_is_order_independent(tmp_path, capi):
+    """The shim's look-ahead predicts the caller's NEXT pixels; it must never change what a call returns.  tests/c/shim_order.c
+    asks for the pixels of an odd-sized, non-square image (37 x 23: central column and row included) in raster order, column by
+    column, shuffled, raster with every third pixel skipped and caught up later, and as two images interleaved row by row: every
+    order must print, pixel for pixel, the text of the raster run with the look-ahead switched off."""
+    exe = _cc(tmp_path, "shim_order.c", "order")
+    a, inc, nx, ny = 0.9, 65.0, 37, 23
+    env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+    run = lambda spin, order, **kw: subprocess.run([exe, str(spin), str(inc), str(nx), str(ny), str(order)], env=dict(env, **kw),
+                                                   capture_output=True, text=True, timeout=600)
+    base = run(a, 0, SIM5_SHIM_NO_LOOKAHEAD="1")
+    assert base.returncode == 0 and len(base.stdout.splitlines()) == nx * ny, base.stderr[-1000:]
+    for order in (0, 1, 2, 3):
+        p = run(a, order)
+        assert p.returncode == 0, p.stderr[-1000:]
+        assert p.stdout == base.stdout, "order %d: output differs from the raster run without look-ahead" % order
+    half = run(a, 5, SIM5_SHIM_NO_LOOKAHEAD="1")
+    p = run(a, 4)
+    first = "\n".join(l for l in p.stdout.splitlines() if not l.startswith("second")) + "\n"
+    second = "\n".join(l[len("second "):] for l in p.stdout.splitlines() if l.startswith("second")) + "\n"
+    assert first == base.stdout and second == half.stdout, "interleaved images differ from the separate runs"
+    # and a larger raster image, where several rows are asked for in one call: against the per-ray record
+    big = [subprocess.run([exe, "0.998", "70", "160", "96", "0"], env=dict(env, **kw), capture_output=True, text=True, timeout=900)
+           for kw in ({}, {"SIM5_SHIM_NO_LOOKAHEAD": "1"})]
+    assert big[0].returncode == 0 and big[0].stdout == big[1].stdout and len(big[0].stdout.splitlines()) == 160 * 96
+
+
+def test_scalar_api_from_eight_host_threads(tmp_path, capi):
+    """ref README.md:16,202: the per-ray functions are callable concurrently from any host thread.  tests/c/shim_threads.c:
+    eight threads share one 48 x 48 image (rows dealt round robin), each through the scalar API -- its own record, look-ahead,
+    staging memory and stream -- and each makes two batch calls of the C-ABI between its rows, checked bit for bit against the
+    scalar calls.  The text printed in image order must be the single-threaded run's."""
+    libdir = os.path.dirname(capi.LIB_PATH)
+    exe = _cc(tmp_path, "shim_threads.c", "threads", ["-I", os.path.join(ROOT, "include"), "-lpthread", "-L", libdir, "-lsim5gpu",
+                                                     "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+    outs = []
+    for threads in (1, 8):
+        p = subprocess.run([exe, "0.9", "65", "48", str(threads)], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (p.stdout[-300:], p.stderr[-1500:])
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] and "0 mismatches" in outs[0] and len(outs[0].splitlines()) == 48 * 48 + 1
 
 
 def test_boundary_prototypes_program(tmp_path, capi):
