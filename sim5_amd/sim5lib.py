@@ -8,12 +8,44 @@ python/sim5diskmodel.py:15) keep working when this module is the `sim5lib` they 
 Each call is one batch call with n = 1 through the C-ABI (sim5_amd/capi.py); no ray arithmetic happens
 here and there is no CPU fallback.  Throughput work should use sim5_amd.diskraytrace (batched) or the
 whole-job kernels instead; this module is the compatibility layer.
+
+The calls of the image loop (ref python/sim5diskraytrace.py:163-172, 228-250: geodesic_init_inf, then the crossing, the
+radius, g-factor and flux of the ray) go through the C host shim built as a shared library (sim5_amd/host/sim5lib.c ->
+lib/libsim5shim.so): its per-ray record and its look-ahead by image rows serve Python callers exactly as they serve C
+callers -- same code, same bit-for-bit argument checks.
 """
 import ctypes as C
+import os
+import subprocess
 
 import numpy as np
 
 from . import capi as _c
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_shim_lib = None
+
+
+def _shim():
+    """libsim5shim.so (built by sim5_amd/host/Makefile; on demand here if the tree was not built), bound to the very
+    libsim5gpu.so that sim5_amd.capi has loaded"""
+    global _shim_lib
+    if _shim_lib is None:
+        path = os.path.join(_HERE, "lib", "libsim5shim.so")
+        src = os.path.join(_HERE, "host", "sim5lib.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "host")], check=True)
+        os.environ.setdefault("SIM5GPU_LIB", _c.LIB_PATH)
+        L = C.CDLL(path)
+        D, I, P = C.c_double, C.c_int, C.c_void_p
+        L.geodesic_init_inf.restype = I; L.geodesic_init_inf.argtypes = [D, D, D, D, P, C.POINTER(I)]
+        L.geodesic_find_midplane_crossing.restype = D; L.geodesic_find_midplane_crossing.argtypes = [P, I]
+        L.geodesic_position_rad.restype = D; L.geodesic_position_rad.argtypes = [P, D]
+        L.gfactorK.restype = D; L.gfactorK.argtypes = [D, D, D]
+        L.disk_nt_flux.restype = D; L.disk_nt_flux.argtypes = [D]
+        L.disk_nt_setup.restype = I; L.disk_nt_setup.argtypes = [D, D, D, D, I]
+        _shim_lib = L
+    return _shim_lib
 
 # ---- constants (ref: src/sim5const.h:24-95) --------------------------------------------------------
 TINY = 1e-40
@@ -182,7 +214,7 @@ def ellK(r, a):
 
 
 def gfactorK(r, a, l):
-    return float(_c.gfactorK([r], a, l)[0])
+    return _shim().gfactorK(r, a, l)
 
 
 def kerr_metric(a, r, m, metric):
@@ -230,11 +262,11 @@ def photon_carter_const(k, metric):
 
 
 def geodesic_init_inf(i, a, alpha, beta, g, status=None):
-    rec, err, ok = _c.geodesic_init_inf(i, a, [alpha], beta)
-    g._rec[:] = rec
+    err = C.c_int(0)
+    ok = _shim().geodesic_init_inf(i, a, alpha, beta, g._rec.ctypes.data, C.byref(err))
     if status is not None:
-        status.assign(int(err[0]))
-    return int(ok[0])
+        status.assign(err.value)
+    return int(ok)
 
 
 def geodesic_init_src(a, r, m, k, ppc, g, status=None):
@@ -246,7 +278,7 @@ def geodesic_init_src(a, r, m, k, ppc, g, status=None):
 
 
 def geodesic_find_midplane_crossing(g, order):
-    return float(_c.geodesic_find_midplane_crossing(g._rec, order)[0])
+    return _shim().geodesic_find_midplane_crossing(g._rec.ctypes.data, int(order))
 
 
 def geodesic_P_int(g, r, ppc):
@@ -254,7 +286,7 @@ def geodesic_P_int(g, r, ppc):
 
 
 def geodesic_position_rad(g, P):
-    return float(_c.geodesic_position_rad(g._rec, P)[0])
+    return _shim().geodesic_position_rad(g._rec.ctypes.data, P)
 
 
 def geodesic_position_pol(g, P):
@@ -285,7 +317,7 @@ def geodesic_follow(g, step, P, r, m, status=None):
 
 
 def disk_nt_setup(M, a, mdot_or_L, alpha, options=0):
-    _c.disk_nt_setup(M, a, mdot_or_L, alpha, options)
+    _shim().disk_nt_setup(M, a, mdot_or_L, alpha, int(options))        # (through the shim: its records know the disk they were made for)
     return 0
 
 
@@ -298,7 +330,7 @@ def disk_nt_r_min():
 
 
 def disk_nt_flux(r):
-    return float(_c.disk_nt_flux([r])[0])
+    return _shim().disk_nt_flux(r)
 
 
 def disk_nt_lumi():

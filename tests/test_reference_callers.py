@@ -23,11 +23,47 @@ REF = "/root/reference"
 needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "python")), reason="reference tree not present on this box")
 
 
+class _OracleShim:
+    """The entry points sim5_amd/sim5lib.py takes from libsim5shim.so (ctypes signatures: pointers as integers), answered by
+    the CPU checker: test infrastructure for the container without a GPU"""
+    def __init__(self, oc):
+        self.oc = oc
+
+    @staticmethod
+    def _rec(ptr):
+        import ctypes as C
+        import sim5_amd.capi as capi
+        return np.frombuffer((C.c_char * 240).from_address(ptr), dtype=capi.GEODESIC_DTYPE)
+
+    def geodesic_init_inf(self, i, a, alpha, beta, gptr, err_ref):
+        rec, err, ok = self.oc.geodesic_init_inf(i, a, [alpha], beta)
+        self._rec(gptr)[:] = rec
+        err_ref._obj.value = int(err[0])
+        return int(ok[0])
+
+    def geodesic_find_midplane_crossing(self, gptr, order):
+        return float(self.oc.geodesic_find_midplane_crossing(self._rec(gptr), order)[0])
+
+    def geodesic_position_rad(self, gptr, P):
+        return float(self.oc.geodesic_position_rad(self._rec(gptr), P)[0])
+
+    def gfactorK(self, r, a, l):
+        return float(self.oc.gfactorK([r], a, l)[0])
+
+    def disk_nt_flux(self, r):
+        return float(self.oc.disk_nt_flux([r])[0])
+
+    def disk_nt_setup(self, M, a, mdot, alpha, options):
+        self.oc.disk_nt_setup(M, a, mdot, alpha, options)
+        return 0
+
+
 @needs_ref
 def test_reference_python_raytracer_runs_unchanged_over_sim5lib_module(golden, monkeypatch):
     import oracle_capi
     import sim5_amd.sim5lib as s5
     monkeypatch.setattr(s5, "_c", oracle_capi)                  # CPU stand-in for the C-ABI (no GPU in this container)
+    monkeypatch.setattr(s5, "_shim", lambda: _OracleShim(oracle_capi))     # ... and for the C host shim the image loop's calls go through
     monkeypatch.setitem(sys.modules, "sim5lib", s5)
     monkeypatch.setattr(np, "float", float, raising=False)      # the reference predates numpy 1.24 (python/sim5diskraytrace.py:154)
     monkeypatch.syspath_prepend(os.path.join(REF, "python"))
