@@ -24,6 +24,7 @@ using namespace s5abi;
 
 constexpr int SPEC_TILE_W = 32, SPEC_TILE_H = 8;
 
+#if !S5_FAST
 S5_DEV double planck_python(double T, double limbf, double f, double E)
 {
     // python/sim5diskspectrum.py:72-86 (its own constants; note kev2freq twice, not 1/freq2kev)
@@ -32,7 +33,216 @@ S5_DEV double planck_python(double T, double limbf, double f, double E)
     return limbf * 2.0 * planck_h * (nu * nu * nu) / c2 / (f * f * f * f) *
            1. / (exp((planck_h * kev2freq * E) / (kB * f * T)) - 1.0) * kev2freq;
 }
+#endif
 
+// (T, g, limb-darkening factor) of one traced ray (python/sim5diskraytrace.py:96-123, 340-390); g = 0: contributes nothing
+template <class PRM>
+S5_DEV void spectrum_pixel(const PRM& p, const SpectrumParams& sp, const ThinRay& t, double& T, double& g, double& limbf)
+{
+    T = 0.0; g = 0.0; limbf = 0.0;
+    if (t.cls == PX_HIT0 && t.flux != 0.0) {
+        double k[4], U[4], N[4];
+        const double e0[4] = { 1.0, 0.0, 0.0, 0.0 }, e2[4] = { 0.0, 0.0, 1.0, 0.0 };
+        photon_momentum(p.a, t.r, 0.0, t.l, t.q, t.dP, 1.0, k);           // ref py :250
+        Metric mt;
+        kerr_metric(p.a, t.r, 0.0, mt);
+        Tetrad tt;
+        tetrad_surface(mt, omega_from_ell(disk_ell(p.disk, t.r), mt), 0.0, 0.0, tt);
+        on2bl(e0, U, tt);
+        on2bl(e2, N, tt);
+        const double kU = dot(k, U, mt);
+        const double gg = mdiv(k[0] * mt.g00 + k[3] * mt.g03, kU);
+        double mue = mdiv(dot(k, N, mt), kU);
+        if ((mue < 0.0) && (mue > -1e-2)) mue = 1e-3;                            // ref py :387
+        if (gg > 0.0) {
+            g = gg;
+            T = sqrt(sqrt(t.flux / 5.670400e-05));
+            limbf = (sp.limb_darkening > 0) ? ((mue >= 0.0) ? 0.5 + 0.75 * mue : 1.0) : 1.0;
+        }
+    }
+}
+
+#if S5_FAST
+// The same three numbers for a crossing of the EQUATORIAL PLANE by a disk on circular orbits (m = 0, v_r = 0, dH/dR = 0: the
+// thin disk of this job) in closed form.  With k_t = -1, k_phi = l (the constants of motion; photon_momentum normalises to
+// them), U = A (1, 0, 0, Omega) with A^-2 = -(g00 + 2 Omega g03 + Omega^2 g33) (ref src/sim5kerr.c:871-875) and the surface
+// normal N = (0, 0, -1/sqrt(g22), 0) (ref :898-902):
+//     k.U = A (-1 + Omega l)            g     = k_t / (k.U)         = 1 / (A (1 - Omega l))
+//     k.N = -sqrt(g22) k^theta          mu_e  = (k.N) / (k.U)       = g sqrt(q) / r        (k^theta = +sqrt(q) / r^2 at m = 0, ref :1179-1207)
+// -- what the tetrad chain of spectrum_pixel evaluates with ~600 operations (photon_momentum, the contravariant metric,
+// three normalised tetrad legs, two on2bl, two dot products), here ~40.  Agreement with the chain: rounding.
+template <class PRM>
+S5_DEV void spectrum_pixel_equatorial(const PRM& p, const SpectrumParams& sp, const ThinRay& t, double& T, double& g, double& limbf)
+{
+    T = 0.0; g = 0.0; limbf = 0.0;
+    if (t.cls == PX_HIT0 && t.flux != 0.0) {
+        Metric mt;
+        kerr_metric(p.a, t.r, 0.0, mt);
+        const double Om = omega_from_ell(disk_ell(p.disk, t.r), mt);
+        const double A2 = -(mt.g00 + 2. * Om * mt.g03 + Om * Om * mt.g33);
+        const double gg = mdiv(msqrt(A2), 1. - Om * t.l);                  // (A2 < 0: NaN, the ray contributes nothing, as there)
+        double mue = mdiv(gg * msqrt(t.q), t.r);
+        if ((mue < 0.0) && (mue > -1e-2)) mue = 1e-3;                      // ref py :387
+        if (gg > 0.0) {
+            g = gg;
+            T = msqrt(msqrt(t.flux * (1.0 / 5.670400e-05)));
+            limbf = (sp.limb_darkening > 0) ? ((mue >= 0.0) ? 0.5 + 0.75 * mue : 1.0) : 1.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// FAST VARIANT.  Three changes against the kernel below (which stays the strict variant's):
+//  * The local frame of a crossing in closed form (spectrum_pixel_equatorial above).
+//  * A row set symmetric about the middle of the image is traced in MIRRORED PAIRS (s5_thindisk.hpp: a lane traces (alpha, beta)
+//    and (alpha, -beta), which share the geodesic) at four waves per SIMD: a workgroup stages 512 pixels, not 256.  The staging
+//    arrays live in the Landen-ladder block of the trace, which is dead by then (LDS stays at 34 KB: four workgroups per CU).
+//  * The Planck factor 1 / (e^x - 1) of a (pixel, energy) pair costs 18 issue slots instead of ~45 (a full-precision exp and
+//    a Newton division): planck_sum below.  The bar on the spectrum is 1e-6 (tests/test_py_diskraytrace.py::test_fused_spectrum_kernel,
+//    against python/sim5diskspectrum.py:54-88).  Per pixel: log2(e) h kev2freq / (kB f T g) and the amplitude; per energy bin
+//    E^3 is applied once, after the loop over the pixels.
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifndef S5_SPEC_WAVES
+#define S5_SPEC_WAVES 4
+#endif
+
+// sum over the staged pixels of amp / (e^x - 1) for this lane's energy, x log2(e) = E sX[q].  18 issue slots per pair: t, n, f, the
+// seven Horner steps of 2^f = 1 + f (c1 + f (c2 + ... + f c7)) with c_k = ln(2)^k / k! (relative error of 2^f - 1: 2e-8; the
+// subtraction below is exact to 1e-16 / x, so small x keeps its accuracy), 2^n by v_ldexp (n beyond the exponent range gives
+// infinity, a reciprocal of 0 and a term of 0: no cap on x needed), one fma for 2^n 2^f - 1, the 26-bit reciprocal seed
+// (four slots), one fma for the sum.
+S5_DEV double planck_sum(const double* __restrict__ sX, const double* __restrict__ sA, int first, int step, int npix, double E)
+{
+    constexpr double L = 0.693147180559945309417;
+    constexpr double C1 = L, C2 = L * L / 2., C3 = L * L * L / 6., C4 = L * L * L * L / 24., C5 = L * L * L * L * L / 120.,
+                     C6 = L * L * L * L * L * L / 720., C7 = L * L * L * L * L * L * L / 5040.;
+    // C7 stays in a vector register pair (a VOP3 instruction takes one scalar operand: the other constants)
+    double c7 = C7;
+    asm volatile("" : "+v"(c7));
+    // one pair: ~17 instructions of ONE dependent chain; two chains interleaved by hand (the loop's trip count is a run-time
+    // value: the compiler does not unroll it) so that an instruction's latency is covered by its twin, two sums added at the end
+    auto term = [&](int q) -> double {
+        const double t = E * sX[q];
+        const double n = __builtin_rint(t);
+        const double f = t - n;
+        double e = hfmac(f, c7, C6);
+        e = hfmac(f, e, C5);
+        e = hfmac(f, e, C4);
+        e = hfmac(f, e, C3);
+        e = hfmac(f, e, C2);
+        e = hfmac(f, e, C1);
+        e = __builtin_fma(f, e, 1.0);                                   // 2^f
+        const double two_n = __builtin_amdgcn_ldexp(1.0, (int)n);        // (the conversion saturates; 2^n overflows to infinity)
+        const double den = __builtin_fma(two_n, e, -1.0);
+        return sA[q] * __builtin_amdgcn_rcp(den);
+    };
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int q = first;
+    for (; q + 3 * step < npix; q += 4 * step) {
+        const double a0 = term(q), a1 = term(q + step), a2 = term(q + 2 * step), a3 = term(q + 3 * step);
+        acc0 += a0; acc1 += a1; acc2 += a2; acc3 += a3;
+    }
+    for (; q < npix; q += step) acc0 += term(q);
+    const double acc = (acc0 + acc1) + (acc2 + acc3);
+    return acc;
+}
+
+// The workgroups' partial spectra are written ENERGY-MAJOR -- partial[j * nblocks + workgroup] -- so that ONE more launch adds
+// them up: spectrum_sum_kernel, a workgroup per energy reading its row contiguously, every value added at a fixed place of a
+// fixed tree (deterministic, no floating-point atomics).  (The strict variant keeps the two-level tree of spectrum_reduce_kernel
+// launches; an in-kernel tree by the last workgroup to arrive was built and measured: the device-scope fences it needs write
+// back and invalidate the L2 of every XCD -- the job went from 0.14 to 0.27 ms.)
+template <bool PAIR>
+__global__ __launch_bounds__(256, S5_SPEC_WAVES)
+void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* __restrict__ energies,
+                               double* __restrict__ partial)
+{
+    const int tid = threadIdx.x;
+    const int lane_x = tid % SPEC_TILE_W, lane_y = tid / SPEC_TILE_W;
+    const int ix = blockIdx.x * SPEC_TILE_W + lane_x;
+    const int lr = blockIdx.y * SPEC_TILE_H + lane_y;                       // PAIR: local row in the upper half
+    const int half = PAIR ? (p.nrows + 1) / 2 : p.nrows;
+    double T0 = 0.0, g0 = 0.0, l0 = 0.0, T1 = 0.0, g1 = 0.0, l1 = 0.0;      // (scalars, not arrays indexed by the loop below: no stack)
+    if (ix < p.nx && lr < half) {
+        const int iy = p.y0 + lr;
+        const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, iy);
+        ThinRay t, t2;
+        if (PAIR) trace_thin_disk_impl<true, true, false, true>(p, alpha, beta, t, t2, iy);      // max_order = 1, rms = 0: first crossing, any radius
+        else trace_thin_disk<true, true>(p, alpha, beta, t, iy);
+        const bool second = PAIR && (p.nrows - 1 - lr != lr);                // (an odd middle row is its own mirror)
+#pragma unroll 1
+        for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
+            if (member == 1 && !second) break;
+            double Tm, gm, lm;
+            spectrum_pixel_equatorial(p, sp, member ? t2 : t, Tm, gm, lm);
+            if (member == 0) { T0 = Tm; g0 = gm; l0 = lm; } else { T1 = Tm; g1 = gm; l1 = lm; }
+        }
+    }
+    // the staging arrays take over the ladder block of the trace (every lane is through with it)
+    double* const lds = thin_disk_ladder_column() - threadIdx.x;
+    double* const sX = lds;                                                  // [512] log2(e) h kev2freq / (kB f T g); harmless 0 for a dark pixel
+    double* const sA = lds + 512;                                            // [512] amplitude (0 for a dark pixel)
+    double* const sAcc = lds + 1024;                                         // [256]
+    __syncthreads();
+    {
+        const double planck_h = 6.626069e-27, kev2freq = 2.417990e+17, c2 = 8.987554e+20, kB = 1.380650e-16;
+        const double f = sp.hardening;
+        const double amp0 = mdiv(2.0 * planck_h * (kev2freq * kev2freq * kev2freq) * kev2freq, c2 * (f * f * f * f));
+#pragma unroll
+        for (int member = 0; member < 2; ++member) {
+            const double Tm = member ? T1 : T0, gm = member ? g1 : g0, lm = member ? l1 : l0;
+            const bool on = (gm > 0.0) && !(Tm < 1e2);                       // ref py :76
+            // a dark pixel keeps exponent 1 (x = E) and amplitude 0: no branch in the loop over the pixels
+            sX[tid + 256 * member] = on ? mdiv(1.44269504088896340736 * (planck_h * kev2freq), kB * f * Tm * gm) : 1.0;
+            sA[tid + 256 * member] = on ? lm * amp0 : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // transposed phase: EB energy bins x (256 / EB) pixel sub-sets
+    const int EB = sp.bins_per_pass;                     // power of two, <= 256
+    const int groups = 256 / EB;
+    const int jj = tid % EB, grp = tid / EB;
+    const int npix = PAIR ? 512 : 256;
+    for (int j0 = 0; j0 < sp.n_energies; j0 += EB) {
+        const int j = j0 + jj;
+        double acc = 0.0;
+        if (j < sp.n_energies) {
+            const double E = energies[j];
+            acc = planck_sum(sX, sA, grp, groups, npix, E) * (E * E * E);
+        }
+        sAcc[tid] = acc;
+        __syncthreads();
+        if (grp == 0 && j < sp.n_energies) {
+            double tot = 0.0;
+            for (int s = 0; s < groups; ++s) tot += sAcc[s * EB + jj];
+            const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            partial[(size_t)j * ((size_t)gridDim.x * gridDim.y) + blk] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// spectrum[j] = sum over the workgroups of partial[j * nblocks + b]: thread t adds b = t, t + 256, ... in order, the 256 sums
+// are added pairwise through LDS in a fixed pattern
+__global__ __launch_bounds__(256)
+void spectrum_sum_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ spectrum)
+{
+    __shared__ double s[256];
+    const double* row = partial + (size_t)blockIdx.x * (size_t)nblocks;
+    double tot = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) tot += row[b];
+    s[threadIdx.x] = tot;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) spectrum[blockIdx.x] = s[0];
+}
+#endif   // S5_FAST
+
+#if !S5_FAST
 __global__ __launch_bounds__(256, 2)
 void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __restrict__ energies,
                           double* __restrict__ partial)
@@ -51,43 +261,9 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
                             ((double)p.ny / (double)p.nx);
         ThinRay t;
         trace_thin_disk<true>(p, alpha, beta, t);            // max_order = 1, rms = 0: first crossing, any radius
-        if (t.cls == PX_HIT0 && t.flux != 0.0) {
-            double k[4], U[4], N[4];
-            const double e0[4] = { 1.0, 0.0, 0.0, 0.0 }, e2[4] = { 0.0, 0.0, 1.0, 0.0 };
-            photon_momentum(p.a, t.r, 0.0, t.l, t.q, t.dP, 1.0, k);           // ref py :250
-            Metric mt;
-            kerr_metric(p.a, t.r, 0.0, mt);
-            Tetrad tt;
-            tetrad_surface(mt, omega_from_ell(disk_ell(p.disk, t.r), mt), 0.0, 0.0, tt);
-            on2bl(e0, U, tt);
-            on2bl(e2, N, tt);
-            const double kU = dot(k, U, mt);
-            double gg = mdiv(k[0] * mt.g00 + k[3] * mt.g03, kU);
-            double mue = mdiv(dot(k, N, mt), kU);
-            if ((mue < 0.0) && (mue > -1e-2)) mue = 1e-3;                            // ref py :387
-            if (gg > 0.0) {
-                g = gg;
-                T = sqrt(sqrt(t.flux / 5.670400e-05));
-                limbf = (sp.limb_darkening > 0) ? ((mue >= 0.0) ? 0.5 + 0.75 * mue : 1.0) : 1.0;
-            }
-        }
+        spectrum_pixel(p, sp, t, T, g, limbf);
     }
-#if S5_FAST
-    // per-pixel factors of the Planck expression, so that a (pixel, energy) pair costs one exp, one division
-    // and a few multiplications: x = E * sT, I_nu g^3 = sL * E^3 / (exp(x) - 1) with
-    //   sT = h kev2freq / (kB f T g),   sL = limbf 2 h kev2freq^4 / (c^2 f^4)   (g^3 from nu^3 cancels the g^3 weight)
-    {
-        const double planck_h = 6.626069e-27, kev2freq = 2.417990e+17, c2 = 8.987554e+20, kB = 1.380650e-16;
-        const bool on = (g > 0.0) && !(T < 1e2);                                 // ref py :76
-        const double f = sp.hardening;
-        const double xs = on ? mdiv(planck_h * kev2freq, kB * f * T * g) : 0.0;
-        const double amp = on ? limbf * mdiv(2.0 * planck_h * (kev2freq * kev2freq * kev2freq) * kev2freq, c2 * (f * f * f * f)) : 0.0;
-        // pixels that contribute nothing keep a harmless exponent (x = E) and amplitude 0: no branch below
-        sT[tid] = on ? xs : 1.0; sG[tid] = on ? 1.0 : 0.0; sL[tid] = amp;
-    }
-#else
     sT[tid] = T; sG[tid] = g; sL[tid] = limbf;
-#endif
     __syncthreads();
 
     // transposed phase: EB energy bins x (256 / EB) pixel sub-sets
@@ -99,14 +275,6 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
         double acc = 0.0;
         if (j < sp.n_energies) {
             const double E = energies[j];
-#if S5_FAST
-            const double E3 = E * E * E;
-            // x capped at 700: exp would overflow to inf, which the Newton division cannot take (the term is 0 to
-            // 300 digits there either way).  Unrolled so that the LDS broadcasts of several pixels are in flight.
-#pragma unroll 4
-            for (int q = grp; q < 256; q += groups)
-                acc += mdiv(sL[q] * E3, mexp(fmin(E * sT[q], 700.0)) - 1.0);
-#else
             for (int q = grp; q < 256; q += groups) {
                 const double gq = sG[q];
                 if (gq > 0.0) {
@@ -115,7 +283,6 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
                         acc += planck_python(Tq, sL[q], sp.hardening, mdiv(E, gq)) * (gq * gq * gq);
                 }
             }
-#endif
         }
         sAcc[tid] = acc;
         __syncthreads();
@@ -128,6 +295,8 @@ void disk_spectrum_kernel(ImageParams p, SpectrumParams sp, const double* __rest
         __syncthreads();
     }
 }
+
+#endif   // !S5_FAST
 
 // one level of the (deterministic) tree sum over workgroup partials: row c of dst = sum of rows
 // [c * SPEC_FAN, (c + 1) * SPEC_FAN) of src, energies across the lanes (coalesced)
@@ -155,8 +324,21 @@ int s5_launch_disk_spectrum_strict(const s5abi::ImageParams& p, const s5abi::Spe
 #endif
 {
     using namespace S5NS;
+#if S5_FAST
+    // a row set symmetric about the middle of the image: mirrored pairs, 32 x (8 + 8) pixels per workgroup
+    const bool pair = (p.y0 + p.y1 == p.ny) && p.nrows >= 2;
+    const int tile_rows = pair ? (p.nrows + 1) / 2 : p.nrows;
+    const dim3 grid((p.nx + SPEC_TILE_W - 1) / SPEC_TILE_W, (tile_rows + SPEC_TILE_H - 1) / SPEC_TILE_H);
+    if (pair) hipLaunchKernelGGL(disk_spectrum_fast_kernel<true>, grid, dim3(256), 0, stream, p, sp, energies, partial);
+    else hipLaunchKernelGGL(disk_spectrum_fast_kernel<false>, grid, dim3(256), 0, stream, p, sp, energies, partial);
+    hipError_t e1 = hipGetLastError();
+    if (e1 != hipSuccess) return (int)e1;
+    hipLaunchKernelGGL(spectrum_sum_kernel, dim3((unsigned)sp.n_energies), dim3(256), 0, stream, partial, (int)(grid.x * grid.y), spectrum);
+    return (int)hipGetLastError();
+#else
     const dim3 grid((p.nx + SPEC_TILE_W - 1) / SPEC_TILE_W, (p.nrows + SPEC_TILE_H - 1) / SPEC_TILE_H);
     hipLaunchKernelGGL(disk_spectrum_kernel, grid, dim3(256), 0, stream, p, sp, energies, partial);
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     // tree sum, fan-in 64 per level, ping-pong between the partial rows and the scratch rows behind them
