@@ -386,6 +386,66 @@ def timed_kernel(capi, stream, launch, reps, warm=1):
     return e0.elapsed_ms(e1) / reps
 
 
+def executed_from_profiles():
+    """FP64 operations the job kernels EXECUTE, from the PMC passes of profiles/collect_jobs.sh (the newest committed
+    profiles/r*_jobs_summary.json; SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, an FMA counted twice): per ray of the
+    polarized image, per raytrace() call of the march (the C4 launches of the profiled program), per ray of the surface search
+    (its four kernels, the walk kernel eight launches per job), per launch of the spectrum kernel -- and the VALU
+    wave-instructions per 64 units next to them.  {} when no summary is there."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_jobs_summary.json")))
+    if not found:
+        return {}
+    try:
+        d = json.load(open(found[-1]))
+        src = "profiles/" + os.path.basename(found[-1])
+        fl = lambda p: (p["SQ_INSTS_VALU_ADD_F64"] + p["SQ_INSTS_VALU_MUL_F64"] + 2.0 * p["SQ_INSTS_VALU_FMA_F64"] + p["SQ_INSTS_VALU_TRANS_F64"]) * 64.0
+        out = {}
+        k = d.get("s5f::disk_image_polarized_mirror_kernel")
+        if k:
+            p_ = k["pmc_mean_per_launch"]; n = 2048 * 2048
+            out["c3"] = {"flops_per_ray": fl(p_) / n, "valu_wave_instr_per_64_rays": p_["SQ_INSTS_VALU"] / (n / 64.0), "valu_busy_pct": p_.get("VALUBusy"),
+                         "lanes_used_pct": p_.get("VALUUtilization"), "source": src}
+        k = d.get("s5f::torus_pool_kernel")
+        if k and "pmc_mean_per_launch_c4_precision_1" in k:
+            p_ = k["pmc_mean_per_launch_c4_precision_1"]
+            calls = None
+            for ln in d.get("_program_output_under_rocprof", []):
+                if "precision 1:" in ln and "mean steps" in ln:
+                    calls = float(ln.split("mean steps")[1].split()[0]) * 1024 * 1024
+            if calls:
+                out["c4"] = {"flops_per_call": fl(p_) / calls, "valu_wave_instr_per_64_calls": p_["SQ_INSTS_VALU"] / (calls / 64.0),
+                             "valu_busy_pct": p_.get("VALUBusy"), "lanes_used_pct": p_.get("VALUUtilization"), "source": src}
+        ks = [d.get("s5f::surface_%s_kernel" % w) for w in ("setup", "walk", "slow", "finish")]
+        if all(ks):
+            jobs = ks[0]["launches"]                                    # one set-up launch per job
+            tot = sum(fl(k_["pmc_mean_per_launch"]) * k_["launches"] for k_ in ks) / jobs
+            valu = sum(k_["pmc_mean_per_launch"]["SQ_INSTS_VALU"] * k_["launches"] for k_ in ks) / jobs
+            n = 1024 * 1024
+            out["f1"] = {"flops_per_ray": tot / n, "valu_wave_instr_per_64_rays": valu / (n / 64.0),
+                         "source": src}
+        k = d.get("s5f::disk_spectrum_fast_kernel")
+        if k:
+            p_ = k["pmc_mean_per_launch"]
+            out["f3"] = {"flops_per_launch_1024x1024x128": fl(p_), "valu_wave_instr_per_launch": p_["SQ_INSTS_VALU"], "valu_busy_pct": p_.get("VALUBusy"),
+                         "lanes_used_pct": p_.get("VALUUtilization"), "source": src}
+        return out
+    except Exception:
+        return {}
+
+
+def surface_flops_counted():
+    """FP64 operations per ray of the surface search COUNTED on the unmodified reference (oracle/opcount.c `surface`: the C calls
+    under python/sim5diskraytrace.py:228-335, ptrace single-stepped), or None where the record is missing"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_opcount_surface.json")), reverse=True):
+        try:
+            return float(json.load(open(f))["fp64_ops_per_unit"]), "profiles/" + os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
+
+
 def extra_configs(torch, capi, dev, stream):
     """The other BASELINE.json configurations on ONE GPU, a few launches each (well under a second in total)."""
     out = {}
@@ -430,6 +490,11 @@ def extra_configs(torch, capi, dev, stream):
     gpl = torch.zeros((n, n), dtype=torch.float64, device=dev)       # one more launch with the g plane: hits = g > 0 (a hit inside the
     capi.disk_image_polarized_device(d, st.data_ptr(), None, aux={"g": gpl.data_ptr()}, stream=stream)     # zero-flux band has I = 0)
     out["c3_2048_polarized"]["disk_hits"] = int((gpl > 0).sum().item())
+    ex = executed_from_profiles()
+    if "c3" in ex:
+        e = ex["c3"]
+        out["c3_2048_polarized"].update({"executed_flops_per_ray": e["flops_per_ray"], "executed_frac": n * n * e["flops_per_ray"] / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                         "valu_wave_instr_per_64_rays": e["valu_wave_instr_per_64_rays"], "executed_flops_source": e["source"]})
     del st, gpl
     # C4: 1024^2 rays through the torus, raytrace() steps at precision 1.0 with transfer
     n = 1024
@@ -448,6 +513,11 @@ def extra_configs(torch, capi, dev, stream):
                                    "roofline_frac": tot * W_STEP / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                    "roofline_frac_with_counted_flops": tot * W_STEP_MEASURED / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                    "stokes_I_sum": float(stokes[:, 0].sum().item())}
+    if "c4" in ex:
+        e = ex["c4"]
+        out["c4_1024_torus_verlet"].update({"executed_flops_per_call": e["flops_per_call"], "executed_frac": tot * e["flops_per_call"] / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                            "valu_wave_instr_per_64_calls": e["valu_wave_instr_per_64_calls"], "valu_busy_pct": e["valu_busy_pct"],
+                                            "lanes_used_pct": e["lanes_used_pct"], "executed_flops_source": e["source"]})
     del stokes, steps
     # the spectrum of the C2 image on 128 energies, fused into the image kernel (k_spectrum.hip).
     # Algorithmic work: the ray (W_ELL + the local frame ~ W_POL) per pixel + 5 FP64 operations and one exp per (pixel, energy)
@@ -464,11 +534,17 @@ def extra_configs(torch, capi, dev, stream):
                                                                 capi.VP(S.data_ptr()), capi.VP(ws.data_ptr()), capi.VP(stream)), "sim5gpu_disk_spectrum")
     ms = timed_kernel(capi, stream, spec, 40, 60)
     w_spec = n * n * (W_ELL + W_POL) + n * n * ne * 6.0
-    out["f3_spectrum_1024_x128"] = {"kernel": "disk_spectrum_kernel + spectrum_reduce_kernel", "job_ms": ms, "pixels": n * n, "energies": ne,
+    out["f3_spectrum_1024_x128"] = {"kernel": "disk_spectrum_fast_kernel + spectrum_sum_kernel", "job_ms": ms, "pixels": n * n, "energies": ne,
                                     "pixel_energy_pairs_per_s": n * n * ne / ms * 1e3, "algorithmic_flops": w_spec,
                                     "roofline_frac": w_spec / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                     "spectrum_sum": float(S.sum().item()),
-                                    "note": "roofline: (W_ell + 3e2) per pixel + 6 FP64 operations (1 exp) per (pixel, energy) pair over the job time"}
+                                    "note": "roofline: (W_ell + 3e2) per pixel + 6 FP64 operations (1 exp) per (pixel, energy) pair over the job time; the kernel spends 18 issue slots on a pair (k_spectrum.hip planck_sum), so the algorithmic fraction cannot pass ~0.36 even with the vector unit full"}
+    if "f3" in ex:
+        e = ex["f3"]
+        out["f3_spectrum_1024_x128"].update({"executed_flops_per_launch": e["flops_per_launch_1024x1024x128"],
+                                             "executed_frac": e["flops_per_launch_1024x1024x128"] / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                             "valu_wave_instr_per_launch": e["valu_wave_instr_per_launch"], "valu_busy_pct": e["valu_busy_pct"],
+                                             "executed_flops_source": e["source"]})
     del E, S, ws
     # the surface search of the reference's Python DiskRaytrace for a thick disk H(R) = 0.25 (R - 2), 1024^2
     # rays (k_surface.hip).  Algorithmic work per ray: ~550 sub-steps of geodesic_follow (ref src/sim5kerr-geod.c:891-925), each
@@ -488,12 +564,21 @@ def extra_configs(torch, capi, dev, stream):
         capi.VP(ob["m"].data_ptr()), capi.VP(ob["k"].data_ptr()), capi.VP(stt.data_ptr()), capi.I(capi.SURFACE_TABLE_CHECKED), capi.VP(stream)),
         "sim5gpu_disk_surface_rays")
     ms = timed_kernel(capi, stream, surf, 10, 10)
-    W_SURF = 2.0e5
+    # W_surf: COUNTED on the unmodified reference where the record exists (oracle/opcount.c `surface`: the C library calls under
+    # python/sim5diskraytrace.py:228-335 for this very job on a sample grid, ptrace single-stepped); the round-4 estimate otherwise
+    w_counted, w_src = surface_flops_counted()
+    W_SURF = w_counted if w_counted else 2.0e5
     out["f1_surface_search_1024"] = {"kernel": "surface_setup / walk / slow / finish kernels", "job_ms": ms, "rays": N, "rays_per_s": N / ms * 1e3,
-                                     "surface_hits": int((stt == 1).sum().item()), "algorithmic_flops_per_ray_estimate": W_SURF,
+                                     "surface_hits": int((stt == 1).sum().item()),
+                                     "algorithmic_flops_per_ray": W_SURF, "algorithmic_flops_source": w_src if w_counted else "estimate: 550 sub-steps x 3.6e2 operations",
                                      "roofline_frac": N * W_SURF / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                                     "note": "thick disk H(R) = 0.25 (R - 2), a = 0.9, i = 70 deg, field of view +-20; W_SURF = 550 "
-                                             "sub-steps x 3.6e2 operations is an estimate (no entry in SURVEY 8(d))"}
+                                     "note": "thick disk H(R) = 0.25 (R - 2), a = 0.9, i = 70 deg, field of view +-20; the reference walks the ray by "
+                                             "geodesic_follow (two jacobi_sncndn per sub-step); the kernel walks it by addition theorems re-anchored every "
+                                             "48 sub-steps, so it executes far fewer operations than the reference does: executed_frac is its utilisation"}
+    if "f1" in ex:
+        e = ex["f1"]
+        out["f1_surface_search_1024"].update({"executed_flops_per_ray": e["flops_per_ray"], "executed_frac": N * e["flops_per_ray"] / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                              "valu_wave_instr_per_64_rays": e["valu_wave_instr_per_64_rays"], "executed_flops_source": e["source"]})
     del tb, ob, stt
     out["scalar_api_example04_loop"] = scalar_api_rate(capi)
     return out

@@ -15,6 +15,7 @@
  *
  *   opcount <libsim5ref.so> image  <n> <a> <inc_deg>          n x n sample grid of the image plane
  *   opcount <libsim5ref.so> verlet <n> <a> <inc_deg> <prec>   n x n rays, r0 = 100, first 200 steps each
+ *   opcount <libsim5ref.so> surface <n> <a> <inc_deg>         n x n rays of the thick-disk surface search (bench.py f1)
  *
  * Output: one JSON object on stdout.  OPCOUNT_TARGETS=1 additionally lists the address of every library call
  * on stderr (on this image: fmax 68 and fmin 19 per ray -- gcc does not inline them without -ffinite-math --
@@ -174,6 +175,75 @@ static void child_verlet(void *lib, int n, double a, double inc, double precisio
     }
 }
 
+/* The surface search of the reference's Python ray tracer (ref python/sim5diskraytrace.py:257-335: DiskRaytrace.__find_surface),
+ * statement for statement, over the reference's C functions; what is counted is what those functions execute (the Python
+ * arithmetic between the calls -- the step rule, H(R) of the disk model -- is not library text, here as there).  The job of
+ * bench.py's f1 line: thick disk H(R) = 0.25 (R - 2) on the table range 2 <= R <= 60 (held constant outside it), a, i,
+ * n x n rays over a field of view of +-20. */
+typedef void (*fn_follow)(void *, double, double *, double *, double *, int *);
+static double disk_h(double R) { const double Rc = R < 2.0 ? 2.0 : (R > 60.0 ? 60.0 : R); return 0.25 * (Rc - 2.0); }
+
+static int find_surface(void *gd, int iteration, double a, fn_Pint P_int, fn_gd_d position_rad, fn_gd_d position_pol,
+                        fn_follow follow, fn_gd_i crossing, double rbh)
+{
+    if (iteration > 3) return 0;
+    const double *g = (const double *)gd;                      /* a@0 alpha@8 beta@16 incl@24 ... rp@160 */
+    const double alpha = g[1], beta = g[2], incl = g[3], rp = g[20];
+    const double disk_theta = atan(disk_h(1e6) / 1e6);
+    double r0 = fmax(200.0, fmax(1.1 * rp, (0.5 + iteration) * sqrt(alpha * alpha + beta * beta) / cos(incl + disk_theta)));
+    const double accuracy = 1e-2;
+    double P1, r1, m1, H1, Hd;
+    for (;;) {
+        P1 = P_int(gd, r0, 0); r1 = position_rad(gd, P1); m1 = position_pol(gd, P1);
+        H1 = r1 * m1; Hd = disk_h(r1 * sqrt(1. - m1 * m1));
+        if (Hd < H1 || r0 > 5e6) break;
+        r0 = 2.0 * r0;
+    }
+    if (Hd >= H1) return 0;
+    double P = P1, r = r1, m = m1, step_factor = 1.0;
+    int status = 0;
+    for (;;) {
+        const double step = fmax(accuracy / 2., fmin((H1 - Hd) / 2., 0.5 * (sqrt(r) - 0.99) * step_factor));
+        follow(gd, step, &P, &r, &m, &status);
+        if (!status) return 0;
+        H1 = r * m; Hd = disk_h(r * sqrt(1. - m * m));
+        if (H1 <= Hd) {
+            if (step < accuracy) { follow(gd, -step / 2., &P, &r, &m, &status); return 1; }
+            follow(gd, -step, &P, &r, &m, &status);
+            step_factor = step_factor / 5.;
+            continue;
+        }
+        if (H1 < 1e-4) { const double Pc = crossing(gd, 0); sink = position_rad(gd, Pc) + position_pol(gd, Pc); return 1; }
+        if (r < 1.05 * rbh) return 0;
+        if (r > 1.1 * r0) return find_surface(gd, iteration + 1, a, P_int, position_rad, position_pol, follow, crossing, rbh);
+        if (m < 0.0) return 0;
+        if (step < accuracy / 2.) break;
+    }
+    return 0;
+}
+
+static void child_surface(void *lib, int n, double a, double inc)
+{
+    fn_init_inf init_inf = (fn_init_inf)dlsym(lib, "geodesic_init_inf");
+    fn_Pint P_int = (fn_Pint)dlsym(lib, "geodesic_P_int");
+    fn_gd_d position_rad = (fn_gd_d)dlsym(lib, "geodesic_position_rad"), position_pol = (fn_gd_d)dlsym(lib, "geodesic_position_pol");
+    fn_follow follow = (fn_follow)dlsym(lib, "geodesic_follow");
+    fn_gd_i crossing = (fn_gd_i)dlsym(lib, "geodesic_find_midplane_crossing");
+    fn_d r_bh = (fn_d)dlsym(lib, "r_bh");
+    const double rmax = 20.0, rbh = r_bh(a);
+    long hits = 0;
+    for (int iy = 0; iy < n; iy++) for (int ix = 0; ix < n; ix++) {
+        const double alpha = (((double)ix + .5) / (double)n - 0.5) * 2.0 * rmax;
+        const double beta = (((double)iy + .5) / (double)n - 0.5) * 2.0 * rmax;
+        raise(SIGUSR1);
+        geodesic_blob gd; int err;
+        if (init_inf(inc, a, alpha, beta, &gd, &err) && !err)                     /* ref py :228-243 */
+            hits += find_surface(&gd, 0, a, P_int, position_rad, position_pol, follow, crossing, rbh);
+        raise(SIGUSR2);
+    }
+    sink = (double)hits;
+}
+
 /* ---- parent ---- */
 static int text_range(pid_t pid, const char *needle, uintptr_t *lo, uintptr_t *hi)
 {
@@ -209,8 +279,8 @@ static int class_at(pid_t pid, uintptr_t rip)
 
 int main(int argc, char **argv)
 {
-    if (argc < 6) { fprintf(stderr, "usage: opcount <lib> image|verlet <n> <a> <inc_deg> [precision]\n"); return 2; }
-    const char *libpath = argv[1]; const int verlet = !strcmp(argv[2], "verlet");
+    if (argc < 6) { fprintf(stderr, "usage: opcount <lib> image|verlet|surface <n> <a> <inc_deg> [precision]\n"); return 2; }
+    const char *libpath = argv[1]; const int verlet = !strcmp(argv[2], "verlet"), surface = !strcmp(argv[2], "surface");
     const int n = atoi(argv[3]); const double a = atof(argv[4]), inc = atof(argv[5]) / 180.0 * M_PI;
     const double precision = argc > 6 ? atof(argv[6]) : 1.0;
 
@@ -221,7 +291,7 @@ int main(int argc, char **argv)
         int devnull = open("/dev/null", 1); dup2(devnull, 2);          /* the reference's diagnostics */
         ptrace(PTRACE_TRACEME, 0, 0, 0);
         raise(SIGSTOP);
-        if (verlet) child_verlet(lib, n, a, inc, precision); else child_image(lib, n, a, inc);
+        if (verlet) child_verlet(lib, n, a, inc, precision); else if (surface) child_surface(lib, n, a, inc); else child_image(lib, n, a, inc);
         _exit(0);
     }
     int st; waitpid(pid, &st, 0);
@@ -287,7 +357,7 @@ int main(int argc, char **argv)
     const double flops = (double)(tot[C_ADD] + tot[C_SUB] + tot[C_MUL] + tot[C_DIV] + tot[C_SQRT] + tot[C_CMP] + tot[C_MINMAX]
                                   + 2 * tot[C_PACKED] + tot[C_X87] + tot[C_LIBCALL]) / u;
     printf("{\"workload\": \"%s\", \"units\": %llu, \"unit\": \"%s\", \"spin\": %g, \"incl_deg\": %g, \"sample_grid\": %d",
-           verlet ? "raytrace() calls, r0 = 100" : "thin-disk pixel loop body (disk-image.c:57-100)", units,
+           verlet ? "raytrace() calls, r0 = 100" : surface ? "surface search of a thick disk H(R) = 0.25 (R - 2), field of view +-20 (python/sim5diskraytrace.py:228-335 over the C library)" : "thin-disk pixel loop body (disk-image.c:57-100)", units,
            verlet ? "raytrace() call" : "ray", a, atof(argv[5]), n);
     if (verlet) printf(", \"precision\": %g", precision);
     printf(", \"per_unit\": {");

@@ -40,6 +40,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.c
         e = kern.setdefault(k, {"launches": 0, "ns": [], "dispatch": {}})
         for c, v in cs.items():
             e.setdefault("pmc_mean_per_launch", {})[c] = sum(v) / len(v)
+            # tests/tools/bench_jobs.py runs the march twice: precision 1 (the C4 job) first, then 0.01 -- the first half of
+            # the launches, in dispatch order, is the C4 job by itself
+            if "torus_pool" in k and len(v) >= 2:
+                h = v[:len(v) // 2]
+                e.setdefault("pmc_mean_per_launch_c4_precision_1", {})[c] = sum(h) / len(h)
 out = {}
 for k, e in kern.items():
     if not any(s in k for s in ("disk_", "torus_", "spectrum", "map_rays", "surface_")):

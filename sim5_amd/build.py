@@ -67,9 +67,12 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(os.path.dirname(HERE), "include", "sim5gpu_rccl.h"))
     sources = sorted(set(os.path.join(CSRC, src) for (src, _, _) in SOURCES)) + [os.path.join(CSRC, "rccl_shard.hip")]
     stamp = os.path.join(LIBDIR, ("ab_%s.stamp" % _VAR) if _VAR else "build.stamp")
+    # experiment flags from the environment reach the VARIANT builds only (S5_VARIANT=<name>: lib/ab_<name>.so); the library
+    # the product loads is compiled with the strict / fast pair and nothing else (tests/test_capi_boundary.py checks the
+    # recorded command lines)
+    env = (lambda k: os.environ.get(k, "")) if _VAR else (lambda k: "")
     fp = _fingerprint(headers + sources + [os.path.abspath(__file__)],
-                      (FLAGS, VARIANT, os.environ.get("S5_FAST_EXTRA", ""), os.environ.get("S5_TORUS_EXTRA", ""),
-                       os.environ.get("S5_TORUS_FAST_EXTRA", ""), os.environ.get("S5_SURF_FAST_EXTRA", "")))
+                      (FLAGS, VARIANT, env("S5_FAST_EXTRA"), env("S5_TORUS_EXTRA"), env("S5_TORUS_FAST_EXTRA"), env("S5_SURF_FAST_EXTRA")))
     if not force and os.path.exists(LIB) and os.path.exists(LIB_RCCL) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
         return LIB
     if os.path.exists(stamp):
@@ -80,16 +83,16 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, obj)
         objs.append(o)
-        extra = os.environ.get("S5_FAST_EXTRA", "").split() if variant == "fast" else []
+        extra = env("S5_FAST_EXTRA").split() if variant == "fast" else []
         if src == "k_torus.hip":
-            extra = extra + os.environ.get("S5_TORUS_EXTRA", "").split()
+            extra = extra + env("S5_TORUS_EXTRA").split()
             if variant == "fast":
                 # the march kernel of the fast variant lets the compiler fuse a*b+c (measured on MI355X: C4 job
                 # 39.7 -> 37.0 ms, step counts identical to the reference's on every ray of the test sets; the
                 # cancellation that rules contraction out for the image kernels is not on this path)
-                extra = extra + ["-ffp-contract=fast"] + os.environ.get("S5_TORUS_FAST_EXTRA", "").split()
+                extra = extra + ["-ffp-contract=fast"] + env("S5_TORUS_FAST_EXTRA").split()
         if src == "k_surface.hip" and variant == "fast":
-            extra = extra + os.environ.get("S5_SURF_FAST_EXTRA", "").split()
+            extra = extra + env("S5_SURF_FAST_EXTRA").split()
         cmd = [hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o]
         # an object is reused only if it is newer than its sources AND was compiled by this very command line
         # (experiment flags from the environment must not survive in objects a later build links)

@@ -64,17 +64,13 @@ S5_DEV void store_ray(const ImageParams& p, size_t o, const RayResult& res)
     }
 }
 
-#ifndef S5_TILE_W
 #define S5_TILE_W 16                     // pixels per wave row: a wave covers 16 x 4 pixels (64-B store segments).
                                          // Compact patches keep more waves class-uniform (s5_thindisk.hpp); measured
                                          // on MI355X, 4096^2, same box: 8x8 0.903 ms, 16x4 0.890, 32x2 0.901-0.906,
                                          // 64x1 0.909
-#endif
-#ifndef S5_LB_WAVES
 #define S5_LB_WAVES 2                    // a floor only: the kernel needs ~110 VGPRs and 34 KB of LDS per workgroup
                                          // (ladder rungs), so 4 waves/SIMD are resident.  Occupancy is not a lever:
                                          // 4 -> 6 waves/SIMD (shorter ladder) 0.922 -> 0.915 ms; forcing 8 spills.
-#endif
 constexpr int TILE_W = S5_TILE_W;        // workgroup tile: TILE_W x (256 / TILE_W) pixels
 constexpr int TILE_H = 256 / TILE_W;
 
@@ -99,56 +95,26 @@ void disk_image_grid_kernel(ImageParams p)
 // takes the pixel (ix, iy) of the upper half AND its mirror image (ix, ny - 1 - iy).  The two rays differ in the sign of
 // beta only and share the geodesic (trace_thin_disk_impl<.., PAIR>) -- about two thirds of a ray's arithmetic.  The image
 // is the plain kernel's bit for bit (pixel_beta above); an odd middle row is its own mirror and is written once.
-// spill experiments only (tests/tools/spill_repro.sh): a register budget below what the pairing kernels need
-#ifdef S5_FORCE_NUM_VGPR
-#define S5_NUM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(S5_FORCE_NUM_VGPR)))
-#else
-#define S5_NUM_VGPR_ATTR
-#endif
-#ifndef S5_LB_WAVES_MIRROR
 #define S5_LB_WAVES_MIRROR 4             // four waves per SIMD (the kernel needs 112 VGPRs, no scratch).  Measured, 4096^2, same
                                          // call: 0.527 ms at three -> 0.478 ms
-#endif
 template <bool AUX>
-__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR) S5_NUM_VGPR_ATTR
+__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
 void disk_image_mirror_kernel(ImageParams p)
 {
     const int lane_x = threadIdx.x % TILE_W;
     const int lane_y = threadIdx.x / TILE_W;
     const int ix = blockIdx.x * TILE_W + lane_x;
-#ifdef S5_ROWS_TOP_DOWN
-    const int lr = blockIdx.y * TILE_H + lane_y;                 // local row in the upper half
-#else
     // Row tiles are handed out from the MIDDLE of the image outwards (workgroups are dispatched in blockIdx order): the rays
     // around the shadow -- second crossings, RC geodesics, deeper Landen ladders -- cost several times the rays of the
     // outer rows, which mostly miss; started first they are done when the cheap rows fill the end of the launch, instead of
     // forming its tail.  Matters for small images (1024^2 is two rounds of resident waves); the pixel a lane traces is the same.
     const int lr = (int)(gridDim.y - 1u - blockIdx.y) * TILE_H + lane_y;      // local row in the upper half
-#endif
     const int half = (p.nrows + 1) / 2;
-#ifndef S5_FLUX_TABLE_LDS
     if (ix >= p.nx || lr >= half) return;
-#endif
     const int lr2 = p.nrows - 1 - lr;                            // its mirror row (== lr for an odd middle row)
     ThinRay t, t2;
     const int iy = image_row_top(p, lr);
-#ifdef S5_FLUX_TABLE_LDS
-    // A/B build only (north_star: "LDS staging of the disk_nt radial profile"): the 8 KB flux table copied to LDS by the
-    // workgroup before it traces.  Measured against the table read from global memory (L1/L2-resident): DESIGN.md 4.
-    __shared__ double s_ftab[FT_N * (FT_DEG + 1)];
-    ImageParams pl = p;
-    if (p.disk.ftab) {
-        for (int i = (int)threadIdx.x; i < FT_N * (FT_DEG + 1); i += 256) s_ftab[i] = p.disk.ftab[i];
-        pl.disk.ftab = s_ftab;
-    }
-    __syncthreads();
-    trace_thin_disk_impl<false, true>(pl, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2, iy);
-#else
     trace_thin_disk_impl<false, true, false, true>(p, pixel_alpha(p, ix), pixel_beta(p, iy), t, t2, iy);   // (p is this kernel's first parameter)
-#endif
-#ifdef S5_FLUX_TABLE_LDS
-    if (ix >= p.nx || lr >= half) return;                        // after the barrier of the table copy (tiles of the bench sizes are full)
-#endif
     store_ray<AUX>(p, (size_t)(p.inplace ? iy : lr) * (size_t)p.nx + (size_t)ix, ray_result(t));
     if (lr2 != lr) store_ray<AUX>(p, (size_t)(p.inplace ? p.ny - 1 - iy : lr2) * (size_t)p.nx + (size_t)ix, ray_result(t2));
 }
@@ -162,7 +128,7 @@ void disk_image_mirror_kernel(ImageParams p)
 // arithmetic is that of disk_image_mirror_kernel<false>, value for value: images are the same bits.
 // SINGLE: the list holds one job (sim5gpu_disk_image of a symmetric row set): no search, the job at a constant offset
 template <bool SINGLE>
-__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR) S5_NUM_VGPR_ATTR
+__global__ __launch_bounds__(256, S5_LB_WAVES_MIRROR)
 void disk_image_jobs_kernel(JobList list_arg)
 {
     const S5_AS4 JobList* L = (const S5_AS4 JobList*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -277,14 +243,12 @@ int s5_launch_disk_image_strict(const s5abi::ImageParams& p, hipStream_t stream)
         const unsigned blocks = (unsigned)((p.n + 255) / 256);
         hipLaunchKernelGGL(disk_image_list_kernel, dim3(blocks), dim3(256), 0, stream, p);
     } else {
-#if S5_FAST && !defined(S5_NO_MIRROR)
+#if S5_FAST
         if ((p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny)) && p.nrows >= 2) {
             // production jobs (two f32 planes): the job-list kernel with a list of one -- same time as the by-value kernel
             // (measured: 0.3123 against 0.3125 ms at 4096^2, 0.0257 / 0.0259 at 1024^2), and its hot path holds no spilled
             // scalar register (parameters are read where they are used); the by-value kernel serves the full-precision planes
-#ifndef S5_SINGLE_BY_VALUE
             if (!aux) return s5_launch_disk_image_jobs_fast(&p, 1, stream);
-#endif
             const dim3 grid((p.nx + TILE_W - 1) / TILE_W, ((p.nrows + 1) / 2 + TILE_H - 1) / TILE_H);
             if (aux) hipLaunchKernelGGL(disk_image_mirror_kernel<true>, grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL(disk_image_mirror_kernel<false>, grid, dim3(256), 0, stream, p);

@@ -170,23 +170,17 @@ void disk_image_polarized_kernel(ImageParams p)
 #if S5_FAST
 // symmetric row sets (k_disk_image.hip: disk_image_mirror_kernel): the pixel and its mirror image in beta share the geodesic;
 // the polarization chain runs for each of the two, as a loop of two passes over ONE inlined copy
-#ifndef S5_LB_POLAR_MIRROR
 #define S5_LB_POLAR_MIRROR 4                // FOUR waves per SIMD since round 4: 120 VGPRs, no scratch -- the polarization chain takes
                                             // nothing of the geodesic but r, the crossing's order and the radial direction (polarize_ray),
                                             // so the trace no longer keeps Tpp, Tip, P, l, q, a, beta of both rays alive (round 3: 148
                                             // VGPRs, three waves; capped at 128 it spilled 20-30 registers, and spills are refused here)
-#endif
 template <bool AUX>
 __global__ __launch_bounds__(256, S5_LB_POLAR_MIRROR)
 void disk_image_polarized_mirror_kernel(ImageParams p_arg)
 {
-#ifndef S5_POLAR_BY_VALUE
     // the job read through the constant address space where its values are used (as the job-list kernel of k_disk_image.hip):
     // the argument block is this kernel's only parameter, at the head of the argument segment
     const S5_AS4 ImageParams& p = *(const S5_AS4 ImageParams*)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    const ImageParams& p = p_arg;
-#endif
     const int lane_x = threadIdx.x & 15;
     const int lane_y = threadIdx.x >> 4;
     const int ix = blockIdx.x * 16 + lane_x;
@@ -199,11 +193,7 @@ void disk_image_polarized_mirror_kernel(ImageParams p_arg)
     const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, iy);
     ThinRay t, t2;
     trace_thin_disk_impl<true, true>(p, alpha, beta, t, t2, iy);
-#ifdef S5_POLAR_ROLLED
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
     for (int member = 0; member < 2; ++member) {
         if (member == 1 && !wave_any(lr2 != lr)) break;
         // a copy of the member's record: the chain is instantiated once
@@ -229,7 +219,7 @@ int s5_launch_disk_image_polarized_strict(const s5abi::ImageParams& p, hipStream
 {
     using namespace S5NS;
     const bool aux = p.chi || p.cls || p.gtype || p.r || p.g || p.flux;
-#if S5_FAST && !defined(S5_NO_MIRROR)
+#if S5_FAST
     if ((p.mirror || (p.stripe_rows == 0 && p.y0 + p.y1 == p.ny)) && p.nrows >= 2) {
         const dim3 grid((p.nx + 15) / 16, ((p.nrows + 1) / 2 + 15) / 16);
         if (aux) hipLaunchKernelGGL(disk_image_polarized_mirror_kernel<true>, grid, dim3(256), 0, stream, p);

@@ -102,9 +102,7 @@ S5_DEV void spectrum_pixel_equatorial(const PRM& p, const SpectrumParams& sp, co
 //    against python/sim5diskspectrum.py:54-88).  Per pixel: log2(e) h kev2freq / (kB f T g) and the amplitude; per energy bin
 //    E^3 is applied once, after the loop over the pixels.
 // ---------------------------------------------------------------------------------------------------------------------------
-#ifndef S5_SPEC_WAVES
 #define S5_SPEC_WAVES 4
-#endif
 
 // sum over the staged pixels of amp / (e^x - 1) for this lane's energy, x log2(e) = E sX[q].  18 issue slots per pair: t, n, f, the
 // seven Horner steps of 2^f = 1 + f (c1 + f (c2 + ... + f c7)) with c_k = ln(2)^k / k! (relative error of 2^f - 1: 2e-8; the

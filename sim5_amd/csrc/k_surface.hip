@@ -149,9 +149,7 @@ S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clam
     // r, mu along the walk by the addition theorems (GeodTrack::Along), re-anchored by the full evaluation every
     // ANCHOR_EVERY sub-steps of the WAVE (a wave-uniform count, so that the lanes take the expensive branch together)
     // and whenever a lane's sub-step is too long for the series
-#ifndef S5_ANCHOR_EVERY
 #define S5_ANCHOR_EVERY 48
-#endif
     constexpr int ANCHOR_EVERY = S5_ANCHOR_EVERY;
     typename Eval::Along along;
     int since_anchor = ANCHOR_EVERY;
@@ -224,9 +222,7 @@ S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clam
     }
 }
 
-#ifndef S5_SETUP_WAVES
 #define S5_SETUP_WAVES 1
-#endif
 __global__ __launch_bounds__(SURF_BLOCK, S5_SETUP_WAVES)
 void surface_setup_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH,
                           const double* __restrict__ alpha, const double* __restrict__ beta)
@@ -272,12 +268,8 @@ void surface_setup_kernel(SurfaceParams p, SurfaceWork wk, const double* __restr
     count_lanes(&wk.counters[CNT_DEEP + 0], w.state == ST_FOLLOW && w.deep);
 }
 
-#ifndef S5_SURF_WAVES
 #define S5_SURF_WAVES 3
-#endif
-#ifndef S5_SURF_WAVES_FAST_PLAIN
 #define S5_SURF_WAVES_FAST_PLAIN 3
-#endif
 // NST = WALK_RUNGS, DEEP = false: the rays whose ladders fit (nearly all);  NST = LADDER_RUNGS_VALID, DEEP = true: the
 // few that need the full ladders (64 KB of LDS per workgroup; launched beside the other on a second stream)
 template <int NST, bool DEEP>

@@ -107,33 +107,21 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
     // differs from run to run, a ray's result does not); a ray wrongly taken for long costs nothing.
     // (A third class -- the SHORTEST rays last: those that fall into the hole, 250 - 450 calls -- is built and measured,
     // -DS5_SHORT_CLASS: 25.85 against 25.55 ms without it; not used.)
-#ifndef S5_FAR_CLASS
 #define S5_FAR_CLASS 8
-#endif
     int cls = 0;                                                         // 0 ordinary, 1 long, 2 last (far rays; -DS5_SHORT_CLASS: the short ones too)
     if (good && !(p.options & 1)) {
         const double crit = (gd.nrr == 4) ? (gd.r1[0] - gd.r2[0]) / gd.r1[0]
                           : (gd.nrr == 2) ? fabs(gd.r3[1]) / fmax(fabs(gd.r3[0]), 1e-9) : 9.0;
-#ifndef S5_LONG_CRIT
 #define S5_LONG_CRIT 0.2
 #define S5_LONG_POLE 0.01
-#endif
         if ((crit < S5_LONG_CRIT) || (1.0 - gd.m2p < S5_LONG_POLE)) cls = 1;
-#ifdef S5_SHORT_CLASS
-        else if (gd.nrr != 4) cls = 2;
-#endif
-#if S5_FAR_CLASS > 0
         // THE RAYS HANDED OUT LAST decide when a CU ends (its pool drains alone: the CUs of the C4 job ended between 90 % and
         // 100 % of the run, half of them before 95 %).  The rays that pass far from the hole -- impact parameter above
         // S5_FAR_CLASS gravitational radii -- are the most uniform in length (472 - 520 calls beyond b = 10 on the C4 job,
         // where the others spread from 220 to 1 900), so they close the order: C4 21.4 -> 20.65 ms in one call (thresholds
         // 6 / 8 / 10 / 12: 20.9 / 20.65 / 20.85 / 20.95; a fourth class for b > 12 behind them: 20.55, not kept).
         else if (alpha * alpha + beta * beta > (double)(S5_FAR_CLASS) * (double)(S5_FAR_CLASS)) cls = 2;
-#endif
     }
-#ifdef S5_SHORT_CLASS
-    if (!good) cls = 2;                                                  // (rejected at start-up: no work at all)
-#endif
     // rank of the ray within its class: counted per wave (ballot), summed per workgroup in LDS, ONE atomic per class and
     // workgroup on the global counters (an atomic per wave and class: 49 k atomics on three addresses, 0.18 ms -- measured);
     // torus_order_kernel turns (class, rank) into the position once the counts are final
@@ -171,9 +159,7 @@ void torus_start_kernel(TorusParams p, RayCols st, int* __restrict__ ok, int* __
 // batches, and the long rays are the ones that fall back at almost every step.  Measured on MI355X, one call, 1024^2 / 2048^2
 // rays: row-major 29.1 / 90.6 ms; all long rays first 26.5 / 95.4 (-8 % asymptotic rate); dealt 1:2 25.9 / 89.8; 1:3 29.2 /
 // 92.7; 1:4 27.4 / 89.8.
-#ifndef S5_ORDER_DEAL
 #define S5_ORDER_DEAL 2
-#endif
 __global__ __launch_bounds__(256)
 void torus_order_kernel(size_t n, const int* __restrict__ ranks, const unsigned long long* __restrict__ counters, int* __restrict__ order)
 {
@@ -204,9 +190,8 @@ S5_DEV double torus_density(const PRM& p, double r, double m)
     return (d2 < 36. * w2) ? exp(-d2 / w2) : 0.0;       // cut at 6 sqrt(2) w: exp(-36) ~ 2e-16
 }
 
-#ifndef S5_MARCH_WAVES
 #define S5_MARCH_WAVES (S5_FAST ? 3 : 1)   // fast: THREE waves per SIMD since round 4 (168 VGPRs, nothing spilled: the lean form of the
-#endif                                     // kernel below); strict: its bodies need ~261 registers -- one wave per SIMD and no scratch
+// kernel below); strict: its bodies need ~261 registers -- one wave per SIMD and no scratch
 // Emission and absorption picked up over one accepted step (see the header comment for the model).  `g` is the
 // metric at the end point of the step, which both halves of raytrace() have just evaluated there.
 template <class PRM>
@@ -318,27 +303,18 @@ S5_DEV void write_ray_end(const AUX& aux, sim5gpu_stokes* __restrict__ out, size
 // two waves per SIMD: 4 waves x 256 slots 25.9 ms, x 320 24.1-24.4, x 384 24.2; 8 waves x 576 23.6, x 640 23.6-23.8 (private
 // 128-ray pools of round 3: 25.7); at three waves per SIMD (the lean form below): 4-wave workgroups 22.4-22.7, twelve waves x 832
 // slots 21.2-21.6, x 896 21.4.  Strict variant: its bodies need one wave per SIMD; four waves per workgroup keep every CU busy.
-#ifndef S5_POOL_WG_WAVES
 #define S5_POOL_WG_WAVES (S5_FAST ? 4 * S5_MARCH_WAVES : 4)      // fast: the twelve waves a CU holds are ONE workgroup
-#endif
-#ifndef S5_POOL_WG_SLOTS
 #define S5_POOL_WG_SLOTS (64 * S5_POOL_WG_WAVES + 64)     // rays per workgroup pool: every wave's batch + 64
-#endif
-#ifndef S5_POOL_REFILL_MIN
 #define S5_POOL_REFILL_MIN 32            // empty slots that make a refill worth its global atomic and loads
-#endif
 constexpr int WG_WAVES = S5_POOL_WG_WAVES;
 constexpr int WG_THREADS = 64 * WG_WAVES;
 constexpr int WG_SLOTS = S5_POOL_WG_SLOTS;
 constexpr int RING = (WG_SLOTS <= 512) ? 512 : 1024;         // entries of a queue: a power of two >= WG_SLOTS (a slot is in one queue at most)
 static_assert(WG_SLOTS % 64 == 0 && WG_SLOTS >= 128 && WG_SLOTS <= RING, "pool size");
-#ifndef POOL_KEEP_NUM
 #define POOL_KEEP_NUM 7                   // ... while at least NUM/DEN of its lanes are still stepping
 #define POOL_KEEP_DEN 8
-#endif
-#ifndef POOL_RUN
 #define POOL_RUN 6                       // Verlet attempts a batch may take before it returns to the pool (measured with the queues
-#endif                                   // of round 4, C4, one call: 4 / 6 / 8 -> 23.8 / 23.4 / 23.4 ms at two waves, 21.3-21.4 at three)
+// of round 4, C4, one call: 4 / 6 / 8 -> 23.8 / 23.4 / 23.4 ms at two waves, 21.3-21.4 at three)
 enum : int { PC_X0 = 0, PC_X1, PC_X2, PC_X3, PC_K0, PC_K1, PC_K2, PC_K3, PC_DK0, PC_DK1, PC_DK2, PC_DK3,
              PC_KT, PC_E, PC_I, PC_TAU, NPC };
 enum : int { TAG_EMPTY = 0, TAG_V = 1, TAG_R = 2 };            // what a ray owes next = the queue its slot goes back to
@@ -376,9 +352,7 @@ struct PoolArgs {
     sim5gpu_stokes* out;
     TorusAux aux;
 };
-#ifndef S5_MARCH_LEAN
 #define S5_MARCH_LEAN (S5_FAST ? 1 : 0)
-#endif
 
 __global__ __launch_bounds__(WG_THREADS, S5_MARCH_WAVES)
 void torus_pool_kernel(PoolArgs args)
@@ -639,10 +613,6 @@ void torus_pool_kernel(PoolArgs args)
 #else
                     const double dl_max = p.dl_max;
 #endif
-#ifdef S5_KO_RK4                 // diagnostic builds only (register budget of the two bodies)
-                    if (false) {
-                        dl = 0.0;
-#else
                     if (run == 0 && do_rk4) {
                         dl = next_step_size(k, dl_max, s);        // the value the rejected attempt used
 #if S5_MARCH_LEAN
@@ -659,15 +629,10 @@ void torus_pool_kernel(PoolArgs args)
                         // HERE (same expression, same operands as inside rk4_step) rather than carried through the four stages
                         s.error = (float)rel_diff(k[0] * g.g00 + k[3] * g.g03, pd[PD_AT(PC_KT, slot)]);
 #endif
-#endif
                         if (!s.opt_gr) flat_metric(x[1], x[2], g); // RK4 leaves the Kerr metric (ref :305); the fluid lives in the flat one
                         advanced = true;
                     } else {
-#ifdef S5_KO_VERLET
-                        advanced = false; dl = 0.0;
-#else
                         advanced = verlet_attempt(x, k, dl_max, dl, s, g);
-#endif
                     }
 #ifdef S5_TORUS_DEBUG
                     {
@@ -700,9 +665,7 @@ void torus_pool_kernel(PoolArgs args)
                         pworst[slot] = worst;
                         double I = pd[PD_AT(PC_I, slot)], tau = pd[PD_AT(PC_TAU, slot)];
                         s.E = pd[PD_AT(PC_E, slot)];
-#ifndef S5_KO_TRANSFER
                         accumulate_transfer(T.p, no_absorption, s, g, x, k, dl, I, tau);
-#endif
                         pd[PD_AT(PC_I, slot)] = I;
                         pd[PD_AT(PC_TAU, slot)] = tau;
                         const bool done = !(x[1] > cwd[1]) || !(x[1] < cwd[2]) || ((double)s.error > T.p.max_error) ||
@@ -710,23 +673,17 @@ void torus_pool_kernel(PoolArgs args)
                         if (done) {
                             const size_t ray = (size_t)pray[slot];
                             s.Q = T.start.d[COL_Q * T.start.cap + ray];
-#ifndef S5_KO_END
                             write_ray_end(T.aux, T.out, ray, x, k, s, I, tau, worst);
-#endif
                             tag = TAG_EMPTY; on = false; finished = true;
                         }
 #else
                         worst = fmaxf(worst, s.error);
-#ifndef S5_KO_TRANSFER
                         accumulate_transfer(p, no_absorption, s, g, x, k, dl, I, tau);
-#endif
                         const bool done = !(x[1] > r_in) || !(x[1] < r_out) || ((double)s.error > p.max_error) ||
                                           (s.pass >= p.max_steps);
                         if (done) {
                             s.Q = sc[COL_Q * scap + ray];
-#ifndef S5_KO_END
                             write_ray_end(A.aux, A.out, ray, x, k, s, I, tau, worst);
-#endif
                             tag = TAG_EMPTY; on = false; finished = true;
                         }
 #endif

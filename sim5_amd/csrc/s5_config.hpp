@@ -29,19 +29,11 @@
 #define S5NS s5
 #endif
 
-// individual features of the fast variant (overridable for ablation builds, -DS5_F_xxx=0)
-#ifndef S5_F_SQRTDIV
+// individual features of the fast variant (what the ablation builds of rounds 1-3 switched off one at a time: header comment)
 #define S5_F_SQRTDIV S5_FAST      // Newton-refined rsq/rcp sequences instead of IEEE sqrt and divide
-#endif
-#ifndef S5_F_RF7
 #define S5_F_RF7 S5_FAST          // 7th-order Carlson series with Carlson's division-free stopping rule
-#endif
-#ifndef S5_F_AGMK
 #define S5_F_AGMK S5_FAST         // K(m) by the arithmetic-geometric mean instead of R_F(0, 1-m, 1): -7 % time
-#endif                            // in the fused image kernel (1.365 -> 1.27 ms), same results
-#ifndef S5_F_LIBM
 #define S5_F_LIBM S5_FAST         // cbrt for x^(1/3), fused sincos, folded constant reciprocals
-#endif
 
 // Selective FMA contraction in the fast variant.  The translation units are compiled with -ffp-contract=off (the
 // reference build has no FMA); a region named below lets the compiler fuse a*b+c when its bit is set in S5_FPC_MASK.
@@ -53,9 +45,7 @@
 // takes it to r 1.4e-7, g 7e-7, flux 2.3e-5 -- the discriminant X = F^2 - 4 E^3 of the resolvent cubic cancels to rounding
 // noise near the double-root locus, and only the reference's own two roundings (F^2 rounded, then the difference) put the
 // same rays on the same side of X = 0.  So everything but the quartic contracts: 0.377 -> 0.366 ms on the headline image.
-#ifndef S5_FPC_MASK
 #define S5_FPC_MASK (S5_FAST ? 62 : 0)
-#endif
 // contract(on), not (fast): a*b+c is fused only inside ONE source expression, decided by the front end (llvm.fmuladd, always
 // v_fma_f64 on gfx950), so a routine rounds the same way in every kernel and template instantiation it is inlined into.
 // With (fast) the back end fuses across statements where it finds it profitable, which differs from one instantiation
@@ -95,8 +85,8 @@
 #endif
 
 // fast variant: the image kernels' rays do not evaluate the radial integral Rpc; r(P) comes from the addition theorem
-// (s5_thindisk.hpp).  -DS5_NO_RPC_BY_ADDITION restores the R_F evaluation for A/B measurements.
-#if S5_FAST && !defined(S5_NO_RPC_BY_ADDITION)
+// (s5_thindisk.hpp).
+#if S5_FAST
 #define S5_RPC_ADD 1
 #else
 #define S5_RPC_ADD 0

@@ -107,11 +107,9 @@ S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
 {
     bool cf;
     double F = disk_flux_table(d, r, x, rx, cf);
-#ifndef S5_KO_FLUXCF
     if (wave_any(cf)) {
         if (cf) F = disk_flux_closed_form(d, r, x);
     }
-#endif
     return F;
 }
 #endif

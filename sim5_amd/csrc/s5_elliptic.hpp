@@ -83,13 +83,8 @@ S5_DEV double carlson_rf_impl(double x, double y, double z, double sqrt_x = 0.0)
         }
     }
     // 1/(4^n A_n) and its square root from one reciprocal square root
-#ifdef S5_RF_TAIL_RCP                               // A/B builds: the reciprocal and its square root separately
-    const double rA = mrcp(A);
-    const double rsA = sqrt_pos(rA);
-#else
     const double rsA = rsqrt_pos(A);
     const double rA = rsA * rsA;
-#endif
     const double X = dx0 * rA, Y = dy0 * rA, Z = -(X + Y);
     const double E2 = X * Y - Z * Z, E3 = X * Y * Z;
     // coefficient of E2^j E3^k: (-1)^j (1/2)_(j+k) / (j! k! (2(2j+3k)+1))  (DLMF 19.19.7 with E1 = 0), all terms
@@ -325,11 +320,7 @@ S5_DEV double inv_tn(double z, double m)
 //               (32 KB fast -- 34 KB in the image kernels, which keep one more row: ladder_descend_squares -- 52 KB strict).
 // 13 rungs as in the reference; the AGM of a double-precision modulus (1 - m >= 1.1e-16, the m == 1 clamp included)
 // reaches 1e-8 at rung index 7 at the latest (scanned over 1e5 moduli up to 1 - 2^-53), so the fast variant keeps 8.
-#ifdef S5_LADDER_RUNGS_OVERRIDE          // timing experiments only
-constexpr int LADDER_RUNGS = S5_LADDER_RUNGS_OVERRIDE;
-#else
 constexpr int LADDER_RUNGS = S5_FAST ? 8 : 13;
-#endif
 
 struct LadderRegs {
     double a[LADDER_RUNGS], g[LADDER_RUNGS];
@@ -570,11 +561,7 @@ S5_DEV void sncndn_lds(double u, double m, double& sn, double& cn, double& dn)
 
 // A kernel launched with 256-thread one-dimensional workgroups may define S5_LADDER_IN_LDS before including the
 // headers: the generic routines (position_rad, position_pol, ...) then keep the ladder rungs in LDS as well.
-#ifdef S5_LADDER_IN_LDS
-#define S5_SNCNDN sncndn_lds
-#else
 #define S5_SNCNDN sncndn
-#endif
 S5_DEV double jac_sn(double u, double m) { double s, c, d; S5_SNCNDN(u, m, s, c, d); return s; }
 S5_DEV double jac_cn(double u, double m) { double s, c, d; S5_SNCNDN(u, m, s, c, d); return c; }
 S5_DEV double jac_dn(double u, double m) { double s, c, d; S5_SNCNDN(u, m, s, c, d); return d; }

@@ -527,12 +527,6 @@ struct GeodTrack {
     // bookkeeping drops out.  The caller re-anchors with the full evaluation (anchor(): the very values of rad(), pol())
     // every few dozen sub-steps, which bounds the accumulated rounding (a few ulp per sub-step) near 2e-14, and
     // whenever step_is_small() says the series does not apply.
-#ifndef S5_ALONG_LONG
-#define S5_ALONG_LONG 0
-#endif
-#ifndef S5_ALONG_SPLIT
-#define S5_ALONG_SPLIT 0
-#endif
     struct Along { double Sr, Cr, Dr, Sp, Mp, Dp; };
     double kr, inv_mK, m_r, m_p, dP_small;
     double ser_r[5], ser_p[5];                   // sn(v | m) = v (1 + s0 v^2 + s1 v^4 + s2 v^6 + s3 v^8 + s4 v^10)
@@ -553,12 +547,12 @@ struct GeodTrack {
         m_r = m_rad; m_p = g.mm;
         sn_series(m_r, ser_r); sn_series(m_p, ser_p);
         const double wr = fabs(kr) * sqrt(fmax(1.0, fabs(m_r))), wp = fabs(inv_mK) * sqrt(fmax(1.0, fabs(m_p)));
-        dP_small = (S5_ALONG_LONG ? 0.075 : 0.04) / fmax(wr, wp);
+        dP_small = 0.04 / fmax(wr, wp);
         if (!(type == T_RR || type == T_RC) || !escapes_ || !(dP_small > 0.0) || m_r == 1.0 || m_p == 1.0 ||
             st_r.degenerate || st_m.degenerate) dP_small = 0.0;                   // always anchor
     }
 
-    S5_DEV bool step_is_small(double dP) const { return fabs(dP) <= (S5_ALONG_SPLIT ? 4. : 1.) * dP_small; }
+    S5_DEV bool step_is_small(double dP) const { return fabs(dP) <= dP_small; }
 
     // sqrt(1 - x) for |x| <= 1.6e-3 (next term 2e-2 x^6; with S5_ALONG_LONG 5.6e-3 and 1.6e-2 x^7);
     // TINY: |x| <= 1.6e-5, three terms (next 4e-2 x^4)
@@ -568,12 +562,7 @@ struct GeodTrack {
         double p;
         if (TINY) p = fma(x, -0.0625, -0.125);
         else {
-#if S5_ALONG_LONG
-            p = fma(x, -0.0205078125, -0.02734375);
-            p = fma(x, p, -0.0390625);
-#else
             p = fma(x, -0.02734375, -0.0390625);
-#endif
             p = fma(x, p, -0.0625);
             p = fma(x, p, -0.125);
         }
@@ -591,12 +580,7 @@ struct GeodTrack {
         double p;
         if (TINY) p = fma(v2, ser[1], ser[0]);
         else {
-#if S5_ALONG_LONG
-            p = fma(v2, ser[4], ser[3]);
-            p = fma(v2, p, ser[2]);
-#else
             p = fma(v2, ser[3], ser[2]);
-#endif
             p = fma(v2, p, ser[1]);
             p = fma(v2, p, ser[0]);
         }
@@ -607,9 +591,6 @@ struct GeodTrack {
         const double y = mx * (S * S);
         double q = y + 1.0;
         if (!TINY) {
-#if S5_ALONG_LONG
-            q = fma(y, q, 1.0);
-#endif
             q = fma(y, q, 1.0);
             q = fma(y, q, 1.0);
         }
@@ -652,18 +633,6 @@ struct GeodTrack {
     // the same after a small move dP (step_is_small) that ended at P
     S5_DEV void advance(double dP, double P, Along& t, double& r, double& mu) const
     {
-#if S5_ALONG_SPLIT
-        const double adP = fabs(dP);
-        const int parts = (adP <= dP_small) ? 1 : (adP <= 2. * dP_small) ? 2 : 4;
-        const double part = (parts == 1) ? dP : (parts == 2) ? 0.5 * dP : 0.25 * dP;
-        for (int k = 0; k < 4; ++k) {
-            if (!wave_any(k < parts)) break;
-            if (k < parts) {
-                add_small<false>(m_r, ser_r, kr * part, t.Sr, t.Cr, t.Dr);
-                add_small<false>(m_p, ser_p, part * inv_mK, t.Sp, t.Mp, t.Dp);
-            }
-        }
-#else
         if (!wave_any(fabs(dP) > 0.1 * dP_small)) {               // v^2 a hundred times below the bound: the short series
             add_small<true>(m_r, ser_r, kr * dP, t.Sr, t.Cr, t.Dr);
             add_small<true>(m_p, ser_p, dP * inv_mK, t.Sp, t.Mp, t.Dp);
@@ -671,7 +640,6 @@ struct GeodTrack {
             add_small<false>(m_r, ser_r, kr * dP, t.Sr, t.Cr, t.Dr);
             add_small<false>(m_p, ser_p, dP * inv_mK, t.Sp, t.Mp, t.Dp);
         }
-#endif
         r = rad_from(t, P);
         mu = sq_m2p * t.Mp;
     }

@@ -21,21 +21,15 @@ S5_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // on scalar instructions alone, while the vote of a flag that was not compared in the same basic block goes through a
 // vector register and back (v_cndmask 0/1, v_cmp_ne: two vector instructions each; 180 of them in the pair kernel of
 // rounds 1-3).  wave_any stays where a wave-uniform DECISION is needed (which instantiation a wave takes).
-#ifdef S5_WAVE_VOTES                 // A/B builds: the explicit votes of rounds 1-3
+// (a translation unit may keep the explicit votes -- `#define S5_WAVE_VOTES 1` before its includes, in the SOURCE, not a build
+// flag: k_surface.hip does, its walk kernel needs two registers fewer that way and sits on its cap of 168)
+#ifdef S5_WAVE_VOTES
 #define S5_ANY(c) wave_any(c)
 #else
 #define S5_ANY(c) (c)
 #endif
-#ifdef S5_VOTE_ORDER
-#define S5_ANY_ORDER(c) wave_any(c)
-#else
 #define S5_ANY_ORDER(c) S5_ANY(c)
-#endif
-#ifdef S5_VOTE_MISC
-#define S5_ANY_MISC(c) wave_any(c)
-#else
 #define S5_ANY_MISC(c) S5_ANY(c)
-#endif
 
 S5_DEV double sq(double x) { return x * x; }
 // A product the back end must not fuse into the sum that follows (no instruction is emitted).  The march kernel's fast build

@@ -26,11 +26,7 @@ static_assert(sizeof(RayState) == 144, "raytrace_data must keep the SIM5 layout"
 
 // Scheduling fence between the phases of a step: without it the compiler overlaps metric, connection
 // and corrector arithmetic for ILP and runs out of registers (spills to scratch).
-#ifdef S5_NO_FENCE
-#define S5_FENCE() do {} while (0)
-#else
 #define S5_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 S5_DEV double rel_diff(double a, double b) { return mdiv(fabs(b - a), fabs(b) + 1e-40); }   // ref :31
 
@@ -72,11 +68,7 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
 // ignored): four registers less through the three stages.  Same expressions, same operands: the same numbers.
 struct NoLateFetch { S5_DEV double operator()(int) const { return 0.0; } };
 template <bool LATE_TPHI = false, class Fetch = NoLateFetch>
-#ifdef S5_RK4_NOINLINE
-static __device__ __noinline__ void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g, const Fetch& late = Fetch())
-#else
 S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g, const Fetch& late = Fetch())
-#endif
 {
     Conn G;
     double xp[4], ki[4], di[4], sx[4], sk[4];
@@ -125,11 +117,7 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
 #else
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ki[i] = 0.0; di[i] = 0.0; sx[i] = 0.0; sk[i] = 0.0; }
-#ifdef S5_RK4_UNROLL
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
     for (int stage = 0; stage < 4; ++stage) {
         const double off = (stage == 0) ? 0.0 : (stage == 3) ? dl : h;
         const double wgt = (stage == 1 || stage == 2) ? 2.0 : 1.0;
@@ -211,7 +199,7 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
     const double half_dl2 = 0.5 * dl * dl;
     xp[0] = x[0] + k[0] * dl + dk[0] * half_dl2;
     xp[1] = x[1] + k[1] * dl + dk[1] * half_dl2;
-#if S5_FAST && !defined(S5_T_POLAR_REF)
+#if S5_FAST
     {   // cos(acos(m) + d) = m cos d - sqrt(1 - m^2) sin d: one bounded sincos and a square root instead of acos
         // and cos (the reference's form, ref :177, stays in the strict variant); same step counts on the C4 job
         const double d = k[2] * dl + dk[2] * half_dl2;

@@ -72,9 +72,6 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
                                     const double beta_test0 = NAN, const double beta_test1 = NAN);
 
 // (param_reload(): s5_config.hpp)
-#ifndef S5_COLD_UNPAIRED
-#define S5_COLD_UNPAIRED 0      // measured by the compiler: 21 spilled SGPRs against 9 with the paired copy; kept for the record
-#endif
 // internal class value: the fast routine leaves this ray to the direct one (never stored)
 constexpr int PX_COLD_MARK = 100;
 // internal error value of the fast routine: the ray's polar range tests are marginal, the direct routine decides (never stored)
@@ -89,7 +86,7 @@ constexpr double FLUX_OWED = -1.0;
 template <bool PAIR, class PRM>
 S5_DEV void thin_disk_owed_flux(const PRM& p, ThinRay& out, ThinRay& out2)
 {
-#if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX) && !defined(S5_KO_FLUXCF)
+#if S5_FAST
     const bool f0 = (out.flux < 0.0), f1 = PAIR && (out2.flux < 0.0);
     S5_MARK("owed flux begin");
     if (S5_ANY(f0 || f1)) {
@@ -166,12 +163,8 @@ S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, Thi
 #if S5_FAST
         // Z^2 = (F^2 - X)/54^2 = 4 E^3/54^2, so Z^(1/3) = sqrt(E)/3: one square root instead of a square
         // root and a cube root; atan2 is scale-free, so the divisions by 54 drop out as well
-#ifdef S5_KO_TRIG
-        A = sqrt_pos(E) * (2. / 3.) * (0.9 + 1e-9 * F);
-#else
         const double z = matan2(sqrt_pos(-X), F);                    // X < 0 here, and then E > 0
         A = sqrt_pos(E) * (2. / 3.) * mcos_third(z);
-#endif
 #else
         const double sX = S5_DIVC(msqrt(-X), 54.);
         const double F54 = S5_DIVC(F, 54.);
@@ -256,13 +249,6 @@ S5_DEV void trace_thin_disk_impl(const PRM& p, double alpha, double beta_in, Thi
                 const s5abi::ImageParams* pk = (const s5abi::ImageParams*)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(pk));                    // opaque: its reads are not merged with the kernel's own
                 trace_thin_disk_impl<WANT_STATE, PAIR, true>(*pk, alpha, beta_in, d0, PAIR ? d1 : d0, -1, t0, t1);
-            } else if constexpr (PAIR && S5_COLD_UNPAIRED) {
-                // constant-address-space parameters (job-list kernel): the two rays of the pair one after the other through
-                // ONE copy of the UNPAIRED direct routine (a ray of a pair is the unpaired routine's ray, value for value:
-                // tests/test_gpu_images.py::test_mirrored_pairs_give_the_plain_image) -- half the code of the paired copy and
-                // well under its scalar-register need, which was the peak of the whole kernel
-                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, beta_in, d0, d0, -1, t0);
-                trace_thin_disk_impl<WANT_STATE, false, true>(param_reload(p), alpha, -beta_in, d1, d1, -1, t1);
             } else {
                 trace_thin_disk_impl<WANT_STATE, PAIR, true>(param_reload(p), alpha, beta_in, d0, PAIR ? d1 : d0, -1, t0, t1);
             }
@@ -438,11 +424,7 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
     double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0;
     // unrolled: three inlined R_F bodies (slot 1 is the table, slot 3 rare).  Rolled into one body it once saved the kernel
     // from 256 VGPRs and spills; at today's 108 VGPRs the copies cost nothing and the rolled loop costs 4 % (measured)
-#if defined(S5_SLOT_ROLLED)
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
     for (int slot = 0; slot < 4; ++slot) {
 #if S5_F_AGMK
         if (slot == 1) continue;                         // K(mmT) comes from the AGM below
@@ -464,12 +446,8 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
             const double s = -zR, s2 = s * s;
             x = 1. - s2; y = 1.0 - s2 * m3; mult = s;
         }
-#ifdef S5_KO_RF                  // diagnostic knock-outs: timing-breakdown builds only, never shipped
-        const double v = mult * (1.5 + 0.1 * x + 0.01 * y);
-#else
         // plain lanes have x, y > 0 by construction (z^2 < 1, moduli in [0,1)); the others are redone out of line
         const double v = mult * carlson_rf_positive(x, y, 1.0);
-#endif
         if (slot == 0) res0 = v; else if (slot == 1) res1 = v; else if (slot == 2) res2 = v; else res3 = v;
     }
     // assemble as the generic routines do
@@ -491,11 +469,9 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
             for (int k = KT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
             res1 = acc;
         }
-#ifndef S5_KO_KAGM
         if (wave_any(!tab)) {
             if (!tab) res1 = ell_K(mmT);
         }
-#endif
     }
 #endif
     double K = res1;
@@ -544,25 +520,12 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
     LadderState lst;
     const bool ladder_class = (type == T_RR) || (type == T_RC);
     const bool may_cross = q_pos && !u_bad;
-#ifndef S5_KO_RAD
     if (wave_any(ladder_class && may_cross)) ladder_climb(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
-#endif
-#ifndef S5_PAIR_MEMBERS
-#define S5_PAIR_MEMBERS 2                    // 1: timing experiments only (the mirror image is not traced)
-#endif
-#ifdef S5_DEBUG_TOP                 // diagnostic: the ladder depth of the ray in the gtype plane
-    out.gtype = (ladder_class && may_cross) ? lst.top : -2;
-    if (PAIR) out2.gtype = out.gtype;
-#endif
     bool cf0 = false, cf1 = false;
     // two inlined passes rather than a run-time loop: as a loop the compiler predicates the pass on per-lane state and the
     // lanes used fall from 97 % to 91 % (measured: +6.5 % VALU instructions, +4.5 % time)
-#if defined(S5_PAIR_ROLLED)
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
-    for (int member = 0; member < (PAIR ? S5_PAIR_MEMBERS : 1); ++member) {
+    for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
         const double beta_m = (member == 0) ? beta : -beta;
         int cls_m = PX_MISS;
         double r_m = NAN, P_m = NAN, g_m = 0.0, flux_m = 0.0, dP_m = NAN;
@@ -596,11 +559,7 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
                     else if (rcx) su = sqAB * (Rpc - P);
                     double sn = 0.0, cn = 1.0, dn = 1.0;
                     if (wave_any(use_ladder)) {
-#ifdef S5_KO_RAD
-                        if (use_ladder) { sn = 0.3 + 1e-3 * su; cn = 0.9 - 1e-3 * mR; }
-#else
                         if (use_ladder) ladder_descend(lad, lst, su, sn, cn, dn);
-#endif
                     }
                     if (!in_range) r = NAN;
                     else if (at_peri) r = rp;
@@ -623,22 +582,14 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
             }
         }
         if (cls_m == PX_HIT0 || cls_m == PX_HIT1) {
-#if S5_FAST && !defined(S5_KO_G) && !defined(S5_KO_FLUX)
+#if S5_FAST
             double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
             sqrt_rsqrt_pos(r_m, x, rx);                   // r >= rms > 0
             g_m = gfactor_kepler_x(r_m, x, a_in, l);
             flux_m = disk_flux_table(p.disk, r_m, x, rx, cf_m);
 #else
-#ifdef S5_KO_G
-            g_m = 0.5 + 1e-3 * r_m;
-#else
             g_m = gfactor_kepler(r_m, a_in, l);
-#endif
-#ifdef S5_KO_FLUX
-            flux_m = 1e20 * r_m;
-#else
             flux_m = disk_flux(p.disk, r_m);
-#endif
 #endif
         }
         (void)cf0; (void)cf1;
@@ -678,13 +629,9 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
                              const double ra, const double rb, const double rc_, const double rd_)
 {
     S5_FPC_FINISH
-#ifdef S5_NO_FINISH_RELOAD
-    const auto& p = p_in;
-#else
     // constant-address-space parameters are loaded from HERE: each class instantiation issues its own scalar loads of the few
     // it reads instead of holding them -- spilled to vector lanes -- from the kernel's first instruction
     const auto& p = param_reload(p_in);
-#endif
     using namespace s5abi;
     constexpr double S5_PI = 3.14159265358979323846;
     const int type = (KNOWN >= 0) ? KNOWN : type_in;
@@ -775,9 +722,7 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
     // every crossing order and both rays of a pair -- and kept in LDS; lanes that cannot use them climb a short dummy
     LadderLds lad{thin_disk_ladder_column()};
     LadderState lst{};
-#ifndef S5_KO_RAD
     if (wave_any(ladder_class && may_cross)) ladder_climb<LadderLds, LADDER_RUNGS, true>(lad, (ladder_class && may_cross) ? mR : 0.5, lst);
-#endif
     const bool by_add = ok && plain0 && ladder_class && may_cross && !lst.flipped && !lst.degenerate && !lst.incomplete;
 
     // ---------------- the polar integrals: cn^-1(u_i | mmT) by R_F, K(mmT) from the table ----------------
@@ -786,13 +731,7 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
         // x = u_i^2 was formed as a square, its root is |u_i| (first pass of the duplication with one square root);
         // plain lanes have x, y > 0 by construction (u^2 < 1, modulus in [0,1)); the others are redone out of line
         const double z2 = u_i * u_i;
-#ifdef S5_KO_RF                  // diagnostic knock-outs: timing-breakdown builds only, never shipped
-        icn_i = sqrt_pos(1. - z2) * (1.5 + 0.1 * z2 + 0.01 * mmT);
-#elif defined(S5_NO_RF_ROOT_X)
-        icn_i = sqrt_pos(1. - z2) * carlson_rf_positive(z2, 1.0 - mmT * (1. - z2), 1.0);
-#else
         icn_i = sqrt_pos(1. - z2) * carlson_rf_root_x(fabs(u_i), z2, 1.0 - mmT * (1. - z2));
-#endif
     }
     double K;
     {
@@ -811,11 +750,9 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
             for (int k = KT_DEG - 1; k >= 0; --k) acc = __builtin_fma(acc, tau, c[k]);
             K = acc;
         }
-#ifndef S5_KO_KAGM
         if (S5_ANY_MISC(!tab)) {
             if (!tab) K = ell_K(mmT);
         }
-#endif
     }
     if (S5_ANY_MISC(ok && !plain2)) {
         if (ok && !plain2) icn_i = inv_cn_cold(u_i, mmT);
@@ -856,23 +793,12 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
             add_s = sqrt_pos((1. - z2) * (1. - mR * z2));       // cn(F0) dn(F0)
         }
     }
-#ifdef S5_DEBUG_TOP                 // diagnostic: the ladder depth of the ray in the gtype plane
-    out.gtype = (ladder_class && may_cross) ? lst.top : -2;
-    if (PAIR) out2.gtype = out.gtype;
-#endif
-#ifndef S5_PAIR_MEMBERS
-#define S5_PAIR_MEMBERS 2                    // 1: timing experiments only (the mirror image is not traced)
-#endif
-    constexpr int MEMBERS = PAIR ? S5_PAIR_MEMBERS : 1;
+    constexpr int MEMBERS = PAIR ? 2 : 1;
     // a ray that may cross but is not served by the addition theorem goes the reference's way, after the loops
     bool cold[2] = {may_cross && !by_add, may_cross && !by_add};
     // two inlined passes rather than a run-time loop: as a loop the compiler predicates the pass on per-lane state and the
     // lanes used fall from 97 % to 91 % (measured: +6.5 % VALU instructions, +4.5 % time)
-#ifdef S5_PAIR_ROLLED
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
     for (int member = 0; member < MEMBERS; ++member) {
         const double beta_m = (member == 0) ? beta : -beta;
         int cls_m = PX_MISS;
@@ -897,23 +823,12 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
                     // sn^2(w - F0) = Pn / Q (RR), cn(F0 - w) = X / Y (RC)
                     double Pn = 0.0, Q = 1.0, X = 1.0, Y = 1.0, dP = NAN, r = NAN;
                     int code = CROSS_FORMULA;
-#ifdef S5_KO_RAD                 // diagnostic knock-out: timing-breakdown builds only, never shipped
-                    Pn = 0.05 + 1e-4 * P; Q = 1.0; X = 0.9 - 1e-3 * P; Y = 1.0; dP = 1.0;
-#else
                     {
                         double s0, c0, C, ga, N, D;
-#ifdef S5_NO_SINCOS_TABLE
-                        msincos(wc, s0, c0);                               // RR: 0 < w c < pi, RC: < 2 pi
-#else
                         // (from the node table where the launcher attached one -- every launcher of the fast variant does, so all
                         // its image kernels form the same numbers: s5_trig.hpp msincos_tab; a wave-uniform test)
                         if (p.sctab) msincos_tab(p.sctab, wc, s0, c0); else msincos(wc, s0, c0);
-#endif
-#ifdef S5_DESCEND_FRACTIONS          // A/B builds: the descent of rounds 2-3
-                        ladder_descend_fractions(lad, lst, s0, c0, C, ga, N, D);
-#else
                         ladder_descend_squares(lad, lst, s0, c0, C, ga, N, D);
-#endif
                         // numerators of sn(w) and cn(w) over rho (the signs as ladder_descend assigns them)
                         const double S = (s0 >= 0.0) ? fabs(ga) : -fabs(ga);
                         const double Cc = ((ga >= 0.0) == (s0 >= 0.0)) ? C : -C;
@@ -942,7 +857,6 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
                             dP = -(num * D);
                         }
                     }
-#endif
                     if (code == CROSS_FORMULA) {
                         if (type == T_RR) {
                             // ref :320 divided through by r1 - r4: (r2 - r4)/(r1 - r4) is zR^2 = sn^2(F0)
@@ -975,23 +889,10 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
         ThinRay& o = (member == 0) ? out : out2;
         if (o.cls == PX_HIT0 || o.cls == PX_HIT1) {
             bool cf = false;
-#if !defined(S5_KO_G) && !defined(S5_KO_FLUX)
             double x, rx;                                 // sqrt(r) and its reciprocal serve the g-factor and the flux
             sqrt_rsqrt_pos(o.r, x, rx);                   // r >= rms > 0
             o.g = gfactor_kepler_x(o.r, x, a_in, l);
             o.flux = disk_flux_table(pd.disk, o.r, x, rx, cf);
-#else
-#ifdef S5_KO_G
-            o.g = 0.5 + 1e-3 * o.r;
-#else
-            o.g = gfactor_kepler(o.r, a_in, l);
-#endif
-#ifdef S5_KO_FLUX
-            o.flux = 1e20 * o.r;
-#else
-            o.flux = disk_flux(p.disk, o.r);
-#endif
-#endif
             if (cf) o.flux = FLUX_OWED;          // the closed form, once, at the end of trace_thin_disk_impl (thin_disk_owed_flux)
         }
     }

@@ -243,6 +243,37 @@ def test_shard_plan_is_the_python_dealing_rule(capi):
         assert total == ny
 
 
+def test_shipped_kernels_are_one_source_one_build():
+    """two readers must be able to tell which kernel is the tested one.  (i) The library the product loads is
+    compiled with the strict / fast pair and nothing else: no -DS5_* besides -DS5_FAST=0|1 in the command line recorded next
+    to every object (experiment flags reach variant builds only, sim5_amd/build.py).  (ii) The image kernels' sources carry
+    no knock-out / ablation / A/B preprocessor branch any more: the only macros their conditionals test are the variant
+    (S5_FAST and what s5_config.hpp derives from it), the assembly-comment marker of tests/tools/isa_spill_sites.py and the
+    march kernel's one instrumentation switch -- in EVERY file of sim5_amd/csrc."""
+    import glob
+    import re
+    from sim5_amd import capi      # (builds the library if it is not there)
+    csrc = os.path.join(ROOT, "sim5_amd", "csrc")
+    cmds = glob.glob(os.path.join(csrc, "_build", "*.o.cmd"))
+    assert len(cmds) >= 16, cmds
+    for f in cmds:
+        flags = re.findall(r"-D(S5_\w+)(?:=(\S+))?", open(f).read())
+        assert [n for n, _ in flags] == ["S5_FAST"] and flags[0][1] in ("0", "1"), (f, flags)
+    allowed = {"S5_FAST", "S5_F_SQRTDIV", "S5_F_RF7", "S5_F_AGMK", "S5_F_LIBM", "S5_FPC_MASK", "S5_RPC_ADD", "S5_ISA_MARKS",
+               "S5_WAVE_VOTES"}         # (set by k_surface.hip in its own source: s5_math.hpp)
+    # (the march kernel keeps ONE instrumentation switch, S5_TORUS_DEBUG: wave timelines and batch-fill counters for
+    # tests/tools/torus_occupancy.py, built as a variant library; S5_MARCH_LEAN is S5_FAST by another name)
+    allowed |= {"S5_TORUS_DEBUG", "S5_MARCH_LEAN"}
+    sources = [f for f in os.listdir(csrc) if f.endswith((".hpp", ".hip"))]
+    assert len(sources) >= 28
+    for name in sources:
+        for ln in open(os.path.join(csrc, name)):
+            t = ln.strip()
+            if re.match(r"#\s*(if|ifdef|ifndef|elif)\b", t):
+                used = set(re.findall(r"\bS5_\w+", t))
+                assert used <= allowed, (name, t)
+
+
 def test_no_register_spills_in_the_image_kernels():
     """The whole-image kernels of the fast variant run without scratch memory: no spilled VGPR, no private segment.  (A build
     of disk_image_mirror_kernel that spilled ONE double under its 128-register cap produced wrong pixels in some launches
