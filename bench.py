@@ -372,6 +372,117 @@ def plan_root_band(torch, dist, capi, sharding, rank, world, n, dev, cdev, strea
     return dealt, rec
 
 
+def all_ok(dist, torch, cdev, world, ok_local):
+    """soft agreement: True on every rank iff every rank says ok (one all-reduce); nobody exits"""
+    if world <= 1:
+        return bool(ok_local)
+    t = torch.tensor([0.0 if ok_local else 1.0], dtype=torch.float32, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()) == 0.0
+
+
+def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, dealt, steps, single):
+    """A/B of the exchange, AFTER the timed region (it never enters `value`): the peer-to-peer form SURVEY 8(e) allows.  Rank 0
+    exports the inter-process handle of ONE whole-image allocation, every peer maps it and traces its mirrored stripes IN
+    PLACE on the mapped planes (SIM5GPU_IMG_INPLACE) -- its rows go straight into rank 0's image over xGMI: no payload buffer,
+    no gather, no placement pass; rank 0 traces its share and its band into the same image.  A step ends with a stream
+    synchronisation and a barrier (the completion signal the gather form gets from the collective), so the figure includes
+    that latency and is not pipelined: a lower bound on what the form can do.  Any rank that cannot take part (no IPC between
+    the two devices, an allocation that fails) makes EVERY rank skip the phase with the reason in the record -- nothing here
+    can take the headline line with it.  Returns the record on rank 0 (None elsewhere)."""
+    rec = {"what": "peers store their rows straight into rank 0's IPC-mapped image (SIM5GPU_IMG_INPLACE on the mapped planes); "
+                   "a step = every rank's launch + stream synchronisation + barrier; measured after the timed region, never part of `value`"}
+    state = {"img": None, "base": None, "err": None}
+
+    def attempt(fn):
+        try:
+            fn()
+            ok = True
+        except Exception as e:                                 # noqa: BLE001 -- reported in the record
+            state["err"] = repr(e)[:300]
+            ok = False
+        return all_ok(dist, torch, cdev, world, ok)
+
+    handle = [None]
+
+    def export():
+        if rank == 0:
+            state["img"] = capi.DeviceBuffer(2 * n * n * 4)
+            state["img"].fill(0)
+            state["base"] = state["img"].ptr
+            handle[0] = capi.ipc_export(state["img"].ptr)
+    if not attempt(export):
+        rec["skipped"] = "rank 0 could not export its image: %s" % state["err"]
+        return rec if rank == 0 else None
+    dist.broadcast_object_list(handle, src=0)
+
+    def open_():
+        if rank != 0:
+            state["base"] = capi.ipc_open(handle[0])
+    opened = attempt(open_)
+    if opened:
+        inc = INCL_DEG / 180.0 * math.pi
+        kw = sharding.job_rows(n, rank, world, dealt=dealt)
+        descs = []
+        if kw["y0"] < kw["y1"]:
+            descs.append(capi.image_desc(n, n, SPIN, inc, inplace=True, **kw))
+        band = sharding.root_band(n, dealt) if rank == 0 else None
+        f_ptr, g_ptr = state["base"], state["base"] + n * n * 4
+
+        def launch():
+            if band and descs:
+                bd = capi.image_desc(n, n, SPIN, inc, y0=band[0], y1=band[1])
+                capi.disk_image_jobs([descs[0], bd], [f_ptr, f_ptr + band[0] * n * 4], [g_ptr, g_ptr + band[0] * n * 4], stream=stream)
+            else:
+                for d in descs:
+                    capi.disk_image_device(d, f_ptr, g_ptr, stream=stream)
+
+        def one_step():
+            launch()
+            torch.cuda.synchronize()
+            dist.barrier()
+
+        times = []
+
+        def run():
+            for _ in range(2):
+                one_step()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_step()
+            times.append(time.perf_counter() - t0)
+        ran = attempt(run)
+        if ran:
+            t = torch.tensor([times[0]], dtype=torch.float64, device=cdev)
+            allv = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allv, t)
+            dt = max(float(v.item()) for v in allv)
+            rec.update({"steps": steps, "ms_per_image": 1e3 * dt / steps, "rays_per_s": n * n * steps / dt})
+            if rank == 0:
+                if single is not None:
+                    rec["words_differing_from_single_launch"] = capi.words_differ(state["img"].ptr, single.data_ptr(), 2 * n * n)
+                else:
+                    import numpy as np
+                    g = state["img"].to_numpy(np.float32, (2, n, n))[1]
+                    hits = int((g > 0).sum())
+                    rec["disk_hits"] = hits
+                    rec["disk_hits_reference"] = HEADLINE_HITS
+        else:
+            rec["skipped"] = "a rank failed while tracing into the mapped image: %s" % state["err"]
+    else:
+        rec["skipped"] = "a peer could not map rank 0's image (no IPC / peer access between the devices?): %s" % state["err"]
+
+    def close():
+        if rank != 0 and state["base"] and opened:
+            torch.cuda.synchronize()
+            capi.ipc_close(state["base"])
+    attempt(close)
+    if world > 1:
+        dist.barrier()                                          # the peers have unmapped before rank 0 frees
+    state["img"] = None
+    return rec if rank == 0 else None
+
+
 def timed_kernel(capi, stream, launch, reps, warm=1):
     """mean ms per launch, HIP events on the launch stream"""
     for _ in range(warm):
@@ -659,6 +770,8 @@ def main():
     ap.add_argument("--root-band", default="auto",
                     help="N > 1, stripes: rows of the upper half dealt over the ranks; the band left in the middle stays with rank 0, "
                          "which needs no link for it (auto: balanced from a measured kernel and gather | off: deal everything | <rows>)")
+    ap.add_argument("--no-direct-ab", action="store_true",
+                    help="N > 1: skip the A/B of the exchange after the timed region (peers storing their rows straight into rank 0's IPC-mapped image)")
     ap.add_argument("--mode", choices=["stripes", "images"], default="stripes",
                     help="N > 1: one image in row stripes + one RCCL gather per image (default) | one complete image per GPU, no collective")
     args = ap.parse_args()
@@ -828,6 +941,9 @@ def main():
             per_rank["place_ms_alone"] = timed_kernel(capi, stream, lambda: pl(src, pipe.full[0]), 10, 2)
             per_rank["assemblies_in_timed_region"] = args.steps * len(inclinations)
         per_rank["root_band_plan"] = plan
+    direct = None
+    if striped and not c5 and not args.no_direct_ab:
+        direct = direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, dealt, max(3, min(args.steps, 20)), single)
     c5_scan = None
     if world > 1 and not args.no_extra and not c5 and striped:
         # collective: every rank enters it, and every rank learns whether all came through
@@ -924,6 +1040,17 @@ def main():
     out["process_group"] = group
     if per_rank:
         out["per_rank"] = per_rank
+    if world > 1:
+        # which number is which: SURVEY 8(d) / BASELINE.md 3 define the metric on KERNEL time (image write
+        # included) with the gather reported separately
+        out["value_definition"] = ("value = rays x K / max-over-ranks wall time of the timed region, INCLUDING the gather to rank 0 and the "
+                                   "placement of the gathered rows (a row-major image on rank 0 every step); value_kernel_only = the same rays "
+                                   "over the slowest rank's kernel time per step = the metric of SURVEY 8(d) (kernel time incl. image write; "
+                                   "the gather is reported separately: per_rank.gather_ms_alone, link_bound)")
+        if direct is not None:
+            out["exchange_ab_direct_stores"] = direct
+            if "ms_per_image" in direct:
+                direct["gather_form_ms_per_image_timed_region"] = 1e3 * dt / args.steps / len(inclinations)
     if striped and plan:
         # Why `value` does not follow the GPU count: a gather to ONE GPU moves (N-1)/N of every image over rank 0's inbound
         # xGMI links, one link per peer, and a GPU writes image rows several times faster than a link carries them

@@ -448,6 +448,17 @@ int sim5gpu_image_desc_check(const sim5gpu_image_desc *desc);
  * they run on distinct GPUs. */
 int sim5gpu_device_bus_id(int device, char *buf, int len);
 
+/* Peer-to-peer form of the multi-GPU exchange ("Alternative without RCCL: ... into a root buffer"): the root
+ * process exports the inter-process handle of its whole-image allocation (a hipMalloc'ed block: d_ptr must be the start of
+ * the allocation), the peers map it and launch their shares with SIM5GPU_IMG_INPLACE on the mapped planes -- their rows go
+ * straight into the root's image over xGMI, no payload buffer, no gather, no placement pass.  `handle` is
+ * SIM5GPU_IPC_HANDLE_BYTES opaque bytes to be carried to the peers by any means; a mapped pointer is valid until
+ * sim5gpu_ipc_close.  Completion is the caller's to signal (stream synchronisation + a barrier of its own). */
+#define SIM5GPU_IPC_HANDLE_BYTES 64
+int sim5gpu_ipc_export(const void *d_ptr, void *handle);
+int sim5gpu_ipc_open(const void *handle, void **d_ptr);
+int sim5gpu_ipc_close(void *d_ptr);
+
 /* Self-check utility of the multi-GPU assembly: the number of 32-bit words in which two DEVICE buffers differ (bit
  * comparison, synchronous on the default stream) -- an assembled image against a single-launch one without a 134 MB
  * copy to the host.  No counterpart in the reference (its images live in host memory: memcmp). */

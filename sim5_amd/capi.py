@@ -208,6 +208,28 @@ class DeviceBuffer:
             pass
 
 
+IPC_HANDLE_BYTES = 64
+
+
+def ipc_export(d_ptr):
+    """inter-process handle (bytes) of a device allocation of this process (its start address)"""
+    h = (C.c_char * IPC_HANDLE_BYTES)()
+    _check(_lib.sim5gpu_ipc_export(VP(d_ptr), h), "sim5gpu_ipc_export")
+    return bytes(h.raw)
+
+
+def ipc_open(handle):
+    """device pointer (int) under which another process's allocation is mapped here; close with ipc_close"""
+    p = C.c_void_p(0)
+    buf = (C.c_char * IPC_HANDLE_BYTES).from_buffer_copy(handle)
+    _check(_lib.sim5gpu_ipc_open(buf, C.byref(p)), "sim5gpu_ipc_open")
+    return int(p.value)
+
+
+def ipc_close(d_ptr):
+    _check(_lib.sim5gpu_ipc_close(VP(d_ptr)), "sim5gpu_ipc_close")
+
+
 def words_differ(d_a, d_b, n_words):
     """number of 32-bit words in which two device buffers differ (bit comparison on the device, synchronous)"""
     n = C.c_ulonglong(0)

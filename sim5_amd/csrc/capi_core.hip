@@ -763,6 +763,38 @@ int sim5gpu_image_place_shares(int n_shares, const sim5gpu_image_desc* descs, co
     return SIM5GPU_OK;
 }
 
+/* peer-to-peer exchange: the root's image mapped into the peers' address spaces (include/sim5gpu.h) */
+int sim5gpu_ipc_export(const void* d_ptr, void* handle)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) <= SIM5GPU_IPC_HANDLE_BYTES, "IPC handle size");
+    if (!d_ptr || !handle) { snprintf(g_err, sizeof g_err, "ipc_export: NULL pointer argument"); return SIM5GPU_E_ARG; }
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    hipIpcMemHandle_t h;
+    S5_HIP(hipIpcGetMemHandle(&h, const_cast<void*>(d_ptr)));
+    memset(handle, 0, SIM5GPU_IPC_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof h);
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_ipc_open(const void* handle, void** d_ptr)
+{
+    if (!handle || !d_ptr) { snprintf(g_err, sizeof g_err, "ipc_open: NULL pointer argument"); return SIM5GPU_E_ARG; }
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    *d_ptr = nullptr;
+    S5_HIP(hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return SIM5GPU_OK;
+}
+
+int sim5gpu_ipc_close(void* d_ptr)
+{
+    if (!d_ptr) return SIM5GPU_OK;
+    if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    S5_HIP(hipIpcCloseMemHandle(d_ptr));
+    return SIM5GPU_OK;
+}
+
 /* self-check utility: number of 32-bit words in which two DEVICE buffers differ (synchronous; bit comparison) */
 int sim5gpu_words_differ(const void* d_a, const void* d_b, size_t n_words, unsigned long long* h_count)
 {

@@ -86,6 +86,12 @@ def test_two_ranks_on_one_gpu(mode, band):
         cs = o["plane_checksums_of_every_assembled_image"]
         assert len(cs) == len(hs) and all(c[2] is True and c[:2] == o["plane_checksums_single_launch"] for c in cs), cs
         assert o["value_kernel_only"] > o["value"] > 0 and o["kernel_ms_per_step_max_over_ranks"] == max(pr["kernel_ms_per_step"])
+        assert "value_kernel_only = the same rays" in o["value_definition"]
+        # the peer-to-peer form of the exchange, A/B'd after the timed region: the peer's rows stored straight into rank 0's
+        # IPC-mapped image (two processes on this one GPU: a real inter-process mapping), bit for bit the single-launch image
+        ab = o["exchange_ab_direct_stores"]
+        assert "skipped" not in ab, ab
+        assert ab["ms_per_image"] > 0 and ab["words_differing_from_single_launch"] == 0 and ab["gather_form_ms_per_image_timed_region"] > 0, ab
         plan = pr["root_band_plan"]
         dealt = plan["dealt_rows_of_upper_half"]
         assert pr["rays_per_launch"][0] == (4096 - dealt) * 4096 and pr["rays_per_launch"][1] == dealt * 4096
