@@ -36,9 +36,16 @@ int main(int argc, char **argv)
     const int rank = atoi(argv[1]), world = atoi(argv[2]);
     char idfile[4096];
     {
+        /* The id file carries a per-RUN stamp, the same on every rank: SIM5_EXAMPLE_NONCE (e.g. the job id, or $$ of the
+         * launching shell).  With more than one rank it is REQUIRED: ranks started by mpirun / srun / xargs or on several nodes
+         * have different parents, so a default derived from the process tree would make the peers wait for a file that never
+         * comes, and a stamp that does not change between runs would hand a crashed run's id to the next one. */
         const char *nonce = getenv("SIM5_EXAMPLE_NONCE");
-        if (nonce && *nonce) snprintf(idfile, sizeof idfile, "%s.%s", argv[3], nonce);
-        else snprintf(idfile, sizeof idfile, "%s.%ld", argv[3], (long)getppid());
+        if (world > 1 && !(nonce && *nonce)) {
+            fprintf(stderr, "ERROR: set SIM5_EXAMPLE_NONCE to a value unique to this run and equal on all %d ranks (e.g. SIM5_EXAMPLE_NONCE=$$ in the launching shell)\n", world);
+            return 2;
+        }
+        snprintf(idfile, sizeof idfile, "%s.%s", argv[3], (nonce && *nonce) ? nonce : "single");
     }
     const double a = argc > 4 ? atof(argv[4]) : 0.998, inc = (argc > 5 ? atof(argv[5]) : 70.0) / 180.0 * M_PI;
     const int n = argc > 6 ? atoi(argv[6]) : 4096, images = argc > 7 ? atoi(argv[7]) : 10;

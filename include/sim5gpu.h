@@ -567,7 +567,9 @@ typedef struct sim5gpu_torus_aux {
  * ~0.5 GB per million rays; torus: 120 B per ray), and the image jobs of the default variant keep one 8 KB block per disk
  * model (spin, mdot / M) and device -- the Novikov-Thorne flux table -- for up to 1024 models per device (least recently
  * used first out).  This gives all of it back (waits for the devices that own it); the next job allocates again.
- * *bytes, if not NULL, receives the number of bytes freed. */
+ * *bytes, if not NULL, receives the number of bytes freed.  NOT to be called while another thread is inside, or about to
+ * launch, a job of this library: a job that has been handed a table block must have been launched before the block goes
+ * (the call waits for launched work, it cannot wait for a thread that has not launched yet). */
 int sim5gpu_release_workspaces(size_t *bytes);
 
 /* d_stokes: (y1-y0) x nx records of sim5gpu_stokes */

@@ -139,6 +139,7 @@ std::mutex g_ftab_lock;
 
 static FluxKey flux_key(double a, double scale)
 {
+    a += 0.0; scale += 0.0;                          // (-0.0 and 0.0 are one model)
     FluxKey k;
     memcpy(&k.a, &a, sizeof a); memcpy(&k.s, &scale, sizeof scale);
     return k;
@@ -334,7 +335,7 @@ size_t release_flux_tables()
         (void)hipSetDevice(dev);
         (void)hipDeviceSynchronize();
         for (auto& kv : Cc.live) { (void)hipFree(kv.second.ptr); freed += (size_t)(s5abi::COLD_N + (kv.second.usable ? s5abi::FT_N * (s5abi::FT_DEG + 1) : 0)) * sizeof(double); }
-        for (double* p : Cc.resting) { (void)hipFree(p); freed += (size_t)s5abi::COLD_N * sizeof(double); }
+        for (double* p : Cc.resting) { (void)hipFree(p); freed += (size_t)(s5abi::COLD_N + s5abi::FT_N * (s5abi::FT_DEG + 1)) * sizeof(double); }   // (a resting block's size is not kept: counted as a full one)
         Cc.live.clear(); Cc.resting.clear();
     }
     (void)hipSetDevice(cur);
