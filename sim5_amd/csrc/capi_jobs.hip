@@ -113,8 +113,10 @@ int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdo
 
 static void spectrum_grid(const sim5gpu_image_desc* desc, size_t& nblocks)
 {
+    // an upper bound for both variants' tilings (strict: 32 x 8 pixels per workgroup; fast: 16 x 16, and 16 x (16 + 16) for a
+    // symmetric row set): the partial spectra and the tree's scratch are sized from it
     const int rows = sim5gpu_image_rows(desc);
-    nblocks = (size_t)((desc->nx + 31) / 32) * (size_t)((rows + 7) / 8);
+    nblocks = (size_t)((desc->nx + 15) / 16) * (size_t)((rows + 7) / 8);
 }
 
 size_t sim5gpu_disk_spectrum_workspace(const sim5gpu_image_desc* desc, int n_energies)

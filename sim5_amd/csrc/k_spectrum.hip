@@ -103,6 +103,7 @@ S5_DEV void spectrum_pixel_equatorial(const PRM& p, const SpectrumParams& sp, co
 //    E^3 is applied once, after the loop over the pixels.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define S5_SPEC_WAVES 4
+constexpr int FAST_TILE_W = 16, FAST_TILE_H = 16;        // a wave: a 16 x 4 patch, as in the image kernels (image neighbours share class and trip counts)
 
 // sum over the staged pixels of amp / (e^x - 1) for this lane's energy, x log2(e) = E sX[q].  18 issue slots per pair: t, n, f, the
 // seven Horner steps of 2^f = 1 + f (c1 + f (c2 + ... + f c7)) with c_k = ln(2)^k / k! (relative error of 2^f - 1: 2e-8; the
@@ -156,9 +157,9 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
                                double* __restrict__ partial)
 {
     const int tid = threadIdx.x;
-    const int lane_x = tid % SPEC_TILE_W, lane_y = tid / SPEC_TILE_W;
-    const int ix = blockIdx.x * SPEC_TILE_W + lane_x;
-    const int lr = blockIdx.y * SPEC_TILE_H + lane_y;                       // PAIR: local row in the upper half
+    const int lane_x = tid % FAST_TILE_W, lane_y = tid / FAST_TILE_W;
+    const int ix = blockIdx.x * FAST_TILE_W + lane_x;
+    const int lr = blockIdx.y * FAST_TILE_H + lane_y;                       // PAIR: local row in the upper half
     const int half = PAIR ? (p.nrows + 1) / 2 : p.nrows;
     double T0 = 0.0, g0 = 0.0, l0 = 0.0, T1 = 0.0, g1 = 0.0, l1 = 0.0;      // (scalars, not arrays indexed by the loop below: no stack)
     if (ix < p.nx && lr < half) {
@@ -326,7 +327,7 @@ int s5_launch_disk_spectrum_strict(const s5abi::ImageParams& p, const s5abi::Spe
     // a row set symmetric about the middle of the image: mirrored pairs, 32 x (8 + 8) pixels per workgroup
     const bool pair = (p.y0 + p.y1 == p.ny) && p.nrows >= 2;
     const int tile_rows = pair ? (p.nrows + 1) / 2 : p.nrows;
-    const dim3 grid((p.nx + SPEC_TILE_W - 1) / SPEC_TILE_W, (tile_rows + SPEC_TILE_H - 1) / SPEC_TILE_H);
+    const dim3 grid((p.nx + FAST_TILE_W - 1) / FAST_TILE_W, (tile_rows + FAST_TILE_H - 1) / FAST_TILE_H);
     if (pair) hipLaunchKernelGGL(disk_spectrum_fast_kernel<true>, grid, dim3(256), 0, stream, p, sp, energies, partial);
     else hipLaunchKernelGGL(disk_spectrum_fast_kernel<false>, grid, dim3(256), 0, stream, p, sp, energies, partial);
     hipError_t e1 = hipGetLastError();

@@ -118,7 +118,12 @@ S5_DEV double disk_ell(const DiskConsts& d, double r)                  // ref :2
 {
     const double a = d.a;
     r = fmax(d.rms, r);
+#if S5_FAST
+    const double x = sqrt_pos(r);                                      // (r >= rms > 0; one root for the three)
+    return mdiv(r * r - 2. * a * x + a * a, x * r - 2. * x + a);
+#else
     return (r * r - 2. * a * sqrt(r) + a * a) / (sqrt(r) * r - 2. * sqrt(r) + a);
+#endif
 }
 
 // Column density of the two inner zones (ref :204-250), the reference's expressions term by term
