@@ -444,6 +444,12 @@ int sim5gpu_image_place_shares(int n_shares, const sim5gpu_image_desc *descs, co
  * arithmetic only, no GPU.  0 or SIM5GPU_E_ARG with the reason in sim5gpu_last_error(). */
 int sim5gpu_image_desc_check(const sim5gpu_image_desc *desc);
 
+/* What a job description resolves to on the host before any ray is traced: rmax (the default r_ms(a) + 8 of ref
+ * examples/04-disk-image-eqplane/disk-image.c:41-42 when desc->rmax <= 0), rms, and sin / cos of the inclination (NULL: not
+ * wanted).  Host arithmetic only, no GPU; the values are the reference binary's bit for bit -- its r_ms, and the sincos() its
+ * geodesic_init_inf calls: an ulp of rmax is an ulp of every alpha and beta, an ulp of cos i reaches Carter's constant. */
+int sim5gpu_image_view(const sim5gpu_image_desc *desc, double *rmax, double *rms, double *sin_i, double *cos_i);
+
 /* PCI bus id of a HIP device as text ("0000:05:00.0", len >= 16): lets the ranks of a multi-process job show that
  * they run on distinct GPUs. */
 int sim5gpu_device_bus_id(int device, char *buf, int len);

@@ -208,6 +208,13 @@ class DeviceBuffer:
             pass
 
 
+def image_view(desc):
+    """(rmax, rms, sin i, cos i) a job description resolves to (host arithmetic, no GPU)"""
+    rmax, rms, si, ci = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    _check(_lib.sim5gpu_image_view(C.byref(desc), C.byref(rmax), C.byref(rms), C.byref(si), C.byref(ci)), "sim5gpu_image_view")
+    return rmax.value, rms.value, si.value, ci.value
+
+
 IPC_HANDLE_BYTES = 64
 
 

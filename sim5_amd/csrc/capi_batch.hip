@@ -40,7 +40,7 @@ static void host_sincos(size_t n, const double* incl, std::vector<double>& s, st
     double last = 0.0, ls = 0.0, lc = 1.0;
     bool have = false;
     for (size_t i = 0; i < n; ++i) {
-        if (!have || memcmp(&incl[i], &last, sizeof last) != 0) { last = incl[i]; ls = sin(last); lc = cos(last); have = true; }
+        if (!have || memcmp(&incl[i], &last, sizeof last) != 0) { last = incl[i]; reference_sincos(last, ls, lc); have = true; }
         s[i] = ls; c[i] = lc;
     }
 }

@@ -60,8 +60,10 @@ int have_device()
 // ISCO radius on the host, the reference's r_ms (src/sim5kerr.c:994-1004)
 static double host_r_ms(double a)
 {
+    // (3 (a a), as the reference's 3.*sqr(a) associates -- not (3 a) a, which is what disk_nt_r_min has: an ulp of r_ms is an
+    // ulp of the default field of view, i.e. of every alpha and beta of the image)
     double z1 = 1. + cbrt(1. - a * a) * (cbrt(1. + a) + cbrt(1. - a));
-    double z2 = sqrt(3. * a * a + z1 * z1);
+    double z2 = sqrt(3. * (a * a) + z1 * z1);
     return 3. + z2 - sqrt((3. - z1) * (3. + z1 + 2. * z2));
 }
 
@@ -389,8 +391,7 @@ int fill_image_params(const sim5gpu_image_desc* desc, ImageParams& p, bool need_
     p.max_order = desc->max_order > 0 ? desc->max_order : 2;
     p.a = desc->a;
     p.incl = desc->incl;
-    p.sin_i = sin(desc->incl);
-    p.cos_i = cos(desc->incl);
+    reference_sincos(desc->incl, p.sin_i, p.cos_i);
     const double rms = host_r_ms(desc->a);                 // ref disk-image.c:41-42
     p.rms = desc->rms > 0.0 ? desc->rms : rms;
     p.rmax = desc->rmax > 0.0 ? desc->rmax : rms + 8.0;
@@ -720,6 +721,19 @@ int sim5gpu_image_desc_check(const sim5gpu_image_desc* desc)
 }
 
 /* PCI bus id of a device ("0000:05:00.0"), so that a multi-process job can show that its ranks sit on distinct GPUs */
+int sim5gpu_image_view(const sim5gpu_image_desc* desc, double* rmax, double* rms, double* sin_i, double* cos_i)
+{
+    if (!desc || !rmax || !rms) { snprintf(g_err, sizeof g_err, "image_view: NULL pointer argument"); return SIM5GPU_E_ARG; }
+    const double r = host_r_ms(desc->a);
+    *rms = desc->rms > 0.0 ? desc->rms : r;
+    *rmax = desc->rmax > 0.0 ? desc->rmax : r + 8.0;
+    double s, c;
+    reference_sincos(desc->incl, s, c);
+    if (sin_i) *sin_i = s;
+    if (cos_i) *cos_i = c;
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_device_bus_id(int device, char* buf, int len)
 {
     if (!buf || len < 16) return SIM5GPU_E_ARG;

@@ -67,7 +67,7 @@ int sim5gpu_disk_surface_rays(double a, double incl, int n_table, const double* 
     if (!(strict & SIM5GPU_SURFACE_TABLE_CHECKED)) { int rc = check_surface_table("disk_surface_rays", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
     strict &= 1;
     SurfaceParams p;
-    p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
+    p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; reference_sincos(incl, p.sin_i, p.cos_i);
     p.tab_vr = nullptr; p.out_g = nullptr; p.out_mue = nullptr; p.out_flux = nullptr;
     memset(&p.disk, 0, sizeof p.disk);
     hipError_t e = (hipError_t)(strict
@@ -100,7 +100,7 @@ int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdo
     if (!(strict & SIM5GPU_SURFACE_TABLE_CHECKED)) { int rc = check_surface_table("disk_surface_frame", n_table, d_R, (hipStream_t)stream); if (rc) return rc; }
     strict &= 1;
     SurfaceParams p;
-    p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; p.sin_i = sin(incl); p.cos_i = cos(incl);
+    p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; reference_sincos(incl, p.sin_i, p.cos_i);
     p.disk = make_disk_consts(bh_mass, disk_spin >= 0.0 ? disk_spin : a, mdot);
     if (!strict) { int rc = attach_flux_table(p.disk); if (rc) return rc; }
     p.tab_vr = d_vr; p.out_g = d_g; p.out_mue = d_mue; p.out_flux = d_flux;

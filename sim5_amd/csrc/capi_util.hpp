@@ -5,6 +5,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <time.h>
+#include <math.h>
 #include "../../include/sim5gpu.h"
 #include "kernels.hpp"
 #include "s5_config.hpp"
@@ -98,6 +99,13 @@ struct Arena {
     ~Arena() { release(); if (pin) (void)hipHostFree(pin); }   // thread exit: the blocks go back
 };
 Arena& arena();
+
+// sin and cos of an inclination as the REFERENCE BINARY forms them: gcc merges the sin(i) and cos(i) of geodesic_init_inf (ref
+// src/sim5kerr-geod.c:73-77) into ONE call of glibc's sincos() (read off the disassembly of the library built by oracle/Makefile
+// with the reference's own flags), and sincos() and cos() are different routines that differ in the last bit for some arguments
+// -- which reaches q and, on the central column of an odd-width image, the class of a pixel (found by the randomised campaign of
+// round 5: a = 0.9999, i = 40.2 deg).  Every host-side sin i / cos i of the library comes from here.
+inline void reference_sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
 
 // The stream of the calling HOST THREAD (capi_core.hip): every batch entry point launches on it and waits for it alone, so
 // host threads that call the per-ray functions concurrently (ref README.md:16,202: "thread-safe", the OpenMP'd caller of

@@ -28,7 +28,7 @@ S5_DEV double r_horizon(double a) { return 1. + sqrt(1. - a * a); }           //
 S5_DEV double r_isco(double a)                                                 // ref :994-1004
 {
     double z1 = 1. + cbrt(1. - a * a) * (cbrt(1. + a) + cbrt(1. - a));
-    double z2 = sqrt(3. * a * a + z1 * z1);
+    double z2 = sqrt(3. * (a * a) + z1 * z1);          // (3.*sqr(a) of the reference: 3 (a a))
     return 3. + z2 - sqrt((3. - z1) * (3. + z1 + 2. * z2));
 }
 

@@ -1,7 +1,17 @@
 """Helpers shared by the GPU parity tests."""
 import numpy as np
 
+import math
+
 REL = 1e-6          # BASELINE.json north_star: redshift / flux / polarization angle within 1e-6 relative
+
+
+def deg2rad(deg):
+    """degrees -> radians as the reference's macro forms them (ref src/sim5math.h:50: (a)/180.0*M_PI), which is what the CPU
+    checker's drivers do with an inclination in degrees.  math.radians(x) = x * (pi/180) differs from it in the last bit for most
+    x -- and the last bit of the inclination reaches cos i, q and, on the central column of an odd-width image, the class of a
+    pixel: a GPU job and the CPU run it is compared with must be given the SAME radians."""
+    return deg / 180.0 * math.pi
 
 
 def rel_err(a, b, floor=0.0):

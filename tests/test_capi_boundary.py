@@ -1,6 +1,7 @@
 """The C-ABI boundary without a GPU: the library loads, exports every symbol include/sim5gpu.h
 declares, keeps the SIM5 struct layouts, and fails loudly (no CPU fallback) when no device exists."""
 import ctypes as C
+import math
 import os
 import re
 
@@ -241,6 +242,37 @@ def test_shard_plan_is_the_python_dealing_rule(capi):
                 assert bool(share.flags & capi.IMG_INPLACE) == (r == 0) and (share.flags & capi.IMG_MIRROR)
             total += rows
         assert total == ny
+
+
+def test_default_field_of_view_is_the_reference_r_ms_bit_for_bit(capi):
+    """rmax = r_ms(a) + 8 (ref disk-image.c:41-42) scales every alpha and beta of an image: the library's host-side r_ms must be
+    the reference's to the last bit for EVERY spin (round 5: 3.*sqr(a) had been written (3 a) a -- one ulp off for random spins,
+    found by the randomised campaign on the central column of one image in 1 500).  Against the unmodified reference, 20 000
+    random spins and the usual ones."""
+    import ctypes as C
+    import oraclelib as ol
+    if not ol.have_reference():
+        pytest.skip("oracle/_ref/libsim5ref.so not present")
+    L = C.CDLL(ol.REF_SO)
+    L.r_ms.restype = C.c_double; L.r_ms.argtypes = [C.c_double]
+    rng = np.random.default_rng(7)
+    spins = np.concatenate([[0.0, 1e-5, 0.3, 0.5, 0.7, 0.9, 0.998, 0.9999, 0.999999], rng.uniform(0.0, 0.999999, 20000)])
+    for a in spins:
+        rmax, rms, _, _ = capi.image_view(capi.image_desc(8, 8, float(a), 1.0))
+        ref = L.r_ms(float(a))
+        assert rms == ref and rmax == ref + 8.0, (float(a), rms, ref)
+    # ... and sin i / cos i are the reference binary's: cos_i and l = -alpha sin i of the record its geodesic_init_inf makes (gcc
+    # merges its sin(i), cos(i) into one sincos() call, whose cosine is not cos()'s in the last bit for every argument)
+    init = L.geodesic_init_inf
+    init.restype = C.c_int; init.argtypes = [C.c_double] * 4 + [C.c_void_p, C.c_void_p]
+    g = (C.c_double * 30)(); err = C.c_int(0)
+    differs_from_plain_cos = 0
+    for inc in np.concatenate([np.radians([10, 20, 30, 40, 50, 60, 70, 80]), rng.uniform(0.02, 1.55, 20000)]):
+        _, _, si, ci = capi.image_view(capi.image_desc(8, 8, 0.5, float(inc)))
+        init(float(inc), 0.5, -1.0, 3.0, g, C.byref(err))
+        assert ci == g[4] and si == g[5], (float(inc), ci, g[4], si, g[5])          # cos_i; l = -(-1) sin i
+        differs_from_plain_cos += int(ci != math.cos(float(inc)))
+    print("inclinations where sincos()'s cosine is not cos()'s: %d of 20008" % differs_from_plain_cos)
 
 
 def test_shipped_kernels_are_one_source_one_build():

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oraclelib as ol
-from gpuutil import assert_close
+from gpuutil import assert_close, deg2rad
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,7 +49,7 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     # geodesic_position_azm / geodesic_timedelay through the scalar API against the CPU checker
     tail = lines[-2].split()
     gd = ol.Geodesic(); e = C.c_int(0)
-    assert orc.geodesic_init_inf(math.radians(inc), a, 6.0, 5.0, C.byref(gd), C.byref(e))
+    assert orc.geodesic_init_inf(deg2rad(inc), a, 6.0, 5.0, C.byref(gd), C.byref(e))
     P1, P2 = 0.6 * gd.Rpc, 1.4 * gd.Rpc
     r1 = orc.geodesic_position_rad(C.byref(gd), P1); m1 = orc.geodesic_position_pol(C.byref(gd), P1)
     assert abs(float(tail[2]) / orc.geodesic_position_azm(C.byref(gd), r1, m1, P1) - 1) < 1e-9
@@ -202,7 +202,7 @@ def test_boundary_prototypes_program(tmp_path, capi):
                                         fn("ell_from_Omega", D, D, PM)(Om, C.byref(g))])
         gd = ol.Geodesic(); e = C.c_int(0)
         v = [float("nan")] * 3
-        if fn("geodesic_init_inf", ol.I, D, D, D, D, ol.PG, ol.PI)(math.radians(65.0), a, 4.0, -3.0, C.byref(gd), C.byref(e)):
+        if fn("geodesic_init_inf", ol.I, D, D, D, D, ol.PG, ol.PI)(deg2rad(65.0), a, 4.0, -3.0, C.byref(gd), C.byref(e)):
             sk = fn("geodesic_position_pol_sign_k_theta", D, ol.PG, D); dms = fn("geodesic_dm_sign", D, ol.PG, D)
             v = [sk(C.byref(gd), 0.4 * gd.Rpc), dms(C.byref(gd), 0.4 * gd.Rpc), sk(C.byref(gd), 1.7 * gd.Rpc)]
         want["sign_k_theta"] = np.array(v)
@@ -296,9 +296,9 @@ def test_rccl_shard_objects_with_a_world_of_one(capi):
     comm = rccl.comm_create(rccl.unique_id(), 0, 1)
     n = 512
     sh = rccl.Shard(comm, 0, 1, n, n)
-    want = capi.disk_image(capi.image_desc(n, n, 0.9, math.radians(60.0)))
+    want = capi.disk_image(capi.image_desc(n, n, 0.9, deg2rad(60.0)))
     f = [capi.DeviceBuffer(n * n * 4) for _ in range(2)]; g = [capi.DeviceBuffer(n * n * 4) for _ in range(2)]
-    d = capi.image_desc(n, n, 0.9, math.radians(60.0))
+    d = capi.image_desc(n, n, 0.9, deg2rad(60.0))
     sh.begin(d, f[0].ptr, g[0].ptr)
     sh.begin(d, f[1].ptr, g[1].ptr)
     with pytest.raises(rccl.Sim5GpuRcclError, match="in flight"):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oraclelib as ol
-from gpuutil import REL, assert_close, rel_err
+from gpuutil import REL, assert_close, rel_err, deg2rad
 
 pytestmark = pytest.mark.gpu
 
@@ -173,7 +173,7 @@ def test_mirrored_pairs_give_the_plain_image(capi):
         for (y0, y1) in [(0, ny), (ny // 3, ny - ny // 3)]:
             if y1 - y0 < 2:
                 continue
-            mk = lambda lo, hi: image_both(capi, capi.image_desc(nx, ny, a, math.radians(inc), y0=lo, y1=hi, max_order=order))
+            mk = lambda lo, hi: image_both(capi, capi.image_desc(nx, ny, a, deg2rad(inc), y0=lo, y1=hi, max_order=order))
             sym = mk(y0, y1)
             cut = y0 + (y1 - y0) // 2 + 1                       # asymmetric pieces: the plain kernel
             top, bot = mk(y0, cut), mk(cut, y1)
@@ -181,7 +181,7 @@ def test_mirrored_pairs_give_the_plain_image(capi):
                 both = np.concatenate([top[k], bot[k]], axis=0)
                 assert np.array_equal(sym[k], both, equal_nan=True), (k, nx, ny, y0, y1)
     c = ol.cpu_disk_image("port", 200, 128, 0.998, 80.0, nthreads=4, full=True)
-    o = capi.disk_image(capi.image_desc(200, 128, 0.998, math.radians(80.0)), full=True)
+    o = capi.disk_image(capi.image_desc(200, 128, 0.998, deg2rad(80.0)), full=True)
     assert np.array_equal(o["cls"], c["cls"])
     assert_close(o["r"], c["r"], what="r"); assert_close(o["g"], c["g"], what="g")
     assert_close(o["flux"], c["flux"], floor=flux_floor(c["flux"]), what="flux")
@@ -210,7 +210,7 @@ def test_random_image_shapes_and_parameters(capi):
         order = int(rng.choice([1, 2]))
         rmax = float(rng.choice([0.0, rng.uniform(3.0, 60.0)]))
         what = (case, a, inc, nx, ny, order, rmax)
-        mk = lambda lo, hi, strict=False: image_both(capi, capi.image_desc(nx, ny, a, math.radians(inc), y0=lo, y1=hi,
+        mk = lambda lo, hi, strict=False: image_both(capi, capi.image_desc(nx, ny, a, deg2rad(inc), y0=lo, y1=hi,
                                                                            max_order=order, rmax=rmax, strict=strict))
         sym = mk(0, ny)
         cut = ny // 2 + 1 if ny > 2 else 1
@@ -274,7 +274,7 @@ def degenerate_sets_report(capi):
         off = ~(sel_col | sel_row)
         rec["reference_flips_under_1_to_3_ulp_of_spin_or_inclination"] = {"column": int(flips[sel_col].sum()), "row": int(flips[sel_row].sum()), "elsewhere": int(flips[off].sum())}
         for strict in (False, True):
-            o = capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), strict=strict), full=True)
+            o = capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), strict=strict), full=True)
             d = o["cls"] != ref["cls"]
             rec["strict" if strict else "fast"] = {"column_px": int(sel_col.sum()), "column_differs": int(d[sel_col].sum()),
                                                     "column_differs_where_reference_is_stable": int((d & ~flips)[sel_col].sum()),
@@ -447,17 +447,17 @@ def test_plain_striping_and_mirror_flag_arguments(capi):
     mirrored job must name rows of the upper half; the spectrum and torus jobs refuse the flag."""
     n, a, inc = 500, 0.9, 60.0
     whole = run(capi, n, a, inc, full=True)
-    d = capi.image_desc(n, n, a, math.radians(inc), y0=64, y1=n, stripe_rows=64, stripe_step=192)
+    d = capi.image_desc(n, n, a, deg2rad(inc), y0=64, y1=n, stripe_rows=64, stripe_step=192)
     t = capi.disk_image(d, full=True)
     rows = [(y, min(n, y + 64)) for y in range(64, n, 192)]
     assert capi.image_rows(d) == sum(y1 - y0 for y0, y1 in rows)
     assert np.array_equal(t["image_g"], np.concatenate([whole["image_g"][y0:y1] for y0, y1 in rows]))
     # mirror without striping: a band of the upper half and its mirror image
-    d = capi.image_desc(n, n, a, math.radians(inc), y0=100, y1=180, mirror=True)
+    d = capi.image_desc(n, n, a, deg2rad(inc), y0=100, y1=180, mirror=True)
     t = capi.disk_image(d, full=True)
     assert capi.image_rows(d) == 160
     assert np.array_equal(t["flux"], np.concatenate([whole["flux"][100:180], whole["flux"][n - 180:n - 100]]))
-    bad = capi.image_desc(n, n, a, math.radians(inc), y0=100, y1=300, mirror=True)
+    bad = capi.image_desc(n, n, a, deg2rad(inc), y0=100, y1=300, mirror=True)
     assert capi.image_rows(bad) == 0
     with pytest.raises(RuntimeError):
         capi.disk_image(bad)
@@ -516,7 +516,7 @@ def test_in_place_rows_and_share_placement(capi):
     included."""
     from sim5_amd import sharding
     for (nx, ny, world, dealt) in [(256, 512, 4, None), (200, 301, 3, None), (320, 512, 2, 128), (192, 1001, 8, None)]:
-        a, inc = 0.9, math.radians(65.0)
+        a, inc = 0.9, deg2rad(65.0)
         whole = capi.disk_image(capi.image_desc(nx, ny, a, inc))
         want = np.stack([whole["image_f"], whole["image_g"]])
         full = capi.DeviceBuffer(2 * ny * nx * 4); full.fill(0xff)              # NaN pattern: rows nobody wrote stay NaN
@@ -564,7 +564,7 @@ def test_job_list_launch_gives_the_single_launch_images(capi):
     kernel does not serve (strict variant, an asymmetric row range: launched by themselves, in order) -- every image bit for
     bit what sim5gpu_disk_image gives for the job; 16 + 3 jobs exercise a full group and the wrap to a second launch."""
     from sim5_amd import sharding
-    rad = math.radians
+    rad = deg2rad
     jobs = []      # (desc, rows, nx)
     def add(d, rows=None):
         jobs.append((d, capi.image_rows(d) if rows is None else rows, d.nx))
@@ -624,7 +624,7 @@ def test_rank0_inplace_share_stress(capi, world, band):
     pattern the buffer was filled with.  With a root band (`band`: the plan of bench.py --root-band, here a quarter of the
     upper half dealt) the band launch into the same buffer is part of every iteration."""
     from sim5_amd import sharding
-    n, a, inc = 4096, 0.998, math.radians(70.0)
+    n, a, inc = 4096, 0.998, deg2rad(70.0)
     plane = n * n * 4
     dealt = 512 if band else None
     whole = capi.DeviceBuffer(2 * plane)
@@ -666,7 +666,7 @@ def test_direct_flag_runs_the_direct_routine_everywhere(capi, a, inc, n, order):
     per million to (radial integral by R_F, the reference's comparisons with Rpc): that path is exercised on whole images
     here -- same classes as the default routine and as the strict variant, r and g within 1e-9, flux within 1e-6; the
     polarized kernel's Stokes planes likewise."""
-    mk = lambda **kw: image_both(capi, capi.image_desc(n, n, a, math.radians(inc), max_order=order, **kw))
+    mk = lambda **kw: image_both(capi, capi.image_desc(n, n, a, deg2rad(inc), max_order=order, **kw))
     f, d, s = mk(), mk(direct=True), mk(strict=True)
     assert np.array_equal(f["cls"], d["cls"]) and np.array_equal(f["gtype"], d["gtype"])
     assert np.array_equal(s["cls"], d["cls"])
@@ -685,7 +685,7 @@ def test_direct_flag_runs_the_direct_routine_everywhere(capi, a, inc, n, order):
     planes = []
     for direct in (False, True):
         bf, bg = capi.DeviceBuffer(n * n * 4), capi.DeviceBuffer(n * n * 4)
-        capi.disk_image_device(capi.image_desc(n, n, a, math.radians(inc), max_order=order, direct=direct), bf.ptr, bg.ptr)
+        capi.disk_image_device(capi.image_desc(n, n, a, deg2rad(inc), max_order=order, direct=direct), bf.ptr, bg.ptr)
         capi.synchronize()
         planes.append((bf.to_numpy(np.float32, (n, n)), bg.to_numpy(np.float32, (n, n))))
     assert np.array_equal(planes[0][1] > 0, planes[1][1] > 0) and np.array_equal(planes[1][1] > 0, hit)
@@ -695,7 +695,7 @@ def test_direct_flag_runs_the_direct_routine_everywhere(capi, a, inc, n, order):
     # the polarized kernel takes the same routine with the ray's state
     st = [capi.DeviceBuffer(3 * n * n * 8) for _ in range(2)]
     for k, direct in enumerate((False, True)):
-        capi.disk_image_polarized_device(capi.image_desc(n, n, a, math.radians(inc), max_order=order, pol_degree=0.1, direct=direct), st[k].ptr, None)
+        capi.disk_image_polarized_device(capi.image_desc(n, n, a, deg2rad(inc), max_order=order, pol_degree=0.1, direct=direct), st[k].ptr, None)
     capi.synchronize()
     S0, S1 = st[0].to_numpy(np.float64, (3, n, n)), st[1].to_numpy(np.float64, (3, n, n))
     lit = ok & (S0[0] > 1e-9 * S0[0].max())
@@ -709,10 +709,10 @@ def test_flux_table_cache_is_bounded_and_released(capi):
     device (the least recently used half is retired, and freed one retirement later), and sim5gpu_release_workspaces gives
     everything back.  1300 models through 16 x 16 images (the same pixels for every model: results must not depend on what
     the cache holds), the first model again after it has been retired, then the release."""
-    d0 = capi.image_desc(16, 16, 0.5, math.radians(60.0), mdot=0.1)
+    d0 = capi.image_desc(16, 16, 0.5, deg2rad(60.0), mdot=0.1)
     first = capi.disk_image(d0)
     for k in range(1300):
-        capi.disk_image(capi.image_desc(16, 16, 0.5, math.radians(60.0), mdot=0.1 + 1e-4 * (k + 1)))
+        capi.disk_image(capi.image_desc(16, 16, 0.5, deg2rad(60.0), mdot=0.1 + 1e-4 * (k + 1)))
     again = capi.disk_image(d0)
     assert np.array_equal(first["image_f"], again["image_f"]) and np.array_equal(first["image_g"], again["image_g"])
     freed = capi.release_workspaces()

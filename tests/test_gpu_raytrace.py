@@ -6,7 +6,7 @@ import pytest
 
 import oraclelib as ol
 import gen_golden_access as gga
-from gpuutil import REL, assert_close
+from gpuutil import REL, assert_close, deg2rad
 
 pytestmark = pytest.mark.gpu
 
@@ -91,7 +91,7 @@ def test_polarized_mirrored_pairs_give_the_plain_image(capi):
     """A symmetric row range is traced by the pairing kernel (pixel + its mirror image in beta per lane), any other by the
     plain one: Stokes I, Q, U, the angle and the aux planes must agree bit for bit; odd height included."""
     def pol(nx, ny, y0, y1, a, inc):
-        d = capi.image_desc(nx, ny, a, math.radians(inc), y0=y0, y1=y1, pol_degree=0.1)
+        d = capi.image_desc(nx, ny, a, deg2rad(inc), y0=y0, y1=y1, pol_degree=0.1)
         rows = y1 - y0
         N = rows * nx
         st = capi.DeviceBuffer(3 * N * 8); chi = capi.DeviceBuffer(N * 8); gg = capi.DeviceBuffer(N * 8); cls = capi.DeviceBuffer(N)
@@ -235,11 +235,11 @@ def test_torus_kernel_matches_cpu_integration(capi, strict, absorb0):
     rmax = ol.Oracle().r_ms(a) + 8.0
     c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
     al, be = np.tile(c, n), np.repeat(c, n)
-    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, r0=r0, absorb0=absorb0)
+    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, deg2rad(inc), al, be, r0=r0, absorb0=absorb0)
 
     def probe(idx):
         sub = {k: v[idx] for k, v in ref.items()}
-        return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al[idx], be[idx], sub, r0=r0, absorb0=absorb0)
+        return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, deg2rad(inc), al[idx], be[idx], sub, r0=r0, absorb0=absorb0)
     compare_rays("24x24 %s absorb0=%g" % ("strict" if strict else "fast", absorb0), S, steps, xe, ke, ref,
                  STEP_MATCH_STRICT if strict else STEP_MATCH_FAST, probe)
     assert (S[:, 0] >= 0).all() and S[:, 0].max() > 1.0
@@ -277,14 +277,14 @@ def test_random_torus_jobs(capi):
         c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
         al, be = np.tile(c, n), np.repeat(c, n)
         job = dict(r0=r0, precision=prec, absorb0=absorb0, torus_r=tr, torus_w=tw)
-        ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, **job)
+        ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, deg2rad(inc), al, be, **job)
         off_axis = np.nonzero(al != 0.0)[0]
         for strict in (True, False):
             regular = off_axis
             sub = {k: v[regular] for k, v in ref.items()}
 
             def probe(idx):
-                return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al[regular][idx], be[regular][idx],
+                return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, deg2rad(inc), al[regular][idx], be[regular][idx],
                                           {k: v[idx] for k, v in sub.items()}, **job)
             d = torus_desc(capi, n, a, inc, **job)
             if strict:
@@ -332,7 +332,7 @@ def test_c4_full_size(capi, golden, strict):
             rmax = ol.Oracle().r_ms(a) + 8.0
             c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
             u = unstarted[:256]
-            o = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), c[u % n], c[u // n], r0=r0)
+            o = gga.torus_rays(ol.ORACLE_SO, "orc_", a, deg2rad(inc), c[u % n], c[u // n], r0=r0)
             assert (o["steps"] == 0).all(), (u[o["steps"] != 0][:8], o["steps"][o["steps"] != 0][:8])
             assert (S[unstarted] == 0).all()
         started = steps > 0
@@ -351,7 +351,7 @@ def test_c4_full_size(capi, golden, strict):
             # the restatement is bit-identical to the reference on these rays (tests/test_oracle_golden.py), so its
             # sensitivity is the reference's
             al, be = cc[g["thin_ix"][idx]], cc[g["thin_iy"][idx]]
-            return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, {k: v[idx] for k, v in ref.items()},
+            return oracle_sensitivity(ol.ORACLE_SO, "orc_", a, deg2rad(inc), al, be, {k: v[idx] for k, v in ref.items()},
                                       r0=r0, absorb0=absorb0)
         same = compare_rays(name, S[sel], steps[sel], xe[sel], ke[sel], ref, STEP_MATCH_STRICT if strict else STEP_MATCH_FAST, probe)
         # conservation: the Carter-constant error of the GPU rays is the reference's on the same rays
@@ -388,7 +388,7 @@ def test_polarized_parameter_sweep(capi, strict):
     rng = np.random.default_rng(5)
     n = 96
     for a, inc in [(0.0, 20.0), (0.5, 45.0), (0.998, 80.0)] + [(float(rng.uniform(0, 0.999)), float(rng.uniform(5, 85))) for _ in range(5)]:
-        d = capi.image_desc(n, n, a, math.radians(inc), pol_degree=0.1, strict=strict)
+        d = capi.image_desc(n, n, a, deg2rad(inc), pol_degree=0.1, strict=strict)
         N = n * n
         st = capi.DeviceBuffer(3 * N * 8); chi = capi.DeviceBuffer(N * 8); gg = capi.DeviceBuffer(N * 8)
         capi.disk_image_polarized_device(d, st.ptr, chi.ptr, aux={"g": gg.ptr})
@@ -398,7 +398,7 @@ def test_polarized_parameter_sweep(capi, strict):
         c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
         al = np.ascontiguousarray(np.tile(c, n)); be = np.ascontiguousarray(np.repeat(c, n))
         rchi = np.zeros(N); rr = np.zeros(N); rg = np.zeros(N); rwp = np.zeros((N, 2))
-        rc = drv.cpu_polarized_rays(ol.ORACLE_SO.encode(), b"orc_", a, math.radians(inc), -1.0, N, al.ctypes.data, be.ctypes.data,
+        rc = drv.cpu_polarized_rays(ol.ORACLE_SO.encode(), b"orc_", a, deg2rad(inc), -1.0, N, al.ctypes.data, be.ctypes.data,
                                     rchi.ctypes.data, rr.ctypes.data, rg.ctypes.data, rwp.ctypes.data)
         assert rc == 0
         assert np.array_equal(np.isnan(CH), np.isnan(rchi)), (a, inc, int((np.isnan(CH) != np.isnan(rchi)).sum()))
@@ -444,12 +444,12 @@ def test_workspaces_can_be_released(capi):
     a = run_torus(capi, d)
     tR = np.linspace(2.0, 40.0, 64); tH = 0.2 * (tR - 2.0)
     c = ((np.arange(24) + .5) / 24 - 0.5) * 40.0
-    s1 = capi.disk_surface_rays(0.9, math.radians(70.0), tR, tH, np.tile(c, 24), np.repeat(c, 24))
+    s1 = capi.disk_surface_rays(0.9, deg2rad(70.0), tR, tH, np.tile(c, 24), np.repeat(c, 24))
     freed = capi.release_workspaces()
     assert freed > 32 * 32 * 100
     assert capi.release_workspaces() == 0
     b = run_torus(capi, d)
-    s2 = capi.disk_surface_rays(0.9, math.radians(70.0), tR, tH, np.tile(c, 24), np.repeat(c, 24))
+    s2 = capi.disk_surface_rays(0.9, deg2rad(70.0), tR, tH, np.tile(c, 24), np.repeat(c, 24))
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True)
     for k in s1:

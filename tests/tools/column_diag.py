@@ -6,10 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oraclelib as ol
 import sim5_amd.capi as capi
+from gpuutil import deg2rad
 a, inc, nx, ny = float(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 ref = ol.cpu_disk_image("reference", nx, ny, a, inc, nthreads=8, full=True)
-st = capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), strict=True), full=True)
-fa = capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), strict=False), full=True)
+st = capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), strict=True), full=True)
+fa = capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), strict=False), full=True)
 print("keys", sorted(fa.keys()))
 if nx % 2:
     c = nx // 2

@@ -3,6 +3,7 @@ with the CPU oracle's value beside them.   usage: python tests/tools/fuzz_case.p
 import sys, math, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import sim5_amd.capi as capi
+from gpuutil import deg2rad
 import oraclelib as ol
 seed, want = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
@@ -13,7 +14,7 @@ for case in range(want + 1):
     order = int(rng.choice([1, 2]))
     rmax = float(rng.choice([0.0, rng.uniform(3.0, 60.0)]))
 print("case %d: a=%r inc=%r %dx%d order=%d rmax=%r" % (want, a, inc, nx, ny, order, rmax))
-mk = lambda strict: capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), max_order=order, rmax=rmax, strict=strict), full=True)
+mk = lambda strict: capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), max_order=order, rmax=rmax, strict=strict), full=True)
 f, s = mk(False), mk(True)
 c = ol.cpu_disk_image("port", nx, ny, a, inc, nthreads=8, full=True) if (order == 2 and rmax == 0.0) else None
 print("classes of fast and strict equal:", bool(np.array_equal(f["cls"], s["cls"])))
@@ -38,10 +39,10 @@ if len(bad):
     rm = rmax if rmax > 0.0 else rms + 8.0
     al = ((ix + .5) / nx - 0.5) * 2.0 * rm
     be = ((iy + .5) / ny - 0.5) * 2.0 * rm * (ny / nx)
-    r0 = o.disk_pixel(math.radians(inc), a, rms, al, be).r
+    r0 = o.disk_pixel(deg2rad(inc), a, rms, al, be).r
     print("checker at the reference's (alpha, beta): r = %.15g" % r0)
     for name, da, db in (("beta + 1 ulp", 0, 1), ("beta - 1 ulp", 0, -1), ("alpha + 1 ulp", 1, 0), ("alpha - 1 ulp", -1, 0)):
         a2 = np.nextafter(al, math.inf if da > 0 else -math.inf) if da else al
         b2 = np.nextafter(be, math.inf if db > 0 else -math.inf) if db else be
-        r1 = o.disk_pixel(math.radians(inc), a, rms, float(a2), float(b2)).r
+        r1 = o.disk_pixel(deg2rad(inc), a, rms, float(a2), float(b2)).r
         print("  %-14s r = %.15g   moved by %.2e (relative)" % (name, r1, abs(r1 / r0 - 1)))

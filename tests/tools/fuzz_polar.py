@@ -5,9 +5,10 @@ fast/strict comparison.   usage: python tests/tools/fuzz_polar.py [n_cases] [see
 import sys, math, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import sim5_amd.capi as capi
+from gpuutil import deg2rad
 
 def pol(nx, ny, y0, y1, a, inc, strict):
-    d = capi.image_desc(nx, ny, a, math.radians(inc), y0=y0, y1=y1, pol_degree=0.1, strict=strict)
+    d = capi.image_desc(nx, ny, a, deg2rad(inc), y0=y0, y1=y1, pol_degree=0.1, strict=strict)
     rows = y1 - y0; N = rows * nx
     st = capi.DeviceBuffer(3 * N * 8); chi = capi.DeviceBuffer(N * 8); cls = capi.DeviceBuffer(N)
     capi.disk_image_polarized_device(d, st.ptr, chi.ptr, aux={"cls": cls.ptr}); capi.synchronize()
@@ -26,7 +27,7 @@ def probe_checker(a, inc, nx, ny, CH, CHs, both):
     al0 = ((ix + .5) / nx - 0.5) * 2.0 * rmax; be0 = ((iy + .5) / ny - 0.5) * 2.0 * rmax * (ny / nx)
     al = np.array([al0, np.nextafter(al0, al0 + 1), np.nextafter(al0, al0 - 1), al0, al0]); be = np.array([be0, be0, be0, np.nextafter(be0, be0 + 1), np.nextafter(be0, be0 - 1)])
     n = 5; rchi = np.zeros(n); rr = np.zeros(n); rg = np.zeros(n); rwp = np.zeros((n, 2))
-    if drv.cpu_polarized_rays(ol.ORACLE_SO.encode(), b"orc_", a, math.radians(inc), -1.0, n, al.ctypes.data, be.ctypes.data,
+    if drv.cpu_polarized_rays(ol.ORACLE_SO.encode(), b"orc_", a, deg2rad(inc), -1.0, n, al.ctypes.data, be.ctypes.data,
                               rchi.ctypes.data, rr.ctypes.data, rg.ctypes.data, rwp.ctypes.data) != 0: return 0.0
     d = np.abs(np.angle(np.exp(1j * (rchi[1:] - rchi[0]))))
     return float(np.nanmax(d)) if np.isfinite(d).any() else 0.0

@@ -4,6 +4,7 @@ usage: python tests/tools/fuzz_polar_case.py <seed> <case>"""
 import sys, math, ctypes as C, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import sim5_amd.capi as capi
+from gpuutil import deg2rad
 import oraclelib as ol
 seed, want = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
@@ -12,7 +13,7 @@ for case in range(want + 1):
     nx, ny = int(rng.integers(17, 260)), int(rng.integers(2, 260))
 print("case %d: a=%r inc=%r %dx%d" % (want, a, inc, nx, ny))
 def pol(strict):
-    d = capi.image_desc(nx, ny, a, math.radians(inc), pol_degree=0.1, strict=strict)
+    d = capi.image_desc(nx, ny, a, deg2rad(inc), pol_degree=0.1, strict=strict)
     N = nx * ny
     st = capi.DeviceBuffer(3 * N * 8); chi = capi.DeviceBuffer(N * 8); r = capi.DeviceBuffer(N * 8)
     capi.disk_image_polarized_device(d, st.ptr, chi.ptr, aux={"r": r.ptr}); capi.synchronize()
@@ -32,7 +33,7 @@ pts = [("the reference's (alpha, beta)", al0, be0)] + [("%s %s 1 ulp" % (nm, "+"
         float(np.nextafter(be0, be0 + s)) if nm == "beta" else be0) for nm in ("alpha", "beta") for s in (1, -1)]
 al = np.array([p[1] for p in pts]); be = np.array([p[2] for p in pts]); n = len(pts)
 rchi = np.zeros(n); rr = np.zeros(n); rg = np.zeros(n); rwp = np.zeros((n, 2))
-assert drv.cpu_polarized_rays(ol.ORACLE_SO.encode(), b"orc_", a, math.radians(inc), -1.0, n, al.ctypes.data, be.ctypes.data,
+assert drv.cpu_polarized_rays(ol.ORACLE_SO.encode(), b"orc_", a, deg2rad(inc), -1.0, n, al.ctypes.data, be.ctypes.data,
                               rchi.ctypes.data, rr.ctypes.data, rg.ctypes.data, rwp.ctypes.data) == 0
 for k, p in enumerate(pts):
     print("checker at %-28s chi = %.12f  r = %.15g  kappa = (%.6e, %.6e)   chi moved by %.2e" % (p[0], rchi[k], rr[k], rwp[k, 0], rwp[k, 1], abs(np.angle(np.exp(1j * (rchi[k] - rchi[0]))))))

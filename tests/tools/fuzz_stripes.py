@@ -4,6 +4,7 @@ whole image bit for bit, and the shares must tile the image exactly once.   usag
 import sys, math, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import sim5_amd.capi as capi
+from gpuutil import deg2rad
 from sim5_amd import sharding as sh
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -19,7 +20,7 @@ for case in range(ncases):
         if dealt >= half: dealt = None
     a, inc = float(rng.choice([0.3, 0.9, 0.998])), float(rng.uniform(10, 80))
     strict = bool(rng.random() < 0.3)
-    whole = capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), strict=strict), full=True)
+    whole = capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), strict=strict), full=True)
     seen = np.zeros(ny, int); msg = []
     for r in range(world):
         kw = sh.job_rows(ny, r, world, stripe=stripe, dealt=dealt)
@@ -28,7 +29,7 @@ for case in range(ncases):
         if kw["y0"] >= kw["y1"]:
             if rows: msg.append("rank %d: rows without a job" % r)
             continue
-        d = capi.image_desc(nx, ny, a, math.radians(inc), strict=strict, **kw)
+        d = capi.image_desc(nx, ny, a, deg2rad(inc), strict=strict, **kw)
         if capi.image_rows(d) != sum(y1 - y0 for y0, y1 in rows):
             msg.append("rank %d: library counts %d rows, dealing %d" % (r, capi.image_rows(d), sum(y1 - y0 for y0, y1 in rows))); continue
         t = capi.disk_image(d, full=True)
@@ -38,7 +39,7 @@ for case in range(ncases):
     band = sh.root_band(ny, dealt)
     if band:
         seen[band[0]:band[1]] += 1
-        t = capi.disk_image(capi.image_desc(nx, ny, a, math.radians(inc), strict=strict, y0=band[0], y1=band[1]), full=True)
+        t = capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), strict=strict, y0=band[0], y1=band[1]), full=True)
         if not np.array_equal(t["image_g"], whole["image_g"][band[0]:band[1]]): msg.append("band differs")
     if not (seen == 1).all(): msg.append("rows covered %s times" % sorted(set(seen.tolist())))
     print("case %3d %dx%d world %d stripe %d dealt %s %s : %s" % (case, nx, ny, world, stripe, dealt, "strict" if strict else "fast", "ok" if not msg else "; ".join(msg[:4])), flush=True)

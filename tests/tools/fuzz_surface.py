@@ -5,6 +5,7 @@ usage: python tests/tools/fuzz_surface.py [n_cases] [seed]"""
 import sys, math, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import sim5_amd.capi as capi
+from gpuutil import deg2rad
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
@@ -23,8 +24,8 @@ for case in range(ncases):
     tH = np.maximum(tH, 0.0)
     ax = ((np.arange(n) + .5) / n - .5) * 2 * rmax
     al, be = np.meshgrid(ax, ax)
-    f = capi.disk_surface_rays(a, math.radians(inc), tR, tH, al.ravel(), be.ravel(), strict=False)
-    s = capi.disk_surface_rays(a, math.radians(inc), tR, tH, al.ravel(), be.ravel(), strict=True)
+    f = capi.disk_surface_rays(a, deg2rad(inc), tR, tH, al.ravel(), be.ravel(), strict=False)
+    s = capi.disk_surface_rays(a, deg2rad(inc), tR, tH, al.ravel(), be.ravel(), strict=True)
     same = f["status"] == s["status"]
     ok = same & (s["status"] == 1)
     msg = []

@@ -6,6 +6,7 @@ usage: python tests/tools/fuzz_torus.py [n_cases] [seed]"""
 import sys, math, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import sim5_amd.capi as capi
+from gpuutil import deg2rad
 import oraclelib as ol
 import gen_golden_access as gga
 import test_gpu_raytrace as T
@@ -26,7 +27,7 @@ for case in range(ncases):
     rmax = ol.Oracle().r_ms(a) + 8.0
     c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * rmax
     al, be = np.tile(c, n), np.repeat(c, n)
-    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, math.radians(inc), al, be, r0=r0, precision=prec,
+    ref = gga.torus_rays(ol.ORACLE_SO, "orc_", a, deg2rad(inc), al, be, r0=r0, precision=prec,
                          absorb0=absorb0, torus_r=tr, torus_w=tw)
     # alpha = 0 (central column of an odd-sized image): l = 0, the start-up of the ray is degenerate in the reference itself
     # (it returns garbage states or rejects the ray depending on rounding) -- left out, counted

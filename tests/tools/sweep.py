@@ -1,7 +1,8 @@
 # fast / strict image kernels against the CPU checker over a sweep of spins and inclinations (256^2 each)
 import sys, math, numpy as np
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-import sim5_amd.capi as capi, oraclelib as ol
+import sim5_amd.capi as capi
+from gpuutil import deg2rad, oraclelib as ol
 rng=np.random.default_rng(11)
 cfgs=[(0.0,1.0),(0.0,89.0),(0.999999,89.9),(0.999999,0.5),(1e-5,45.0),(0.5,5.0),(0.998,85.0),(0.9999,60.0)]
 cfgs+=[(float(rng.uniform(0,0.9999)), float(rng.uniform(1,89))) for _ in range(24)]
@@ -9,7 +10,7 @@ n=256; tot_f=tot_s=0
 for a,inc in cfgs:
     c=ol.cpu_disk_image("port", n, n, a, inc, nthreads=8, full=True)
     for strict in (False, True):
-        d=capi.image_desc(n,n,a,math.radians(inc),strict=strict)
+        d=capi.image_desc(n,n,a,deg2rad(inc),strict=strict)
         o=capi.disk_image(d, full=True)
         flips=int((o["cls"]!=c["cls"]).sum())
         hit=(c["cls"]==2)|(c["cls"]==4); hit&=(o["cls"]==c["cls"])
