@@ -101,8 +101,8 @@ struct Arena {
 Arena& arena();
 
 // sin and cos of an inclination as the REFERENCE BINARY forms them: gcc merges the sin(i) and cos(i) of geodesic_init_inf (ref
-// src/sim5kerr-geod.c:73-77) into ONE call of glibc's sincos() (read off the disassembly of the library built by oracle/Makefile
-// with the reference's own flags), and sincos() and cos() are different routines that differ in the last bit for some arguments
+// src/sim5kerr-geod.c:73-77) into ONE call of glibc's sincos() (read off the disassembly of the reference library built here with the
+// reference's own flags), and sincos() and cos() are different routines that differ in the last bit for some arguments
 // -- which reaches q and, on the central column of an odd-width image, the class of a pixel (found by the randomised campaign of
 // round 5: a = 0.9999, i = 40.2 deg).  Every host-side sin i / cos i of the library comes from here.
 inline void reference_sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
