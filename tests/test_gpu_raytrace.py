@@ -168,6 +168,12 @@ def oracle_sensitivity(lib, prefix, a, inc_rad, alpha, beta, base, **job):
     return kap
 
 
+# every comparison of this module, by tag: how many rays it held to 1e-6 and how many of them passed through the one
+# exemption (a ray above 1e-6 whose difference the reference's own +-1 ulp sensitivity covers): written to
+# gpurun_out/torus_exemptions.json by the last test of the module, so that the count survives `pytest -q`
+EXEMPTIONS = {}
+
+
 def compare_rays(tag, S, steps, xe, ke, ref, need_same, probe=None):
     """GPU rays against the CPU integration of the same rays (dict of oracle/cpu_driver.c:cpu_torus_rays arrays):
     step counts, and for rays with identical counts the end point (all four coordinates), the end momentum and
@@ -178,6 +184,7 @@ def compare_rays(tag, S, steps, xe, ke, ref, need_same, probe=None):
     a looser bar but by a measurement: `probe(indices)` reruns the CHECKER on those rays with its start state moved by
     +-1 ulp (oracle_sensitivity) and the ray passes only if the checker's own result moves by at least as much as the
     GPU's differs.  Such rays are counted and printed; more than 0.1 % of a set fails."""
+    EXEMPTIONS.setdefault(tag, {"rays": int(steps.size), "above_1e-6": 0, "excused_by_the_reference_own_sensitivity": 0})
     same = steps == ref["steps"]
     print("%s: %d of %d rays with identical step counts (the others differ by %s steps)" % (
         tag, int(same.sum()), same.size, sorted(set((steps - ref["steps"])[~same].tolist()))[:8]))
@@ -194,6 +201,8 @@ def compare_rays(tag, S, steps, xe, ke, ref, need_same, probe=None):
         kap = probe(over)
         print("   %d ray(s) above 1e-6: difference %s, the checker's own +-1 ulp sensitivity %s" % (
             over.size, ["%.1e" % v for v in tot[over][:8]], ["%.1e" % v for v in kap[:8]]))
+        EXEMPTIONS[tag].update({"above_1e-6": int(over.size), "excused_by_the_reference_own_sensitivity": int((tot[over] <= kap).sum()),
+                                "worst_difference": float(tot[over].max()), "smallest_sensitivity_of_an_excused_ray": float(kap.min())})
         assert (tot[over] <= kap).all(), "%s: rays above 1e-6 that are well-conditioned in the checker: %s" % (
             tag, [(int(i), float(t), float(k)) for i, t, k in zip(over, tot[over], kap) if t > k][:8])
     assert (S[:, 1:4] == 0).all()
@@ -454,3 +463,20 @@ def test_workspaces_can_be_released(capi):
         assert np.array_equal(x, y, equal_nan=True)
     for k in s1:
         assert np.array_equal(s1[k], s2[k], equal_nan=True)
+
+
+def test_zz_exemption_record(capi):
+    """Not a comparison: writes what the comparisons above recorded -- per set the rays held to 1e-6 and how many of them used
+    the ill-conditioned-ray exemption of compare_rays -- to gpurun_out/torus_exemptions.json (committed under profiles/), and
+    holds the total of excused rays under 0.1 %."""
+    import json, os
+    total = sum(v["rays"] for v in EXEMPTIONS.values())
+    excused = sum(v["excused_by_the_reference_own_sensitivity"] for v in EXEMPTIONS.values())
+    rec = {"sets": len(EXEMPTIONS), "rays_compared": total, "rays_excused": excused,
+           "sets_with_excused_rays": {k: v for k, v in EXEMPTIONS.items() if v["above_1e-6"]}}
+    print("step-wise comparisons: %d sets, %d rays, %d excused by the reference's own sensitivity" % (len(EXEMPTIONS), total, excused))
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(outdir):
+        with open(os.path.join(outdir, "torus_exemptions.json"), "w") as fh:
+            json.dump(rec, fh, indent=1)
+    assert total == 0 or excused <= 1e-3 * total, rec
