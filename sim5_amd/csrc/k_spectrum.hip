@@ -97,7 +97,7 @@ S5_DEV void spectrum_pixel_equatorial(const PRM& p, const SpectrumParams& sp, co
 //  * A row set symmetric about the middle of the image is traced in MIRRORED PAIRS (s5_thindisk.hpp: a lane traces (alpha, beta)
 //    and (alpha, -beta), which share the geodesic) at four waves per SIMD: a workgroup stages 512 pixels, not 256.  The staging
 //    arrays live in the Landen-ladder block of the trace, which is dead by then (LDS stays at 34 KB: four workgroups per CU).
-//  * The Planck factor 1 / (e^x - 1) of a (pixel, energy) pair costs 18 issue slots instead of ~45 (a full-precision exp and
+//  * The Planck factor 1 / (e^x - 1) of a (pixel, energy) pair costs 16 issue slots instead of ~45 (a full-precision exp and
 //    a Newton division): planck_sum below.  The bar on the spectrum is 1e-6 (tests/test_py_diskraytrace.py::test_fused_spectrum_kernel,
 //    against python/sim5diskspectrum.py:54-88).  Per pixel: log2(e) h kev2freq / (kB f T g) and the amplitude; per energy bin
 //    E^3 is applied once, after the loop over the pixels.
@@ -105,45 +105,82 @@ S5_DEV void spectrum_pixel_equatorial(const PRM& p, const SpectrumParams& sp, co
 #define S5_SPEC_WAVES 4
 constexpr int FAST_TILE_W = 16, FAST_TILE_H = 16;        // a wave: a 16 x 4 patch, as in the image kernels (image neighbours share class and trip counts)
 
-// sum over the staged pixels of amp / (e^x - 1) for this lane's energy, x log2(e) = E sX[q].  18 issue slots per pair: t, n, f, the
-// seven Horner steps of 2^f = 1 + f (c1 + f (c2 + ... + f c7)) with c_k = ln(2)^k / k! (relative error of 2^f - 1: 2e-8; the
-// subtraction below is exact to 1e-16 / x, so small x keeps its accuracy), 2^n by v_ldexp (n beyond the exponent range gives
-// infinity, a reciprocal of 0 and a term of 0: no cap on x needed), one fma for 2^n 2^f - 1, the 26-bit reciprocal seed
-// (four slots), one fma for the sum.
-S5_DEV double planck_sum(const double* __restrict__ sX, const double* __restrict__ sA, int first, int step, int npix, double E)
+// sum over the staged pixels of amp / (e^x - 1) for this lane's energy, x log2(e) = E sX[q] = n + f.  16 issue slots per pair:
+//  * t + M with M = 1.5 2^52 in ONE fma (the sum is rounded to an integer: that is n, to nearest even, and its two's
+//    complement sits in the low word of the result: no conversion), n = (t + M) - M, f = fma(E, sX, -n) -- exact;
+//  * 2^f = 1 + f (c1 + f (c2 + ... + f c6)): (2^f - 1) / f on [-1/2, 1/2] by the degree-5 polynomial of least maximal RELATIVE
+//    error (tests/tools/exp2_coefficients.py: 1.07e-8; the subtraction of 1 below is exact to 1e-16 / x, so small x keeps
+//    its accuracy) -- five Horner steps with the constants in scalar registers and one fma;
+//  * 2^n by v_ldexp on the low word (n beyond the exponent range gives infinity, a reciprocal of 0 and a term of 0: no cap
+//    on x needed), one fma for 2^n 2^f - 1, the 26-bit reciprocal seed (four slots), one fma for the sum.
+// The low word is n only while |t| < 2^31.  CLAMP (a workgroup with a pixel whose sX times the largest energy is beyond 2^30:
+// T g of a few kelvin) bounds t first, a few more slots; 2^(2^30) is as infinite as 2^t.
+// The pixels are staged as (sX, amplitude) pairs: one 16-byte LDS read per term.
+//
+// GROUPS > 0: the stride over the pixels is that compile-time number and `first` is the same in every lane of the wave (256 /
+// GROUPS >= 64 energies per pass: a wave is 64 energies of ONE pixel sub-set) -- the loop counter lives on the scalar unit
+// and eight terms are read at immediate offsets from one address: no vector instruction of the loop is bookkeeping.
+// GROUPS == 0: stride and start at run time (fewer than 64 energies per pass).
+template <bool CLAMP, int GROUPS>
+S5_DEV double planck_sum(const double2* __restrict__ sXA, int first, int step, int npix, double E)
 {
-    constexpr double L = 0.693147180559945309417;
-    constexpr double C1 = L, C2 = L * L / 2., C3 = L * L * L / 6., C4 = L * L * L * L / 24., C5 = L * L * L * L * L / 120.,
-                     C6 = L * L * L * L * L * L / 720., C7 = L * L * L * L * L * L * L / 5040.;
-    // C7 stays in a vector register pair (a VOP3 instruction takes one scalar operand: the other constants)
-    double c7 = C7;
-    asm volatile("" : "+v"(c7));
-    // one pair: ~17 instructions of ONE dependent chain; two chains interleaved by hand (the loop's trip count is a run-time
-    // value: the compiler does not unroll it) so that an instruction's latency is covered by its twin, two sums added at the end
-    auto term = [&](int q) -> double {
-        const double t = E * sX[q];
-        const double n = __builtin_rint(t);
-        const double f = t - n;
-        double e = hfmac(f, c7, C6);
-        e = hfmac(f, e, C5);
+    constexpr double C1 = 0.6931471879266856, C2 = 0.2402264979496441, C3 = 0.05550357433648187, C4 = 0.009618237494183314,
+                     C5 = 0.0013390735475399872, C6 = 0.00015403512618661003;
+    constexpr double M = 6755399441055744.0;                             // 1.5 2^52
+    // C6 stays in a vector register pair (a VOP3 instruction takes one scalar operand: the other constants)
+    double c6 = C6;
+    asm volatile("" : "+v"(c6));
+    // one pair: ~14 instructions of ONE dependent chain; four chains interleaved by hand (the compiler does not unroll a loop
+    // of run-time trip count) so that an instruction's latency is covered by its twins, four sums added at the end
+    auto term = [&](const double2 xa, double acc) -> double {
+        double tm, f;
+        if (CLAMP) {
+            double t = E * xa.x;
+            if (t > 1073741824.0) t = 1073741824.0;                      // (not fmin: a NaN stays one)
+            tm = t + M;
+            f = t - (tm - M);
+        } else {
+            tm = __builtin_fma(E, xa.x, M);
+            f = __builtin_fma(E, xa.x, -(tm - M));
+        }
+        double e = hfmac(f, c6, C5);
         e = hfmac(f, e, C4);
         e = hfmac(f, e, C3);
         e = hfmac(f, e, C2);
         e = hfmac(f, e, C1);
         e = __builtin_fma(f, e, 1.0);                                   // 2^f
-        const double two_n = __builtin_amdgcn_ldexp(1.0, (int)n);        // (the conversion saturates; 2^n overflows to infinity)
+        const double two_n = __builtin_amdgcn_ldexp(1.0, __double2loint(tm));
         const double den = __builtin_fma(two_n, e, -1.0);
-        return sA[q] * __builtin_amdgcn_rcp(den);
+        return __builtin_fma(xa.y, __builtin_amdgcn_rcp(den), acc);
     };
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int q = first;
-    for (; q + 3 * step < npix; q += 4 * step) {
-        const double a0 = term(q), a1 = term(q + step), a2 = term(q + 2 * step), a3 = term(q + 3 * step);
-        acc0 += a0; acc1 += a1; acc2 += a2; acc3 += a3;
+    if (GROUPS > 0) {
+        // npix is 256 or 512, GROUPS 1, 2 or 4: a whole number of rounds of eight
+        const int start = __builtin_amdgcn_readfirstlane(first);
+        for (int q = start; q < npix; q += 8 * GROUPS) {
+            const double2* const at = sXA + q;
+            acc0 = term(at[0 * GROUPS], acc0); acc1 = term(at[1 * GROUPS], acc1); acc2 = term(at[2 * GROUPS], acc2); acc3 = term(at[3 * GROUPS], acc3);
+            acc0 = term(at[4 * GROUPS], acc0); acc1 = term(at[5 * GROUPS], acc1); acc2 = term(at[6 * GROUPS], acc2); acc3 = term(at[7 * GROUPS], acc3);
+        }
+    } else {
+        int q = first;
+        for (; q + 3 * step < npix; q += 4 * step) {
+            acc0 = term(sXA[q], acc0); acc1 = term(sXA[q + step], acc1); acc2 = term(sXA[q + 2 * step], acc2); acc3 = term(sXA[q + 3 * step], acc3);
+        }
+        for (; q < npix; q += step) acc0 = term(sXA[q], acc0);
     }
-    for (; q < npix; q += step) acc0 += term(q);
-    const double acc = (acc0 + acc1) + (acc2 + acc3);
-    return acc;
+    return (acc0 + acc1) + (acc2 + acc3);
+}
+
+template <bool CLAMP>
+S5_DEV double planck_sum_for(const double2* __restrict__ sXA, int first, int groups, int npix, double E)
+{
+    switch (groups) {
+        case 1: return planck_sum<CLAMP, 1>(sXA, first, 1, npix, E);
+        case 2: return planck_sum<CLAMP, 2>(sXA, first, 2, npix, E);
+        case 4: return planck_sum<CLAMP, 4>(sXA, first, 4, npix, E);
+        default: return planck_sum<CLAMP, 0>(sXA, first, groups, npix, E);
+    }
 }
 
 // The workgroups' partial spectra are written ENERGY-MAJOR -- partial[j * nblocks + workgroup] -- so that ONE more launch adds
@@ -177,10 +214,15 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
             if (member == 0) { T0 = Tm; g0 = gm; l0 = lm; } else { T1 = Tm; g1 = gm; l1 = lm; }
         }
     }
+    // the largest |energy| of the job, by every wave for itself (a few loads and six lane exchanges; no LDS)
+    double e_max = 0.0;
+    for (int j = tid % 64; j < sp.n_energies; j += 64) e_max = fmax(e_max, fabs(energies[j]));
+    for (int w = 32; w > 0; w >>= 1) e_max = fmax(e_max, __shfl_xor(e_max, w));
+    bool beyond = false;
     // the staging arrays take over the ladder block of the trace (every lane is through with it)
     double* const lds = thin_disk_ladder_column() - threadIdx.x;
-    double* const sX = lds;                                                  // [512] log2(e) h kev2freq / (kB f T g); harmless 0 for a dark pixel
-    double* const sA = lds + 512;                                            // [512] amplitude (0 for a dark pixel)
+    // [512] pairs: log2(e) h kev2freq / (kB f T g) (a harmless 1 for a dark pixel), amplitude (0 for a dark pixel)
+    double2* const sXA = reinterpret_cast<double2*>(lds);                    // (the ladder block starts on a 16-byte boundary: s5_thindisk.hpp)
     double* const sAcc = lds + 1024;                                         // [256]
     __syncthreads();
     {
@@ -192,11 +234,13 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
             const double Tm = member ? T1 : T0, gm = member ? g1 : g0, lm = member ? l1 : l0;
             const bool on = (gm > 0.0) && !(Tm < 1e2);                       // ref py :76
             // a dark pixel keeps exponent 1 (x = E) and amplitude 0: no branch in the loop over the pixels
-            sX[tid + 256 * member] = on ? mdiv(1.44269504088896340736 * (planck_h * kev2freq), kB * f * Tm * gm) : 1.0;
-            sA[tid + 256 * member] = on ? lm * amp0 : 0.0;
+            const double x1 = on ? mdiv(1.44269504088896340736 * (planck_h * kev2freq), kB * f * Tm * gm) : 1.0;
+            sXA[tid + 256 * member] = make_double2(x1, on ? lm * amp0 : 0.0);
+            beyond |= !(x1 * e_max < 1073741824.0);
         }
     }
-    __syncthreads();
+    // (the barrier the staged pixels need anyway)  any pixel whose exponent could leave the 32-bit range: planck_sum<true>
+    const bool clamp = __syncthreads_or(beyond) != 0;
 
     // transposed phase: EB energy bins x (256 / EB) pixel sub-sets
     const int EB = sp.bins_per_pass;                     // power of two, <= 256
@@ -208,7 +252,7 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
         double acc = 0.0;
         if (j < sp.n_energies) {
             const double E = energies[j];
-            acc = planck_sum(sX, sA, grp, groups, npix, E) * (E * E * E);
+            acc = (clamp ? planck_sum_for<true>(sXA, grp, groups, npix, E) : planck_sum_for<false>(sXA, grp, groups, npix, E)) * (E * E * E);
         }
         sAcc[tid] = acc;
         __syncthreads();

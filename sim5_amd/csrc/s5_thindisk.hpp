@@ -271,7 +271,7 @@ S5_DEV void trace_thin_disk(const PRM& p, double alpha, double beta_in, ThinRay&
 // this lane's column of the workgroup's ladder block (256-thread one-dimensional workgroups: all callers)
 S5_DEV double* thin_disk_ladder_column()
 {
-    __shared__ double s_ladder[(2 * LADDER_RUNGS + 1) * 256];      // (the extra row: a_{top+1} of ladder_descend_squares)
+    __shared__ alignas(16) double s_ladder[(2 * LADDER_RUNGS + 1) * 256];      // (the extra row: a_{top+1} of ladder_descend_squares; 16 bytes: k_spectrum.hip re-uses the block for double2)
     return &s_ladder[threadIdx.x];
 }
 

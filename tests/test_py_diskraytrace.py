@@ -123,6 +123,30 @@ def test_fused_spectrum_kernel(golden, capi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_energies,lo,hi", [(128, -1.0, 1.5), (64, -2.0, 2.0), (256, -3.0, 3.0), (300, -2.0, 2.0), (17, -1.0, 1.0),
+                                              (128, -3.0, 12.0), (40, -6.0, 13.0), (1, 0.0, 0.0)],
+                         ids=["128", "64", "256", "300-two-passes", "17-run-time-stride", "128-to-1e12-keV", "40-to-1e13-keV", "one"])
+def test_spectrum_fast_against_strict_over_energy_grids(capi, n_energies, lo, hi):
+    """The fast kernel's Planck factor (k_spectrum.hip planck_sum: 2^n from the low word of t + 1.5 2^52, a degree-6 2^f, the
+    reciprocal seed) against the strict kernel's full-precision evaluation (ref python/sim5diskspectrum.py:54-88), for every
+    loop form: compile-time strides 1, 2, 4 (256, 128, 64 energies per pass), the run-time stride (< 64), several passes, and grids
+    whose largest energy takes x log2(e) beyond the 32-bit range of that low word (the bounded form of the loop: exactly-zero
+    terms, never a wrapped exponent).  1e-6 of the bin, bins below 1e-280 of the peak compared as zeros."""
+    d_fast = capi.image_desc(160, 96, 0.9, 1.2)
+    d_strict = capi.image_desc(160, 96, 0.9, 1.2, strict=True)
+    E = 10.0 ** np.linspace(lo, hi, n_energies)
+    f = capi.disk_spectrum(d_fast, E)
+    s = capi.disk_spectrum(d_strict, E)
+    assert np.isfinite(f).all() and np.isfinite(s).all() and s.max() > 0
+    live = s > 1e-280 * s.max()
+    assert np.array_equal(f[~live] > 1e-270 * s.max(), np.zeros((~live).sum(), bool)), "bins that must be (next to) nothing"
+    err = np.max(np.abs(f[live] / s[live] - 1))
+    assert err < 1e-6, (n_energies, lo, hi, err, int(np.argmax(np.abs(f[live] / s[live] - 1))))
+    if hi > 9:
+        assert (f[E > 1e6] == 0).all(), "x beyond the exponent range is an exact zero"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fast"])
 def test_thick_disk_surface_search(golden, capi, strict):
     """sim5gpu_disk_surface_rays against the reference's Python __find_surface run on the same table."""
