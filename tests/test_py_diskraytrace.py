@@ -144,6 +144,14 @@ def test_spectrum_fast_against_strict_over_energy_grids(capi, n_energies, lo, hi
     assert err < 1e-6, (n_energies, lo, hi, err, int(np.argmax(np.abs(f[live] / s[live] - 1))))
     if hi > 9:
         assert (f[E > 1e6] == 0).all(), "x beyond the exponent range is an exact zero"
+    # a row set that is not symmetric about the middle (the unpaired instantiation, 256 pixels per workgroup), and the two
+    # parts of the image add up to the whole
+    top = capi.disk_spectrum(capi.image_desc(160, 96, 0.9, 1.2, y0=0, y1=37), E)
+    rest = capi.disk_spectrum(capi.image_desc(160, 96, 0.9, 1.2, y0=37, y1=96), E)
+    top_s = capi.disk_spectrum(capi.image_desc(160, 96, 0.9, 1.2, y0=0, y1=37, strict=True), E)
+    lt = top_s > 1e-280 * max(top_s.max(), 1e-300)
+    assert np.max(np.abs(top[lt] / top_s[lt] - 1)) < 1e-6
+    assert np.max(np.abs((top + rest)[live] / f[live] - 1)) < 1e-9
 
 
 @pytest.mark.gpu
