@@ -63,37 +63,59 @@ S5_DEV void spectrum_pixel(const PRM& p, const SpectrumParams& sp, const ThinRay
 }
 
 #if S5_FAST
-// The same three numbers for a crossing of the EQUATORIAL PLANE by a disk on circular orbits (m = 0, v_r = 0, dH/dR = 0: the
-// thin disk of this job) in closed form.  With k_t = -1, k_phi = l (the constants of motion; photon_momentum normalises to
-// them), U = A (1, 0, 0, Omega) with A^-2 = -(g00 + 2 Omega g03 + Omega^2 g33) (ref src/sim5kerr.c:871-875) and the surface
-// normal N = (0, 0, -1/sqrt(g22), 0) (ref :898-902):
+// What the loop over the energies needs of a pixel -- x1 = log2(e) h kev2freq / (kB f T g) and the amplitude limb(mu_e) amp0 -- for a
+// crossing of the EQUATORIAL PLANE by a disk on circular orbits (m = 0, v_r = 0, dH/dR = 0: the thin disk of this job), in closed
+// form; (1, 0) for a dark pixel (no branch in the loop over the pixels).  With k_t = -1, k_phi = l (the constants of motion;
+// photon_momentum normalises to them), U = A (1, 0, 0, Omega) with A^-2 = -(g00 + 2 Omega g03 + Omega^2 g33) (ref
+// src/sim5kerr.c:871-875) and the surface normal N = (0, 0, -1/sqrt(g22), 0) (ref :898-902):
 //     k.U = A (-1 + Omega l)            g     = k_t / (k.U)         = 1 / (A (1 - Omega l))
 //     k.N = -sqrt(g22) k^theta          mu_e  = (k.N) / (k.U)       = g sqrt(q) / r        (k^theta = +sqrt(q) / r^2 at m = 0, ref :1179-1207)
-// -- what the tetrad chain of spectrum_pixel evaluates with ~600 operations (photon_momentum, the contravariant metric,
-// three normalised tetrad legs, two on2bl, two dot products), here ~40.  Agreement with the chain: rounding.
+// -- what the tetrad chain of spectrum_pixel evaluates with ~600 operations (photon_momentum, the contravariant metric, three
+// normalised tetrad legs, two on2bl, two dot products).  Omega is the reference's own mix: the Keplerian l(r) of the DISK MODEL,
+// whose spin is a float static (ref src/sim5disk-nt.c:27-28, :260-266), turned into an angular velocity by the metric of the
+// hole's double spin (ref :1101-1111) -- 3e-8 from the Omega_K of either spin, and x = E / (kT g) carries that into the Wien tail
+// multiplied by x, so the trace's own g-factor (gfactorK of the double spin) is NOT used here.  Written without the intermediate
+// quotients: with l(r) = Nl / Dl, r g00 = 2 - r, r g03 = -2a, r g33 = r (r^2 + a^2) + 2 a^2 (m = 0),
+//     Omega = No / Do,   No = -(r g03 Dl + Nl r g00),   Do = r g33 Dl + Nl r g03
+//     A^-2  = P / (r Do^2),   P = -(r g00 Do^2 + 2 No Do r g03 + No^2 r g33)
+//     g     = sign(Do) sqrt(P / r) / (Do - No l)
+// and g, 1 / (g T) from ONE reciprocal of sqrt(P / r) (Do - No l) T: four square roots and two reciprocals per pixel (the chain of
+// quotients: four and five).  Agreement with the tetrad chain: rounding (tests/test_py_diskraytrace.py, 1e-6 of every bin against
+// the strict kernel and against the reference's Python classes).
 template <class PRM>
-S5_DEV void spectrum_pixel_equatorial(const PRM& p, const SpectrumParams& sp, const ThinRay& t, double& T, double& g, double& limbf)
+S5_DEV void spectrum_stage_equatorial(const PRM& p, const SpectrumParams& sp, const ThinRay& t, double l, double sqrt_q,
+                                      double x_scale, double amp0, double& x1, double& amp)
 {
-    T = 0.0; g = 0.0; limbf = 0.0;
+    x1 = 1.0; amp = 0.0;
     if (t.cls == PX_HIT0 && t.flux != 0.0) {
-        Metric mt;
-        kerr_metric(p.a, t.r, 0.0, mt);
-        const double Om = omega_from_ell(disk_ell(p.disk, t.r), mt);
-        const double A2 = -(mt.g00 + 2. * Om * mt.g03 + Om * Om * mt.g33);
-        const double gg = mdiv(msqrt(A2), 1. - Om * t.l);                  // (A2 < 0: NaN, the ray contributes nothing, as there)
-        double mue = mdiv(gg * msqrt(t.q), t.r);
-        if ((mue < 0.0) && (mue > -1e-2)) mue = 1e-3;                      // ref py :387
-        if (gg > 0.0) {
-            g = gg;
-            T = msqrt(msqrt(t.flux * (1.0 / 5.670400e-05)));
-            limbf = (sp.limb_darkening > 0) ? ((mue >= 0.0) ? 0.5 + 0.75 * mue : 1.0) : 1.0;
+        const double a = p.a, af = p.disk.a, r = t.r;
+        const double rl = fmax(p.disk.rms, r);                                 // disk_ell: l(r) of the inner edge below it
+        const double x = sqrt_pos(rl);
+        const double Nl = rl * rl - 2. * af * x + af * af, Dl = x * rl - 2. * x + af;
+        const double G00 = 2. - r, G03 = -2. * a, G33 = r * (r * r + a * a) + 2. * (a * a);
+        const double No = -(G03 * Dl + Nl * G00), Do = G33 * Dl + Nl * G03;
+        const double P = -(G00 * (Do * Do) + 2. * (No * Do) * G03 + (No * No) * G33);
+        const double rr = mrcp(r);
+        const double s = msqrt(P * rr);                                        // (P < 0: NaN, the ray contributes nothing, as there)
+        double den = Do - No * l;
+        if (Do < 0.0) den = -den;
+        const double u = t.flux * (1.0 / 5.670400e-05);                        // T^4
+        const double T = sqrt_pos(sqrt_pos(u));
+        const double R = mrcp((s * den) * T);
+        const double gg = (s * s) * (T * R);
+        if ((gg > 0.0) && !(T < 1e2)) {                                        // ref py :76
+            double mue = (gg * sqrt_q) * rr;
+            if ((mue < 0.0) && (mue > -1e-2)) mue = 1e-3;                      // ref py :387
+            const double limbf = (sp.limb_darkening > 0) ? ((mue >= 0.0) ? 0.5 + 0.75 * mue : 1.0) : 1.0;
+            x1 = x_scale * ((den * den) * R);
+            amp = limbf * amp0;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // FAST VARIANT.  Three changes against the kernel below (which stays the strict variant's):
-//  * The local frame of a crossing in closed form (spectrum_pixel_equatorial above).
+//  * The local frame of a crossing in closed form (spectrum_stage_equatorial above).
 //  * A row set symmetric about the middle of the image is traced in MIRRORED PAIRS (s5_thindisk.hpp: a lane traces (alpha, beta)
 //    and (alpha, -beta), which share the geodesic) at four waves per SIMD: a workgroup stages 512 pixels, not 256.  The staging
 //    arrays live in the Landen-ladder block of the trace, which is dead by then (LDS stays at 34 KB: four workgroups per CU).
@@ -198,47 +220,39 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
     const int ix = blockIdx.x * FAST_TILE_W + lane_x;
     const int lr = blockIdx.y * FAST_TILE_H + lane_y;                       // PAIR: local row in the upper half
     const int half = PAIR ? (p.nrows + 1) / 2 : p.nrows;
-    double T0 = 0.0, g0 = 0.0, l0 = 0.0, T1 = 0.0, g1 = 0.0, l1 = 0.0;      // (scalars, not arrays indexed by the loop below: no stack)
+    // what this lane stages for its (two) pixels: (1, 0) = dark
+    double x0 = 1.0, amp_0 = 0.0, x1 = 1.0, amp_1 = 0.0;
     if (ix < p.nx && lr < half) {
         const int iy = p.y0 + lr;
         const double alpha = pixel_alpha(p, ix), beta = pixel_beta(p, iy);
         ThinRay t, t2;
-        if (PAIR) trace_thin_disk_impl<true, true, false, true>(p, alpha, beta, t, t2, iy);      // max_order = 1, rms = 0: first crossing, any radius
-        else trace_thin_disk<true, true>(p, alpha, beta, t, iy);
+        if (PAIR) trace_thin_disk_impl<false, true, false, true>(p, alpha, beta, t, t2, iy);     // max_order = 1, rms = 0: first crossing, any radius
+        else trace_thin_disk<false, true>(p, alpha, beta, t, iy);
         const bool second = PAIR && (p.nrows - 1 - lr != lr);                // (an odd middle row is its own mirror)
-#pragma unroll 1
-        for (int member = 0; member < (PAIR ? 2 : 1); ++member) {
-            if (member == 1 && !second) break;
-            double Tm, gm, lm;
-            spectrum_pixel_equatorial(p, sp, member ? t2 : t, Tm, gm, lm);
-            if (member == 0) { T0 = Tm; g0 = gm; l0 = lm; } else { T1 = Tm; g1 = gm; l1 = lm; }
-        }
+        // the constants of motion of the pair (ref src/sim5kerr-geod.c:76-77) for the frame: l, sqrt(q)
+        const double l = -alpha * p.sin_i;
+        const double b = (beta == 0.0) ? +1e-6 : beta;
+        const double sqrt_q = msqrt(b * b + (p.cos_i * p.cos_i) * (alpha * alpha - p.a * p.a));     // (q < 0: NaN, no limb darkening, as with the tetrads)
+        const double planck_h = 6.626069e-27, kev2freq = 2.417990e+17, c2 = 8.987554e+20, kB = 1.380650e-16;
+        const double f = sp.hardening;
+        const double amp0 = mdiv(2.0 * planck_h * (kev2freq * kev2freq * kev2freq) * kev2freq, c2 * (f * f * f * f));
+        const double x_scale = mdiv(1.44269504088896340736 * (planck_h * kev2freq), kB * f);
+        spectrum_stage_equatorial(p, sp, t, l, sqrt_q, x_scale, amp0, x0, amp_0);
+        if (second) spectrum_stage_equatorial(p, sp, t2, l, sqrt_q, x_scale, amp0, x1, amp_1);
     }
     // the largest |energy| of the job, by every wave for itself (a few loads and six lane exchanges; no LDS)
     double e_max = 0.0;
     for (int j = tid % 64; j < sp.n_energies; j += 64) e_max = fmax(e_max, fabs(energies[j]));
     for (int w = 32; w > 0; w >>= 1) e_max = fmax(e_max, __shfl_xor(e_max, w));
-    bool beyond = false;
     // the staging arrays take over the ladder block of the trace (every lane is through with it)
     double* const lds = thin_disk_ladder_column() - threadIdx.x;
     // [512] pairs: log2(e) h kev2freq / (kB f T g) (a harmless 1 for a dark pixel), amplitude (0 for a dark pixel)
     double2* const sXA = reinterpret_cast<double2*>(lds);                    // (the ladder block starts on a 16-byte boundary: s5_thindisk.hpp)
     double* const sAcc = lds + 1024;                                         // [256]
     __syncthreads();
-    {
-        const double planck_h = 6.626069e-27, kev2freq = 2.417990e+17, c2 = 8.987554e+20, kB = 1.380650e-16;
-        const double f = sp.hardening;
-        const double amp0 = mdiv(2.0 * planck_h * (kev2freq * kev2freq * kev2freq) * kev2freq, c2 * (f * f * f * f));
-#pragma unroll
-        for (int member = 0; member < 2; ++member) {
-            const double Tm = member ? T1 : T0, gm = member ? g1 : g0, lm = member ? l1 : l0;
-            const bool on = (gm > 0.0) && !(Tm < 1e2);                       // ref py :76
-            // a dark pixel keeps exponent 1 (x = E) and amplitude 0: no branch in the loop over the pixels
-            const double x1 = on ? mdiv(1.44269504088896340736 * (planck_h * kev2freq), kB * f * Tm * gm) : 1.0;
-            sXA[tid + 256 * member] = make_double2(x1, on ? lm * amp0 : 0.0);
-            beyond |= !(x1 * e_max < 1073741824.0);
-        }
-    }
+    sXA[tid] = make_double2(x0, amp_0);
+    sXA[tid + 256] = make_double2(x1, amp_1);
+    const bool beyond = !(x0 * e_max < 1073741824.0) || !(x1 * e_max < 1073741824.0);
     // (the barrier the staged pixels need anyway)  any pixel whose exponent could leave the 32-bit range: planck_sum<true>
     const bool clamp = __syncthreads_or(beyond) != 0;
 

@@ -1,11 +1,12 @@
 """Spectrum job on the GPU box: time per job and the roofline fraction of bench.py's f3 line, for a few
-energy counts (python tests/tools/bench_spectrum.py)."""
+energy counts (python tests/tools/bench_spectrum.py [image side, default 1024])."""
 import ctypes as C, math, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sim5_amd.capi as capi
-n = 1024
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+warm, reps = (300, 50) if n <= 1024 else (40, 10)
 d = capi.image_desc(n, n, 0.998, math.radians(70.0))
 for ne in (1, 128, 256):
     E = 10.0 ** np.linspace(-1, 1.5, ne)
@@ -13,10 +14,10 @@ for ne in (1, 128, 256):
     capi._lib.sim5gpu_disk_spectrum_workspace.restype = capi.SZ
     ws = capi.DeviceBuffer(max(capi._lib.sim5gpu_disk_spectrum_workspace(C.byref(d), capi.I(ne)), 8))
     run = lambda: capi._check(capi._lib.sim5gpu_disk_spectrum(C.byref(d), capi.I(ne), capi.VP(dE.ptr), capi.D(1.7), capi.I(1), capi.VP(dS.ptr), capi.VP(ws.ptr), capi.VP(0)), "spectrum")
-    for _ in range(300): run()
+    for _ in range(warm): run()
     capi.synchronize(); e0 = capi.Event(); e1 = capi.Event(); e0.record()
-    for _ in range(50): run()
-    e1.record(); ms = e0.elapsed_ms(e1) / 50
+    for _ in range(reps): run()
+    e1.record(); ms = e0.elapsed_ms(e1) / reps
     w = n * n * 1.6e3 + n * n * ne * 6.0
     S = dS.to_numpy(np.float64, (ne,))
     print("%3d energies: %.4f ms  roofline %.3f  sum %.12e" % (ne, ms, w / (ms * 1e-3) / 78.6e12, S.sum()))
