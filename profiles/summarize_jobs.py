@@ -34,8 +34,19 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv")):
                                              "Workgroup_Size_X", "Grid_Size_X", "Grid_Size_Y") if c in row}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    per_dispatch = collections.defaultdict(lambda: collections.defaultdict(dict))
     for row in csv.DictReader(open(d)):
         acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        per_dispatch[short(row["Kernel_Name"])][row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
+    # VALUBusy / VALUUtilization are per-launch percentages: a kernel launched several times per job, most launches finding nothing
+    # to do (the surface search's walk rounds 2-4), has a plain mean that says nothing -- weight them by the launch's active cycles
+    for k, ds in per_dispatch.items():
+        rows = [v for v in ds.values() if "GRBM_GUI_ACTIVE" in v and "VALUBusy" in v]
+        tot = sum(v["GRBM_GUI_ACTIVE"] for v in rows)
+        if rows and tot > 0:
+            e = kern.setdefault(k, {"launches": 0, "ns": [], "dispatch": {}})
+            e["pmc_weighted_by_active_cycles"] = {c: sum(v[c] * v["GRBM_GUI_ACTIVE"] for v in rows) / tot
+                                                  for c in ("VALUBusy", "VALUUtilization") if all(c in v for v in rows)}
     for k, cs in acc.items():
         e = kern.setdefault(k, {"launches": 0, "ns": [], "dispatch": {}})
         for c, v in cs.items():
@@ -65,8 +76,8 @@ with open(os.path.join(root, "profiles", tag + "_jobs_summary.json"), "w") as fh
 for k, e in out.items():
     if k.startswith("_"):
         continue
-    p = e.get("pmc_mean_per_launch", {})
-    print("%-40s n=%-3d %10.3f ms  VGPR %s scratch %s LDS %s  VALUBusy %s VALUUtil %s" % (
+    p = e.get("pmc_weighted_by_active_cycles", e.get("pmc_mean_per_launch", {}))
+    print("%-40s n=%-3d %10.3f ms  VGPR %s scratch %s LDS %s  VALUBusy %s VALUUtil %s (weighted by active cycles)" % (
         k, e["launches"], (e["kernel_ns_avg"] or 0) / 1e6, e["dispatch"].get("VGPR_Count"), e["dispatch"].get("Scratch_Size"),
         e["dispatch"].get("LDS_Block_Size"), "%.1f" % p["VALUBusy"] if "VALUBusy" in p else "-",
         "%.1f" % p["VALUUtilization"] if "VALUUtilization" in p else "-"))
