@@ -656,7 +656,21 @@ def extra_configs(torch, capi, dev, stream):
                                              "executed_frac": e["flops_per_launch_1024x1024x128"] / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                              "valu_wave_instr_per_launch": e["valu_wave_instr_per_launch"], "valu_busy_pct": e["valu_busy_pct"],
                                              "executed_flops_source": e["source"]})
-    del E, S, ws
+    # the same job on the headline image (4096^2): the launch ramp, the ragged second round of a 1024^2 job (two rounds of resident
+    # workgroups) and the summing launch are 1/16 of what they are above
+    n4 = 4096
+    d4 = capi.image_desc(n4, n4, 0.998, 70.0 * rad)
+    wsb4 = capi._lib.sim5gpu_disk_spectrum_workspace(C.byref(d4), capi.I(ne))
+    ws4 = torch.zeros(max(int(wsb4), 8), dtype=torch.uint8, device=dev)
+    spec4 = lambda: capi._check(capi._lib.sim5gpu_disk_spectrum(C.byref(d4), capi.I(ne), capi.VP(E.data_ptr()), capi.D(1.7), capi.I(1),
+                                                                 capi.VP(S.data_ptr()), capi.VP(ws4.data_ptr()), capi.VP(stream)), "sim5gpu_disk_spectrum")
+    ms4 = timed_kernel(capi, stream, spec4, 10, 15)
+    w_spec4 = n4 * n4 * (W_ELL + W_POL) + n4 * n4 * ne * 6.0
+    out["f3_spectrum_4096_x128"] = {"kernel": "disk_spectrum_fast_kernel + spectrum_sum_kernel", "job_ms": ms4, "pixels": n4 * n4, "energies": ne,
+                                    "pixel_energy_pairs_per_s": n4 * n4 * ne / ms4 * 1e3, "algorithmic_flops": w_spec4,
+                                    "roofline_frac": w_spec4 / (ms4 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                    "spectrum_sum": float(S.sum().item())}
+    del E, S, ws, ws4
     # the surface search of the reference's Python DiskRaytrace for a thick disk H(R) = 0.25 (R - 2), 1024^2
     # rays (k_surface.hip).  Algorithmic work per ray: ~550 sub-steps of geodesic_follow (ref src/sim5kerr-geod.c:891-925), each
     # r(P) + mu(P) = two jacobi_sncndn (~4 AGM levels, a sincos, the back recurrence) ~ 3.6e2 FP64 operations by SURVEY 8(d)'s
