@@ -437,9 +437,18 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
                 for d in descs:
                     capi.disk_image_device(d, f_ptr, g_ptr, stream=stream)
 
+        # a rank whose launch fails keeps taking part in every barrier (a rank that left the loop would meet the others'
+        # barrier with another collective): it stops launching, the failure is agreed on after the loop
+        failed = [False]
+
         def one_step():
-            launch()
-            torch.cuda.synchronize()
+            if not failed[0]:
+                try:
+                    launch()
+                    torch.cuda.synchronize()
+                except Exception as e:                         # noqa: BLE001 -- reported in the record
+                    failed[0] = True
+                    state["err"] = repr(e)[:300]
             dist.barrier()
 
         times = []
@@ -451,6 +460,8 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
             for _ in range(steps):
                 one_step()
             times.append(time.perf_counter() - t0)
+            if failed[0]:
+                raise RuntimeError(state["err"])
         ran = attempt(run)
         if ran:
             t = torch.tensor([times[0]], dtype=torch.float64, device=cdev)
