@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
     # recorded command lines)
     env = (lambda k: os.environ.get(k, "")) if _VAR else (lambda k: "")
     fp = _fingerprint(headers + sources + [os.path.abspath(__file__)],
-                      (FLAGS, VARIANT, env("S5_FAST_EXTRA"), env("S5_TORUS_EXTRA"), env("S5_TORUS_FAST_EXTRA"), env("S5_SURF_FAST_EXTRA")))
+                      (FLAGS, VARIANT, env("S5_FAST_EXTRA"), env("S5_TORUS_EXTRA"), env("S5_TORUS_FAST_EXTRA"), env("S5_SURF_FAST_EXTRA"), env("S5_IMAGE_FAST_EXTRA")))
     if not force and os.path.exists(LIB) and os.path.exists(LIB_RCCL) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
         return LIB
     if os.path.exists(stamp):
@@ -93,6 +93,8 @@ def build(force=False, verbose=False):
                 extra = extra + ["-ffp-contract=fast"] + env("S5_TORUS_FAST_EXTRA").split()
         if src == "k_surface.hip" and variant == "fast":
             extra = extra + env("S5_SURF_FAST_EXTRA").split()
+        if src == "k_disk_image.hip" and variant == "fast":
+            extra = extra + env("S5_IMAGE_FAST_EXTRA").split()
         cmd = [hipcc] + FLAGS + VARIANT[variant] + extra + ["-c", s, "-o", o]
         # an object is reused only if it is newer than its sources AND was compiled by this very command line
         # (experiment flags from the environment must not survive in objects a later build links)
