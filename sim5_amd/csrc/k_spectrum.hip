@@ -131,8 +131,8 @@ constexpr int FAST_TILE_W = 16, FAST_TILE_H = 16;        // a wave: a 16 x 4 pat
 //  * t + M with M = 1.5 2^52 in ONE fma (the sum is rounded to an integer: that is n, to nearest even, and its two's
 //    complement sits in the low word of the result: no conversion), n = (t + M) - M, f = fma(E, sX, -n) -- exact;
 //  * 2^f = 1 + f (c1 + f (c2 + ... + f c6)): (2^f - 1) / f on [-1/2, 1/2] by the degree-5 polynomial of least maximal RELATIVE
-//    error (tests/tools/exp2_coefficients.py: 1.07e-8; the subtraction of 1 below is exact to 1e-16 / x, so small x keeps
-//    its accuracy) -- five Horner steps with the constants in scalar registers and one fma;
+//    error (tests/tools/exp2_coefficients.py: 1.07e-8; the subtraction of 1 below is exact to 1e-16 / x -- the
+//    property of the reference's own exp(x) - 1.0, ref python/sim5diskspectrum.py:84 -- so small x keeps its accuracy) -- five Horner steps with the constants in scalar registers and one fma;
 //  * 2^n by v_ldexp on the low word (n beyond the exponent range gives infinity, a reciprocal of 0 and a term of 0: no cap
 //    on x needed), one fma for 2^n 2^f - 1, the 26-bit reciprocal seed (four slots), one fma for the sum.
 // The low word is n only while |t| < 2^31.  CLAMP (a workgroup with a pixel whose sX times the largest energy is beyond 2^30:
