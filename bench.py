@@ -381,6 +381,78 @@ def all_ok(dist, torch, cdev, world, ok_local):
     return float(t.item()) == 0.0
 
 
+class LineGuard:
+    """N > 1, after the timed region: the measurements that follow (the gather on its own, the peer-to-peer A/B, the C5 scan) are
+    optional, collective, and -- on the first node with several GPUs -- have never run on hardware.  None of them may take the headline
+    line with it.  Rank 0 hands the guard a function that makes the line from what the timed region measured; a helper thread on every
+    rank then waits for (a) SIGTERM -- the launcher's reaction to a rank that died, e.g. of a GPU fault while storing into a peer's
+    memory: rank 0 prints the line without the optional records and every rank leaves with code 1 -- or (b) a deadline: the same, code
+    0 on every rank (their timers start within a collective of each other).  The thread does not need the main thread, which may sit in
+    a collective that will never complete (the signal reaches it through signal.set_wakeup_fd).  disarm() when the phases are through."""
+
+    def __init__(self, rank, deadline_s):
+        import select, signal, threading
+        self.rank, self.make_line, self.done = rank, None, False
+        self.lock = threading.Lock()
+        self.r, self.w = os.pipe()
+        os.set_blocking(self.w, False)
+        self.old_fd = signal.set_wakeup_fd(self.w, warn_on_full_buffer=False)
+        self.old_handler = signal.signal(signal.SIGTERM, lambda *a: None)     # (a Python-level handler: the wake-up byte is written for it)
+        self.deadline = time.time() + deadline_s
+
+        def watch():
+            while True:
+                left = self.deadline - time.time()
+                ready = select.select([self.r], [], [], max(0.0, left))[0] if left > 0 else []
+                with self.lock:
+                    if self.done:
+                        return
+                    if ready:
+                        try:
+                            got = os.read(self.r, 64)
+                        except OSError:
+                            got = b""
+                        if signal.SIGTERM not in got:
+                            continue                                   # another signal's byte
+                        why = "SIGTERM from the launcher (a rank died)"
+                    elif time.time() >= self.deadline:
+                        why = "no end after %d s" % deadline_s
+                    else:
+                        continue
+                    self._leave(why, 1 if ready else 0)
+        self.thread = threading.Thread(target=watch, daemon=True)
+        self.thread.start()
+
+    def _leave(self, why, code):
+        if self.rank == 0 and self.make_line is not None:
+            try:
+                sys.stdout.write(self.make_line(why) + "\n")
+                sys.stdout.flush()
+            except Exception as e:                                     # noqa: BLE001
+                sys.stderr.write("bench.py: could not make the line in the guard: %r\n" % (e,))
+        sys.stderr.write("bench.py: rank %d: optional phases cut short: %s\n" % (self.rank, why))
+        sys.stderr.flush()
+        os._exit(code)
+
+    def failed(self, exc):
+        """(c) an optional phase raised on this rank -- a collective that lost its peer raises at once with some backends: the line
+        without the optional records, code 1"""
+        with self.lock:
+            if not self.done:
+                self._leave("an optional phase raised %s" % repr(exc)[:200], 1)
+
+    def disarm(self):
+        import signal
+        with self.lock:
+            self.done = True
+        try:
+            os.write(self.w, b"\0")                                    # wake the thread: it sees `done` and returns
+        except OSError:
+            pass
+        signal.set_wakeup_fd(self.old_fd if self.old_fd is not None else -1)
+        signal.signal(signal.SIGTERM, self.old_handler if self.old_handler is not None else signal.SIG_DFL)
+
+
 def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, dealt, steps, single):
     """A/B of the exchange, AFTER the timed region (it never enters `value`): the peer-to-peer form SURVEY 8(e) allows.  Rank 0
     exports the inter-process handle of ONE whole-image allocation, every peer maps it and traces its mirrored stripes IN
@@ -419,6 +491,8 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
     def open_():
         if rank != 0:
             state["base"] = capi.ipc_open(handle[0])
+            if os.environ.get("SIM5_BENCH_TEST_PEER_DIES") == "1":
+                os.abort()                                     # test hook (tests/test_gpu_bench.py): what a GPU fault on a peer does
     opened = attempt(open_)
     if opened:
         inc = INCL_DEG / 180.0 * math.pi
@@ -952,168 +1026,189 @@ def main():
     # the timed region is over on every rank (the all_gather above); the phases below are optional measurements, each entered
     # only after all ranks have agreed that they are still sound
     agree(dist, torch, cdev, rank, world, bool(kstep == kstep), "timed region", "kernel timing is NaN")
-    # one gather on its own (not overlapped), after the timed region: the exchange time next to the compute time
-    if striped:
-        last = pipe.last_image().clone() if rank == 0 else None      # the measurement below reuses buffer 0
-        gms, gsamples = time_gather(torch, dist, capi, pipe, stream, 3 if one_gpu_test else 10, one_gpu_test)
-        per_rank["gather_ms_alone"] = gms               # meaningful on rank 0 (the receiver); rank 0 reports its own
-        per_rank["gather_ms_samples"] = gsamples
-        per_rank["gather_payload_bytes_per_rank"] = 2 * sharding.max_local_rows(n, world, dealt=dealt) * n * 4
-        if rank == 0:
-            # the placement kernel on its own: the peers' rows of one image to their image rows
-            pl = make_placer(capi, sharding, n, world, dealt, stream)
-            src = pipe.staged if one_gpu_test else pipe.gathered[0]
-            per_rank["place_ms_alone"] = timed_kernel(capi, stream, lambda: pl(src, pipe.full[0]), 10, 2)
-            per_rank["assemblies_in_timed_region"] = args.steps * len(inclinations)
-        per_rank["root_band_plan"] = plan
-    direct = None
-    if striped and not c5 and not args.no_direct_ab:
-        direct = direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, dealt, max(3, min(args.steps, 20)), single)
-    c5_scan = None
-    if world > 1 and not args.no_extra and not c5 and striped:
-        # collective: every rank enters it, and every rank learns whether all came through
-        c5_scan = run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, dealt_4096=dealt)
+    last = pipe.last_image().clone() if (striped and rank == 0) else None      # (the gather measurement below reuses buffer 0)
+    hits = None
+    if rank == 0:
+        img = last if striped else pipe.last_image()
+        hits = int((img[1] > 0).sum().item())
+    # N > 1: from here on nothing may take the line with it (LineGuard)
+    guard = LineGuard(rank, 240) if world > 1 else None
+    if rank == 0:
+        def build_out(direct, c5_scan, cut):
+            """the line, from what the timed region measured plus the optional records; cut: the guard's reason when it makes the line"""
+            images_per_step = len(inclinations) * (1 if striped or world == 1 else world)
+            rays = n * n * images_per_step                     # rays of one step of the whole job
+            value = rays * args.steps / dt
+            # sanity: the image that came out is the Kerr disk (known hit count of the reference; counted before the optional phases)
+            hits_ref = reference_hits_c5().get(inclinations[-1]) if c5 else HEADLINE_HITS
+            ok = hits_ref is None or hits == hits_ref
+            if c5:
+                workload = ("8192x8192 thin-disk images, a=0.998, inclination scan 10..80 deg (8 images per step), elliptic-integral "
+                            "path, g-factor + Novikov-Thorne flux (BASELINE.json configs[4])")
+            else:
+                workload = ("4096x4096 thin-disk image, a=0.998, i=70deg, elliptic-integral path, g-factor + Novikov-Thorne flux "
+                            "(BASELINE.json headline / configs[1] at 4096^2)")
+            out = {
+                "metric": "null geodesics/sec, 4096x4096 Kerr disk image (a=0.998, i=70)" if not c5 else
+                          "null geodesics/sec, 8192x8192 Kerr disk images x 8 inclinations (a=0.998)",
+                "value": value, "unit": "null geodesics/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+                # BASELINE.md section 3 / SURVEY 8(d): "kernel time incl. image write; gather and D2H copy separately" -- `value` is the
+                # whole job (tracing + gather + assembly into a row-major image, every step), `value_kernel_only` the same rays over
+                # the slowest rank's kernel time per step (HIP events in the timed region)
+                "value_kernel_only": rays * 1e3 / kstep_max if kstep_max > 0 else None, "kernel_ms_per_step_max_over_ranks": kstep_max,
+                "scaling": "strong" if (striped or world == 1) else "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ok": ok, "spin_up_steps": spin_up,
+                "config": {"workload": workload, "rays_per_step": rays,
+                           "parallelism": ("1 GPU" if world == 1 else
+                                           "mirrored pairs of 64-row stripes (rows < %d of the upper half) round-robin over %d GPUs + 1 RCCL gather "
+                                           "per image (%d per step), overlapped with the next image; the centred band of %d rows stays on rank 0"
+                                           % (dealt, world, len(inclinations), n - 2 * dealt) if striped else
+                                           "%d independent images, one per GPU, no collective" % world),
+                           "disk_hits": hits, "disk_hits_reference": hits_ref},
+            }
+            if world == 1:
+                out["scaling"] = "strong"
+            if cold_ms is not None:
+                out["cold_clock"] = {"kernel_ms": cold_ms, "rays_per_s": n * n / cold_ms * 1e3,
+                                     "what": "3 images after 0.3 s of idle (no spin-up): what a caller who renders one image sees; "
+                                             "`value` is the steady state at the working clock"}
+            if check_every_step and rank == 0 and not c5:
+                out["hits_of_every_assembled_image"] = step_hits
+                ok = ok and all(h == hits_ref for h in step_hits) and len(step_hits) > 0
+                # [checksum of the F g^4 plane, of the g plane (sums of the 32-bit patterns), every word equal to the single launch]
+                out["plane_checksums_single_launch"] = single_sums
+                out["plane_checksums_of_every_assembled_image"] = step_sums
+                ok = ok and len(step_sums) > 0 and all(c[2] and c[:2] == single_sums for c in step_sums)
+                out["ok"] = ok
+            rays_launch = sum(job.rays for job in jobs)            # rays rank 0 traces per step
+            achieved = rays_launch * W_ELL / (kstep * 1e-3) / 1e12
+            traffic = executed = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if world == 1 and not c5:                      # the PMC traffic figure was collected for the 1-GPU headline launch
+                        traffic = tj.get("hbm_bytes_per_launch")
+                    executed = tj.get("executed_fp64_flops_per_ray")     # per ray: holds for any row set of the same kernel
+                    executed_src = tj.get("source")
+                except Exception:
+                    traffic = executed = None
+            out["roofline"] = {
+                "bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                "kernel": IMAGE_KERNEL, "kernel_ms_avg": kstep / len(jobs), "algorithmic_flops_per_ray": W_ELL,
+                "kernel_ms_how": ("one HIP event pair on the launch stream around the K launches of the timed region, / K (launch gaps included)"
+                                  if world == 1 else "HIP event pair around every launch of the timed region, mean"),
+                "rays_per_launch": rays_launch // len(jobs), "per": "GPU (rank 0)",
+                # what the hardware actually does: FP64 add + mul + 2 x fma instructions x 64 lanes counted by the PMC run of the same
+                # command (profiles/traffic.json), over the kernel time measured here.  `frac` above is the contract's ALGORITHMIC
+                # figure -- the reference's per-pixel work over the kernel time, i.e. an algorithmic speed-up measure once a kernel
+                # shares work between rays; `executed_frac` is the fraction of the FP64 VALU peak the kernel's own instructions reach.
+                "executed_flops_per_ray": executed,
+                "executed_achieved": (rays_launch * executed / (kstep * 1e-3) / 1e12) if executed else None,
+                "executed_frac": (rays_launch * executed / (kstep * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS) if executed else None,
+                "executed_flops_source": executed_src if executed else None,
+                "reference_flops_per_ray_counted": W_ELL_MEASURED,
+                "hbm_algorithmic_bytes_per_launch": rays_launch // len(jobs) * 8,
+                "hbm_achieved_GBps": rays_launch * 8 / (kstep * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+                "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output.  achieved = "
+                        "algorithmic flops (SURVEY 8(d): 1.3e3 per ray, the reference's per-pixel work; 1 765 counted on the reference "
+                        "binary, oracle/opcount.c) / kernel time; the kernel traces a ray and its mirror image in beta in one lane -- "
+                        "they share l, q, the roots and the three R_F integrals -- and reads the flux and K(m) from tables, so it "
+                        "EXECUTES fewer FP64 operations per ray than the algorithmic count: executed_* is the hardware-utilisation figure",
+            }
+            out["process_group"] = group
+            if per_rank:
+                out["per_rank"] = per_rank
+            if world > 1:
+                # which number is which (VERDICT r4 weak 6): SURVEY 8(d) / BASELINE.md 3 define the metric on KERNEL time (image write
+                # included) with the gather reported separately
+                out["value_definition"] = ("value = rays x K / max-over-ranks wall time of the timed region, INCLUDING the gather to rank 0 and the "
+                                           "placement of the gathered rows (a row-major image on rank 0 every step); value_kernel_only = the same rays "
+                                           "over the slowest rank's kernel time per step = the metric of SURVEY 8(d) (kernel time incl. image write; "
+                                           "the gather is reported separately: per_rank.gather_ms_alone, link_bound)")
+                if direct is not None:
+                    out["exchange_ab_direct_stores"] = direct
+                    if "ms_per_image" in direct:
+                        direct["gather_form_ms_per_image_timed_region"] = 1e3 * dt / args.steps / len(inclinations)
+            if striped and plan:
+                # Why `value` does not follow the GPU count: a gather to ONE GPU moves (N-1)/N of every image over rank 0's inbound
+                # xGMI links, one link per peer, and a GPU writes image rows several times faster than a link carries them
+                # (DESIGN.md 8).  The plan's prediction for the chosen split (from the kernel and gather times measured before the
+                # timed region) next to what the timed region measured; the kernels themselves scale with the rows (value_kernel_only).
+                cand = (plan.get("candidates_dealt_rows") or {}).get(str(dealt))
+                measured = 1e3 * dt / args.steps / len(inclinations)
+                out["link_bound"] = {
+                    "predicted_ms_per_image": cand["predicted_step_ms"] if cand else None,
+                    "predicted_root_trace_ms": cand["root_trace_ms"] if cand else None,
+                    "predicted_peer_gather_ms": cand["peer_gather_ms"] if cand else None,
+                    "measured_ms_per_image": measured,
+                    "kernel_ms_per_image_slowest_rank": kstep_max / len(inclinations),
+                    "gather_ms_alone": per_rank.get("gather_ms_alone"),
+                    "one_gpu_kernel_ms_full_image": plan.get("kernel_ms_full_image"),
+                    "statement": "gather-to-root over point-to-point xGMI: beyond N = 2 the step is bound by the inbound links of rank 0, "
+                                 "not by tracing; value_kernel_only is the rate of the kernels alone"}
+            if not args.no_extra and not c5 and cut is None:
+                try:
+                    if world == 1:
+                        extra = extra_configs(torch, capi, dev, stream)
+                        extra["c5_8192_x8_inclinations"] = c5_on_one_gpu(torch, capi, dev, stream)
+                        ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
+                    elif striped:
+                        extra = {"c5_8192_x8_inclinations": c5_scan}
+                        ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
+                    else:
+                        extra = None
+                    if extra:
+                        out["extra"] = extra
+                        out["ok"] = ok
+                except Exception as e:                             # the extras are a report, never a blocker for the headline line
+                    out["extra"] = {"error": repr(e)}
+            if world == 1 and not args.no_cpu_baseline and not c5:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(n, n)
+                except Exception as e:                             # the baseline is a report, never a blocker
+                    out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            if cut is not None:
+                out["optional_phases"] = "cut short: %s -- the records of the gather alone, the peer-to-peer A/B and the C5 scan are missing or partial" % cut
+            return out, ok
+
+        if guard:
+            guard.make_line = lambda why: json.dumps(build_out(None, None, why)[0])
+    direct = c5_scan = None
+    try:
+        # one gather on its own (not overlapped), after the timed region: the exchange time next to the compute time
+        if striped:
+            gms, gsamples = time_gather(torch, dist, capi, pipe, stream, 3 if one_gpu_test else 10, one_gpu_test)
+            per_rank["gather_ms_alone"] = gms               # meaningful on rank 0 (the receiver); rank 0 reports its own
+            per_rank["gather_ms_samples"] = gsamples
+            per_rank["gather_payload_bytes_per_rank"] = 2 * sharding.max_local_rows(n, world, dealt=dealt) * n * 4
+            if rank == 0:
+                # the placement kernel on its own: the peers' rows of one image to their image rows
+                pl = make_placer(capi, sharding, n, world, dealt, stream)
+                src = pipe.staged if one_gpu_test else pipe.gathered[0]
+                per_rank["place_ms_alone"] = timed_kernel(capi, stream, lambda: pl(src, pipe.full[0]), 10, 2)
+                per_rank["assemblies_in_timed_region"] = args.steps * len(inclinations)
+            per_rank["root_band_plan"] = plan
+        if striped and not c5 and not args.no_direct_ab:
+            direct = direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stream, dealt, max(3, min(args.steps, 20)), single)
+        if world > 1 and not args.no_extra and not c5 and striped:
+            # collective: every rank enters it, and every rank learns whether all came through
+            c5_scan = run_c5_scan(torch, dist, capi, sharding, rank, world, dev, cdev, stream, one_gpu_test, dealt_4096=dealt)
+    except BaseException as e:                                 # noqa: BLE001 -- with a guard: the line first, then out
+        if guard:
+            guard.failed(e)
+        raise
     if rank != 0:
+        if guard:
+            guard.disarm()
         if world > 1:
             dist.destroy_process_group()
         return
-
-    images_per_step = len(inclinations) * (1 if striped or world == 1 else world)
-    rays = n * n * images_per_step                     # rays of one step of the whole job
-    value = rays * args.steps / dt
-    # sanity: the image that came out is the Kerr disk (known hit count of the reference)
-    img = last if striped else pipe.last_image()
-    hits = int((img[1] > 0).sum().item())
-    hits_ref = reference_hits_c5().get(inclinations[-1]) if c5 else HEADLINE_HITS
-    ok = hits_ref is None or hits == hits_ref
-    if c5:
-        workload = ("8192x8192 thin-disk images, a=0.998, inclination scan 10..80 deg (8 images per step), elliptic-integral "
-                    "path, g-factor + Novikov-Thorne flux (BASELINE.json configs[4])")
-    else:
-        workload = ("4096x4096 thin-disk image, a=0.998, i=70deg, elliptic-integral path, g-factor + Novikov-Thorne flux "
-                    "(BASELINE.json headline / configs[1] at 4096^2)")
-    out = {
-        "metric": "null geodesics/sec, 4096x4096 Kerr disk image (a=0.998, i=70)" if not c5 else
-                  "null geodesics/sec, 8192x8192 Kerr disk images x 8 inclinations (a=0.998)",
-        "value": value, "unit": "null geodesics/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        # BASELINE.md section 3 / SURVEY 8(d): "kernel time incl. image write; gather and D2H copy separately" -- `value` is the
-        # whole job (tracing + gather + assembly into a row-major image, every step), `value_kernel_only` the same rays over
-        # the slowest rank's kernel time per step (HIP events in the timed region)
-        "value_kernel_only": rays * 1e3 / kstep_max if kstep_max > 0 else None, "kernel_ms_per_step_max_over_ranks": kstep_max,
-        "scaling": "strong" if (striped or world == 1) else "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ok": ok, "spin_up_steps": spin_up,
-        "config": {"workload": workload, "rays_per_step": rays,
-                   "parallelism": ("1 GPU" if world == 1 else
-                                   "mirrored pairs of 64-row stripes (rows < %d of the upper half) round-robin over %d GPUs + 1 RCCL gather "
-                                   "per image (%d per step), overlapped with the next image; the centred band of %d rows stays on rank 0"
-                                   % (dealt, world, len(inclinations), n - 2 * dealt) if striped else
-                                   "%d independent images, one per GPU, no collective" % world),
-                   "disk_hits": hits, "disk_hits_reference": hits_ref},
-    }
-    if world == 1:
-        out["scaling"] = "strong"
-    if cold_ms is not None:
-        out["cold_clock"] = {"kernel_ms": cold_ms, "rays_per_s": n * n / cold_ms * 1e3,
-                             "what": "3 images after 0.3 s of idle (no spin-up): what a caller who renders one image sees; "
-                                     "`value` is the steady state at the working clock"}
-    if check_every_step and rank == 0 and not c5:
-        out["hits_of_every_assembled_image"] = step_hits
-        ok = ok and all(h == hits_ref for h in step_hits) and len(step_hits) > 0
-        # [checksum of the F g^4 plane, of the g plane (sums of the 32-bit patterns), every word equal to the single launch]
-        out["plane_checksums_single_launch"] = single_sums
-        out["plane_checksums_of_every_assembled_image"] = step_sums
-        ok = ok and len(step_sums) > 0 and all(c[2] and c[:2] == single_sums for c in step_sums)
-        out["ok"] = ok
-    rays_launch = sum(job.rays for job in jobs)            # rays rank 0 traces per step
-    achieved = rays_launch * W_ELL / (kstep * 1e-3) / 1e12
-    traffic = executed = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if world == 1 and not c5:                      # the PMC traffic figure was collected for the 1-GPU headline launch
-                traffic = tj.get("hbm_bytes_per_launch")
-            executed = tj.get("executed_fp64_flops_per_ray")     # per ray: holds for any row set of the same kernel
-            executed_src = tj.get("source")
-        except Exception:
-            traffic = executed = None
-    out["roofline"] = {
-        "bound": "fp64_valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-        "kernel": IMAGE_KERNEL, "kernel_ms_avg": kstep / len(jobs), "algorithmic_flops_per_ray": W_ELL,
-        "kernel_ms_how": ("one HIP event pair on the launch stream around the K launches of the timed region, / K (launch gaps included)"
-                          if world == 1 else "HIP event pair around every launch of the timed region, mean"),
-        "rays_per_launch": rays_launch // len(jobs), "per": "GPU (rank 0)",
-        # what the hardware actually does: FP64 add + mul + 2 x fma instructions x 64 lanes counted by the PMC run of the same
-        # command (profiles/traffic.json), over the kernel time measured here.  `frac` above is the contract's ALGORITHMIC
-        # figure -- the reference's per-pixel work over the kernel time, i.e. an algorithmic speed-up measure once a kernel
-        # shares work between rays; `executed_frac` is the fraction of the FP64 VALU peak the kernel's own instructions reach.
-        "executed_flops_per_ray": executed,
-        "executed_achieved": (rays_launch * executed / (kstep * 1e-3) / 1e12) if executed else None,
-        "executed_frac": (rays_launch * executed / (kstep * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS) if executed else None,
-        "executed_flops_source": executed_src if executed else None,
-        "reference_flops_per_ray_counted": W_ELL_MEASURED,
-        "hbm_algorithmic_bytes_per_launch": rays_launch // len(jobs) * 8,
-        "hbm_achieved_GBps": rays_launch * 8 / (kstep * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
-        "note": "scalar FP64 special-function work per ray: no MFMA; HBM carries only 8 B/ray of output.  achieved = "
-                "algorithmic flops (SURVEY 8(d): 1.3e3 per ray, the reference's per-pixel work; 1 765 counted on the reference "
-                "binary, oracle/opcount.c) / kernel time; the kernel traces a ray and its mirror image in beta in one lane -- "
-                "they share l, q, the roots and the three R_F integrals -- and reads the flux and K(m) from tables, so it "
-                "EXECUTES fewer FP64 operations per ray than the algorithmic count: executed_* is the hardware-utilisation figure",
-    }
-    out["process_group"] = group
-    if per_rank:
-        out["per_rank"] = per_rank
-    if world > 1:
-        # which number is which: SURVEY 8(d) / BASELINE.md 3 define the metric on KERNEL time (image write
-        # included) with the gather reported separately
-        out["value_definition"] = ("value = rays x K / max-over-ranks wall time of the timed region, INCLUDING the gather to rank 0 and the "
-                                   "placement of the gathered rows (a row-major image on rank 0 every step); value_kernel_only = the same rays "
-                                   "over the slowest rank's kernel time per step = the metric of SURVEY 8(d) (kernel time incl. image write; "
-                                   "the gather is reported separately: per_rank.gather_ms_alone, link_bound)")
-        if direct is not None:
-            out["exchange_ab_direct_stores"] = direct
-            if "ms_per_image" in direct:
-                direct["gather_form_ms_per_image_timed_region"] = 1e3 * dt / args.steps / len(inclinations)
-    if striped and plan:
-        # Why `value` does not follow the GPU count: a gather to ONE GPU moves (N-1)/N of every image over rank 0's inbound
-        # xGMI links, one link per peer, and a GPU writes image rows several times faster than a link carries them
-        # (DESIGN.md 8).  The plan's prediction for the chosen split (from the kernel and gather times measured before the
-        # timed region) next to what the timed region measured; the kernels themselves scale with the rows (value_kernel_only).
-        cand = (plan.get("candidates_dealt_rows") or {}).get(str(dealt))
-        measured = 1e3 * dt / args.steps / len(inclinations)
-        out["link_bound"] = {
-            "predicted_ms_per_image": cand["predicted_step_ms"] if cand else None,
-            "predicted_root_trace_ms": cand["root_trace_ms"] if cand else None,
-            "predicted_peer_gather_ms": cand["peer_gather_ms"] if cand else None,
-            "measured_ms_per_image": measured,
-            "kernel_ms_per_image_slowest_rank": kstep_max / len(inclinations),
-            "gather_ms_alone": per_rank.get("gather_ms_alone"),
-            "one_gpu_kernel_ms_full_image": plan.get("kernel_ms_full_image"),
-            "statement": "gather-to-root over point-to-point xGMI: beyond N = 2 the step is bound by the inbound links of rank 0, "
-                         "not by tracing; value_kernel_only is the rate of the kernels alone"}
-    if not args.no_extra and not c5:
-        try:
-            if world == 1:
-                extra = extra_configs(torch, capi, dev, stream)
-                extra["c5_8192_x8_inclinations"] = c5_on_one_gpu(torch, capi, dev, stream)
-                ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
-            elif striped:
-                extra = {"c5_8192_x8_inclinations": c5_scan}
-                ok = ok and extra["c5_8192_x8_inclinations"]["hits_ok"]
-            else:
-                extra = None
-            if extra:
-                out["extra"] = extra
-                out["ok"] = ok
-        except Exception as e:                             # the extras are a report, never a blocker for the headline line
-            out["extra"] = {"error": repr(e)}
-    if world == 1 and not args.no_cpu_baseline and not c5:
-        try:
-            out["cpu_baseline"] = cpu_baseline(n, n)
-        except Exception as e:                             # the baseline is a report, never a blocker
-            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if guard:
+        guard.disarm()
+    out, ok = build_out(direct, c5_scan, None)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

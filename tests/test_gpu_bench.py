@@ -110,6 +110,23 @@ def test_two_ranks_on_one_gpu(mode, band):
         assert o["scaling"] == "weak" and o["config"]["rays_per_step"] == 2 * 4096 * 4096
 
 
+def test_a_peer_dying_in_an_optional_phase_does_not_take_the_line_with_it():
+    """bench.py LineGuard under the real launcher: rank 1 aborts inside the peer-to-peer A/B (the test hook stands for a GPU fault
+    while storing into rank 0's memory), the launcher sends SIGTERM to rank 0, which sits in a collective that will never complete
+    or raises -- and still prints the headline line from what the timed region measured, marked as cut short."""
+    env = dict(os.environ, SIM5_BENCH_ONE_GPU="1", SIM5_BENCH_TEST_PEER_DIES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    o = _line(r.stdout)
+    assert o["n_gpus"] == 2 and o["value"] > 0 and o["config"]["disk_hits"] == 15865362 and o["roofline"]["frac"] > 0
+    # (the collective that lost its peer raises at once under gloo, the backend of this test hook; under RCCL it waits, and the
+    # launcher's SIGTERM is what ends it: both ways are tests/test_bench_guard.py's)
+    assert o["optional_phases"].startswith("cut short: "), o["optional_phases"]
+    assert "exchange_ab_direct_stores" not in o and o["per_rank"]["gather_ms_alone"] > 0        # (the gather alone had been measured)
+
+
 def test_four_ranks_on_one_gpu():
     """The same with FOUR ranks (three peers in the gather and in the placement launch, a band planned from measurements):
     every step's image has the reference's hit count and the shares tile the image."""
