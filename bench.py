@@ -734,7 +734,7 @@ def extra_configs(torch, capi, dev, stream):
                                     "pixel_energy_pairs_per_s": n * n * ne / ms * 1e3, "algorithmic_flops": w_spec,
                                     "roofline_frac": w_spec / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                     "spectrum_sum": float(S.sum().item()),
-                                    "note": "roofline: (W_ell + 3e2) per pixel + 6 FP64 operations (1 exp) per (pixel, energy) pair over the job time; the kernel spends 16 issue slots on a pair (k_spectrum.hip planck_sum), so the algorithmic fraction cannot pass ~0.40 even with the vector unit full"}
+                                    "note": "roofline: (W_ell + 3e2) per pixel + 6 FP64 operations (1 exp) per (pixel, energy) pair over the job time; the kernel spends 15.25 issue slots on a pair (k_spectrum.hip planck_sum), so the algorithmic fraction cannot pass ~0.42 even with the vector unit full"}
     if "f3" in ex:
         e = ex["f3"]
         out["f3_spectrum_1024_x128"].update({"executed_flops_per_launch": e["flops_per_launch_1024x1024x128"],

@@ -33,7 +33,8 @@ out = {"what": "disk_spectrum_fast_kernel<true>, 1024^2 pixels x 128 energies (t
                    "round_5_18_slots": "51.6 M, 0.1116 ms, busy 82.6 %",
                    "round_5_16_slots": "42.2 M, 0.0960 ms: n from the low word of t + 1.5 2^52, degree-6 minimax 2^f, fused sum, (x, amplitude) "
                                        "pairs read at immediate offsets with the loop counter on the scalar unit",
-                   "round_5_frame_without_quotients": "this record: the local frame in four square roots and two reciprocals per pixel"}}
+                   "round_5_frame_without_quotients": "41.5 M, 0.0949 ms: the local frame in four square roots and two reciprocals per pixel",
+                   "round_5_eight_terms_per_reciprocal": "this record: u = e^-x, term = a u / (1 - u), eight terms over one reciprocal seed through a tree of (N, D) pairs: 15.25 slots per pair"}}
 json.dump(out, open(os.path.join(root, "profiles", tag + "_spectrum_pmc.json"), "w"), indent=1)
 print("kernel %.2f us, sum %.2f us, VALU %.1f M, busy %.1f %%, executed flop %.3e" % (
     out["kernel_time_us_rocprof_128_energies_second_half_of_its_launches"], out["sum_kernel_us"], c["SQ_INSTS_VALU"] / 1e6,

@@ -119,7 +119,7 @@ S5_DEV void spectrum_stage_equatorial(const PRM& p, const SpectrumParams& sp, co
 //  * A row set symmetric about the middle of the image is traced in MIRRORED PAIRS (s5_thindisk.hpp: a lane traces (alpha, beta)
 //    and (alpha, -beta), which share the geodesic) at four waves per SIMD: a workgroup stages 512 pixels, not 256.  The staging
 //    arrays live in the Landen-ladder block of the trace, which is dead by then (LDS stays at 34 KB: four workgroups per CU).
-//  * The Planck factor 1 / (e^x - 1) of a (pixel, energy) pair costs 16 issue slots instead of ~45 (a full-precision exp and
+//  * The Planck factor 1 / (e^x - 1) of a (pixel, energy) pair costs 15.25 issue slots instead of ~45 (a full-precision exp and
 //    a Newton division): planck_sum below.  The bar on the spectrum is 1e-6 (tests/test_py_diskraytrace.py::test_fused_spectrum_kernel,
 //    against python/sim5diskspectrum.py:54-88).  Per pixel: log2(e) h kev2freq / (kB f T g) and the amplitude; per energy bin
 //    E^3 is applied once, after the loop over the pixels.
@@ -127,14 +127,19 @@ S5_DEV void spectrum_stage_equatorial(const PRM& p, const SpectrumParams& sp, co
 #define S5_SPEC_WAVES 4
 constexpr int FAST_TILE_W = 16, FAST_TILE_H = 16;        // a wave: a 16 x 4 patch, as in the image kernels (image neighbours share class and trip counts)
 
-// sum over the staged pixels of amp / (e^x - 1) for this lane's energy, x log2(e) = E sX[q] = n + f.  16 issue slots per pair:
+// sum over the staged pixels of amp / (e^x - 1) for this lane's energy, x log2(e) = E sX[q] = n + f.  15.25 issue slots per pair
+// (16 in the form for fewer than 64 energies per pass):
 //  * t + M with M = 1.5 2^52 in ONE fma (the sum is rounded to an integer: that is n, to nearest even, and its two's
 //    complement sits in the low word of the result: no conversion), n = (t + M) - M, f = fma(E, sX, -n) -- exact;
 //  * 2^f = 1 + f (c1 + f (c2 + ... + f c6)): (2^f - 1) / f on [-1/2, 1/2] by the degree-5 polynomial of least maximal RELATIVE
-//    error (tests/tools/exp2_coefficients.py: 1.07e-8; the subtraction of 1 below is exact to 1e-16 / x -- the
-//    property of the reference's own exp(x) - 1.0, ref python/sim5diskspectrum.py:84 -- so small x keeps its accuracy) -- five Horner steps with the constants in scalar registers and one fma;
-//  * 2^n by v_ldexp on the low word (n beyond the exponent range gives infinity, a reciprocal of 0 and a term of 0: no cap
-//    on x needed), one fma for 2^n 2^f - 1, the 26-bit reciprocal seed (four slots), one fma for the sum.
+//    error (tests/tools/exp2_coefficients.py: 1.07e-8; the subtraction of 1 below is exact to 1e-16 / x -- the property of the
+//    reference's own exp(x) - 1.0, ref python/sim5diskspectrum.py:84 -- so small x keeps its accuracy) -- five Horner steps
+//    with the constants in scalar registers and one fma;
+//  * 2^n by v_ldexp on the low word.  Run-time stride (GROUPS == 0): 2^n 2^f - 1 in one fma (n beyond the exponent range gives
+//    infinity, a reciprocal of 0 and a term of 0: no cap on x needed), the 26-bit reciprocal seed (four slots), one fma for the sum.
+//    Compile-time stride: the same with t = -x log2(e): u = 2^n 2^f = e^-x in (0, 1] (an n below the exponent range gives 0 and a
+//    term of 0), w = 1 - u, b = amp u, and EIGHT terms b_i / w_i share one reciprocal: N / D from a tree of seven (N, D) pairs
+//    (N = N1 D2 + N2 D1, D = D1 D2: three slots each; every w is in (0, 1], so D cannot overflow) -- 12 + (21 + 4 + 1) / 8 slots.
 // The low word is n only while |t| < 2^31.  CLAMP (a workgroup with a pixel whose sX times the largest energy is beyond 2^30:
 // T g of a few kelvin) bounds t first, a few more slots; 2^(2^30) is as infinite as 2^t.
 // The pixels are staged as (sX, amplitude) pairs: one 16-byte LDS read per term.
@@ -177,12 +182,43 @@ S5_DEV double planck_sum(const double2* __restrict__ sXA, int first, int step, i
     };
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     if (GROUPS > 0) {
-        // npix is 256 or 512, GROUPS 1, 2 or 4: a whole number of rounds of eight
+        // eight terms over ONE reciprocal (see above): u = e^-x = 2^(-t), term = a u / (1 - u), the sum of eight as N / D
+        const double nE = -E;
+        auto uw = [&](const double2 xa, double& b, double& w) {
+            double tm, f;
+            if (CLAMP) {
+                double t = nE * xa.x;
+                if (t < -1073741824.0) t = -1073741824.0;
+                tm = t + M;
+                f = t - (tm - M);
+            } else {
+                tm = __builtin_fma(nE, xa.x, M);
+                f = __builtin_fma(nE, xa.x, -(tm - M));
+            }
+            double e = hfmac(f, c6, C5);
+            e = hfmac(f, e, C4);
+            e = hfmac(f, e, C3);
+            e = hfmac(f, e, C2);
+            e = hfmac(f, e, C1);
+            e = __builtin_fma(f, e, 1.0);
+            const double u = __builtin_amdgcn_ldexp(e, __double2loint(tm));
+            w = 1.0 - u;
+            b = xa.y * u;
+        };
         const int start = __builtin_amdgcn_readfirstlane(first);
         for (int q = start; q < npix; q += 8 * GROUPS) {
             const double2* const at = sXA + q;
-            acc0 = term(at[0 * GROUPS], acc0); acc1 = term(at[1 * GROUPS], acc1); acc2 = term(at[2 * GROUPS], acc2); acc3 = term(at[3 * GROUPS], acc3);
-            acc0 = term(at[4 * GROUPS], acc0); acc1 = term(at[5 * GROUPS], acc1); acc2 = term(at[6 * GROUPS], acc2); acc3 = term(at[7 * GROUPS], acc3);
+            double b0, b1, b2, b3, b4, b5, b6, b7, w0, w1, w2, w3, w4, w5, w6, w7;
+            uw(at[0 * GROUPS], b0, w0); uw(at[1 * GROUPS], b1, w1); uw(at[2 * GROUPS], b2, w2); uw(at[3 * GROUPS], b3, w3);
+            uw(at[4 * GROUPS], b4, w4); uw(at[5 * GROUPS], b5, w5); uw(at[6 * GROUPS], b6, w6); uw(at[7 * GROUPS], b7, w7);
+            const double N01 = __builtin_fma(b0, w1, b1 * w0), D01 = w0 * w1;
+            const double N23 = __builtin_fma(b2, w3, b3 * w2), D23 = w2 * w3;
+            const double N45 = __builtin_fma(b4, w5, b5 * w4), D45 = w4 * w5;
+            const double N67 = __builtin_fma(b6, w7, b7 * w6), D67 = w6 * w7;
+            const double Na = __builtin_fma(N01, D23, N23 * D01), Da = D01 * D23;
+            const double Nb = __builtin_fma(N45, D67, N67 * D45), Db = D45 * D67;
+            const double N = __builtin_fma(Na, Db, Nb * Da), D = Da * Db;
+            acc0 = __builtin_fma(N, __builtin_amdgcn_rcp(D), acc0);
         }
     } else {
         int q = first;
