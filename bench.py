@@ -9,7 +9,9 @@ include/sim5gpu.h.
 Before the W warm-up steps the program runs ~0.3 s of the same steps untimed ("spin_up_steps" in the line; --no-spin-up
 skips them): an idle MI355X needs some 50 ms of work to reach its working clock, and W = 3 images are 1.3 ms.
 N = 1: a step is one complete image.
-N > 1 (launched by torch.distributed.run, one rank per GPU), default `--mode stripes`, the split BASELINE.json's
+N > 1: one rank per GPU.  `python bench.py --gpus N` by itself starts its ranks (a child `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`; the parent never touches a GPU); under a launcher (WORLD_SIZE set)
+it is a rank.  Default `--mode stripes`, the split BASELINE.json's
 north_star names: ONE image per step, its rows dealt to the ranks in 64-row stripes round-robin -- in mirrored pairs,
 so that every rank runs the pairing kernel (sim5_amd/sharding.py; one kernel launch per rank and image) -- and
 assembled on rank 0 INSIDE the timed region: rank 0 traces its own rows in place in the image (SIM5GPU_IMG_INPLACE), ONE
@@ -22,8 +24,9 @@ outer rows are dealt and gathered, a centred band stays with rank 0, which trace
 while the gather is in flight; the band's size balances a kernel time and a gather time measured (HIP events, medians
 of 12) before the timed region (recorded in per_rank.root_band_plan with the predicted step time of every candidate;
 `--root-band off` deals everything).  Total work is fixed: "scaling": "strong", `value` = rays of one image * K /
-max-over-ranks time; `value_kernel_only` = the same rays over the slowest rank's kernel time per step (BASELINE.md 3:
-"kernel time incl. image write; gather ... separately"), `per_rank.gather_ms_alone` / `place_ms_alone` the exchange.
+max-over-ranks time; `value_kernel_only` = the same rays x K over a wall-clocked region of its own in which every rank
+traces its share of K images back to back between barriers, no gather (BASELINE.md 3: "kernel time incl. image write;
+gather ... separately"; `kernel_only_region`), `per_rank.gather_ms_alone` / `place_ms_alone` the exchange.
 `--mode images` (opt-in) is the other way to use N GPUs: N independent images, one per GPU, no collective
 ("scaling": "weak").
 `--workload c5` is BASELINE.json configs[4]: a step is the inclination scan 10..80 deg of 8192 x 8192 images
@@ -392,7 +395,7 @@ class LineGuard:
 
     def __init__(self, rank, deadline_s):
         import select, signal, threading
-        self.rank, self.make_line, self.done = rank, None, False
+        self.rank, self.make_line, self.done, self.fallback = rank, None, False, None
         self.lock = threading.Lock()
         self.r, self.w = os.pipe()
         os.set_blocking(self.w, False)
@@ -425,11 +428,16 @@ class LineGuard:
 
     def _leave(self, why, code):
         if self.rank == 0 and self.make_line is not None:
+            # the main thread may be writing to the records the line is made from (this is the helper thread): a line that cannot be
+            # made now ("dictionary changed size during iteration") is replaced by the one serialised when the guard was armed
             try:
-                sys.stdout.write(self.make_line(why) + "\n")
-                sys.stdout.flush()
+                line = self.make_line(why)
             except Exception as e:                                     # noqa: BLE001
-                sys.stderr.write("bench.py: could not make the line in the guard: %r\n" % (e,))
+                sys.stderr.write("bench.py: could not make the line in the guard (%r): printing the one made before the optional phases\n" % (e,))
+                line = self.fallback
+            if line:
+                sys.stdout.write(line + "\n")
+                sys.stdout.flush()
         sys.stderr.write("bench.py: rank %d: optional phases cut short: %s\n" % (self.rank, why))
         sys.stderr.flush()
         os._exit(code)
@@ -464,7 +472,7 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
     can take the headline line with it.  Returns the record on rank 0 (None elsewhere)."""
     rec = {"what": "peers store their rows straight into rank 0's IPC-mapped image (SIM5GPU_IMG_INPLACE on the mapped planes); "
                    "a step = every rank's launch + stream synchronisation + barrier; measured after the timed region, never part of `value`"}
-    state = {"img": None, "base": None, "err": None}
+    state = {"img": None, "base": None, "err": None, "mapped": False}
 
     def attempt(fn):
         try:
@@ -491,8 +499,11 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
     def open_():
         if rank != 0:
             state["base"] = capi.ipc_open(handle[0])
+            state["mapped"] = True                             # THIS rank holds a mapping, whatever the others say
             if os.environ.get("SIM5_BENCH_TEST_PEER_DIES") == "1":
                 os.abort()                                     # test hook (tests/test_gpu_bench.py): what a GPU fault on a peer does
+            if os.environ.get("SIM5_BENCH_TEST_PEER_DIES") == "hang":
+                time.sleep(3600)                               # test hook: a peer that HANGS (the others wait in a collective)
     opened = attempt(open_)
     if opened:
         inc = INCL_DEG / 180.0 * math.pi
@@ -503,13 +514,16 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
         band = sharding.root_band(n, dealt) if rank == 0 else None
         f_ptr, g_ptr = state["base"], state["base"] + n * n * 4
 
+        bd = capi.image_desc(n, n, SPIN, inc, y0=band[0], y1=band[1]) if band else None
+
         def launch():
-            if band and descs:
-                bd = capi.image_desc(n, n, SPIN, inc, y0=band[0], y1=band[1])
+            if bd is not None and descs:
                 capi.disk_image_jobs([descs[0], bd], [f_ptr, f_ptr + band[0] * n * 4], [g_ptr, g_ptr + band[0] * n * 4], stream=stream)
             else:
                 for d in descs:
                     capi.disk_image_device(d, f_ptr, g_ptr, stream=stream)
+                if bd is not None:                             # a band but no dealt stripes on rank 0: the band alone
+                    capi.disk_image_device(bd, f_ptr + band[0] * n * 4, g_ptr + band[0] * n * 4, stream=stream)
 
         # a rank whose launch fails keeps taking part in every barrier (a rank that left the loop would meet the others'
         # barrier with another collective): it stops launching, the failure is agreed on after the loop
@@ -523,6 +537,8 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
                 except Exception as e:                         # noqa: BLE001 -- reported in the record
                     failed[0] = True
                     state["err"] = repr(e)[:300]
+            # (a barrier that raises -- a peer is gone -- is caught by attempt(), whose agreement all-reduce then raises as well:
+            # up to main() and into guard.failed(): the line first, then out)
             dist.barrier()
 
         times = []
@@ -558,9 +574,10 @@ def direct_store_ab(torch, dist, capi, sharding, rank, world, n, dev, cdev, stre
         rec["skipped"] = "a peer could not map rank 0's image (no IPC / peer access between the devices?): %s" % state["err"]
 
     def close():
-        if rank != 0 and state["base"] and opened:
+        if rank != 0 and state["mapped"]:                       # whoever mapped unmaps, also when another rank could not
             torch.cuda.synchronize()
             capi.ipc_close(state["base"])
+            state["mapped"] = False
     attempt(close)
     if world > 1:
         dist.barrier()                                          # the peers have unmapped before rank 0 frees
@@ -857,6 +874,35 @@ def c5_on_one_gpu(torch, capi, dev, stream):
             "per_inclination": per, "hits_ok": ok}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N ...` without a launcher around it: start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`
+    as a child process, pass its stdout / stderr through (inherited: rank 0's one JSON line is this program's one JSON line)
+    and return its exit code.  SIGTERM / SIGINT sent to this process are forwarded to the launcher, which ends its ranks."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and sim5gpu_ipc_* between processes need it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, cwd=os.getcwd())
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, lambda signum, frame: child.send_signal(signum))
+    while True:
+        try:
+            rc = child.wait()
+            break
+        except KeyboardInterrupt:
+            continue
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -878,10 +924,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher.  It has not imported torch and never
+        # touches a GPU; the ranks are CHILD processes of torch.distributed.run (no exec of anything that initialised HIP)
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
         args.gpus = world
 
     import torch
@@ -1023,6 +1070,42 @@ def main():
         kstep_max = max(float(v[1].item()) for v in allv)
         per_rank = {"kernel_ms_per_step": [float(v[1].item()) for v in allv],
                     "rays_per_launch": [sharding.rank_rows(n, r, world, dealt=dealt) * n if striped else n * n for r in range(world)]}
+    # N > 1: SURVEY 8(d) / BASELINE.md 3 quote the scaling metric on KERNEL time (image write included, gather reported apart).  A
+    # wall-clocked region of its own: every rank traces its share of K images back to back -- the launches of the timed region, no
+    # gather, no placement -- between a barrier + device synchronisation on both sides; max over ranks.  (Buffer: the one that does
+    # NOT hold the last assembled image; a rank's rows are rewritten with the same values.)
+    kernel_only = None
+    if world > 1:
+        def kernel_only_region():
+            b = pipe.count % pipe.nbuf
+            fence()
+            k0 = time.perf_counter()
+            for _ in range(args.steps):
+                for job in jobs:
+                    if not striped:
+                        job.trace(pipe.full[0], True)
+                    elif rank == 0:
+                        view = pipe.full[b][:, pipe.band[0]:pipe.band[1]] if pipe.band else None
+                        if job.band_desc is not None and job.desc is not None:
+                            job.trace_both(pipe.full[b], view)
+                        else:
+                            job.trace(pipe.full[b], True)
+                            if job.band_desc is not None:
+                                job.trace_band(view)
+                    else:
+                        job.trace(pipe.tiles[b], False)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            return time.perf_counter() - k0
+        kdt = guarded(dist, torch, cdev, rank, world, "kernel-only region", kernel_only_region)
+        t = torch.tensor([kdt], dtype=torch.float64, device=cdev)
+        allk = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allk, t)
+        kernel_only = {"wall_s_max_over_ranks": max(float(v[0].item()) for v in allk), "wall_s_per_rank": [float(v[0].item()) for v in allk],
+                       "steps": args.steps,
+                       "what": "every rank's launches of the timed region (its share of K images, written to its buffers) back to back, "
+                               "no gather and no placement, between barrier + device synchronisation on both sides; host wall clock, max over ranks"}
     # the timed region is over on every rank (the all_gather above); the phases below are optional measurements, each entered
     # only after all ranks have agreed that they are still sound
     agree(dist, torch, cdev, rank, world, bool(kstep == kstep), "timed region", "kernel timing is NaN")
@@ -1032,7 +1115,9 @@ def main():
         img = last if striped else pipe.last_image()
         hits = int((img[1] > 0).sum().item())
     # N > 1: from here on nothing may take the line with it (LineGuard)
-    guard = LineGuard(rank, 240) if world > 1 else None
+    # (the deadline lies well inside the collective timeout: under RCCL a peer that HANGS in an optional phase makes the watchdog
+    # abort the process at `timeout`; the guard must have printed the line and left before that)
+    guard = LineGuard(rank, float(os.environ.get("SIM5_BENCH_GUARD_S", min(240.0, 0.5 * timeout.total_seconds())))) if world > 1 else None
     if rank == 0:
         def build_out(direct, c5_scan, cut):
             """the line, from what the timed region measured plus the optional records; cut: the guard's reason when it makes the line"""
@@ -1056,7 +1141,10 @@ def main():
                 # BASELINE.md section 3 / SURVEY 8(d): "kernel time incl. image write; gather and D2H copy separately" -- `value` is the
                 # whole job (tracing + gather + assembly into a row-major image, every step), `value_kernel_only` the same rays over
                 # the slowest rank's kernel time per step (HIP events in the timed region)
-                "value_kernel_only": rays * 1e3 / kstep_max if kstep_max > 0 else None, "kernel_ms_per_step_max_over_ranks": kstep_max,
+                "value_kernel_only": (rays * args.steps / kernel_only["wall_s_max_over_ranks"] if kernel_only else
+                                      rays * 1e3 / kstep_max if kstep_max > 0 else None),
+                "value_kernel_only_from_events": rays * 1e3 / kstep_max if kstep_max > 0 else None,
+                "kernel_ms_per_step_max_over_ranks": kstep_max,
                 "scaling": "strong" if (striped or world == 1) else "weak",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ok": ok, "spin_up_steps": spin_up,
                 "config": {"workload": workload, "rays_per_step": rays,
@@ -1121,13 +1209,17 @@ def main():
             out["process_group"] = group
             if per_rank:
                 out["per_rank"] = per_rank
+            if kernel_only:
+                out["kernel_only_region"] = kernel_only
             if world > 1:
                 # which number is which: SURVEY 8(d) / BASELINE.md 3 define the metric on KERNEL time (image write
                 # included) with the gather reported separately
                 out["value_definition"] = ("value = rays x K / max-over-ranks wall time of the timed region, INCLUDING the gather to rank 0 and the "
                                            "placement of the gathered rows (a row-major image on rank 0 every step); value_kernel_only = the same rays "
-                                           "over the slowest rank's kernel time per step = the metric of SURVEY 8(d) (kernel time incl. image write; "
-                                           "the gather is reported separately: per_rank.gather_ms_alone, link_bound)")
+                                           "x K / max-over-ranks wall time of the kernel-only region (every rank's launches of K images back to back "
+                                           "between barriers: kernel_only_region) = the metric of SURVEY 8(d) (kernel time incl. image write; the gather "
+                                           "is reported separately: per_rank.gather_ms_alone, link_bound); value_kernel_only_from_events = the same rays "
+                                           "over the slowest rank's mean kernel time per step, HIP events inside the overlapped pipeline")
                 if direct is not None:
                     out["exchange_ab_direct_stores"] = direct
                     if "ms_per_image" in direct:
@@ -1175,6 +1267,7 @@ def main():
             return out, ok
 
         if guard:
+            guard.fallback = json.dumps(build_out(None, None, "line serialised before the optional phases started")[0])
             guard.make_line = lambda why: json.dumps(build_out(None, None, why)[0])
     direct = c5_scan = None
     try:

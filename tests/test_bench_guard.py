@@ -75,3 +75,38 @@ def test_line_gets_out_when_an_optional_phase_raises():
         print("not reached")
         """)
     assert p.returncode == 1 and p.stdout.strip().startswith('{"value": 3.0, "cut": "an optional phase raised RuntimeError'), (p.returncode, p.stdout)
+
+
+def test_a_line_that_cannot_be_made_falls_back_to_the_one_serialised_at_arming():
+    """the helper thread makes the line while the main thread may be writing to its records: if that raises, the line serialised
+    before the optional phases is printed instead"""
+    p = _run("""
+        g = bench.LineGuard(0, 1)
+        g.fallback = '{"value": 3.0, "cut": "armed"}'
+        def boom(why):
+            raise RuntimeError("dictionary changed size during iteration")
+        g.make_line = boom
+        import threading
+        l = threading.Lock(); l.acquire(); l.acquire()
+        """)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert p.stdout.strip() == '{"value": 3.0, "cut": "armed"}' and "printing the one made before" in p.stderr, (p.stdout, p.stderr)
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` by itself (the shape of the driver's 1-GPU command): the process becomes the launcher -- it
+    starts torch.distributed.run as a CHILD, never imports torch itself, and returns the ranks' exit code.  In a container
+    without a GPU both ranks stop at "no GPU visible", which is what this CPU test sees."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        return                                                       # (on a GPU box tests/test_gpu_bench.py covers the real run)
+    assert p.returncode != 0
+    assert p.stderr.count("no GPU visible; the HIP path has no CPU fallback") >= 1, p.stderr[-2000:]
+    assert "must be launched with" not in p.stderr
+    # the launcher itself: free port on 127.0.0.1, same arguments, child process (read off the source: no exec)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def launch_ranks"):src.index("def main()")]
+    assert "subprocess.Popen" in body and "os.exec" not in body and "import torch" not in body

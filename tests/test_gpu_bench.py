@@ -131,6 +131,35 @@ def test_a_peer_dying_in_an_optional_phase_does_not_take_the_line_with_it():
     assert "exchange_ab_direct_stores" not in o and o["per_rank"]["gather_ms_alone"] > 0        # (the gather alone had been measured)
 
 
+def test_gpus_2_without_a_launcher_prefix():
+    """`python bench.py --gpus 2 --steps 3` exactly as the driver writes its 1-GPU command -- no
+    torch.distributed.run in front: bench.py starts its ranks itself (a child launcher; the parent never touches the GPU) and the
+    one JSON line comes out with n_gpus 2, a wall-clocked kernel-only region of its own beside the whole-job value."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SIM5_BENCH_ONE_GPU="1", SIM5_BENCH_CHECK_EVERY_STEP="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extra"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    o = _line(r.stdout)
+    assert o["ok"] is True and o["n_gpus"] == 2 and o["steps"] == 3 and o["config"]["disk_hits"] == 15865362
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1          # ONE line
+    ko = o["kernel_only_region"]
+    assert ko["steps"] == 3 and len(ko["wall_s_per_rank"]) == 2 and ko["wall_s_max_over_ranks"] == max(ko["wall_s_per_rank"]) > 0
+    assert abs(o["value_kernel_only"] - 4096 * 4096 * 3 / ko["wall_s_max_over_ranks"]) < 1e-6 * o["value_kernel_only"]
+    assert o["value_kernel_only_from_events"] > 0 and o["value_kernel_only"] > o["value"] > 0
+
+
+def test_a_peer_hanging_in_an_optional_phase_does_not_take_the_line_with_it():
+    """the peer HANGS instead of dying -- nobody sends a signal, rank 0 waits in a collective; the guard's deadline (well
+    inside the collective timeout, after which RCCL's watchdog would abort the process) prints the line and every rank leaves."""
+    env = dict(os.environ, SIM5_BENCH_ONE_GPU="1", SIM5_BENCH_TEST_PEER_DIES="hang", SIM5_BENCH_GUARD_S="20", SIM5_BENCH_TIMEOUT_S="120")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extra"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    o = _line(r.stdout)
+    assert o["n_gpus"] == 2 and o["value"] > 0 and o["config"]["disk_hits"] == 15865362
+    assert o["optional_phases"].startswith("cut short: no end after 20 s"), o["optional_phases"]
+
+
 def test_four_ranks_on_one_gpu():
     """The same with FOUR ranks (three peers in the gather and in the placement launch, a band planned from measurements):
     every step's image has the reference's hit count and the shares tile the image."""
