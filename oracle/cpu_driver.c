@@ -175,6 +175,34 @@ int cpu_disk_image(const char *libpath, int kind, int nx, int ny, double a, doub
     return 0;
 }
 
+/*
+ * disk_nt_flux of either checker library at n given radii (ref: src/sim5disk-nt.c:110-146), after its own
+ * disk_nt_setup(M, a, mdot, alpha, 0).  The parity tests use it to hold the GPU's flux to the reference's AT THE GPU's OWN
+ * RADII -- the same input bits -- where the closed form cancels to its rounding pattern (inner edge of the disk).
+ */
+int cpu_disk_flux(const char *libpath, int kind, double M, double a, double mdot, double alpha_visc,
+                  long n, const double *r, double *flux)
+{
+    void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "cpu_driver: %s\n", dlerror()); return -1; }
+    if (kind == 1) {
+        disk_t disk;
+        void (*setup)(disk_t *, double, double, double, double) = dlsym(h, "orc_disk_nt_setup");
+        double (*fl)(const disk_t *, double) = dlsym(h, "orc_disk_nt_flux");
+        if (!setup || !fl) return -2;
+        memset(&disk, 0, sizeof disk);
+        setup(&disk, M, a, mdot, alpha_visc);
+        for (long i = 0; i < n; i++) flux[i] = fl(&disk, r[i]);
+    } else {
+        int (*setup)(double, double, double, double, int) = dlsym(h, "disk_nt_setup");
+        double (*fl)(double) = dlsym(h, "disk_nt_flux");
+        if (!setup || !fl) return -2;
+        setup(M, a, mdot, alpha_visc, 0);
+        for (long i = 0; i < n; i++) flux[i] = fl(r[i]);
+    }
+    return 0;
+}
+
 /* ====================================================================================== */
 /*  Recipes assembled from public SIM5 routines, run through either checker library        */
 /*  (prefix "" = reference symbols, "orc_" = our restatement; same signatures).            */

@@ -342,6 +342,33 @@ def kat_disk(ref, rng):
     save("kat_disk.npz", **out)
 
 
+def kat_disk_edge():
+    """disk_nt_flux in the band where its closed form cancels (ref src/sim5disk-nt.c:129-135): for ten spins (and three other
+    masses / accretion rates) 2 000 radii at distances 1e-14 ... 1e-2 r_g outside the float-rounded inner edge, log-uniform, plus
+    the 64 doubles next above the edge.  Within ~1e-5 of the edge the reference's value moves by more than 1e-6 for one ulp of r:
+    these vectors pin the ROUNDINGS (same radii in, the reference's bits out); the parity tests hold the device to them
+    without a floor (tests/test_gpu_kat.py::test_disk_flux_inner_edge_band)."""
+    ref = ol.Reference()
+    rng = np.random.default_rng(606)
+    models = [(10.0, a, 0.1, 0.1) for a in (0.0, 1e-4, 0.3, 0.5, 0.7, 0.9, 0.99, 0.998, 0.9999, 0.999999)]
+    models += [(3.7e6, 0.7, 0.31, 0.05), (1e8, 0.95, 1.5, 0.02), (5.0, 0.2, 0.01, 0.3)]
+    out = {"models": np.array(models)}
+    for j, (M, a, mdot, al) in enumerate(models):
+        ref.disk_nt_setup(M, a, mdot, al, 0)
+        edge = float(np.float32(ref.disk_nt_r_min()))                  # the float static the flux compares with (ref :58, :119)
+        nxt = [edge]
+        for _ in range(64):
+            nxt.append(float(np.nextafter(nxt[-1], 1e9)))
+        r = np.concatenate([np.array(nxt), edge + 10.0 ** rng.uniform(-14, -2, 2000)])
+        out["r_%d" % j] = r
+        out["edge_%d" % j] = np.array([edge])
+        out["flux_%d" % j] = ol.cpu_disk_flux(r, a, kind="reference", M=M, mdot=mdot, alpha_visc=al)
+        # (next to the edge the reference's value is its rounding pattern: exact zeros where sqrt(r) is still sqrt(edge), and
+        # NEGATIVE fluxes -- e.g. -5.5e7 three doubles above the edge at a = 0 -- are part of what it returns)
+        assert out["flux_%d" % j][0] == 0.0, (j, out["flux_%d" % j][:4])
+    save("kat_disk_edge.npz", **out)
+
+
 def kat_disk_model():
     """The rest of the Novikov-Thorne module the reference's callers use (python/sim5diskmodel.py:77-90, disk_nt_dump):
     disk_nt_mdot, disk_nt_lumi (Simpson rule over the flux), disk_nt_sigma, for set-ups by accretion rate and by
@@ -889,6 +916,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "init_src":
             kat_init_src()
             return
+        if len(sys.argv) > 1 and sys.argv[1] == "disk_edge":
+            kat_disk_edge()
+            return
         if len(sys.argv) > 1 and sys.argv[1] == "disk_model":
             kat_disk_model()
             return
@@ -916,6 +946,7 @@ def main():
         kat_init_src()
         torus_c4()
         kat_disk_model()
+        kat_disk_edge()
         kat_vectors(ref)
         kat_boundary()
         kat_kerr_newman()

@@ -310,7 +310,7 @@ int attach_flux_table(DiskConsts& d)
     // the profile (1e-10 at a = 0.998, 1e-8 at 0.9995): such spins keep the closed form (remembered as a block without table)
     const bool usable = (fit_error <= 2e-9);
     std::vector<double> block(s5abi::COLD_N, 0.0);
-    const double cold[] = { d.a, d.x0, d.x1, d.x2, d.x3, d.p1, d.p2, d.p3, d.inv_x0, d.inv_d1, d.inv_d2, d.inv_d3, d.scale };
+    const double cold[] = { d.a, d.x0, d.x1, d.x2, d.x3, d.p1, d.p2, d.p3, d.d1, d.d2, d.d3, d.mdot, d.mass };    // s5_disk.hpp ClosedFormConsts
     static_assert(sizeof cold / sizeof cold[0] <= s5abi::COLD_N, "cold block");
     for (size_t i = 0; i < sizeof cold / sizeof cold[0]; i++) block[i] = cold[i];
     if (usable) block.insert(block.end(), tab.begin(), tab.end());

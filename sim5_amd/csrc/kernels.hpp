@@ -33,8 +33,8 @@ struct DiskConsts {
     // covering x0 <= x <= 16; NULL = evaluate the closed form
     const double* ftab;
     double ft_wmin, ft_inv_dw;
-    // the constants of the closed form once more, in DEVICE memory (a, x0, x1, x2, x3, p1, p2, p3, inv_x0, inv_d1, inv_d2,
-    // inv_d3, scale): the image kernels' fast variant reads them from here in the rare lanes that need the closed form,
+    // the constants of the closed form once more, in DEVICE memory (a, x0, x1, x2, x3, p1, p2, p3, d1, d2, d3, mdot, mass):
+    // the image kernels' fast variant reads them from here in the rare lanes that need the closed form,
     // instead of holding them in SGPRs through the whole kernel.  Set by attach_flux_table (capi_core.hip)
     const double* cold;
     int    ready;

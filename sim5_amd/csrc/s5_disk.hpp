@@ -16,27 +16,35 @@ using s5abi::DiskConsts;
 using s5abi::FT_N;
 using s5abi::FT_DEG;
 
-// the closed form, ref :110-146
-S5_DEV double disk_flux_closed_form(const DiskConsts& d, double r, double x)
+// The closed form, ref :110-146 -- ONE body for both arithmetic variants, the reference's statement sequence in IEEE
+// operations (correctly rounded sqrt and divisions, no contraction).  Near the inner edge the four terms cancel: each is
+// O(x - x0) while their sum is O((x - x0)(x0 - x_ms)), and the quotients x / x0, (x - x_i) / (x0 - x_i) are rounded to
+// doubles next to 1 -- 1.1e-16 of noise per term against a sum of 1e-10: the reference's own value is its rounding
+// pattern to 1e-6 and more (2.9e-5 outside the edge: 1.6e-6 between a quotient and a product with the reciprocal, the
+// fast variant's form until round 5).  Parity at the bar therefore needs the reference's ROUNDINGS, i.e. its operations
+// on its bits: x = sqrt(r) correctly rounded, true divisions, the sums in its order.  The logarithm itself is not the
+// problem: it is taken of 1 + delta, and an error of an ulp of log(1 + delta) ~ delta is 1e-16 RELATIVE to the term.
+// Only lanes the flux table does not serve come here in the fast variant (within 2e-4 of the edge in x, beyond x = 16,
+// spins without a table): rare, so the IEEE sequences cost nothing measurable.
+struct ClosedFormConsts { double a, x0, x1, x2, x3, p1, p2, p3, d1, d2, d3, mdot, mass; };
+
+S5_DEV double disk_flux_closed_form_ieee(const ClosedFormConsts& c, double r)
 {
-    const double a = d.a;
-#if S5_FAST
-    // same expression with the constant divisors replaced by their host-computed reciprocals and the two
-    // prefactor divisions merged into one
-    const double f0 = x - d.x0 - 1.5 * a * mlog(x * d.inv_x0);
-    const double f1 = d.p1 * mlog((x - d.x1) * d.inv_d1);
-    const double f2 = d.p2 * mlog((x - d.x2) * d.inv_d2);
-    const double f3 = d.p3 * mlog((x - d.x3) * d.inv_d3);
-    const double F = mdiv(1.5, (4. * M_PI * r) * (x * x * (x * x * x - 3. * x + 2. * a))) * (f0 - f1 - f2 - f3);
-    return d.scale * F;
-#else
-    const double f0 = x - d.x0 - 1.5 * a * mlog(mdiv(x, d.x0));
-    const double f1 = d.p1 * mlog(mdiv(x - d.x1, d.d1));
-    const double f2 = d.p2 * mlog(mdiv(x - d.x2, d.d2));
-    const double f3 = d.p3 * mlog(mdiv(x - d.x3, d.d3));
-    const double F = mdiv(mdiv(1., 4. * M_PI * r) * 1.5, x * x * (x * x * x - 3. * x + 2. * a)) * (f0 - f1 - f2 - f3);
-    return mdiv(9.1721376255e+28 * F * d.mdot, d.mass);
-#endif
+    S5_FPC_PRAGMA_OFF
+    const double a = c.a;
+    const double x = __builtin_sqrt(r);                         // IEEE in both variants (never the refined-seed root)
+    const double f0 = x - c.x0 - 1.5 * a * log(x / c.x0);
+    const double f1 = c.p1 * log((x - c.x1) / c.d1);
+    const double f2 = c.p2 * log((x - c.x2) / c.d2);
+    const double f3 = c.p3 * log((x - c.x3) / c.d3);
+    const double F = 1. / (4. * M_PI * r) * 1.5 / (x * x * (x * x * x - 3. * x + 2. * a)) * (f0 - f1 - f2 - f3);
+    return 9.1721376255e+28 * F * c.mdot / c.mass;
+}
+
+S5_DEV double disk_flux_closed_form(const DiskConsts& d, double r)
+{
+    const ClosedFormConsts c = { d.a, d.x0, d.x1, d.x2, d.x3, d.p1, d.p2, d.p3, d.d1, d.d2, d.d3, d.mdot, d.mass };
+    return disk_flux_closed_form_ieee(c, r);
 }
 
 #if S5_FAST
@@ -51,7 +59,7 @@ S5_DEV double disk_flux(const DiskConsts& d, double r)                 // ref :1
     sqrt_rsqrt_pos(r, x, rx);                         // r > rms > 0
     return disk_flux_x(d, r, x, rx);
 #else
-    return disk_flux_closed_form(d, r, sqrt_pos(r));
+    return disk_flux_closed_form(d, r);
 #endif
 }
 
@@ -86,17 +94,12 @@ S5_DEV double disk_flux_table(const DISK& d, double r, double x, double rx, bool
     return F;
 }
 
-// the closed form (fast expression above) with its constants read from the disk model's device block
-// (DiskConsts::cold: a, x0, x1, x2, x3, p1, p2, p3, inv_x0, inv_d1, inv_d2, inv_d3, scale) -- same operations, same values
-S5_DEV double disk_flux_closed_form_mem(const double* __restrict__ c, double r, double x)
+// the closed form with its constants read from the disk model's device block (DiskConsts::cold: a, x0, x1, x2, x3, p1,
+// p2, p3, d1, d2, d3, mdot, mass -- the members of ClosedFormConsts in order): same operations, same values
+S5_DEV double disk_flux_closed_form_mem(const double* __restrict__ c, double r)
 {
-    const double a = c[0], x0 = c[1];
-    const double f0 = x - x0 - 1.5 * a * mlog(x * c[8]);
-    const double f1 = c[5] * mlog((x - c[2]) * c[9]);
-    const double f2 = c[6] * mlog((x - c[3]) * c[10]);
-    const double f3 = c[7] * mlog((x - c[4]) * c[11]);
-    const double F = mdiv(1.5, (4. * M_PI * r) * (x * x * (x * x * x - 3. * x + 2. * a))) * (f0 - f1 - f2 - f3);
-    return c[12] * F;
+    const ClosedFormConsts k = { c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], c[12] };
+    return disk_flux_closed_form_ieee(k, r);
 }
 
 // the same with x = sqrt(r) and 1/x supplied by the caller (the g-factor of the same point needs sqrt(r) too); the lanes the
@@ -108,7 +111,7 @@ S5_DEV double disk_flux_x(const DiskConsts& d, double r, double x, double rx)
     bool cf;
     double F = disk_flux_table(d, r, x, rx, cf);
     if (wave_any(cf)) {
-        if (cf) F = disk_flux_closed_form(d, r, x);
+        if (cf) F = disk_flux_closed_form(d, r);
     }
     return F;
 }

@@ -99,7 +99,7 @@ S5_DEV void thin_disk_owed_flux(const PRM& p, ThinRay& out, ThinRay& out2)
             if (!S5_ANY(f)) continue;
             const double r = member ? out2.r : out.r;
             double F = 0.0;
-            if (f) { double x, rx; sqrt_rsqrt_pos(r, x, rx); F = cold ? disk_flux_closed_form_mem(cold, r, x) : NAN; }
+            if (f) F = cold ? disk_flux_closed_form_mem(cold, r) : NAN;
             if (f) { if (member) out2.flux = F; else out.flux = F; }
         }
     }

@@ -294,3 +294,27 @@ def cpu_disk_image(kind, nx, ny, a, inc_deg, y0=0, y1=None, ystride=1, xstride=1
     out["seconds"] = sec.value
     out["rays"] = onx * ony
     return out
+
+
+def cpu_disk_flux(r, a, kind=None, M=10.0, mdot=0.1, alpha_visc=0.1):
+    """disk_nt_flux of the live reference (kind "reference"; default when oracle/_ref is there) or of our restatement
+    ("port", pinned to it byte for byte) at the radii `r` (any shape, NaNs pass through), for the disk model
+    disk_nt_setup(M, a, mdot, alpha_visc, 0) -- the reference's flux AT GIVEN INPUT BITS (ref src/sim5disk-nt.c:110-146)."""
+    import numpy as np
+    if not os.path.exists(DRIVER_SO) or not os.path.exists(ORACLE_SO):
+        build_oracle()
+    kind = kind or ("reference" if have_reference() else "port")
+    drv = C.CDLL(DRIVER_SO)
+    fn = drv.cpu_disk_flux
+    fn.argtypes = [C.c_char_p, I, D, D, D, D, C.c_long, C.c_void_p, C.c_void_p]
+    fn.restype = I
+    rr = np.ascontiguousarray(np.asarray(r, np.float64)).ravel()
+    nan = np.isnan(rr)
+    rin = np.where(nan, 1e3, rr)
+    out = np.zeros_like(rin)
+    rc = fn({"reference": REF_SO, "port": ORACLE_SO}[kind].encode(), 0 if kind == "reference" else 1, M, a, mdot, alpha_visc,
+            rin.size, rin.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("cpu_disk_flux failed rc=%d" % rc)
+    out[nan] = np.nan
+    return out.reshape(np.shape(r))

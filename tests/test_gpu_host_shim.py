@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oraclelib as ol
-from gpuutil import assert_close, deg2rad
+from gpuutil import assert_close, assert_flux, deg2rad
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +36,7 @@ def test_scalar_api_program_matches_oracle(tmp_path, capi):
     assert np.array_equal(rec[:, 3].astype(int), hit)
     m = hit > 0
     assert_close(rec[m, 4], c["r"].ravel()[m], what="r"); assert_close(rec[m, 5], c["g"].ravel()[m], what="g")
-    assert_close(rec[m, 6], c["flux"].ravel()[m], floor=1e-9 * c["flux"].max(), what="flux")
+    assert_flux(rec[m, 6], rec[m, 4], c["flux"].ravel()[m], a, what="flux")
     tail = lines[-3].split()
     assert tail[1] == "verlet" and int(tail[3]) > 100 and float(tail[7]) < 1e-2
     # the integrals of sim5elliptic.h and vector_norm_to through the scalar API
@@ -94,7 +94,7 @@ def test_c1_through_the_scalar_api_one_round_trip_per_ray(tmp_path, capi, golden
     assert hit.astype(bool).sum() == 3544
     m = hit > 0
     assert_close(rec[m, 4], g["r"].ravel()[m], what="r"); assert_close(rec[m, 5], g["g"].ravel()[m], what="g")
-    assert_close(rec[m, 6], g["flux"].ravel()[m], floor=1e-9 * g["flux"].max(), what="flux")
+    assert_flux(rec[m, 6], rec[m, 4], g["flux"].ravel()[m], 0.0, what="flux")
     # pixels the reference rejects (error from geodesic_init_inf) are rejected here with the same code
     err_ref = (g["cls"] == 0).ravel()
     assert np.array_equal(rec[:, 2] != 0, err_ref)

@@ -244,10 +244,39 @@ def test_disk_nt(capi, golden):
         fl = capi.disk_nt_flux(g["r_%d" % j])
         ref = g["flux_%d" % j]
         assert np.array_equal(fl == 0, ref == 0), "zero-flux band (r <= float-rounded inner edge) differs"
-        assert_close(fl, ref, floor=1e-9 * ref.max(), what="disk_nt_flux a=%g" % a)
+        assert_close(fl, ref, what="disk_nt_flux a=%g (no floor: same radii, the reference's roundings)" % a)
         assert_close(capi.disk_nt_ell(g["r_%d" % j]), g["ell_%d" % j], what="disk_nt_ell")
     capi.disk_nt_setup(3.7e6, 0.7, 0.31, 0.05)
-    assert_close(capi.disk_nt_flux(g["r_x"]), g["flux_x"], floor=1e-9 * g["flux_x"].max(), what="flux (other M, mdot)")
+    assert_close(capi.disk_nt_flux(g["r_x"]), g["flux_x"], what="flux (other M, mdot)")
+
+
+def test_disk_flux_inner_edge_band(capi, golden):
+    """the band where the closed form of the flux cancels (ref src/sim5disk-nt.c:129-135), NO floor.  Within
+    ~1e-5 r_g of the float-rounded inner edge the reference's value is its rounding pattern (negative fluxes and exact zeros
+    included: tests/golden/kat_disk_edge.npz, 13 disk models x 2 065 radii at 1e-14 ... 1e-2 outside the edge); the device
+    evaluates the reference's statement sequence in IEEE operations (s5_disk.hpp disk_flux_closed_form_ieee) and is held to
+    1e-6 of every one of those values -- and, against the live reference on this box, on 100 000 radii in [edge, edge + 1e-2]
+    for each of ten spins."""
+    g = golden("kat_disk_edge.npz")
+    worst = 0.0
+    for j, (M, a, mdot, al) in enumerate(g["models"]):
+        capi.disk_nt_setup(float(M), float(a), float(mdot), float(al))
+        assert np.float32(capi.disk_nt_r_min()) == np.float32(g["edge_%d" % j][0])
+        fl = capi.disk_nt_flux(g["r_%d" % j])
+        ref = g["flux_%d" % j]
+        assert np.array_equal(fl == 0, ref == 0) and np.array_equal(fl < 0, ref < 0), "model %d: zeros / signs of the rounding pattern differ" % j
+        worst = max(worst, assert_close(fl, ref, what="inner-edge band, model %d (no floor)" % j))
+    live = 0.0
+    rng = np.random.default_rng(66)
+    for a in (0.0, 0.1, 0.3, 0.5, 0.7, 0.9, 0.95, 0.998, 0.9999, 0.999999):
+        capi.disk_nt_setup(10.0, a, 0.1, 0.1)
+        edge = float(np.float32(capi.disk_nt_r_min()))
+        r = np.concatenate([edge + 1e-2 * rng.random(50000), edge + 10.0 ** rng.uniform(-13, -2, 50000)])
+        ref = ol.cpu_disk_flux(r, a)                                   # the live reference when it is on the box
+        fl = capi.disk_nt_flux(r)
+        assert np.array_equal(fl == 0, ref == 0)
+        live = max(live, assert_close(fl, ref, what="inner-edge band vs %s, a=%g (no floor)" % ("live reference" if ol.have_reference() else "port", a)))
+    print("disk_nt_flux in the cancelling band, no floor: worst %.2e on the fixture, %.2e on 1e6 radii against the live checker" % (worst, live))
 
 
 def test_disk_model_rest(capi, golden):

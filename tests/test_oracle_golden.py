@@ -219,6 +219,23 @@ def test_disk_nt(oracle, golden):
     close([oracle.disk_nt_flux(r) for r in g["r_x"]], g["flux_x"], what="flux other M, mdot")
 
 
+def test_disk_flux_inner_edge_band_bit_for_bit(oracle, golden):
+    """the band where the closed form of the flux is the reference's rounding pattern (negative values and exact zeros
+    included; oracle/gen_golden.py:kat_disk_edge): the restatement returns the reference's BITS on all 13 x 2 065 radii -- and,
+    in the build container, on 100 000 more per spin against the live library"""
+    g = golden("kat_disk_edge.npz")
+    for j, (M, a, mdot, al) in enumerate(g["models"]):
+        got = ol.cpu_disk_flux(g["r_%d" % j], float(a), kind="port", M=float(M), mdot=float(mdot), alpha_visc=float(al))
+        assert np.array_equal(got.view(np.uint64), g["flux_%d" % j].view(np.uint64)), j
+    if ol.have_reference():
+        rng = np.random.default_rng(67)
+        for a in (0.0, 0.3, 0.9, 0.998, 0.9999):
+            ref = ol.Reference(); ref.disk_nt_setup(10.0, a, 0.1, 0.1, 0)
+            edge = float(np.float32(ref.disk_nt_r_min()))
+            r = edge + 10.0 ** rng.uniform(-14, -2, 100000)
+            assert np.array_equal(ol.cpu_disk_flux(r, a, kind="port").view(np.uint64), ol.cpu_disk_flux(r, a, kind="reference").view(np.uint64)), a
+
+
 def test_polarization_and_blackbody(oracle, golden):
     g = golden("kat_polar.npz")
     for i in range(len(g["a"])):
