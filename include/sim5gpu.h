@@ -258,6 +258,11 @@ int sim5gpu_integral(int which, size_t n, int nargs, const double *args, double 
  * (ref :151-188), its integrand evaluated on the device; disk_nt_sigma the column density (ref :204-250). */
 #define SIM5GPU_DISK_NT_OPTION_LUMINOSITY 1
 int sim5gpu_disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int options);
+/* Number of successful sim5gpu_disk_nt_setup calls of this process so far.  The model is process-global (ref
+ * src/sim5disk-nt.c:27-32), so anything that remembers a disk_nt_* value -- the host shim's per-ray and look-ahead records
+ * (sim5_amd/host/sim5lib.c) -- stamps it with this counter and compares before it answers from memory, whoever made the
+ * set-up call (C shim, ctypes, another library in the process). */
+unsigned long sim5gpu_disk_nt_generation(void);
 int sim5gpu_disk_nt_r_min(double *r_min);
 int sim5gpu_disk_nt_mdot(double *mdot);
 int sim5gpu_disk_nt_lumi(double *lumi);

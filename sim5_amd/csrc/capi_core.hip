@@ -5,6 +5,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -133,11 +134,14 @@ struct FluxKey { unsigned long long a, s; bool operator==(const FluxKey& o) cons
 struct FluxKeyHash { size_t operator()(const FluxKey& k) const { return (size_t)(k.a * 0x9e3779b97f4a7c15ull ^ (k.s + (k.a << 7))); } };
 struct FluxCache {
     std::unordered_map<FluxKey, FluxTable, FluxKeyHash> live;
-    std::vector<double*> resting;                   // retired at the last round: freed at the next
+    std::vector<double*> resting;                   // retired at the last round: freed at the next, unless pinned
+    std::unordered_map<const double*, int> pinned;  // blocks held by entry points between attach and the end of their launches
     unsigned long long clock = 0;
 };
 FluxCache g_ftab[FT_DEVICES];
 std::mutex g_ftab_lock;
+typedef std::vector<std::pair<int, const double*>> PinList;
+thread_local FluxPinScope* t_pin_scope = nullptr;
 
 static FluxKey flux_key(double a, double scale)
 {
@@ -147,13 +151,14 @@ static FluxKey flux_key(double a, double scale)
     return k;
 }
 
-// called under the lock, on the device that owns the cache
-static void flux_cache_retire(FluxCache& Cc)
+// called under the lock, on the device that owns the cache: the resting blocks nobody holds are handed to the caller, who
+// frees them AFTER it has left the lock (a device synchronisation and hipFree under the lock stalled every other thread's launch)
+static void flux_cache_retire(FluxCache& Cc, std::vector<double*>& to_free)
 {
     if (Cc.live.size() < FT_CACHE_MAX) return;
-    (void)hipDeviceSynchronize();                   // every launch that was handed a resting block has long been issued
-    for (double* p : Cc.resting) (void)hipFree(p);
-    Cc.resting.clear();
+    std::vector<double*> keep;
+    for (double* p : Cc.resting) (Cc.pinned.count(p) ? keep : to_free).push_back(p);
+    Cc.resting.swap(keep);
     std::vector<unsigned long long> stamps;
     stamps.reserve(Cc.live.size());
     for (auto& kv : Cc.live) stamps.push_back(kv.second.stamp);
@@ -288,22 +293,32 @@ int attach_flux_table(DiskConsts& d)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return SIM5GPU_E_HIP;
     if (dev < 0 || dev >= FT_DEVICES) { snprintf(g_err, sizeof g_err, "device %d: more than %d devices", dev, FT_DEVICES); return SIM5GPU_E_ARG; }
+    if (!t_pin_scope) { snprintf(g_err, sizeof g_err, "attach_flux_table outside a FluxPinScope"); return SIM5GPU_E_ARG; }
+    std::vector<double*> to_free;
+    // blocks nobody holds any more: freed after the lock has been left (every launch that read them was enqueued before its
+    // entry point dropped the pin; the synchronisation waits for those launches)
+    struct FreeLater {
+        std::vector<double*>& v;
+        ~FreeLater() { if (!v.empty()) { (void)hipDeviceSynchronize(); for (double* p : v) (void)hipFree(p); } }
+    } free_later{to_free};
     std::lock_guard<std::mutex> hold(g_ftab_lock);
     const double wmin = d.x0 / 16.0;
     d.ft_wmin = wmin;
     d.ft_inv_dw = (double)s5abi::FT_N / (1.0 - wmin);
     FluxCache& Cc = g_ftab[dev];
     const FluxKey key = flux_key(d.a, d.scale);
+    auto pin = [&](const double* ptr) { Cc.pinned[ptr]++; ((PinList*)t_pin_scope->held)->emplace_back(dev, ptr); };
     {
         auto it = Cc.live.find(key);
         if (it != Cc.live.end()) {
             it->second.stamp = ++Cc.clock;
             d.cold = it->second.ptr;
             d.ftab = it->second.usable ? it->second.ptr + s5abi::COLD_N : nullptr;
+            pin(it->second.ptr);
             return SIM5GPU_OK;
         }
     }
-    flux_cache_retire(Cc);
+    flux_cache_retire(Cc, to_free);
     std::vector<double> tab;
     const double fit_error = build_flux_table(d, wmin, tab);
     // towards a = 1 the inner edge approaches the logarithmic singularity at x1 and the uniform grid stops resolving
@@ -321,7 +336,24 @@ int attach_flux_table(DiskConsts& d)
     Cc.live.emplace(key, FluxTable{ d.a, d.scale, ptr, usable, ++Cc.clock });
     d.cold = ptr;
     d.ftab = usable ? ptr + s5abi::COLD_N : nullptr;
+    pin(ptr);
     return SIM5GPU_OK;
+}
+
+FluxPinScope::FluxPinScope() : held(new PinList), outer(t_pin_scope) { t_pin_scope = this; }
+FluxPinScope::~FluxPinScope()
+{
+    PinList* mine = (PinList*)held;
+    if (!mine->empty()) {
+        std::lock_guard<std::mutex> hold(g_ftab_lock);
+        for (auto& dp : *mine) {
+            auto& pinned = g_ftab[dp.first].pinned;
+            auto it = pinned.find(dp.second);
+            if (it != pinned.end() && --it->second <= 0) pinned.erase(it);
+        }
+    }
+    delete mine;
+    t_pin_scope = (FluxPinScope*)outer;
 }
 
 // every flux-table block of every device given back (sim5gpu_release_workspaces); returns the bytes freed
@@ -336,9 +368,17 @@ size_t release_flux_tables()
         if (Cc.live.empty() && Cc.resting.empty()) continue;
         (void)hipSetDevice(dev);
         (void)hipDeviceSynchronize();
-        for (auto& kv : Cc.live) { (void)hipFree(kv.second.ptr); freed += (size_t)(s5abi::COLD_N + (kv.second.usable ? s5abi::FT_N * (s5abi::FT_DEG + 1) : 0)) * sizeof(double); }
-        for (double* p : Cc.resting) { (void)hipFree(p); freed += (size_t)(s5abi::COLD_N + s5abi::FT_N * (s5abi::FT_DEG + 1)) * sizeof(double); }   // (a resting block's size is not kept: counted as a full one)
-        Cc.live.clear(); Cc.resting.clear();
+        // (a block an entry point of another thread still holds stays: it goes to the resting list and is freed by a later retirement)
+        std::vector<double*> keep;
+        for (auto& kv : Cc.live) {
+            if (Cc.pinned.count(kv.second.ptr)) { keep.push_back(kv.second.ptr); continue; }
+            (void)hipFree(kv.second.ptr); freed += (size_t)(s5abi::COLD_N + (kv.second.usable ? s5abi::FT_N * (s5abi::FT_DEG + 1) : 0)) * sizeof(double);
+        }
+        for (double* p : Cc.resting) {
+            if (Cc.pinned.count(p)) { keep.push_back(p); continue; }
+            (void)hipFree(p); freed += (size_t)(s5abi::COLD_N + s5abi::FT_N * (s5abi::FT_DEG + 1)) * sizeof(double);   // (a resting block's size is not kept: counted as a full one)
+        }
+        Cc.live.clear(); Cc.resting.swap(keep);
     }
     (void)hipSetDevice(cur);
     return freed;
@@ -499,6 +539,7 @@ int sim5gpu_event_destroy(void* event)
 }
 
 // ---- disk model (process-global, like SIM5) -------------------------------------------------
+static std::atomic<unsigned long> g_disk_generation{0ul};
 int sim5gpu_disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int options)
 {
     if (options & ~SIM5GPU_DISK_NT_OPTION_LUMINOSITY) {
@@ -533,8 +574,13 @@ int sim5gpu_disk_nt_setup(double M, double a, double mdot_or_L, double alpha, in
         }
     }
     g_disk = d;
+    g_disk_generation.fetch_add(1ul, std::memory_order_release);
     return SIM5GPU_OK;
 }
+
+// how many disk models this process has set up so far (0: none): whoever keeps values of disk_nt_* of the process-global
+// model -- the host shim's per-ray and look-ahead records -- stamps them with it and compares before answering from them
+unsigned long sim5gpu_disk_nt_generation(void) { return g_disk_generation.load(std::memory_order_acquire); }
 
 int sim5gpu_disk_nt_mdot(double* mdot)
 {
@@ -596,6 +642,7 @@ int sim5gpu_disk_image(const sim5gpu_image_desc* desc, float* d_image_f, float* 
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    FluxPinScope pins;                                       // the table block stays until the launch below has been enqueued
     if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.img_f = d_image_f; p.img_g = d_image_g;
     attach_aux(p, d_aux);
@@ -623,6 +670,7 @@ int sim5gpu_disk_image_jobs(int n_jobs, const sim5gpu_image_desc* descs, float* 
         ps[(size_t)j].img_f = d_image_f[j]; ps[(size_t)j].img_g = d_image_g[j];
     }
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    FluxPinScope pins;                                       // every job's table block stays until the last launch has been enqueued
     std::vector<ImageParams> group;
     auto flush = [&]() -> int {
         if (group.empty()) return SIM5GPU_OK;
@@ -666,6 +714,7 @@ int sim5gpu_disk_rays(const sim5gpu_image_desc* desc, size_t n, const double* d_
     if (n == 0) return SIM5GPU_OK;
     if (desc->flags & SIM5GPU_IMG_INPLACE) { snprintf(g_err, sizeof g_err, "disk_rays: SIM5GPU_IMG_INPLACE needs the pixel grid"); return SIM5GPU_E_ARG; }
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    FluxPinScope pins;                                       // the table block stays until the launch below has been enqueued
     if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.img_f = d_image_f; p.img_g = d_image_g;
     p.alpha = d_alpha; p.beta = d_beta; p.n = n;

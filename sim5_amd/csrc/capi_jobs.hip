@@ -18,6 +18,7 @@ int sim5gpu_disk_image_polarized(const sim5gpu_image_desc* desc, double* d_stoke
     if (rc) return rc;
     if (desc->flags & SIM5GPU_IMG_INPLACE) { snprintf(g_err, sizeof g_err, "disk_image_polarized: SIM5GPU_IMG_INPLACE is not supported"); return SIM5GPU_E_ARG; }
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    FluxPinScope pins;                                       // the table block stays until the launches below have been enqueued
     if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.stokes = d_stokes;
     p.chi = d_chi;
@@ -102,6 +103,7 @@ int sim5gpu_disk_surface_frame(double a, double incl, double bh_mass, double mdo
     SurfaceParams p;
     p.n = n; p.n_table = n_table; p.a = a; p.incl = incl; reference_sincos(incl, p.sin_i, p.cos_i);
     p.disk = make_disk_consts(bh_mass, disk_spin >= 0.0 ? disk_spin : a, mdot);
+    FluxPinScope pins;                                       // the table block stays until the launches below have been enqueued
     if (!strict) { int rc = attach_flux_table(p.disk); if (rc) return rc; }
     p.tab_vr = d_vr; p.out_g = d_g; p.out_mue = d_mue; p.out_flux = d_flux;
     hipError_t e = (hipError_t)(strict
@@ -139,6 +141,7 @@ int sim5gpu_disk_spectrum(const sim5gpu_image_desc* desc, int n_energies, const 
     int rc = fill_image_params(desc, p);
     if (rc) return rc;
     if (!have_device()) return SIM5GPU_E_NO_DEVICE;
+    FluxPinScope pins;                                       // the table block stays until the launches below have been enqueued
     if (!(desc->flags & SIM5GPU_IMG_STRICT) && ((rc = attach_flux_table(p.disk)) != 0 || (rc = attach_K_table(p)) != 0)) return rc;
     p.max_order = 1;                  // the Python ray tracer uses the first crossing only
     p.rms = 0.0;                      // and lets the disk model decide (zero flux inside its inner edge)

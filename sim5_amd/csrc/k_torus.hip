@@ -354,6 +354,33 @@ struct PoolArgs {
 };
 #define S5_MARCH_LEAN (S5_FAST ? 1 : 0)
 
+#ifdef S5_TORUS_DEBUG
+// Instrumented build only (tests/tools/torus_phases.py): cycles between the phase marks of s5_raytrace.hpp, summed per
+// workgroup in LDS by the first active lane of the wave that passes a mark (s_memtime; scheduling barriers on both sides so
+// that the mark stays where it is written).  The wave's last time stamp lives in `t` (a scalar register pair).
+struct PhaseClock {
+    unsigned long long* acc;      // LDS [PH_N] cycles
+    unsigned* cnt;                // LDS [PH_N] marks passed
+    unsigned long long* t;
+    S5_DEV void mark(int i) const
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_readcyclecounter();
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+        if (__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) == 0u) {
+            atomicAdd(&acc[i], now - *t);
+            atomicAdd(&cnt[i], 1u);
+        }
+        *t = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+constexpr int PHASE_LDS_BYTES = PH_N * 8 + PH_N * 4;
+constexpr size_t PHASE_DBG_AT = 12000;        // index into the debug buffer (aux.k_end as 64-bit words): PH_N sums, PH_N counts
+#else
+constexpr int PHASE_LDS_BYTES = 0;
+#endif
+
 __global__ __launch_bounds__(WG_THREADS, S5_MARCH_WAVES)
 void torus_pool_kernel(PoolArgs args)
 {
@@ -366,6 +393,16 @@ void torus_pool_kernel(PoolArgs args)
     unsigned short* ring = (unsigned short*)(pworst + WG_SLOTS);     // [NQ][RING]
     unsigned* cw = (unsigned*)(ring + NQ * RING);                    // [NCW]
     double* cwd = (double*)(cw + NCW);                               // [4]: step_epsilon, r_in, r_out (formed once, below)
+#ifdef S5_TORUS_DEBUG
+    unsigned long long* ph_acc = (unsigned long long*)(pool_raw + POOL_WG_BYTES);
+    unsigned* ph_cnt = (unsigned*)(ph_acc + PH_N);
+    if (threadIdx.x < PH_N) { ph_acc[threadIdx.x] = 0ull; ph_cnt[threadIdx.x] = 0u; }
+    unsigned long long ph_t = __builtin_readcyclecounter();
+    const unsigned long long ph_t0 = ph_t;
+    const PhaseClock ph = { ph_acc, ph_cnt, &ph_t };
+#else
+    const NoPhases ph;
+#endif
 
 #if S5_MARCH_LEAN
     // LEAN: between two attempts a ray lives in its LDS slot, not in registers -- an attempt loads what it needs when it needs
@@ -590,6 +627,7 @@ void torus_pool_kernel(PoolArgs args)
                     double dl;
                     bool advanced;
                     Metric g;                                      // metric at the end point of the step
+                    ph.mark(PH_QUEUES);                            // (everything since the previous mark: queues, loop control, waits)
 #if S5_MARCH_LEAN
                     // ---- the ray's dynamical state from its slot; the job's parameters from the argument segment, from here
                     const auto& P = param_reload(A);
@@ -613,13 +651,15 @@ void torus_pool_kernel(PoolArgs args)
 #else
                     const double dl_max = p.dl_max;
 #endif
+                    ph.mark(PH_LOAD);
                     if (run == 0 && do_rk4) {
                         dl = next_step_size(k, dl_max, s);        // the value the rejected attempt used
+                        ph.mark(PH_STEPSIZE);
 #if S5_MARCH_LEAN
                         {
                             auto late = [&](int c) -> double { return pd[PD_AT(PC_X0 + c, slot)]; };
                             x[0] = 0.0; x[3] = 0.0;               // (t and phi are read from the slot at the end of the step)
-                            rk4_step<true>(x, k, dl, s, g, late);
+                            rk4_step<true>(x, k, dl, s, g, late, ph);
                         }
 #else
                         rk4_step(x, k, dl, s, g);
@@ -632,7 +672,7 @@ void torus_pool_kernel(PoolArgs args)
                         if (!s.opt_gr) flat_metric(x[1], x[2], g); // RK4 leaves the Kerr metric (ref :305); the fluid lives in the flat one
                         advanced = true;
                     } else {
-                        advanced = verlet_attempt(x, k, dl_max, dl, s, g);
+                        advanced = verlet_attempt(x, k, dl_max, dl, s, g, ph);
                     }
 #ifdef S5_TORUS_DEBUG
                     {
@@ -688,6 +728,7 @@ void torus_pool_kernel(PoolArgs args)
                         }
 #endif
                     }
+                    ph.mark(PH_STORE_TRANSFER);
                 }
                 if (POOL_KEEP_DEN * __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)) < POOL_KEEP_NUM * take) break;
             }
@@ -719,6 +760,17 @@ void torus_pool_kernel(PoolArgs args)
     }
 #ifdef S5_TORUS_DEBUG
     if (lane == 0) tl[2] = wall_clock64();
+    __syncthreads();                                                 // (debug build: every wave has left the loop)
+    if (threadIdx.x < PH_N) {
+        unsigned long long* dbg = (unsigned long long*)A.aux.k_end + PHASE_DBG_AT;
+        atomicAdd(&dbg[threadIdx.x], ph_acc[threadIdx.x]);
+        atomicAdd(&dbg[PH_N + threadIdx.x], (unsigned long long)ph_cnt[threadIdx.x]);
+    }
+    if (threadIdx.x == 0) {                                          // the two clocks over the workgroup's life: cycles per 100 MHz tick
+        unsigned long long* dbg = (unsigned long long*)A.aux.k_end + PHASE_DBG_AT + 2 * PH_N;
+        atomicAdd(&dbg[0], __builtin_readcyclecounter() - ph_t0);
+        atomicAdd(&dbg[1], wall_clock64() - t_begin);
+    }
 #endif
 }
 
@@ -789,7 +841,7 @@ int launch_torus_strict(const TorusParams& p, sim5gpu_stokes* out, const TorusAu
     size_t blocks_b = (size_t)cus * S5_MARCH_WAVES * 4 / WG_WAVES;
     const size_t needed = (n + WG_SLOTS - 1) / WG_SLOTS;
     if (blocks_b > needed) blocks_b = needed;
-    const size_t lds = (size_t)POOL_WG_BYTES;
+    const size_t lds = (size_t)POOL_WG_BYTES + (size_t)PHASE_LDS_BYTES;
     if (!g_ws.attr_set) {
         if ((e = hipFuncSetAttribute((const void*)torus_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
         g_ws.attr_set = true;

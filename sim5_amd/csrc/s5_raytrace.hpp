@@ -58,6 +58,13 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
     transport_self(G, k, s.dk);
 }
 
+// Phase marks of one raytrace() call.  The step routines take a policy object and call ph.mark(PH_*) where one phase of the
+// call ends; the default policy is empty (nothing is emitted).  The march kernel's instrumented build (-DS5_TORUS_DEBUG,
+// k_torus.hip) passes a cycle counter: profiles/r06_torus_call_phases.json is the table of where a lone ray's ~15 000 cycles go.
+enum : int { PH_STEPSIZE = 0, PH_PREDICT, PH_CONNECTION, PH_CORR1, PH_CORR2, PH_CORR3, PH_CHECK, PH_ACCEL,
+             PH_RK4_HEAD, PH_RK4_STAGE1, PH_RK4_STAGE2, PH_RK4_STAGE3, PH_RK4_TAIL, PH_LOAD, PH_STORE_TRANSFER, PH_QUEUES, PH_N };
+struct NoPhases { S5_DEV void mark(int) const {} };
+
 // classical RK4 on (x,k), theta as the angle (ref :251-323).  The four stages run as one rolled loop
 // (stage offsets 0, h, h, dl and weights 1, 2, 2, 1 selected by the wave-uniform stage index): one copy of
 // the connection code, and only the latest stage plus the running sums are live -- 8+8 doubles instead of
@@ -67,8 +74,8 @@ S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4
 // memory passes a functor that returns x[0] / x[3] when asked and the routine asks only at the very end (x[0], x[3] on entry are
 // ignored): four registers less through the three stages.  Same expressions, same operands: the same numbers.
 struct NoLateFetch { S5_DEV double operator()(int) const { return 0.0; } };
-template <bool LATE_TPHI = false, class Fetch = NoLateFetch>
-S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g, const Fetch& late = Fetch())
+template <bool LATE_TPHI = false, class Fetch = NoLateFetch, class Phases = NoPhases>
+S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g, const Fetch& late = Fetch(), const Phases& ph = Phases())
 {
     Conn G;
     double xp[4], ki[4], di[4], sx[4], sk[4];
@@ -98,6 +105,7 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
         sk[i] = 0.0 + 1.0 * di[i];
     }
     xp[0] = xp[3] = 0.0;
+    ph.mark(PH_RK4_HEAD);
 #pragma unroll 1
     for (int stage = 1; stage < 4; ++stage) {
         const double off = (stage == 3) ? dl : 0.5 * dl;           // (0.5 dl is exact: formed here, not carried)
@@ -113,6 +121,7 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sx[i] = sx[i] + wgt * ki[i]; sk[i] = sk[i] + wgt * di[i]; }
+        ph.mark(PH_RK4_HEAD + stage);
     }
 #else
 #pragma unroll
@@ -153,6 +162,7 @@ S5_DEV void rk4_step(double x[4], double k[4], double dl, RayState& s, Metric& g
 #endif
     const double kt1 = k[0] * g.g00 + k[3] * g.g03;
     s.error = (float)rel_diff(kt1, kt0);
+    ph.mark(PH_RK4_TAIL);
 }
 
 // Verlet part of one adaptive step (ref :109-245 up to the precision check :217-220).  Returns true if
@@ -187,13 +197,15 @@ S5_DEV double next_step_size(const double k[4], double step_cap, const RayState&
     return dl;
 }
 
-S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl, RayState& s, Metric& g)
+template <class Phases = NoPhases>
+S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl, RayState& s, Metric& g, const Phases& ph = Phases())
 {
     double xp[4], kh[4], kp[4], kq[4];
     const double* dk = s.dk;
 
     dl = next_step_size(k, step_cap, s);
     s.pass++;
+    ph.mark(PH_STEPSIZE);
 
     const double half_dl = 0.5 * dl;
     const double half_dl2 = 0.5 * dl * dl;
@@ -213,6 +225,7 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
     xp[3] = x[3] + k[3] * dl + dk[3] * half_dl2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) kh[i] = k[i] + dk[i] * half_dl;          // the reference updates k in place
+    ph.mark(PH_PREDICT);
 
     S5_FENCE();
     Conn G;
@@ -227,6 +240,7 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
     S5_FENCE();
 #pragma unroll
     for (int i = 0; i < 4; ++i) kp[i] = kh[i] + dk[i] * half_dl;
+    ph.mark(PH_CONNECTION);
 
 #if S5_FAST
     // The corrector's convergence measure k_frac_error = sum_i |kp_i - kq_i| / (|kq_i| + 1e-40), accumulated in
@@ -264,10 +278,12 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
             }
         }
         S5_FENCE();
+        ph.mark(PH_CORR1 + iter);
     }
     const double kt = kp[0] * g.g00 + kp[3] * g.g03;
     const double kk = fabs(dot(kp, kp, g));
     s.error = (float)fmax(rel_diff(kt, s.kt), kk);
+    ph.mark(PH_CHECK);
     if (reject || ((double)s.error > 1e-2 * 1e-2)) return false;
 #else
     float kerr = 0.0f;
@@ -303,6 +319,7 @@ S5_DEV bool verlet_attempt(double x[4], double k[4], double step_cap, double& dl
     geodesic_accel(G, kp, s.dk);
 #endif
     s.kt = kt;
+    ph.mark(PH_ACCEL);
     return true;
 }
 

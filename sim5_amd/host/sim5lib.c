@@ -8,6 +8,8 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
+#include <stddef.h>
 #include "sim5lib.h"
 
 #ifndef SIM5GPU_LIB_DEFAULT
@@ -23,9 +25,10 @@ static void s5_die(const char *what)
     exit(EXIT_FAILURE);
 }
 
-static void *s5_sym(const char *name)
+static pthread_once_t s5_handle_once = PTHREAD_ONCE_INIT;
+static void s5_load(void)
 {
-    if (!s5_handle) {
+    {
         const char *env = getenv("SIM5GPU_LIB");
         char fromfile[4096];
         const char *cand[4];
@@ -46,6 +49,11 @@ static void *s5_sym(const char *name)
         for (int i = 0; i < n && !s5_handle; i++) s5_handle = dlopen(cand[i], RTLD_NOW | RTLD_LOCAL);
         if (!s5_handle) s5_die("cannot load libsim5gpu.so (set SIM5GPU_LIB); there is no CPU fallback");
     }
+}
+
+static void *s5_sym(const char *name)
+{
+    pthread_once(&s5_handle_once, s5_load);         /* the library is opened once, whichever thread comes first */
     void *p = dlsym(s5_handle, name);
     if (!p) s5_die(name);
     return p;
@@ -54,17 +62,20 @@ static void *s5_sym(const char *name)
 /* A failed call: the reference's convention is error() -- print "ERROR: ..." to stderr and return (ref src/sim5utils.c:41-54);
  * nothing exits, the caller gets the NaN / FALSE the wrapper initialised its result with.  Only a machine without a usable
  * GPU ends the program: there is no CPU path behind this API, and every later call would fail the same way. */
-static void s5_check(int rc, const char *fn)
+static int s5_check(int rc, const char *fn)
 {
     if (rc != 0) {
         const char *(*last)(void) = (const char *(*)(void))s5_sym("sim5gpu_last_error");
         fprintf(stderr, "ERROR: sim5lib (MI355X): %s failed (%d): %s\n", fn, rc, last());
         if (rc == -1) exit(EXIT_FAILURE);               /* SIM5GPU_E_NO_DEVICE */
     }
+    return rc;
 }
 
-/* resolve once per call site */
-#define S5_FN(type, var, name) static type var; if (!var) var = (type)s5_sym(name)
+/* resolve once per call site (threads may race to resolve the same pointer: the slot is read and written atomically, and
+ * every racer writes the same value) */
+#define S5_FN(type, var, name) static type var##_slot; type var = __atomic_load_n(&var##_slot, __ATOMIC_ACQUIRE); \
+    if (!var) { var = (type)s5_sym(name); __atomic_store_n(&var##_slot, var, __ATOMIC_RELEASE); }
 
 typedef int (*fn_geod_init_inf)(size_t, const double *, const double *, const double *, const double *, geodesic *, int *, int *);
 typedef int (*fn_geod_init_src)(size_t, const double *, const double *, const double *, const double *, const int *, geodesic *, int *, int *);
@@ -106,9 +117,26 @@ typedef struct {
 } s5_chain;
 typedef int (*fn_geod_chain)(size_t, const double *, const double *, const double *, const double *, geodesic *, int *, int *, s5_chain *);
 static __thread struct { int live; unsigned long disk_gen; geodesic g; s5_chain c; } s5_last;
-static unsigned long s5_disk_gen = 1;             /* bumped by every disk set-up of this process */
-static int s5_chain_mode = -1;                    /* -1 unknown, 0 off, 2 on (strict routines) */
-static int s5_lookahead = -1;                     /* -1 unknown, 0 off, 1 on */
+/* Which disk model a record's flux belongs to: the generation counter lives INSIDE libsim5gpu (bumped by every successful
+ * sim5gpu_disk_nt_setup, whoever calls it -- this shim, sim5_amd/capi.py, DiskModel_ThinDisk, a C program beside the shim:
+ * ADVICE r5), and a record carries the value read BEFORE the batch call that made it. */
+static unsigned long s5_disk_generation(void)
+{
+    typedef unsigned long (*fn)(void);
+    S5_FN(fn, f, "sim5gpu_disk_nt_generation");
+    return f();
+}
+/* record / look-ahead switches: read from the environment ONCE, both before any thread can see either (pthread_once) */
+static int s5_chain_mode = 2;                     /* 0 off, 2 on (strict routines) */
+static int s5_lookahead = 1;                      /* 0 off, 1 on */
+static pthread_once_t s5_modes_once = PTHREAD_ONCE_INIT;
+static void s5_modes_init(void)
+{
+    const char *e = getenv("SIM5_SHIM_NO_CHAIN"), *la = getenv("SIM5_SHIM_NO_LOOKAHEAD");
+    const int chain = (e && *e && *e != '0') ? 0 : 2;
+    s5_lookahead = (chain && !(la && *la && *la != '0')) ? 1 : 0;
+    s5_chain_mode = chain;
+}
 
 static int s5_same_bits(double x, double y) { return memcmp(&x, &y, sizeof x) == 0; }
 static int s5_record_for(const geodesic *g) { return s5_last.live && memcmp(g, &s5_last.g, sizeof *g) == 0; }
@@ -137,6 +165,26 @@ typedef struct {
     unsigned long disk_gen;
 } s5_ahead;
 static __thread s5_ahead s5_la;
+/* the buffers of a thread's look-ahead (up to ~11 MB) go when the thread does */
+static pthread_key_t s5_la_key;
+static pthread_once_t s5_la_key_once = PTHREAD_ONCE_INIT;
+static void s5_la_free(void *p)
+{
+    s5_ahead *L = (s5_ahead *)p;
+    if (!L) return;
+    free(L->alpha); free(L->tmpl); free(L->spec_alpha); free(L->spec_beta); free(L->arg_i); free(L->arg_a);
+    free(L->g); free(L->err); free(L->ok); free(L->c);
+    memset(L, 0, sizeof *L);
+}
+static void s5_la_key_make(void) { (void)pthread_key_create(&s5_la_key, s5_la_free); }
+static void s5_la_register(void)
+{
+    static __thread int done;
+    if (done) return;
+    done = 1;
+    pthread_once(&s5_la_key_once, s5_la_key_make);
+    (void)pthread_setspecific(s5_la_key, &s5_la);     /* (the destructor runs while the thread's TLS block is still there) */
+}
 
 static int s5_grow(double **p, int *cap, int need)
 {
@@ -295,11 +343,12 @@ static int s5_make_ahead(fn_geod_chain fc, int what, double i, double a, double 
         }
     }
     for (int k = 0; k < n; k++) { L->arg_i[k] = i; L->arg_a[k] = a; }
+    const unsigned long gen = s5_disk_generation();           /* before the call: a set-up during it leaves the records stale, not wrong */
     const int rc = fc((size_t)n, L->arg_i, L->arg_a, L->spec_alpha, L->spec_beta, L->g, L->err, L->ok, L->c);
     if (rc != 0) { s5_check(rc, "geodesic_init_inf (look-ahead)"); return 0; }
     L->spec_n = n; L->cursor = 0;
     L->spec_i = i; L->spec_a = a;
-    L->disk_gen = s5_disk_gen;
+    L->disk_gen = gen;
     return 1;
 }
 
@@ -317,17 +366,14 @@ static int s5_row_take(double i, double a, double alpha, double beta)
 
 int geodesic_init_inf(double i, double a, double alpha, double beta, geodesic *g, int *error)
 {
-    int err = 0, ok = 0;
-    if (s5_chain_mode < 0) {
-        const char *e = getenv("SIM5_SHIM_NO_CHAIN"), *la = getenv("SIM5_SHIM_NO_LOOKAHEAD");
-        s5_chain_mode = (e && *e && *e != '0') ? 0 : 2;
-        s5_lookahead = (s5_chain_mode && !(la && *la && *la != '0')) ? 1 : 0;
-    }
+    int err = 0, ok = 0, rc = 0;
+    pthread_once(&s5_modes_once, s5_modes_init);
     if (s5_chain_mode) {
         S5_FN(fn_geod_chain, fc, "sim5gpu_geodesic_init_inf_chain");
         s5_last.live = 0;
         int k = -1;
         if (s5_lookahead) {
+            s5_la_register();
             k = s5_row_take(i, a, alpha, beta);
             const int what = s5_row_note(i, a, alpha, beta);
             if (k < 0 && what == 1 && s5_make_ahead(fc, 1, i, a, beta)) k = s5_row_take(i, a, alpha, beta);
@@ -335,17 +381,23 @@ int geodesic_init_inf(double i, double a, double alpha, double beta, geodesic *g
         }
         if (k >= 0) {
             const s5_ahead *L = &s5_la;
-            memcpy(g, &L->g[k], sizeof *g);
+            /* what geodesic_init_inf writes, and nothing else: dmdp_inf, k[4] and p (ref src/sim5kerr-geod.h:59,66-67) are never
+             * set by it -- the caller's bytes stay there, as they do when the call goes to the GPU alone */
+            memcpy(g, &L->g[k], offsetof(geodesic, dmdp_inf));
+            memcpy(&g->Rpc, &L->g[k].Rpc, offsetof(geodesic, k) - offsetof(geodesic, Rpc));
             err = L->err[k]; ok = L->ok[k];
             if (ok) { memcpy(&s5_last.g, g, sizeof *g); s5_last.c = L->c[k]; s5_last.disk_gen = L->disk_gen; s5_last.live = 1; }
         } else {
-            s5_check(fc(1, &i, &a, &alpha, &beta, g, &err, &ok, &s5_last.c), "geodesic_init_inf");
-            if (ok) { memcpy(&s5_last.g, g, sizeof *g); s5_last.disk_gen = s5_disk_gen; s5_last.live = 1; }
+            const unsigned long gen = s5_disk_generation();
+            rc = s5_check(fc(1, &i, &a, &alpha, &beta, g, &err, &ok, &s5_last.c), "geodesic_init_inf");
+            if (ok && !rc) { memcpy(&s5_last.g, g, sizeof *g); s5_last.disk_gen = gen; s5_last.live = 1; }
         }
     } else {
         S5_FN(fn_geod_init_inf, f, "sim5gpu_geodesic_init_inf");
-        s5_check(f(1, &i, &a, &alpha, &beta, g, &err, &ok), "geodesic_init_inf");
+        rc = s5_check(f(1, &i, &a, &alpha, &beta, g, &err, &ok), "geodesic_init_inf");
     }
+    /* a failed batch call: FALSE with a non-zero status, like every failure of the reference (ref src/sim5kerr-geod.c:59-98) */
+    if (rc) { ok = 0; if (!err) err = GD_ERROR_UNKNOWN_SOLUTION; }
     if (error) *error = err;
     return ok ? TRUE : FALSE;
 }
@@ -577,7 +629,7 @@ int disk_nt_setup(double M, double a, double mdot_or_L, double alpha, int option
     S5_FN(fn, f, "sim5gpu_disk_nt_setup");
     s5_check(f(M, a, mdot_or_L, alpha, options), "disk_nt_setup");
     s5_disk_M = M; s5_disk_a = a; s5_disk_alpha = alpha; s5_disk_options = options;
-    s5_disk_gen++;                                    /* records made for the previous model no longer answer disk_nt_flux */
+    /* (records made for the previous model no longer answer disk_nt_flux: the library bumped its generation counter) */
     return 0;
 }
 
@@ -599,7 +651,7 @@ double disk_nt_dhdr(double r) { (void)r; return 0.0; }
 
 double disk_nt_flux(double r)
 {
-    if (s5_last.live && s5_last.c.flux_valid && s5_last.disk_gen == s5_disk_gen) {
+    if (s5_last.live && s5_last.c.flux_valid && s5_last.disk_gen == s5_disk_generation()) {
         for (int k = 0; k < 2; k++) if (s5_last.c.have_r[k] && !isnan(r) && s5_same_bits(r, s5_last.c.r[k])) return s5_last.c.flux[k];
     }
     S5_FN(fn_d1, f, "sim5gpu_disk_nt_flux"); double o = NAN; s5_check(f(1, &r, &o), "disk_nt_flux"); return o;

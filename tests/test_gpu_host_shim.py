@@ -313,3 +313,27 @@ def test_rccl_shard_objects_with_a_world_of_one(capi):
         assert np.array_equal(f[b].to_numpy(np.float32, (n, n)), want["image_f"]) and np.array_equal(g[b].to_numpy(np.float32, (n, n)), want["image_g"])
     sh.destroy()
     rccl.comm_destroy(comm)
+
+
+def test_a_disk_setup_beside_the_shim_invalidates_its_records(tmp_path, capi):
+    """sim5gpu_disk_nt_setup called BESIDE the shim (ctypes, DiskModel_ThinDisk, a C program) changes the
+    process-global disk model; the shim's per-ray and look-ahead records carry the library's generation counter
+    (sim5gpu_disk_nt_generation) and stop answering disk_nt_flux.  From C (tests/c/shim_generation.c, 34 model changes in the
+    middle of a raster walk) and from Python (sim5_amd.sim5lib after capi.disk_nt_setup)."""
+    libdir = os.path.dirname(capi.LIB_PATH)
+    exe = _cc(tmp_path, "shim_generation.c", "gen", ["-I", os.path.join(ROOT, "include"), "-L", libdir, "-lsim5gpu",
+                                                      "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    p = subprocess.run([exe], env=dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith("ok:"), (p.stdout[-1500:], p.stderr[-1500:])
+    import sim5_amd.sim5lib as s5
+    a, inc = 0.9, deg2rad(60.0)
+    s5.disk_nt_setup(10.0, a, 0.1, 0.1, 0)
+    gd = s5.geodesic(); err = s5.intp()
+    assert s5.geodesic_init_inf(inc, a, 4.0, 3.0, gd, err)
+    P = s5.geodesic_find_midplane_crossing(gd, 0)
+    r = s5.geodesic_position_rad(gd, P)
+    f1 = s5.disk_nt_flux(r)                                     # (answered from the record)
+    capi.disk_nt_setup(10.0, a, 1.0, 0.1)                       # beside the shim: ten times the accretion rate
+    f2 = s5.disk_nt_flux(r)
+    assert f1 > 0 and abs(f2 / f1 - 10.0) < 1e-6, (f1, f2)
+    assert f2 == float(capi.disk_nt_flux(np.array([r]))[0])
