@@ -808,6 +808,7 @@ def extra_configs(torch, capi, dev, stream):
                                               "valu_wave_instr_per_64_rays": e["valu_wave_instr_per_64_rays"], "executed_flops_source": e["source"]})
     del tb, ob, stt
     out["scalar_api_example04_loop"] = scalar_api_rate(capi)
+    out["scalar_api_raytrace_loop"] = scalar_raytrace_loop(capi)
     return out
 
 
@@ -850,6 +851,58 @@ def scalar_api_rate(capi):
                 "rays_per_s": head["rays_per_s"], "us_per_ray": 1e6 / head["rays_per_s"], "image": "1024 x 1024, first pass of the process",
                 "disk_hits": head["hits"], "disk_hits_reference": 991579, "runs": runs,
                 "one_launch_per_ray_rays_per_s": 4096 / min(one) if one else None, "a": 0.998, "incl_deg": 70.0}
+    except Exception as e:                      # a host-side extra must never take the bench line with it
+        return {"skipped": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
+def scalar_raytrace_loop(capi):
+    """The OTHER scalar loop north_star names -- raytrace_prepare / raytrace() one call at a time (ref README.md:184-193; the
+    timing loop of ref src/sim5unittests.c:116-127) -- through sim5_amd/host/sim5lib.c: tests/c/raytrace_loop.c, six rays, timed
+    inside the program around the loops.  Two modes of the shim: look-ahead (sim5gpu_raytrace_record: up to 64 consecutive calls
+    of the ray per launch, each call served after a bit-for-bit check of x, k, *step and *rtd) and one launch per call.  The
+    SAME program linked against the unmodified reference library runs on one host core beside it (the cpu_baseline leg's
+    checker library: timed, never on the product path) -- a ray alone advances one call per ~6 us on the GPU, the dependent chain
+    of one lane, so this loop is the one use of the API that stays far behind a CPU core."""
+    import shutil
+    import subprocess
+    import tempfile
+    try:
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if not cc:
+            return {"skipped": "no C compiler on this box"}
+        tmp = tempfile.mkdtemp(prefix="s5rt_")
+        host = os.path.join(ROOT, "sim5_amd", "host")
+        src = os.path.join(ROOT, "tests", "c", "raytrace_loop.c")
+        exe = os.path.join(tmp, "rtloop")
+        subprocess.run([cc, src, os.path.join(host, "sim5lib.c"), "-I", host, "-o", exe, "-lm", "-O3", "-w", "-fgnu89-inline"],
+                       check=True, capture_output=True, timeout=120)
+
+        def run(cmd, env):
+            p = subprocess.run(cmd, env=env, check=True, capture_output=True, text=True, timeout=300)
+            rows = [ln.split() for ln in p.stdout.splitlines() if ln and not ln.startswith("#")]
+            tail = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("# raytrace loop")][0]
+            return {"calls": int(tail[6]), "loop_s": float(tail[8]), "calls_per_s": float(tail[10]),
+                    "calls_per_ray": [int(r[1]) for r in rows if r[1] != "rejected"], "r_end": [float(r[2]) for r in rows if r[1] != "rejected"]}
+        env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
+        ahead = run([exe, "0.9", "60", "6", "quiet"], env)
+        single = run([exe, "0.9", "60", "2", "quiet"], dict(env, SIM5_SHIM_NO_LOOKAHEAD="1"))
+        out = {"what": "tests/c/raytrace_loop.c: raytrace() one call at a time (precision 0.01, cap 1e9, 6 rays from r0 = 50), through sim5_amd/host/sim5lib.c",
+               "calls_per_s": ahead["calls_per_s"], "us_per_call": 1e6 / ahead["calls_per_s"], "calls": ahead["calls"],
+               "calls_per_ray": ahead["calls_per_ray"],
+               "one_launch_per_call_calls_per_s": single["calls_per_s"], "one_launch_per_call_us": 1e6 / single["calls_per_s"]}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oraclelib as ol
+        if ol.have_reference():
+            ref_exe = os.path.join(tmp, "rtloop_ref")
+            rdir = os.path.dirname(ol.REF_SO)
+            subprocess.run([cc, src, "-I", host, "-o", ref_exe, "-L", rdir, "-lsim5ref", "-Wl,-rpath," + rdir, "-lm", "-O3", "-w", "-fgnu89-inline"],
+                           check=True, capture_output=True, timeout=120)
+            ref = run([ref_exe, "0.9", "60", "6", "quiet"], dict(os.environ))
+            out.update({"reference_one_core_calls_per_s": ref["calls_per_s"], "reference_one_core_us_per_call": 1e6 / ref["calls_per_s"],
+                        "same_calls_per_ray_as_the_reference": ref["calls_per_ray"] == ahead["calls_per_ray"],
+                        "gpu_over_reference_one_core": ahead["calls_per_s"] / ref["calls_per_s"]})
+        shutil.rmtree(tmp, ignore_errors=True)
+        return out
     except Exception as e:                      # a host-side extra must never take the bench line with it
         return {"skipped": "%s: %s" % (type(e).__name__, str(e)[:200])}
 

@@ -281,6 +281,14 @@ int sim5gpu_raytrace(size_t n, double *x, double *k, double *step, sim5gpu_raytr
                      int nsteps);
 int sim5gpu_raytrace_error(size_t n, const double *x, const double *k,
                            const sim5gpu_raytrace_data *rtd, double *err);
+/* ONE ray, `nsteps` (1 .. 4096) consecutive raytrace() calls with the cap `step_cap` re-applied at each; records[j] = what
+ * the j-th call leaves in x, k, *step and *rtd (bytes of *rtd the integrator does not write are the caller's).  For callers
+ * that make the calls one by one -- the loop of ref README.md:184-193 / src/sim5unittests.c:116-127 through the scalar API:
+ * one launch per nsteps calls (sim5_amd/host/sim5lib.c serves a call from a record only after a bit-for-bit check of x, k,
+ * *step and *rtd against what the record was made from). */
+typedef struct sim5gpu_raytrace_step { double x[4], k[4], step; sim5gpu_raytrace_data rtd; } sim5gpu_raytrace_step;   /* 216 B */
+int sim5gpu_raytrace_record(const double *x, const double *k, double step_cap, const sim5gpu_raytrace_data *rtd, int nsteps,
+                            sim5gpu_raytrace_step *records);
 
 /* polarization_constant / _vector / _constant_infinity / _angle_rotation
  * (ref src/sim5polarization.c:145-158, 14-105, 249-258, 272-285); wp is n x 2 {re, im} */

@@ -761,6 +761,37 @@ int sim5gpu_raytrace(size_t n, double* x, double* k, double* step, sim5gpu_raytr
     return SIM5GPU_OK;
 }
 
+// ONE ray, `nsteps` consecutive raytrace() calls with the same cap re-applied at each, every intermediate result kept: record j
+// holds what the j-th call leaves in x, k, *step and *rtd.  For callers that make the calls one by one (the scalar API of
+// sim5_amd/host/sim5lib.c: ref README.md:184-193, src/sim5unittests.c:116-127) -- one launch per `nsteps` calls instead of one per call.
+int sim5gpu_raytrace_record(const double* x, const double* k, double step_cap, const sim5gpu_raytrace_data* rtd, int nsteps,
+                            sim5gpu_raytrace_step* records)
+{
+    S5_NEED("raytrace_record", x && k && rtd && records);
+    if (nsteps < 1 || nsteps > 4096) { snprintf(g_err, sizeof g_err, "raytrace_record: nsteps must be in 1 .. 4096"); return SIM5GPU_E_ARG; }
+    static_assert(sizeof(sim5gpu_raytrace_step) == 216 && offsetof(sim5gpu_raytrace_step, rtd) == 72, "raytrace_step layout");
+    S5_DEVICE_OR_FAIL();
+    DevBuf<double> dx(x, 4), dk(k, 4); DevBuf<RayState> ds((const RayState*)rtd, 1); DevBuf<sim5gpu_raytrace_step> dr((size_t)nsteps);
+    S5_BUFS_OK("raytrace_record", dx.ok() && dk.ok() && ds.ok() && dr.ok());
+    const double *px = dx.ptr, *pk = dk.ptr; const RayState* ps = ds.ptr; sim5gpu_raytrace_step* pr = dr.ptr;
+    S5_RUN(1, "raytrace_record", [=] __device__(size_t) {
+        RayState s = ps[0];
+        double xx[4] = { px[0], px[1], px[2], px[3] };
+        double kk[4] = { pk[0], pk[1], pk[2], pk[3] };
+        for (int it = 0; it < nsteps; ++it) {
+            double taken = step_cap;
+            raytrace_step(xx, kk, taken, s);
+            sim5gpu_raytrace_step& o = pr[it];
+            o.x[0] = xx[0]; o.x[1] = xx[1]; o.x[2] = xx[2]; o.x[3] = xx[3];
+            o.k[0] = kk[0]; o.k[1] = kk[1]; o.k[2] = kk[2]; o.k[3] = kk[3];
+            o.step = taken;
+            *(RayState*)&o.rtd = s;
+        }
+    });
+    S5_HIP(dr.to_host(records));
+    return SIM5GPU_OK;
+}
+
 int sim5gpu_raytrace_error(size_t n, const double* x, const double* k, const sim5gpu_raytrace_data* rtd, double* err)
 {
     S5_NEED("raytrace_error", x && k && rtd && err);

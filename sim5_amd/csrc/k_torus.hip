@@ -356,26 +356,35 @@ struct PoolArgs {
 
 #ifdef S5_TORUS_DEBUG
 // Instrumented build only (tests/tools/torus_phases.py): cycles between the phase marks of s5_raytrace.hpp, summed per
-// workgroup in LDS by the first active lane of the wave that passes a mark (s_memtime; scheduling barriers on both sides so
-// that the mark stays where it is written).  The wave's last time stamp lives in `t` (a scalar register pair).
+// workgroup in LDS.  A mark reads the cycle counter FIRST (s_memtime between scheduling barriers, after everything the
+// phase issued has completed), then does its book-keeping -- the wave's previous time stamp is a word of LDS (a register
+// would be a per-lane copy: the marks sit in divergent code and the lanes that pass them change), the sums are LDS atomics of
+// the first active lane -- and stamps the END of the book-keeping as the start of the next phase: the marks themselves are
+// outside every interval (PH_N: the interval between two marks with nothing in between, as a check: a few cycles).
 struct PhaseClock {
-    unsigned long long* acc;      // LDS [PH_N] cycles
-    unsigned* cnt;                // LDS [PH_N] marks passed
-    unsigned long long* t;
+    unsigned long long* acc;      // LDS [PH_N + 1] cycles
+    unsigned* cnt;                // LDS [PH_N + 1] marks passed
+    unsigned long long* tw;       // LDS: this wave's last time stamp
     S5_DEV void mark(int i) const
     {
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long now = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long old = *tw;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
         if (__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) == 0u) {
-            atomicAdd(&acc[i], now - *t);
+            atomicAdd(&acc[i], now - old);
             atomicAdd(&cnt[i], 1u);
         }
-        *t = now;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_sched_barrier(0);
+        *tw = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_sched_barrier(0);
     }
 };
-constexpr int PHASE_LDS_BYTES = PH_N * 8 + PH_N * 4;
+constexpr int PHASE_LDS_BYTES = (PH_N + 1) * 8 + (PH_N + 1) * 4 + 4 + 16 * 8;       // sums, counts, pad, one stamp per wave
 constexpr size_t PHASE_DBG_AT = 12000;        // index into the debug buffer (aux.k_end as 64-bit words): PH_N sums, PH_N counts
 #else
 constexpr int PHASE_LDS_BYTES = 0;
@@ -395,11 +404,12 @@ void torus_pool_kernel(PoolArgs args)
     double* cwd = (double*)(cw + NCW);                               // [4]: step_epsilon, r_in, r_out (formed once, below)
 #ifdef S5_TORUS_DEBUG
     unsigned long long* ph_acc = (unsigned long long*)(pool_raw + POOL_WG_BYTES);
-    unsigned* ph_cnt = (unsigned*)(ph_acc + PH_N);
-    if (threadIdx.x < PH_N) { ph_acc[threadIdx.x] = 0ull; ph_cnt[threadIdx.x] = 0u; }
-    unsigned long long ph_t = __builtin_readcyclecounter();
-    const unsigned long long ph_t0 = ph_t;
-    const PhaseClock ph = { ph_acc, ph_cnt, &ph_t };
+    unsigned* ph_cnt = (unsigned*)(ph_acc + PH_N + 1);
+    unsigned long long* ph_tw = (unsigned long long*)(ph_cnt + PH_N + 2);
+    if (threadIdx.x <= PH_N) { ph_acc[threadIdx.x] = 0ull; ph_cnt[threadIdx.x] = 0u; }
+    const unsigned long long ph_t0 = __builtin_readcyclecounter();
+    ph_tw[threadIdx.x >> 6] = ph_t0;
+    const PhaseClock ph = { ph_acc, ph_cnt, ph_tw + (threadIdx.x >> 6) };
 #else
     const NoPhases ph;
 #endif
@@ -729,6 +739,7 @@ void torus_pool_kernel(PoolArgs args)
 #endif
                     }
                     ph.mark(PH_STORE_TRANSFER);
+                    ph.mark(PH_N);                                 // (two marks with nothing in between: the cost a mark leaves in an interval)
                 }
                 if (POOL_KEEP_DEN * __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)) < POOL_KEEP_NUM * take) break;
             }
@@ -761,13 +772,13 @@ void torus_pool_kernel(PoolArgs args)
 #ifdef S5_TORUS_DEBUG
     if (lane == 0) tl[2] = wall_clock64();
     __syncthreads();                                                 // (debug build: every wave has left the loop)
-    if (threadIdx.x < PH_N) {
+    if (threadIdx.x <= PH_N) {
         unsigned long long* dbg = (unsigned long long*)A.aux.k_end + PHASE_DBG_AT;
         atomicAdd(&dbg[threadIdx.x], ph_acc[threadIdx.x]);
-        atomicAdd(&dbg[PH_N + threadIdx.x], (unsigned long long)ph_cnt[threadIdx.x]);
+        atomicAdd(&dbg[PH_N + 1 + threadIdx.x], (unsigned long long)ph_cnt[threadIdx.x]);
     }
     if (threadIdx.x == 0) {                                          // the two clocks over the workgroup's life: cycles per 100 MHz tick
-        unsigned long long* dbg = (unsigned long long*)A.aux.k_end + PHASE_DBG_AT + 2 * PH_N;
+        unsigned long long* dbg = (unsigned long long*)A.aux.k_end + PHASE_DBG_AT + 2 * (PH_N + 1);
         atomicAdd(&dbg[0], __builtin_readcyclecounter() - ph_t0);
         atomicAdd(&dbg[1], wall_clock64() - t_begin);
     }

@@ -603,8 +603,63 @@ void raytrace_prepare(double bh_spin, double x[4], double k[4], double presision
     s5_check(f(1, &bh_spin, x, k, &presision_factor, &options, rtd), "raytrace_prepare");
 }
 
+/* raytrace() one call at a time (ref README.md:184-193, src/sim5unittests.c:116-127: while (...) { dl = cap; raytrace(x, k, &dl,
+ * &rtd); }).  A single call is a kernel launch of one lane (~20 us); the loop above feeds every call the previous call's results
+ * and the same cap, so the shim asks the GPU for the NEXT calls as well -- sim5gpu_raytrace_record: K consecutive calls of the
+ * same ray in one launch, every intermediate state kept -- and answers the following calls from those records: each ONLY after
+ * its x, k, *step and the 144 bytes of *rtd have been compared, bit for bit, with what its record was made from (the previous
+ * record's output, the same cap).  Any other call (a caller that changes the cap, the state, the ray) drops the records and goes
+ * to the GPU; two misses in a row switch the look-ahead off for the next 256 calls.  K doubles from 8 to 64 while the records are
+ * being used up.  SIM5_SHIM_NO_LOOKAHEAD=1: one launch per call.  (A ray alone advances one call per ~6 us on the GPU -- the
+ * dependent chain of one lane -- so this loop stays an order of magnitude behind one CPU core whatever the shim does:
+ * INTEGRATION.md 1; whole images of rays belong to sim5gpu_torus_image.) */
+typedef struct { double x[4], k[4], step; raytrace_data rtd; } s5_rt_step;          /* = sim5gpu_raytrace_step */
+#define S5_RT_MAX 64
+static __thread struct {
+    int n, cursor, K, misses, off_for;
+    double cap;
+    double x0[4], k0[4]; raytrace_data rtd0;                 /* what record 0 was made from */
+    s5_rt_step rec[S5_RT_MAX];
+} s5_rt;
+
+static int s5_rt_matches(const double x[4], const double k[4], double cap, const raytrace_data *rtd)
+{
+    if (s5_rt.cursor >= s5_rt.n || !s5_same_bits(cap, s5_rt.cap)) return 0;
+    const double *px = s5_rt.cursor ? s5_rt.rec[s5_rt.cursor - 1].x : s5_rt.x0;
+    const double *pk = s5_rt.cursor ? s5_rt.rec[s5_rt.cursor - 1].k : s5_rt.k0;
+    const raytrace_data *pr = s5_rt.cursor ? &s5_rt.rec[s5_rt.cursor - 1].rtd : &s5_rt.rtd0;
+    return memcmp(x, px, 4 * sizeof(double)) == 0 && memcmp(k, pk, 4 * sizeof(double)) == 0 && memcmp(rtd, pr, sizeof *rtd) == 0;
+}
+
 void raytrace(double x[4], double k[4], double *step, raytrace_data *rtd)
 {
+    pthread_once(&s5_modes_once, s5_modes_init);
+    if (s5_lookahead) {
+        if (s5_rt.n && s5_rt_matches(x, k, *step, rtd)) {
+            const s5_rt_step *o = &s5_rt.rec[s5_rt.cursor++];
+            memcpy(x, o->x, sizeof o->x); memcpy(k, o->k, sizeof o->k); *step = o->step; memcpy(rtd, &o->rtd, sizeof *rtd);
+            s5_rt.misses = 0;
+            return;
+        }
+        /* not the call the records were made for (or none left) */
+        const int used_up = s5_rt.n > 0 && s5_rt.cursor == s5_rt.n;
+        if (s5_rt.n > 0 && s5_rt.cursor <= 1 && !used_up && ++s5_rt.misses >= 2) { s5_rt.off_for = 256; s5_rt.misses = 0; }
+        s5_rt.K = used_up ? (s5_rt.K * 2 > S5_RT_MAX ? S5_RT_MAX : s5_rt.K * 2) : 8;
+        s5_rt.n = 0;
+        if (s5_rt.off_for > 0) s5_rt.off_for--;
+        else {
+            typedef int (*fnr)(const double *, const double *, double, const raytrace_data *, int, s5_rt_step *);
+            S5_FN(fnr, fr, "sim5gpu_raytrace_record");
+            memcpy(s5_rt.x0, x, sizeof s5_rt.x0); memcpy(s5_rt.k0, k, sizeof s5_rt.k0); memcpy(&s5_rt.rtd0, rtd, sizeof *rtd);
+            s5_rt.cap = *step;
+            if (s5_check(fr(x, k, *step, rtd, s5_rt.K, s5_rt.rec), "raytrace (look-ahead)") == 0) {
+                s5_rt.n = s5_rt.K; s5_rt.cursor = 1;
+                const s5_rt_step *o = &s5_rt.rec[0];
+                memcpy(x, o->x, sizeof o->x); memcpy(k, o->k, sizeof o->k); *step = o->step; memcpy(rtd, &o->rtd, sizeof *rtd);
+                return;
+            }
+        }
+    }
     typedef int (*fn)(size_t, double *, double *, double *, raytrace_data *, int);
     S5_FN(fn, f, "sim5gpu_raytrace");
     s5_check(f(1, x, k, step, rtd, 1), "raytrace");

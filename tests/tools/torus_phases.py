@@ -12,7 +12,8 @@ import test_gpu_raytrace as T
 
 PH = ["stepsize", "predict (incl. sincos, sqrt)", "metric+connection", "corrector 1", "corrector 2", "corrector 3", "error check (k.k, k_t)",
       "acceleration at the new point", "rk4 head", "rk4 stage 1", "rk4 stage 2", "rk4 stage 3", "rk4 tail (update, metric+connection, accel)",
-      "state load (LDS, kernarg)", "state store + transfer + end test", "queues, loop control, waits"]
+      "state load (LDS, kernarg)", "state store + transfer + end test", "queues, loop control, waits",
+      "(two marks with nothing in between)"]
 AT = 12000
 
 
@@ -29,16 +30,16 @@ def job(n, rows, label):
         capi.torus_image_device(d, sb.ptr, aux={"steps": steps.ptr, "k_end": dbg.ptr}); capi.synchronize()
         wall = time.perf_counter() - t0
     w = dbg.to_numpy(np.uint64, (16 * 8192,))
-    acc = w[AT:AT + 16].astype(np.float64); cnt = w[AT + 16:AT + 32].astype(np.float64)
-    cyc, ticks = float(w[AT + 32]), float(w[AT + 33])
+    acc = w[AT:AT + 17].astype(np.float64); cnt = w[AT + 17:AT + 34].astype(np.float64)
+    cyc, ticks = float(w[AT + 34]), float(w[AT + 35])
     s = steps.to_numpy(np.int32, (max(N, 1),))[:N]
     calls = float(s.sum())
     mhz = 100.0 * cyc / ticks if ticks else float("nan")
     rec = {"job": label, "rays": int(N), "raytrace_calls": int(calls), "calls_of_the_longest_ray": int(s.max()), "host_wall_ms": 1e3 * wall,
            "s_memtime_MHz (cycles per 100 MHz tick, summed over workgroups)": mhz,
            "phases": [{"phase": PH[i], "marks": int(cnt[i]), "cycles_per_mark": acc[i] / cnt[i] if cnt[i] else 0.0,
-                       "cycles_per_call": acc[i] / calls if calls else 0.0} for i in range(16)],
-           "cycles_per_call_sum": float(acc.sum() / calls) if calls else 0.0,
+                       "cycles_per_call": acc[i] / calls if calls else 0.0} for i in range(17)],
+           "cycles_per_call_sum": float(acc[:16].sum() / calls) if calls else 0.0,
            "V_batches": int(w[0]), "V_lanes_avg": float(w[1]) / max(float(w[0]), 1), "R_batches": int(w[2]), "R_lanes_avg": float(w[3]) / max(float(w[2]), 1)}
     return rec
 
