@@ -772,7 +772,23 @@ def extra_configs(torch, capi, dev, stream):
                                     "pixel_energy_pairs_per_s": n4 * n4 * ne / ms4 * 1e3, "algorithmic_flops": w_spec4,
                                     "roofline_frac": w_spec4 / (ms4 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                     "spectrum_sum": float(S.sum().item())}
-    del E, S, ws, ws4
+    # the same two jobs on a UNIFORM energy grid (0.1 ... 30 keV in equal steps): the recurrence along the energies
+    # (k_spectrum.hip planck_runs_uniform, ~7.5 issue slots per pair instead of 15.25; the kernel detects the grid itself)
+    Eu = torch.tensor(np.linspace(0.1, 30.0, ne), dtype=torch.float64, device=dev)
+    specu = lambda: capi._check(capi._lib.sim5gpu_disk_spectrum(C.byref(d), capi.I(ne), capi.VP(Eu.data_ptr()), capi.D(1.7), capi.I(1),
+                                                                 capi.VP(S.data_ptr()), capi.VP(ws.data_ptr()), capi.VP(stream)), "sim5gpu_disk_spectrum")
+    msu = timed_kernel(capi, stream, specu, 40, 60)
+    su = float(S.sum().item())
+    specu4 = lambda: capi._check(capi._lib.sim5gpu_disk_spectrum(C.byref(d4), capi.I(ne), capi.VP(Eu.data_ptr()), capi.D(1.7), capi.I(1),
+                                                                  capi.VP(S.data_ptr()), capi.VP(ws4.data_ptr()), capi.VP(stream)), "sim5gpu_disk_spectrum")
+    msu4 = timed_kernel(capi, stream, specu4, 10, 15)
+    out["f3_spectrum_uniform_grid"] = {
+        "what": "the two jobs above on 128 energies 0.1 ... 30 keV in EQUAL steps: e^-x of a pixel follows a recurrence along the energies",
+        "1024_x128": {"job_ms": msu, "pixel_energy_pairs_per_s": n * n * ne / msu * 1e3, "roofline_frac": w_spec / (msu * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                      "spectrum_sum": su},
+        "4096_x128": {"job_ms": msu4, "pixel_energy_pairs_per_s": n4 * n4 * ne / msu4 * 1e3,
+                      "roofline_frac": w_spec4 / (msu4 * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, "spectrum_sum": float(S.sum().item())}}
+    del E, Eu, S, ws, ws4
     # the surface search of the reference's Python DiskRaytrace for a thick disk H(R) = 0.25 (R - 2), 1024^2
     # rays (k_surface.hip).  Algorithmic work per ray: ~550 sub-steps of geodesic_follow (ref src/sim5kerr-geod.c:891-925), each
     # r(P) + mu(P) = two jacobi_sncndn (~4 AGM levels, a sincos, the back recurrence) ~ 3.6e2 FP64 operations by SURVEY 8(d)'s

@@ -230,6 +230,64 @@ S5_DEV double planck_sum(const double2* __restrict__ sXA, int first, int step, i
     return (acc0 + acc1) + (acc2 + acc3);
 }
 
+// UNIFORM ENERGY GRID (round 6): E_j = E_0 + j dE.  Then u_j = e^-x_j = 2^(-E_j sX) of a pixel obeys u_(j+1) = u_j tau with
+// tau = 2^(-dE sX): ONE multiplication where the general loop spends eleven slots on an exponential.  Lanes own RUNS of eight
+// consecutive energies (thread t: run t mod RP, pixel sub-set t / RP); a lane takes eight of its pixels at a time -- u at the
+// head of its run by the exponential of planck_sum (1e-8, as there; the energy is the grid's own value, not E_0 + j dE), tau
+// from the staged column (made once per pixel by the exponential of s5_trig.hpp: the eight-fold product must not carry eight
+// times 1e-8) -- and walks the eight energies: per energy w = 1 - u, b = amp u for the eight pixels, their eight terms b / w over
+// ONE reciprocal (the tree of planck_sum), u *= tau.  3 + 3.25 slots per (pixel, energy) pair + 10 / 8 for the head of the
+// run: ~7.5 against 15.25.  acc[k] = the lane's sum for energy k of its run.
+template <int RP>
+S5_DEV void planck_runs_uniform(const double2* __restrict__ sXA, const double* __restrict__ sTau, int subset, int npix, double E_head, double acc[8])
+{
+    constexpr double C1 = 0.6931471879266856, C2 = 0.2402264979496441, C3 = 0.05550357433648187, C4 = 0.009618237494183314,
+                     C5 = 0.0013390735475399872, C6 = 0.00015403512618661003;
+    constexpr double M = 6755399441055744.0;                             // 1.5 2^52
+    constexpr int SUBSETS = 256 / RP;
+    double c6 = C6;
+    asm volatile("" : "+v"(c6));
+    const double nE = -E_head;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    for (int q = subset; q < npix; q += 8 * SUBSETS) {
+        double u[8], tau[8], amp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double2 xa = sXA[q + i * SUBSETS];
+            tau[i] = sTau[q + i * SUBSETS];
+            amp[i] = xa.y;
+            const double tm = __builtin_fma(nE, xa.x, M);
+            const double f = __builtin_fma(nE, xa.x, -(tm - M));
+            double e = hfmac(f, c6, C5);
+            e = hfmac(f, e, C4);
+            e = hfmac(f, e, C3);
+            e = hfmac(f, e, C2);
+            e = hfmac(f, e, C1);
+            e = __builtin_fma(f, e, 1.0);
+            u[i] = __builtin_amdgcn_ldexp(e, __double2loint(tm));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double b[8], w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { w[i] = 1.0 - u[i]; b[i] = amp[i] * u[i]; }
+            const double N01 = __builtin_fma(b[0], w[1], b[1] * w[0]), D01 = w[0] * w[1];
+            const double N23 = __builtin_fma(b[2], w[3], b[3] * w[2]), D23 = w[2] * w[3];
+            const double N45 = __builtin_fma(b[4], w[5], b[5] * w[4]), D45 = w[4] * w[5];
+            const double N67 = __builtin_fma(b[6], w[7], b[7] * w[6]), D67 = w[6] * w[7];
+            const double Na = __builtin_fma(N01, D23, N23 * D01), Da = D01 * D23;
+            const double Nb = __builtin_fma(N45, D67, N67 * D45), Db = D45 * D67;
+            const double N = __builtin_fma(Na, Db, Nb * Da), D = Da * Db;
+            acc[k] = __builtin_fma(N, __builtin_amdgcn_rcp(D), acc[k]);
+            if (k < 7) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) u[i] *= tau[i];
+            }
+        }
+    }
+}
+
 template <bool CLAMP>
 S5_DEV double planck_sum_for(const double2* __restrict__ sXA, int first, int groups, int npix, double E)
 {
@@ -280,6 +338,18 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
     double e_max = 0.0;
     for (int j = tid % 64; j < sp.n_energies; j += 64) e_max = fmax(e_max, fabs(energies[j]));
     for (int w = 32; w > 0; w >>= 1) e_max = fmax(e_max, __shfl_xor(e_max, w));
+    // a UNIFORM grid E_j = E_0 + j dE of at least 64 energies (every wave looks at all of them: the four agree): the recurrence
+    // of planck_runs_uniform.  The tolerance, 1e-13 of the largest energy, is what grids made by different expressions of the
+    // same step differ by; in the spectrum it is x 1e-13 <= 1e-10.
+    double dE = 0.0;
+    bool uniform = false;
+    if (sp.n_energies >= 64) {
+        const double E0 = energies[0];
+        dE = (energies[sp.n_energies - 1] - E0) / (double)(sp.n_energies - 1);
+        bool off = !(dE > 0.0) || !(E0 > 0.0);
+        for (int j = tid % 64; j < sp.n_energies; j += 64) off = off || !(fabs(energies[j] - (E0 + (double)j * dE)) <= 1e-13 * e_max);
+        uniform = __builtin_amdgcn_ballot_w64(off) == 0ull;
+    }
     // the staging arrays take over the ladder block of the trace (every lane is through with it)
     double* const lds = thin_disk_ladder_column() - threadIdx.x;
     // [512] pairs: log2(e) h kev2freq / (kB f T g) (a harmless 1 for a dark pixel), amplitude (0 for a dark pixel)
@@ -288,9 +358,49 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
     __syncthreads();
     sXA[tid] = make_double2(x0, amp_0);
     sXA[tid + 256] = make_double2(x1, amp_1);
+    double* const sTau = lds + 1024;                                         // [512] uniform grid: 2^(-dE sX) of every staged pixel
+    double* const sRed = lds + 1536;                                         // [2048] uniform grid: the lanes' sums, [energy of the pass][sub-set]
+    if (uniform) {
+        // e^(-dE x) to full precision (s5_trig.hpp mexp: 1.7e-16); an argument below -700 is 0 for every purpose of the loop
+        const double ln2 = 0.693147180559945309417;
+        sTau[tid] = mexp(fmax(-(dE * x0) * ln2, -700.0));
+        sTau[tid + 256] = mexp(fmax(-(dE * x1) * ln2, -700.0));
+    }
     const bool beyond = !(x0 * e_max < 1073741824.0) || !(x1 * e_max < 1073741824.0);
     // (the barrier the staged pixels need anyway)  any pixel whose exponent could leave the 32-bit range: planck_sum<true>
     const bool clamp = __syncthreads_or(beyond) != 0;
+
+    if (uniform && !clamp) {
+        // transposed phase of the uniform grid: RP runs of eight energies x (256 / RP) pixel sub-sets per pass
+        const int npix_u = PAIR ? 512 : 256;
+        const int runs = (sp.n_energies + 7) / 8;
+        const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        for (int r0 = 0; r0 < runs; r0 += 16) {
+            const int rp = (runs - r0 >= 16) ? 16 : 8;                        // (runs >= 8: the last pass may be half empty)
+            const int run = r0 + tid % rp, subset = tid / rp;
+            const int jh = 8 * run;
+            double acc[8];
+            const bool live = run < runs;
+            const double Eh = live ? energies[jh] : 1.0;
+            if (rp == 16) planck_runs_uniform<16>(sXA, sTau, subset, npix_u, Eh, acc);
+            else planck_runs_uniform<8>(sXA, sTau, subset, npix_u, Eh, acc);
+            const int subsets = 256 / rp;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sRed[((tid % rp) * 8 + k) * subsets + subset] = acc[k];
+            __syncthreads();
+            if (tid < rp * 8) {
+                const int j = 8 * r0 + tid;
+                if (j < sp.n_energies) {
+                    double tot = 0.0;
+                    for (int g2 = 0; g2 < subsets; ++g2) tot += sRed[tid * subsets + g2];
+                    const double E = energies[j];
+                    partial[(size_t)j * nblk + blk] = tot * (E * E * E);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 
     // transposed phase: EB energy bins x (256 / EB) pixel sub-sets
     const int EB = sp.bins_per_pass;                     // power of two, <= 256

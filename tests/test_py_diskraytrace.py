@@ -156,6 +156,45 @@ def test_spectrum_fast_against_strict_over_energy_grids(capi, n_energies, lo, hi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_energies,lo,hi", [(128, 0.1, 30.0), (64, 0.05, 12.0), (256, 0.01, 100.0), (300, 0.5, 20.0), (71, 1.0, 9.0),
+                                              (128, 1.0, 3.0e4), (200, 1e-3, 1.0), (63, 0.1, 30.0)],
+                         ids=["128", "64-one-half-pass", "256-two-passes", "300", "71-ragged-run", "128-into-the-Wien-tail",
+                              "200-Rayleigh-Jeans", "63-general-loop"])
+def test_spectrum_on_uniform_energy_grids(capi, n_energies, lo, hi):
+    """a UNIFORM grid E_j = E_0 + j dE of >= 64 energies takes the recurrence along the energies
+    (k_spectrum.hip planck_runs_uniform: e^-x_(j+1) = e^-x_j e^(-dE s), runs of eight energies per lane).  Against the strict
+    kernel's full-precision evaluation (ref python/sim5diskspectrum.py:54-88): 1e-6 of every bin; the same for the grid with
+    its last bit(s) disturbed (still uniform to 1e-13: same path) and for a grid that is NOT uniform (one energy moved by 1e-6:
+    the general loop), which must agree with the uniform path on the undisturbed bins to 1e-7 (two different loops, one
+    26-bit reciprocal seed each); the unpaired instantiation (an asymmetric row range) as well."""
+    E = np.linspace(lo, hi, n_energies)
+    d_fast = capi.image_desc(160, 96, 0.9, 1.2)
+    f = capi.disk_spectrum(d_fast, E)
+    s = capi.disk_spectrum(capi.image_desc(160, 96, 0.9, 1.2, strict=True), E)
+    assert np.isfinite(f).all() and np.isfinite(s).all() and s.max() > 0
+    live = s > 1e-280 * s.max()
+    assert not (f[~live] > 1e-270 * s.max()).any()
+    err = np.max(np.abs(f[live] / s[live] - 1))
+    assert err < 1e-6, (n_energies, lo, hi, err, int(np.argmax(np.abs(f[live] / s[live] - 1))))
+    # the general loop on (almost) the same grid: one energy moved, every other bin must agree with the recurrence
+    E2 = E.copy(); E2[n_energies // 2] *= 1.0 + 1e-6
+    g = capi.disk_spectrum(d_fast, E2)
+    keep = live.copy(); keep[n_energies // 2] = False
+    assert np.max(np.abs(g[keep] / f[keep] - 1)) < 1e-7
+    # a grid made by another expression of the same step (last bits differ): the same path, the same numbers to rounding
+    E3 = lo + np.arange(n_energies) * ((hi - lo) / (n_energies - 1))
+    h = capi.disk_spectrum(d_fast, E3)
+    assert np.max(np.abs(h[live] / f[live] - 1)) < 1e-9
+    # the unpaired instantiation and additivity over the rows
+    top = capi.disk_spectrum(capi.image_desc(160, 96, 0.9, 1.2, y0=0, y1=37), E)
+    rest = capi.disk_spectrum(capi.image_desc(160, 96, 0.9, 1.2, y0=37, y1=96), E)
+    top_s = capi.disk_spectrum(capi.image_desc(160, 96, 0.9, 1.2, y0=0, y1=37, strict=True), E)
+    lt = top_s > 1e-280 * max(top_s.max(), 1e-300)
+    assert np.max(np.abs(top[lt] / top_s[lt] - 1)) < 1e-6
+    assert np.max(np.abs((top + rest)[live] / f[live] - 1)) < 1e-7
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fast"])
 def test_thick_disk_surface_search(golden, capi, strict):
     """sim5gpu_disk_surface_rays against the reference's Python __find_surface run on the same table."""
