@@ -898,7 +898,7 @@ def scalar_raytrace_loop(capi):
             rows = [ln.split() for ln in p.stdout.splitlines() if ln and not ln.startswith("#")]
             tail = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("# raytrace loop")][0]
             return {"calls": int(tail[6]), "loop_s": float(tail[8]), "calls_per_s": float(tail[10]),
-                    "calls_per_ray": [int(r[1]) for r in rows if r[1] != "rejected"], "r_end": [float(r[2]) for r in rows if r[1] != "rejected"]}
+                    "calls_per_ray": [int(r[1]) for r in rows], "r_end": [float(r[2]) for r in rows]}
         env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
         ahead = run([exe, "0.9", "60", "6", "quiet"], env)
         single = run([exe, "0.9", "60", "2", "quiet"], dict(env, SIM5_SHIM_NO_LOOKAHEAD="1"))

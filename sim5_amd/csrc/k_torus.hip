@@ -313,6 +313,7 @@ constexpr int RING = (WG_SLOTS <= 512) ? 512 : 1024;         // entries of a que
 static_assert(WG_SLOTS % 64 == 0 && WG_SLOTS >= 128 && WG_SLOTS <= RING, "pool size");
 #define POOL_KEEP_NUM 7                   // ... while at least NUM/DEN of its lanes are still stepping
 #define POOL_KEEP_DEN 8
+#define POOL_RUN_THIN 48                 // ... of a THIN batch (the cursor exhausted, less than a batch left in the queues: see the main loop)
 #define POOL_RUN 6                       // Verlet attempts a batch may take before it returns to the pool (measured with the queues
 // of round 4, C4, one call: 4 / 6 / 8 -> 23.8 / 23.4 / 23.4 ms at two waves, 21.3-21.4 at three)
 enum : int { PC_X0 = 0, PC_X1, PC_X2, PC_X3, PC_K0, PC_K1, PC_K2, PC_K3, PC_DK0, PC_DK1, PC_DK2, PC_DK3,
@@ -384,7 +385,7 @@ struct PhaseClock {
         __builtin_amdgcn_sched_barrier(0);
     }
 };
-constexpr int PHASE_LDS_BYTES = (PH_N + 1) * 8 + (PH_N + 1) * 4 + 4 + 16 * 8;       // sums, counts, pad, one stamp per wave
+constexpr int PHASE_LDS_BYTES = (PH_N + 1) * 8 + (PH_N + 1) * 4 + 4 + 16 * 8 + WG_SLOTS * 8;   // sums, counts, pad, one stamp per wave, one per slot
 constexpr size_t PHASE_DBG_AT = 12000;        // index into the debug buffer (aux.k_end as 64-bit words): PH_N sums, PH_N counts
 #else
 constexpr int PHASE_LDS_BYTES = 0;
@@ -409,6 +410,8 @@ void torus_pool_kernel(PoolArgs args)
     if (threadIdx.x <= PH_N) { ph_acc[threadIdx.x] = 0ull; ph_cnt[threadIdx.x] = 0u; }
     const unsigned long long ph_t0 = __builtin_readcyclecounter();
     ph_tw[threadIdx.x >> 6] = ph_t0;
+    unsigned long long* ph_slot = ph_tw + 16;                        // [WG_SLOTS]: when the ray of a slot was last given to a queue
+    for (int i = (int)threadIdx.x; i < WG_SLOTS; i += WG_THREADS) ph_slot[i] = 0ull;
     const PhaseClock ph = { ph_acc, ph_cnt, ph_tw + (threadIdx.x >> 6) };
 #else
     const NoPhases ph;
@@ -589,12 +592,30 @@ void torus_pool_kernel(PoolArgs args)
             continue;
         }
         const bool do_rk4 = (nR >= 64u) || (nV == 0u) || (nV < 64u && nR > nV);
+        // THIN (round 6): the cursor is exhausted and the queues hold less than one batch -- from here on the job is no longer
+        // bound by the vector unit but by the LATENCY of the calls of the rays that are left (profiles/r06_torus_call_phases.json:
+        // a lone ray spends as long in the queues between two halves of a call as in the arithmetic of a Verlet attempt).  A
+        // thin batch keeps its rays: a rejected attempt is followed by the RK4 half IN THIS WAVE at the next pass of the loop
+        // (no trip through the R queue and another wave), and the batch runs POOL_RUN_THIN calls before it looks at the queues
+        // again, while any lane is stepping.  The arithmetic of a ray is what it was: same calls, same operands, same order.
+        const bool thin = drained && (nV + nR < 64u);
 
         // ---- 3. take up to 64 rays of the chosen kind
         int slot;
         const int take = q_take(do_rk4 ? Q_R : Q_V, 64, slot);
         if (take == 0) continue;                     // another wave was faster: look again
         const bool active = lane < take;
+#ifdef S5_TORUS_DEBUG
+        if (active) {
+            // PH_QUEUES = the transit of a RAY through the queues: from the stamp its slot got when it was given back to this take
+            // (the first active lane's ray stands for the batch); the wave's own stamp starts here -- its idle time is no phase
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long now = __builtin_readcyclecounter();
+            const unsigned long long given = ph_slot[slot];
+            if (lane == 0 && given != 0ull) { atomicAdd(&ph_acc[PH_QUEUES], now - given); atomicAdd(&ph_cnt[PH_QUEUES], 1u); }
+            ph_tw[threadIdx.x >> 6] = __builtin_readcyclecounter();
+        }
+#endif
 
         // ---- 4. the batch: [RK4 half of the pending call for an R batch], then up to POOL_RUN Verlet attempts;
         //         a lane whose attempt is rejected stops (tag R), the wave goes back to the pool when an eighth
@@ -604,6 +625,8 @@ void torus_pool_kernel(PoolArgs args)
         if (active) {
             tag = do_rk4 ? TAG_R : TAG_V;
             bool on = true;
+            bool rk4_now = do_rk4;                                 // this lane owes the RK4 half of a call (whole R batch; thin: after a rejection)
+            const int run_max = thin ? POOL_RUN_THIN : POOL_RUN;
 #if !S5_MARCH_LEAN
             // by-value parameters (strict variant): the state of the ray in registers through the batch, as in round 3
             const TorusParams& p = A.p;
@@ -632,12 +655,12 @@ void torus_pool_kernel(PoolArgs args)
             float worst = pworst[slot];
 #endif
 #pragma unroll 1
-            for (int run = 0; run <= POOL_RUN; ++run) {
+            for (int run = 0; run <= run_max; ++run) {
                 if (on) {
+                    const bool was_rk4 = rk4_now;
                     double dl;
                     bool advanced;
                     Metric g;                                      // metric at the end point of the step
-                    ph.mark(PH_QUEUES);                            // (everything since the previous mark: queues, loop control, waits)
 #if S5_MARCH_LEAN
                     // ---- the ray's dynamical state from its slot; the job's parameters from the argument segment, from here
                     const auto& P = param_reload(A);
@@ -654,7 +677,7 @@ void torus_pool_kernel(PoolArgs args)
                         k[c] = pd[PD_AT(PC_K0 + c, slot)];
                         s.dk[c] = pd[PD_AT(PC_DK0 + c, slot)];
                     }
-                    s.kt = (run == 0 && do_rk4) ? 0.0 : pd[PD_AT(PC_KT, slot)];      // (RK4: read after the step, below)
+                    s.kt = was_rk4 ? 0.0 : pd[PD_AT(PC_KT, slot)];      // (RK4: read after the step, below)
                     s.pass = ppass[slot];
                     s.error = 0.0f;
                     const double dl_max = P.p.dl_max;
@@ -662,7 +685,8 @@ void torus_pool_kernel(PoolArgs args)
                     const double dl_max = p.dl_max;
 #endif
                     ph.mark(PH_LOAD);
-                    if (run == 0 && do_rk4) {
+                    if (was_rk4) {
+                        rk4_now = false;
                         dl = next_step_size(k, dl_max, s);        // the value the rejected attempt used
                         ph.mark(PH_STEPSIZE);
 #if S5_MARCH_LEAN
@@ -688,7 +712,7 @@ void torus_pool_kernel(PoolArgs args)
                     {
                         unsigned long long* dbg = (unsigned long long*)A.aux.k_end;
                         const unsigned long long mA = __builtin_amdgcn_ballot_w64(true);
-                        const int w = (run == 0 && do_rk4) ? 2 : 0;
+                        const int w = was_rk4 ? 2 : 0;
                         if (__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u)) == 0u) {
                             atomicAdd(&dbg[w], 1ull); atomicAdd(&dbg[w + 1], (unsigned long long)__builtin_popcountll(mA));
                         }
@@ -698,7 +722,9 @@ void torus_pool_kernel(PoolArgs args)
                     ppass[slot] = s.pass;                          // the attempt counts as a pass either way (ref :168)
 #endif
                     if (!advanced) {
-                        tag = TAG_R; on = false;                  // x, k, dk untouched
+                        tag = TAG_R;                              // x, k, dk untouched
+                        if (thin) rk4_now = true;                 // the RK4 half at the next pass of this loop, in this wave
+                        else on = false;
                     } else {
                         tag = TAG_V;
 #if S5_MARCH_LEAN
@@ -709,7 +735,7 @@ void torus_pool_kernel(PoolArgs args)
                             pd[PD_AT(PC_K0 + c, slot)] = k[c];
                             pd[PD_AT(PC_DK0 + c, slot)] = s.dk[c];
                         }
-                        if (!(run == 0 && do_rk4)) pd[PD_AT(PC_KT, slot)] = s.kt;      // (an RK4 step leaves kt as it was)
+                        if (!was_rk4) pd[PD_AT(PC_KT, slot)] = s.kt;      // (an RK4 step leaves kt as it was)
                         const auto& T = param_reload(A);
                         const float worst = fmaxf(pworst[slot], s.error);
                         pworst[slot] = worst;
@@ -741,7 +767,8 @@ void torus_pool_kernel(PoolArgs args)
                     ph.mark(PH_STORE_TRANSFER);
                     ph.mark(PH_N);                                 // (two marks with nothing in between: the cost a mark leaves in an interval)
                 }
-                if (POOL_KEEP_DEN * __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)) < POOL_KEEP_NUM * take) break;
+                const int still = __builtin_popcountll(__builtin_amdgcn_ballot_w64(on));
+                if (thin ? (still == 0) : (POOL_KEEP_DEN * still < POOL_KEEP_NUM * take)) break;
             }
 #if !S5_MARCH_LEAN
             if (tag != TAG_EMPTY) {
@@ -760,6 +787,9 @@ void torus_pool_kernel(PoolArgs args)
 #endif
         }
         // ---- 5. the slots back into their queues (the state before the entries)
+#ifdef S5_TORUS_DEBUG
+        if (active) ph_slot[slot] = (tag != TAG_EMPTY) ? __builtin_readcyclecounter() : 0ull;
+#endif
         wg_release();
         q_give(Q_V, active && tag == TAG_V, slot);
         q_give(Q_R, active && tag == TAG_R, slot);

@@ -18,7 +18,7 @@ int main(int argc, char **argv)
     for (int j = 0; j < rays; j++) {
         const double alpha = -7.0 + 14.0 * (j + 0.5) / rays, beta = 2.0 + 0.37 * j;
         geodesic gd; int err = 0;
-        if (!geodesic_init_inf(inc, a, alpha, beta, &gd, &err)) { printf("%d rejected %d\n", j, err); continue; }
+        if (!geodesic_init_inf(inc, a, alpha, beta, &gd, &err)) { printf("# ray %d rejected by geodesic_init_inf: %d\n", j, err); continue; }
         const double P0 = geodesic_P_int(&gd, r0, 0);
         double x[4] = { 0.0, r0, geodesic_position_pol(&gd, P0), 0.0 }, k[4];
         geodesic_momentum(&gd, P0, x[1], x[2], k);

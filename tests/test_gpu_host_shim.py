@@ -349,11 +349,11 @@ def test_raytrace_loop_call_by_call_and_with_the_look_ahead(tmp_path, capi):
     env = dict(os.environ, SIM5GPU_LIB=capi.LIB_PATH)
     outs = []
     for extra in ({}, {"SIM5_SHIM_NO_LOOKAHEAD": "1"}):
-        p = subprocess.run([exe, "0.9", "60", "3"], env=dict(env, **extra), capture_output=True, text=True, timeout=600)
+        p = subprocess.run([exe, "0.9", "60", "4"], env=dict(env, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(p.stdout)
     body = [[ln for ln in o.splitlines() if not ln.startswith("#")] for o in outs]
-    assert body[0] == body[1] and len(body[0]) == 3, "the look-ahead run differs from the call-by-call run"
+    assert body[0] == body[1] and len(body[0]) >= 2, "the look-ahead run differs from the call-by-call run"
     rate = [float([ln for ln in o.splitlines() if ln.startswith("# raytrace loop")][0].split()[10]) for o in outs]
     print("raytrace() call by call through the scalar API: %.3e calls/s with the look-ahead, %.3e with one launch per call" % tuple(rate))
     assert rate[0] > 1.5 * rate[1]
@@ -362,9 +362,10 @@ def test_raytrace_loop_call_by_call_and_with_the_look_ahead(tmp_path, capi):
         ref_exe = str(tmp_path / "rtloop_ref")
         subprocess.run(["gcc", os.path.join(ROOT, "tests", "c", "raytrace_loop.c"), "-I", HOST, "-o", ref_exe, "-L", rdir, "-lsim5ref",
                         "-Wl,-rpath," + rdir, "-lm", "-O3", "-w", "-fgnu89-inline"], check=True)
-        r = subprocess.run([ref_exe, "0.9", "60", "3"], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([ref_exe, "0.9", "60", "4"], capture_output=True, text=True, timeout=600)
         ref = [[float(v) for v in ln.split()] for ln in r.stdout.splitlines() if not ln.startswith("#")]
         got = [[float(v) for v in ln.split()] for ln in body[0]]
+        assert len(got) == len(ref) and [g[0] for g in got] == [w[0] for w in ref]
         for g, w in zip(got, ref):
             assert g[1] == w[1], ("raytrace() calls", g[1], w[1])
             for c, floor in ((2, 1.0), (3, 0.0), (4, 1e-2), (5, 1.0), (6, 1e-2), (7, 1e-4)):

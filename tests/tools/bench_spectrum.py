@@ -8,8 +8,8 @@ import sim5_amd.capi as capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 warm, reps = (300, 50) if n <= 1024 else (40, 10)
 d = capi.image_desc(n, n, 0.998, math.radians(70.0))
-for ne in (1, 128, 256):
-    E = 10.0 ** np.linspace(-1, 1.5, ne)
+for ne, uniform in ((1, False), (128, False), (256, False), (64, True), (128, True), (256, True), (512, True)):
+    E = np.linspace(0.1, 30.0, ne) if uniform else 10.0 ** np.linspace(-1, 1.5, ne)
     dE = capi.DeviceBuffer(E.nbytes); dE.from_numpy(E); dS = capi.DeviceBuffer(E.nbytes)
     capi._lib.sim5gpu_disk_spectrum_workspace.restype = capi.SZ
     ws = capi.DeviceBuffer(max(capi._lib.sim5gpu_disk_spectrum_workspace(C.byref(d), capi.I(ne)), 8))
@@ -20,4 +20,4 @@ for ne in (1, 128, 256):
     e1.record(); ms = e0.elapsed_ms(e1) / reps
     w = n * n * 1.6e3 + n * n * ne * 6.0
     S = dS.to_numpy(np.float64, (ne,))
-    print("%3d energies: %.4f ms  roofline %.3f  sum %.12e" % (ne, ms, w / (ms * 1e-3) / 78.6e12, S.sum()))
+    print("%3d energies (%s grid): %.4f ms  roofline %.3f  sum %.12e" % (ne, "uniform" if uniform else "log", ms, w / (ms * 1e-3) / 78.6e12, S.sum()))
