@@ -375,8 +375,8 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
         const int npix_u = PAIR ? 512 : 256;
         const int runs = (sp.n_energies + 7) / 8;
         const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        for (int r0 = 0; r0 < runs; r0 += 16) {
-            const int rp = (runs - r0 >= 16) ? 16 : 8;                        // (runs >= 8: the last pass may be half empty)
+        for (int r0 = 0, rp = 16; r0 < runs; r0 += rp) {
+            rp = (runs - r0 > 8) ? 16 : 8;                                    // (a last pass of up to eight runs: twice the pixel sub-sets)
             const int run = r0 + tid % rp, subset = tid / rp;
             const int jh = 8 * run;
             double acc[8];

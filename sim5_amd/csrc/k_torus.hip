@@ -194,6 +194,14 @@ S5_DEV double torus_density(const PRM& p, double r, double m)
 // kernel below); strict: its bodies need ~261 registers -- one wave per SIMD and no scratch
 // Emission and absorption picked up over one accepted step (see the header comment for the model).  `g` is the
 // metric at the end point of the step, which both halves of raytrace() have just evaluated there.
+// what accumulate_transfer reads of the job (the members of TorusParams it uses, same names): the march kernel's lean form
+// fetches them together at the head of its store / transfer / end-test phase
+struct TorusModel { int shape; double torus_w, torus_r, cut_d2, inv_2w2, torus_l, emis0, absorb0; };
+// a value loaded through the constant address space is in its scalar register(s) from HERE on (the optimiser would otherwise
+// sink the load to its use, behind whatever branch that sits)
+S5_DEV void keep_here(const double& v) { asm volatile("" :: "s"(v)); }
+S5_DEV void keep_here(const int& v) { asm volatile("" :: "s"(v)); }
+
 template <class PRM>
 S5_DEV void accumulate_transfer(const PRM& p, const bool no_absorption, const RayState& s, const Metric& g, const double x[4],
                                 const double k[4], double dl_taken, double& I, double& tau)
@@ -313,7 +321,6 @@ constexpr int RING = (WG_SLOTS <= 512) ? 512 : 1024;         // entries of a que
 static_assert(WG_SLOTS % 64 == 0 && WG_SLOTS >= 128 && WG_SLOTS <= RING, "pool size");
 #define POOL_KEEP_NUM 7                   // ... while at least NUM/DEN of its lanes are still stepping
 #define POOL_KEEP_DEN 8
-#define POOL_RUN_THIN 48                 // ... of a THIN batch (the cursor exhausted, less than a batch left in the queues: see the main loop)
 #define POOL_RUN 6                       // Verlet attempts a batch may take before it returns to the pool (measured with the queues
 // of round 4, C4, one call: 4 / 6 / 8 -> 23.8 / 23.4 / 23.4 ms at two waves, 21.3-21.4 at three)
 enum : int { PC_X0 = 0, PC_X1, PC_X2, PC_X3, PC_K0, PC_K1, PC_K2, PC_K3, PC_DK0, PC_DK1, PC_DK2, PC_DK3,
@@ -366,10 +373,13 @@ struct PhaseClock {
     unsigned long long* acc;      // LDS [PH_N + 1] cycles
     unsigned* cnt;                // LDS [PH_N + 1] marks passed
     unsigned long long* tw;       // LDS: this wave's last time stamp
+    bool sampled;                 // this wave keeps the book (a big job: one wave of one workgroup, so that the marks of 3 071 other
+                                  // waves do not load the LDS the measured wave shares with eleven of them)
     S5_DEV void mark(int i) const
     {
+        if (!sampled) return;
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): LDS and scalar loads of the phase (not its global stores)
         const unsigned long long now = __builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long old = *tw;
@@ -412,7 +422,8 @@ void torus_pool_kernel(PoolArgs args)
     ph_tw[threadIdx.x >> 6] = ph_t0;
     unsigned long long* ph_slot = ph_tw + 16;                        // [WG_SLOTS]: when the ray of a slot was last given to a queue
     for (int i = (int)threadIdx.x; i < WG_SLOTS; i += WG_THREADS) ph_slot[i] = 0ull;
-    const PhaseClock ph = { ph_acc, ph_cnt, ph_tw + (threadIdx.x >> 6) };
+    const bool ph_sampled = (args.p.nrays <= 64) || (blockIdx.x == 0 && (threadIdx.x >> 6) == 0);
+    const PhaseClock ph = { ph_acc, ph_cnt, ph_tw + (threadIdx.x >> 6), ph_sampled };
 #else
     const NoPhases ph;
 #endif
@@ -592,13 +603,11 @@ void torus_pool_kernel(PoolArgs args)
             continue;
         }
         const bool do_rk4 = (nR >= 64u) || (nV == 0u) || (nV < 64u && nR > nV);
-        // THIN (round 6): the cursor is exhausted and the queues hold less than one batch -- from here on the job is no longer
-        // bound by the vector unit but by the LATENCY of the calls of the rays that are left (profiles/r06_torus_call_phases.json:
-        // a lone ray spends as long in the queues between two halves of a call as in the arithmetic of a Verlet attempt).  A
-        // thin batch keeps its rays: a rejected attempt is followed by the RK4 half IN THIS WAVE at the next pass of the loop
-        // (no trip through the R queue and another wave), and the batch runs POOL_RUN_THIN calls before it looks at the queues
-        // again, while any lane is stepping.  The arithmetic of a ray is what it was: same calls, same operands, same order.
-        const bool thin = drained && (nV + nR < 64u);
+        // (Round 6 built and measured a THIN mode for the end of the job -- once the cursor is exhausted and the pool holds at most
+        // eight rays per wave, a batch keeps its rays, runs the RK4 half of a rejected call in the same wave at the next pass and
+        // stays away from the queues for 48 calls -- and dropped it: C4 20.8 -> 21.5 ms at 96 rays, 21.0 at 24 (one call, twice:
+        // profiles/r06_torus_ab_thin.txt).  A wave that serves both halves runs them one after the other for all its lanes; two
+        // waves on two SIMDs run them side by side.  A shorter sleep of the idle waves after the cursor's end: +-0.)
 
         // ---- 3. take up to 64 rays of the chosen kind
         int slot;
@@ -606,7 +615,7 @@ void torus_pool_kernel(PoolArgs args)
         if (take == 0) continue;                     // another wave was faster: look again
         const bool active = lane < take;
 #ifdef S5_TORUS_DEBUG
-        if (active) {
+        if (active && ph_sampled) {
             // PH_QUEUES = the transit of a RAY through the queues: from the stamp its slot got when it was given back to this take
             // (the first active lane's ray stands for the batch); the wave's own stamp starts here -- its idle time is no phase
             __builtin_amdgcn_s_waitcnt(0);
@@ -625,8 +634,6 @@ void torus_pool_kernel(PoolArgs args)
         if (active) {
             tag = do_rk4 ? TAG_R : TAG_V;
             bool on = true;
-            bool rk4_now = do_rk4;                                 // this lane owes the RK4 half of a call (whole R batch; thin: after a rejection)
-            const int run_max = thin ? POOL_RUN_THIN : POOL_RUN;
 #if !S5_MARCH_LEAN
             // by-value parameters (strict variant): the state of the ray in registers through the batch, as in round 3
             const TorusParams& p = A.p;
@@ -655,9 +662,9 @@ void torus_pool_kernel(PoolArgs args)
             float worst = pworst[slot];
 #endif
 #pragma unroll 1
-            for (int run = 0; run <= run_max; ++run) {
+            for (int run = 0; run <= POOL_RUN; ++run) {
                 if (on) {
-                    const bool was_rk4 = rk4_now;
+                    const bool was_rk4 = (run == 0 && do_rk4);     // the RK4 half of the pending call, then Verlet attempts
                     double dl;
                     bool advanced;
                     Metric g;                                      // metric at the end point of the step
@@ -686,7 +693,6 @@ void torus_pool_kernel(PoolArgs args)
 #endif
                     ph.mark(PH_LOAD);
                     if (was_rk4) {
-                        rk4_now = false;
                         dl = next_step_size(k, dl_max, s);        // the value the rejected attempt used
                         ph.mark(PH_STEPSIZE);
 #if S5_MARCH_LEAN
@@ -713,7 +719,7 @@ void torus_pool_kernel(PoolArgs args)
                         unsigned long long* dbg = (unsigned long long*)A.aux.k_end;
                         const unsigned long long mA = __builtin_amdgcn_ballot_w64(true);
                         const int w = was_rk4 ? 2 : 0;
-                        if (__builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u)) == 0u) {
+                        if (ph_sampled && __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u)) == 0u) {
                             atomicAdd(&dbg[w], 1ull); atomicAdd(&dbg[w + 1], (unsigned long long)__builtin_popcountll(mA));
                         }
                     }
@@ -722,9 +728,7 @@ void torus_pool_kernel(PoolArgs args)
                     ppass[slot] = s.pass;                          // the attempt counts as a pass either way (ref :168)
 #endif
                     if (!advanced) {
-                        tag = TAG_R;                              // x, k, dk untouched
-                        if (thin) rk4_now = true;                 // the RK4 half at the next pass of this loop, in this wave
-                        else on = false;
+                        tag = TAG_R; on = false;                  // x, k, dk untouched
                     } else {
                         tag = TAG_V;
 #if S5_MARCH_LEAN
@@ -737,15 +741,27 @@ void torus_pool_kernel(PoolArgs args)
                         }
                         if (!was_rk4) pd[PD_AT(PC_KT, slot)] = s.kt;      // (an RK4 step leaves kt as it was)
                         const auto& T = param_reload(A);
-                        const float worst = fmaxf(pworst[slot], s.error);
-                        pworst[slot] = worst;
+                        // Everything this phase reads of the job and of the pool is asked for HERE, in one go (round 6).  Read where
+                        // it was used -- the torus model inside accumulate_transfer, the four operands of the end test behind its
+                        // short-circuit branches -- every scalar load and LDS read was a round trip of its own with a wait behind it:
+                        // the phase took 2 400 cycles, more than metric + connection, for ~100 vector instructions
+                        // (profiles/r06_torus_call_phases.json); asked for together the round trips overlap.
+                        const TorusModel tm = { T.p.shape, T.p.torus_w, T.p.torus_r, T.p.cut_d2, T.p.inv_2w2, T.p.torus_l, T.p.emis0, T.p.absorb0 };
+                        const double max_error = T.p.max_error;
+                        const int max_steps = T.p.max_steps;
+                        const double r_in = cwd[1], r_out = cwd[2];
+                        const float worst_before = pworst[slot];
                         double I = pd[PD_AT(PC_I, slot)], tau = pd[PD_AT(PC_TAU, slot)];
                         s.E = pd[PD_AT(PC_E, slot)];
-                        accumulate_transfer(T.p, no_absorption, s, g, x, k, dl, I, tau);
+                        keep_here(tm.shape); keep_here(tm.torus_w); keep_here(tm.torus_r); keep_here(tm.cut_d2); keep_here(tm.inv_2w2);
+                        keep_here(tm.torus_l); keep_here(tm.emis0); keep_here(tm.absorb0); keep_here(max_error); keep_here(max_steps);
+                        const float worst = fmaxf(worst_before, s.error);
+                        pworst[slot] = worst;
+                        accumulate_transfer(tm, no_absorption, s, g, x, k, dl, I, tau);
                         pd[PD_AT(PC_I, slot)] = I;
                         pd[PD_AT(PC_TAU, slot)] = tau;
-                        const bool done = !(x[1] > cwd[1]) || !(x[1] < cwd[2]) || ((double)s.error > T.p.max_error) ||
-                                          (s.pass >= T.p.max_steps);
+                        // (no short circuit: four comparisons and three ORs instead of three branches)
+                        const bool done = (!(x[1] > r_in)) | (!(x[1] < r_out)) | ((double)s.error > max_error) | (s.pass >= max_steps);
                         if (done) {
                             const size_t ray = (size_t)pray[slot];
                             s.Q = T.start.d[COL_Q * T.start.cap + ray];
@@ -767,8 +783,7 @@ void torus_pool_kernel(PoolArgs args)
                     ph.mark(PH_STORE_TRANSFER);
                     ph.mark(PH_N);                                 // (two marks with nothing in between: the cost a mark leaves in an interval)
                 }
-                const int still = __builtin_popcountll(__builtin_amdgcn_ballot_w64(on));
-                if (thin ? (still == 0) : (POOL_KEEP_DEN * still < POOL_KEEP_NUM * take)) break;
+                if (POOL_KEEP_DEN * __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)) < POOL_KEEP_NUM * take) break;
             }
 #if !S5_MARCH_LEAN
             if (tag != TAG_EMPTY) {
