@@ -86,30 +86,24 @@ S5_DEV bool radial_roots(Geod& g, double r0, int& err)
     const double c_hi = +B / 2., c_lo = -B / 2.;
 
     g.nrr = (hi_real ? 2 : 0) + (lo_real ? 2 : 0);
-    if (hi_real && lo_real) {
-        // four real roots, descending.  Within a pair the "+" root is the larger one.
-        double p0 = c_hi + h_hi, p1 = c_hi - h_hi, p2 = c_lo + h_lo, p3 = c_lo - h_lo;
-        // merge the two ordered pairs (p0>=p1, p2>=p3)
-        double s0 = fmax(p0, p2), t0 = fmin(p0, p2);
-        double s3 = fmin(p1, p3), t3 = fmax(p1, p3);
-        double s1 = fmax(t0, t3), s2 = fmin(t0, t3);
-        g.r1[0] = s0; g.r2[0] = s1; g.r3[0] = s2; g.r4[0] = s3;
-        g.r1[1] = g.r2[1] = g.r3[1] = g.r4[1] = 0.0;
-    } else if (hi_real) {
-        g.r1[0] = c_hi + h_hi; g.r1[1] = 0.0;
-        g.r2[0] = c_hi - h_hi; g.r2[1] = 0.0;
-        g.r3[0] = c_lo; g.r3[1] = +h_lo;
-        g.r4[0] = c_lo; g.r4[1] = -h_lo;
-    } else if (lo_real) {
-        g.r1[0] = c_lo + h_lo; g.r1[1] = 0.0;
-        g.r2[0] = c_lo - h_lo; g.r2[1] = 0.0;
-        g.r3[0] = c_hi; g.r3[1] = +h_hi;
-        g.r4[0] = c_hi; g.r4[1] = -h_hi;
-    } else {
-        g.r1[0] = c_hi; g.r1[1] = +h_hi;
-        g.r2[0] = c_hi; g.r2[1] = -h_hi;
-        g.r3[0] = c_lo; g.r3[1] = +h_lo;
-        g.r4[0] = c_lo; g.r4[1] = -h_lo;
+    {
+        // The four cases -- both pairs real (four real roots, descending: within a pair the "+" root is the larger one, the two
+        // ordered pairs merged), the upper pair real, the lower pair real, none -- as SELECTS over values every lane forms: written
+        // as four branches that store into the struct, the compiler turned the imaginary parts into an indexed store to a
+        // private array (32 bytes of scratch in every kernel that inlines this routine).  Same values, same signs of zero.
+        const double p0 = c_hi + h_hi, p1 = c_hi - h_hi, p2 = c_lo + h_lo, p3 = c_lo - h_lo;
+        const double s0 = fmax(p0, p2), t0 = fmin(p0, p2);
+        const double s3 = fmin(p1, p3), t3 = fmax(p1, p3);
+        const double s1 = fmax(t0, t3), s2 = fmin(t0, t3);
+        const bool both = hi_real && lo_real, none = !hi_real && !lo_real;
+        g.r1[0] = both ? s0 : hi_real ? p0 : lo_real ? p2 : c_hi;
+        g.r2[0] = both ? s1 : hi_real ? p1 : lo_real ? p3 : c_hi;
+        g.r3[0] = both ? s2 : lo_real ? c_hi : c_lo;
+        g.r4[0] = both ? s3 : lo_real ? c_hi : c_lo;
+        g.r1[1] = none ? +h_hi : 0.0;
+        g.r2[1] = none ? -h_hi : 0.0;
+        g.r3[1] = both ? 0.0 : lo_real ? +h_hi : +h_lo;
+        g.r4[1] = both ? 0.0 : lo_real ? -h_hi : -h_lo;
     }
 
     if (g.nrr == 4) {
