@@ -7,7 +7,8 @@ import csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 job_ms = float(sys.argv[2]) if len(sys.argv) > 2 else None
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", "prof_spec")
+grid = sys.argv[3] if len(sys.argv) > 3 else "log"             # "uniform": the raw output of prof_spectrum.sh uniform
+src = os.path.join(root, "gpurun_out", "prof_spec_uniform" if grid == "uniform" else "prof_spec")
 pm = json.load(open(os.path.join(src, "spectrum_pmc.json")))
 c = {k: v["mean_128_energies"] for k, v in pm.items()}
 traces = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv")), key=os.path.getmtime)
@@ -35,7 +36,11 @@ out = {"what": "disk_spectrum_fast_kernel<true>, 1024^2 pixels x 128 energies (t
                                        "pairs read at immediate offsets with the loop counter on the scalar unit",
                    "round_5_frame_without_quotients": "41.5 M, 0.0949 ms: the local frame in four square roots and two reciprocals per pixel",
                    "round_5_eight_terms_per_reciprocal": "this record: u = e^-x, term = a u / (1 - u), eight terms over one reciprocal seed through a tree of (N, D) pairs: 15.25 slots per pair"}}
-json.dump(out, open(os.path.join(root, "profiles", tag + "_spectrum_pmc.json"), "w"), indent=1)
+if grid == "uniform":
+    out["what"] = out["what"].replace("128 energies", "128 energies in EQUAL steps 0.1 ... 30 keV (the recurrence along the energies: k_spectrum.hip planck_runs_uniform)")
+    out["history"]["round_6_uniform_grid"] = ("this record: lanes own runs of eight consecutive energies, e^-x of a pixel advances by one multiplication per energy, "
+                                              "eight pixels share a reciprocal: ~7.5 issue slots per pair (15.25 on an arbitrary grid)")
+json.dump(out, open(os.path.join(root, "profiles", tag + ("_spectrum_uniform_pmc.json" if grid == "uniform" else "_spectrum_pmc.json")), "w"), indent=1)
 print("kernel %.2f us, sum %.2f us, VALU %.1f M, busy %.1f %%, executed flop %.3e" % (
     out["kernel_time_us_rocprof_128_energies_second_half_of_its_launches"], out["sum_kernel_us"], c["SQ_INSTS_VALU"] / 1e6,
     c.get("VALUBusy", float("nan")), fl))

@@ -1,5 +1,5 @@
 """Spectrum job on the GPU box: time per job and the roofline fraction of bench.py's f3 line, for a few
-energy counts (python tests/tools/bench_spectrum.py [image side, default 1024])."""
+energy counts (python tests/tools/bench_spectrum.py [image side, default 1024] [log | uniform | all])."""
 import ctypes as C, math, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,13 @@ import sim5_amd.capi as capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 warm, reps = (300, 50) if n <= 1024 else (40, 10)
 d = capi.image_desc(n, n, 0.998, math.radians(70.0))
-for ne, uniform in ((1, False), (128, False), (256, False), (64, True), (128, True), (256, True), (512, True)):
+# grids: "log" (default: 1, 128, 256 energies on a logarithmic grid -- what tests/tools/prof_spectrum.sh profiles: its summary takes the
+# middle third of the launches for the 128-energy job), "uniform" (64, 128, 256 energies in equal steps: the recurrence along the
+# energies; same three-job shape), "all" (both, and 512 uniform)
+mode = sys.argv[2] if len(sys.argv) > 2 else "log"
+jobs = {"log": ((1, False), (128, False), (256, False)), "uniform": ((64, True), (128, True), (256, True)),
+        "all": ((1, False), (128, False), (256, False), (64, True), (128, True), (256, True), (512, True))}[mode]
+for ne, uniform in jobs:
     E = np.linspace(0.1, 30.0, ne) if uniform else 10.0 ** np.linspace(-1, 1.5, ne)
     dE = capi.DeviceBuffer(E.nbytes); dE.from_numpy(E); dS = capi.DeviceBuffer(E.nbytes)
     capi._lib.sim5gpu_disk_spectrum_workspace.restype = capi.SZ
