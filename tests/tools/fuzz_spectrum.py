@@ -4,7 +4,7 @@ full-precision Planck function, ref python/sim5diskraytrace.py:340-390, python/s
 inclination, image size (odd and even), field of view, hardening factor, limb darkening on/off, disk spin equal or not, 1..400
 energies on log grids of random span (up to 1e13 keV: the bounded form of the loop), and random row sub-sets (the unpaired kernel).
 Every bin above 1e-250 of the peak within 1e-6; bins the strict kernel has at zero at zero; two runs identical.
-usage: python tests/tools/fuzz_spectrum.py [n_cases] [seed]"""
+usage: python tests/tools/fuzz_spectrum.py [n_cases] [seed] [uniform]   (uniform: grids in equal steps, 64 .. 400 energies)"""
 import sys, math, time, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import sim5_amd.capi as capi
@@ -26,6 +26,11 @@ for case in range(ncases):
     ne = int(rng.choice([1, 7, 64, 128, 200, 256, 400, rng.integers(1, 400)]))
     lo = float(rng.uniform(-4, 0)); hi = lo + float(rng.choice([rng.uniform(0.5, 4), rng.uniform(4, 16)]))
     E = 10.0 ** np.linspace(lo, hi, ne)
+    if len(sys.argv) > 3 and sys.argv[3] == "uniform":
+        # round 6: EQUAL steps (>= 64 energies take the recurrence along the energies, k_spectrum.hip planck_runs_uniform) -- from
+        # 10^lo up to a random multiple of it, so that runs start in the Rayleigh-Jeans range and end in the Wien tail
+        ne = int(rng.choice([64, 71, 128, 200, 256, 400, rng.integers(64, 400)]))
+        E = np.linspace(10.0 ** lo, 10.0 ** lo * float(rng.choice([3.0, 30.0, 1e3, 1e5])), ne)
     if rng.random() < 0.3:
         y0 = int(rng.integers(0, ny)); y1 = int(rng.integers(y0 + 1, ny + 1))
     else:
