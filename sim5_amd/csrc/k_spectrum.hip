@@ -83,11 +83,29 @@ S5_DEV void spectrum_pixel(const PRM& p, const SpectrumParams& sp, const ThinRay
 // quotients: four and five).  Agreement with the tetrad chain: rounding (tests/test_py_diskraytrace.py, 1e-6 of every bin against
 // the strict kernel and against the reference's Python classes).
 template <class PRM>
-S5_DEV void spectrum_stage_equatorial(const PRM& p, const SpectrumParams& sp, const ThinRay& t, double l, double sqrt_q,
+S5_DEV void spectrum_stage_equatorial(const PRM& p, const SpectrumParams& sp, const ThinRay& t, double l, double q, double sqrt_q,
                                       double x_scale, double amp0, double& x1, double& amp)
 {
     x1 = 1.0; amp = 0.0;
-    if (t.cls == PX_HIT0 && t.flux != 0.0) {
+    // The reference forms the photon's momentum at the crossing (photon_momentum, ref src/sim5kerr.c:1175-1195) and drops the
+    // pixel when that is not a number (g = NaN fails `g > 0`, ref python/sim5diskraytrace.py:113): R(r) = (r^2 + a^2 - a l)^2 -
+    // Delta ((l - a)^2 + q) below -1e-8.  In real arithmetic R >= 0 on a geodesic; a crossing AT the ray's pericentre (P = Rpc:
+    // r = rp exactly, ref src/sim5kerr-geod.c:309) has R = 0 and the reference's sum of terms of 1e8 comes out at +-1e-8 -- a
+    // pixel it keeps or drops by rounding.  The closed form below needs no k^r, but the same pixels must count: the
+    // reference's expression, its operations in its order (round 6: tests/tools/fuzz_spectrum.py 1500 6301 uniform, case 575 --
+    // the strict kernel without the pixel at r = rp = 99.43, this one with it: 2.8e-5 of the spectrum).
+    bool momentum_is_a_number = true;
+    {
+        const double a = p.a, r = t.r;
+        const double a2 = a * a, r2 = r * r;
+        const double D = r2 - 2. * r + a2;
+        double R = sq(r2 + a2 - a * l) - D * (sq(l - a) + q);
+        if ((R < 0.0) && (-R < 1e-8)) R = 0.0;
+        double M = q;                                                          // (m = 0: M = q - l^2 m^2 / (1 - m^2) + a^2 m^2)
+        if ((M < 0.0) && (-M < 1e-8)) M = 0.0;
+        momentum_is_a_number = !(R < 0.0) && !(M < 0.0);
+    }
+    if (t.cls == PX_HIT0 && t.flux != 0.0 && momentum_is_a_number) {
         const double a = p.a, af = p.disk.a, r = t.r;
         const double rl = fmax(p.disk.rms, r);                                 // disk_ell: l(r) of the inner edge below it
         const double x = sqrt_pos(rl);
@@ -235,11 +253,11 @@ S5_DEV double planck_sum(const double2* __restrict__ sXA, int first, int step, i
 // consecutive energies (thread t: run t mod RP, pixel sub-set t / RP); a lane takes eight of its pixels at a time -- u at the
 // head of its run by the exponential of planck_sum (1e-8, as there; the energy is the grid's own value, not E_0 + j dE), tau
 // from the staged column (made once per pixel by the exponential of s5_trig.hpp: the eight-fold product must not carry eight
-// times 1e-8) -- and walks the eight energies: per energy w = 1 - u, b = amp u for the eight pixels, their eight terms b / w over
-// ONE reciprocal (the tree of planck_sum), u *= tau.  3 + 3.25 slots per (pixel, energy) pair + 10 / 8 for the head of the
-// run: ~7.5 against 15.25.  acc[k] = the lane's sum for energy k of its run.
+// times 1e-8) -- and walks the eight energies: per energy w = 1 - b / amp for the eight pixels (one fma each), their eight terms b / w
+// over ONE reciprocal (the tree of planck_sum), b *= tau.  2 + 3.25 slots per (pixel, energy) pair + 11 / 8 for the head of the
+// run: ~6.6 against 15.25.  acc[k] = the lane's sum for energy k of its run.
 template <int RP>
-S5_DEV void planck_runs_uniform(const double2* __restrict__ sXA, const double* __restrict__ sTau, int subset, int npix, double E_head, double acc[8])
+S5_DEV void planck_runs_uniform(const double2* __restrict__ sXA, const double2* __restrict__ sTR, int subset, int npix, double E_head, double acc[8])
 {
     constexpr double C1 = 0.6931471879266856, C2 = 0.2402264979496441, C3 = 0.05550357433648187, C4 = 0.009618237494183314,
                      C5 = 0.0013390735475399872, C6 = 0.00015403512618661003;
@@ -251,12 +269,15 @@ S5_DEV void planck_runs_uniform(const double2* __restrict__ sXA, const double* _
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.0;
     for (int q = subset; q < npix; q += 8 * SUBSETS) {
-        double u[8], tau[8], amp[8];
+        // what is carried along a run is b = amp u (the numerator of the term); the denominator 1 - u = 1 - b / amp is ONE fma
+        // with the staged reciprocal of the amplitude (0 for a dark pixel: b = 0, w = 1, a term of 0) -- two slots per pair
+        // before the tree instead of three (u *= tau, w = 1 - u, b = amp u)
+        double b[8], tau[8], ramp[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const double2 xa = sXA[q + i * SUBSETS];
-            tau[i] = sTau[q + i * SUBSETS];
-            amp[i] = xa.y;
+            const double2 tr = sTR[q + i * SUBSETS];
+            tau[i] = tr.x; ramp[i] = tr.y;
             const double tm = __builtin_fma(nE, xa.x, M);
             const double f = __builtin_fma(nE, xa.x, -(tm - M));
             double e = hfmac(f, c6, C5);
@@ -265,13 +286,13 @@ S5_DEV void planck_runs_uniform(const double2* __restrict__ sXA, const double* _
             e = hfmac(f, e, C2);
             e = hfmac(f, e, C1);
             e = __builtin_fma(f, e, 1.0);
-            u[i] = __builtin_amdgcn_ldexp(e, __double2loint(tm));
+            b[i] = xa.y * __builtin_amdgcn_ldexp(e, __double2loint(tm));
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            double b[8], w[8];
+            double w[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { w[i] = 1.0 - u[i]; b[i] = amp[i] * u[i]; }
+            for (int i = 0; i < 8; ++i) w[i] = __builtin_fma(-b[i], ramp[i], 1.0);
             const double N01 = __builtin_fma(b[0], w[1], b[1] * w[0]), D01 = w[0] * w[1];
             const double N23 = __builtin_fma(b[2], w[3], b[3] * w[2]), D23 = w[2] * w[3];
             const double N45 = __builtin_fma(b[4], w[5], b[5] * w[4]), D45 = w[4] * w[5];
@@ -282,7 +303,7 @@ S5_DEV void planck_runs_uniform(const double2* __restrict__ sXA, const double* _
             acc[k] = __builtin_fma(N, __builtin_amdgcn_rcp(D), acc[k]);
             if (k < 7) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) u[i] *= tau[i];
+                for (int i = 0; i < 8; ++i) b[i] *= tau[i];
             }
         }
     }
@@ -326,13 +347,14 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
         // the constants of motion of the pair (ref src/sim5kerr-geod.c:76-77) for the frame: l, sqrt(q)
         const double l = -alpha * p.sin_i;
         const double b = (beta == 0.0) ? +1e-6 : beta;
-        const double sqrt_q = msqrt(b * b + (p.cos_i * p.cos_i) * (alpha * alpha - p.a * p.a));     // (q < 0: NaN, no limb darkening, as with the tetrads)
+        const double q = constant_q(b, p.cos_i, alpha, p.a);                                        // ref src/sim5kerr-geod.c:77 (the caller's spin; its roundings: s5_geod.hpp)
+        const double sqrt_q = msqrt(q);                                                             // (q < 0: NaN, no limb darkening, as with the tetrads)
         const double planck_h = 6.626069e-27, kev2freq = 2.417990e+17, c2 = 8.987554e+20, kB = 1.380650e-16;
         const double f = sp.hardening;
         const double amp0 = mdiv(2.0 * planck_h * (kev2freq * kev2freq * kev2freq) * kev2freq, c2 * (f * f * f * f));
         const double x_scale = mdiv(1.44269504088896340736 * (planck_h * kev2freq), kB * f);
-        spectrum_stage_equatorial(p, sp, t, l, sqrt_q, x_scale, amp0, x0, amp_0);
-        if (second) spectrum_stage_equatorial(p, sp, t2, l, sqrt_q, x_scale, amp0, x1, amp_1);
+        spectrum_stage_equatorial(p, sp, t, l, q, sqrt_q, x_scale, amp0, x0, amp_0);
+        if (second) spectrum_stage_equatorial(p, sp, t2, l, q, sqrt_q, x_scale, amp0, x1, amp_1);
     }
     // the largest |energy| of the job, by every wave for itself (a few loads and six lane exchanges; no LDS)
     double e_max = 0.0;
@@ -358,13 +380,13 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
     __syncthreads();
     sXA[tid] = make_double2(x0, amp_0);
     sXA[tid + 256] = make_double2(x1, amp_1);
-    double* const sTau = lds + 1024;                                         // [512] uniform grid: 2^(-dE sX) of every staged pixel
-    double* const sRed = lds + 1536;                                         // [2048] uniform grid: the lanes' sums, [energy of the pass][sub-set]
+    double2* const sTR = reinterpret_cast<double2*>(lds + 1024);             // [512] uniform grid: (2^(-dE sX), 1 / amplitude) of every staged pixel
+    double* const sRed = lds + 2048;                                         // [2048] uniform grid: the lanes' sums, [energy of the pass][sub-set]
     if (uniform) {
         // e^(-dE x) to full precision (s5_trig.hpp mexp: 1.7e-16); an argument below -700 is 0 for every purpose of the loop
         const double ln2 = 0.693147180559945309417;
-        sTau[tid] = mexp(fmax(-(dE * x0) * ln2, -700.0));
-        sTau[tid + 256] = mexp(fmax(-(dE * x1) * ln2, -700.0));
+        sTR[tid] = make_double2(mexp(fmax(-(dE * x0) * ln2, -700.0)), (amp_0 > 0.0) ? 1.0 / amp_0 : 0.0);
+        sTR[tid + 256] = make_double2(mexp(fmax(-(dE * x1) * ln2, -700.0)), (amp_1 > 0.0) ? 1.0 / amp_1 : 0.0);
     }
     const bool beyond = !(x0 * e_max < 1073741824.0) || !(x1 * e_max < 1073741824.0);
     // (the barrier the staged pixels need anyway)  any pixel whose exponent could leave the 32-bit range: planck_sum<true>
@@ -382,8 +404,8 @@ void disk_spectrum_fast_kernel(ImageParams p, SpectrumParams sp, const double* _
             double acc[8];
             const bool live = run < runs;
             const double Eh = live ? energies[jh] : 1.0;
-            if (rp == 16) planck_runs_uniform<16>(sXA, sTau, subset, npix_u, Eh, acc);
-            else planck_runs_uniform<8>(sXA, sTau, subset, npix_u, Eh, acc);
+            if (rp == 16) planck_runs_uniform<16>(sXA, sTR, subset, npix_u, Eh, acc);
+            else planck_runs_uniform<8>(sXA, sTR, subset, npix_u, Eh, acc);
             const int subsets = 256 / rp;
 #pragma unroll
             for (int k = 0; k < 8; ++k) sRed[((tid % rp) * 8 + k) * subsets + subset] = acc[k];
