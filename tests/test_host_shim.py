@@ -57,6 +57,10 @@ def test_scalar_api_host_side_is_clean_under_thread_sanitizer(tmp_path):
     between -- with the host shim compiled by gcc -fsanitize=thread over the test double: no data race reported (the lazily
     resolved function pointers, the library handle, the record / look-ahead switches and the per-thread records), and the
     text of the eight-thread run is the single-threaded run's."""
+    probe = tmp_path / "tsan_probe.c"
+    probe.write_text("int main(void) { return 0; }\n")
+    if subprocess.run(["gcc", "-fsanitize=thread", str(probe), "-o", str(tmp_path / "tsan_probe")], capture_output=True).returncode != 0:
+        pytest.skip("this gcc has no ThreadSanitizer runtime")
     so = _stub(tmp_path, tsan=True)
     exe = str(tmp_path / "threads_tsan")
     subprocess.run(["gcc", "-fsanitize=thread", "-g", "-O1", "-w", "-fgnu89-inline", os.path.join(ROOT, "tests", "c", "shim_threads.c"),
