@@ -52,6 +52,19 @@ def test_single_gpu_line_carries_every_config():
     # worth of the same rays: its spectrum is 16 times the other's to the accuracy of the pixel quadrature
     assert x["f3_spectrum_1024_x128"]["roofline_frac"] > 0.25 and x["f3_spectrum_4096_x128"]["roofline_frac"] > 0.30
     assert abs(x["f3_spectrum_4096_x128"]["spectrum_sum"] / (16 * x["f3_spectrum_1024_x128"]["spectrum_sum"]) - 1) < 1e-3
+    # round 6: a uniform energy grid takes the recurrence along the energies (measured 0.47 / 0.57; floors well under), and its
+    # spectrum at 4096^2 is 16 times the one at 1024^2 to the accuracy of the pixel quadrature
+    fu = x["f3_spectrum_uniform_grid"]
+    assert fu["1024_x128"]["roofline_frac"] > 0.40 and fu["4096_x128"]["roofline_frac"] > 0.48, fu
+    assert fu["1024_x128"]["job_ms"] < 0.85 * x["f3_spectrum_1024_x128"]["job_ms"]
+    assert abs(fu["4096_x128"]["spectrum_sum"] / (16 * fu["1024_x128"]["spectrum_sum"]) - 1) < 1e-3
+    # round 6: the march kernel with the loads of its store phase issued together (measured 0.257; round 5: 0.2525)
+    assert x["c4_1024_torus_verlet"]["roofline_frac"] > 0.24
+    # round 6: raytrace() one call at a time through the scalar API (host-side; skipped without gcc): the look-ahead's records
+    # against one launch per call, and the same call counts as the same program over the reference library
+    rt = x["scalar_api_raytrace_loop"]
+    assert ("skipped" in rt) or (rt["calls_per_s"] > 1.5e5 and rt["calls_per_s"] > 2 * rt["one_launch_per_call_calls_per_s"]
+                                 and rt.get("same_calls_per_ray_as_the_reference", True) is True), rt
     c5 = x["c5_8192_x8_inclinations"]
     assert c5["hits_ok"] and len(c5["per_inclination"]) == 8
     assert all(v["disk_hits"] == v["disk_hits_reference"] for v in c5["per_inclination"].values())
