@@ -1139,42 +1139,7 @@ def main():
         kstep_max = max(float(v[1].item()) for v in allv)
         per_rank = {"kernel_ms_per_step": [float(v[1].item()) for v in allv],
                     "rays_per_launch": [sharding.rank_rows(n, r, world, dealt=dealt) * n if striped else n * n for r in range(world)]}
-    # N > 1: SURVEY 8(d) / BASELINE.md 3 quote the scaling metric on KERNEL time (image write included, gather reported apart).  A
-    # wall-clocked region of its own: every rank traces its share of K images back to back -- the launches of the timed region, no
-    # gather, no placement -- between a barrier + device synchronisation on both sides; max over ranks.  (Buffer: the one that does
-    # NOT hold the last assembled image; a rank's rows are rewritten with the same values.)
-    kernel_only = None
-    if world > 1:
-        def kernel_only_region():
-            b = pipe.count % pipe.nbuf
-            fence()
-            k0 = time.perf_counter()
-            for _ in range(args.steps):
-                for job in jobs:
-                    if not striped:
-                        job.trace(pipe.full[0], True)
-                    elif rank == 0:
-                        view = pipe.full[b][:, pipe.band[0]:pipe.band[1]] if pipe.band else None
-                        if job.band_desc is not None and job.desc is not None:
-                            job.trace_both(pipe.full[b], view)
-                        else:
-                            job.trace(pipe.full[b], True)
-                            if job.band_desc is not None:
-                                job.trace_band(view)
-                    else:
-                        job.trace(pipe.tiles[b], False)
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            return time.perf_counter() - k0
-        kdt = guarded(dist, torch, cdev, rank, world, "kernel-only region", kernel_only_region)
-        t = torch.tensor([kdt], dtype=torch.float64, device=cdev)
-        allk = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allk, t)
-        kernel_only = {"wall_s_max_over_ranks": max(float(v[0].item()) for v in allk), "wall_s_per_rank": [float(v[0].item()) for v in allk],
-                       "steps": args.steps,
-                       "what": "every rank's launches of the timed region (its share of K images, written to its buffers) back to back, "
-                               "no gather and no placement, between barrier + device synchronisation on both sides; host wall clock, max over ranks"}
+    kernel_only = {}                        # N > 1: filled by the kernel-only region, the first of the phases behind the guard (below)
     # the timed region is over on every rank (the all_gather above); the phases below are optional measurements, each entered
     # only after all ranks have agreed that they are still sound
     agree(dist, torch, cdev, rank, world, bool(kstep == kstep), "timed region", "kernel timing is NaN")
@@ -1210,7 +1175,7 @@ def main():
                 # BASELINE.md section 3 / SURVEY 8(d): "kernel time incl. image write; gather and D2H copy separately" -- `value` is the
                 # whole job (tracing + gather + assembly into a row-major image, every step), `value_kernel_only` the same rays over
                 # the slowest rank's kernel time per step (HIP events in the timed region)
-                "value_kernel_only": (rays * args.steps / kernel_only["wall_s_max_over_ranks"] if kernel_only else
+                "value_kernel_only": (rays * args.steps / kernel_only["wall_s_max_over_ranks"] if kernel_only.get("wall_s_max_over_ranks") else
                                       rays * 1e3 / kstep_max if kstep_max > 0 else None),
                 "value_kernel_only_from_events": rays * 1e3 / kstep_max if kstep_max > 0 else None,
                 "kernel_ms_per_step_max_over_ranks": kstep_max,
@@ -1278,8 +1243,8 @@ def main():
             out["process_group"] = group
             if per_rank:
                 out["per_rank"] = per_rank
-            if kernel_only:
-                out["kernel_only_region"] = kernel_only
+            if kernel_only.get("wall_s_max_over_ranks"):
+                out["kernel_only_region"] = dict(kernel_only)
             if world > 1:
                 # which number is which: SURVEY 8(d) / BASELINE.md 3 define the metric on KERNEL time (image write
                 # included) with the gather reported separately
@@ -1338,8 +1303,47 @@ def main():
         if guard:
             guard.fallback = json.dumps(build_out(None, None, "line serialised before the optional phases started")[0])
             guard.make_line = lambda why: json.dumps(build_out(None, None, why)[0])
+    # N > 1: SURVEY 8(d) / BASELINE.md 3 quote the scaling metric on KERNEL time (image write included, gather reported apart).  A
+    # wall-clocked region of its own: every rank traces its share of K images back to back -- the launches of the timed region, no
+    # gather, no placement -- between a barrier + device synchronisation on both sides; max over ranks.  (Buffer: the one that does
+    # NOT hold the last assembled image; a rank's rows are rewritten with the same values.)  It runs BEHIND the guard, as the first of
+    # the phases after the timed region: it is collective (barriers), so a rank that failed in it would leave the others waiting --
+    # the headline line must be safe before it starts; if it does not come through, value_kernel_only falls back to the events.
+    def measure_kernel_only():
+        def kernel_only_region():
+            b = pipe.count % pipe.nbuf
+            fence()
+            k0 = time.perf_counter()
+            for _ in range(args.steps):
+                for job in jobs:
+                    if not striped:
+                        job.trace(pipe.full[0], True)
+                    elif rank == 0:
+                        view = pipe.full[b][:, pipe.band[0]:pipe.band[1]] if pipe.band else None
+                        if job.band_desc is not None and job.desc is not None:
+                            job.trace_both(pipe.full[b], view)
+                        else:
+                            job.trace(pipe.full[b], True)
+                            if job.band_desc is not None:
+                                job.trace_band(view)
+                    else:
+                        job.trace(pipe.tiles[b], False)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            return time.perf_counter() - k0
+        kdt = kernel_only_region()
+        t = torch.tensor([kdt], dtype=torch.float64, device=cdev)
+        allk = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allk, t)
+        kernel_only.update({"wall_s_max_over_ranks": max(float(v[0].item()) for v in allk), "wall_s_per_rank": [float(v[0].item()) for v in allk],
+                       "steps": args.steps,
+                       "what": "every rank's launches of the timed region (its share of K images, written to its buffers) back to back, "
+                               "no gather and no placement, between barrier + device synchronisation on both sides; host wall clock, max over ranks"})
     direct = c5_scan = None
     try:
+        if world > 1:
+            measure_kernel_only()
         # one gather on its own (not overlapped), after the timed region: the exchange time next to the compute time
         if striped:
             gms, gsamples = time_gather(torch, dist, capi, pipe, stream, 3 if one_gpu_test else 10, one_gpu_test)
