@@ -36,7 +36,11 @@ S5_DEV void rt_metric(const RayState& s, double r, double m, Metric& g)
 }
 S5_DEV void rt_connection(const RayState& s, double r, double m, Conn& G)
 {
+#if S5_FAST
+    if (s.opt_gr) kerr_connection_compact<false>(s.bh_spin, r, m, nullptr, G); else flat_connection(r, m, G);
+#else
     if (s.opt_gr) kerr_connection(s.bh_spin, r, m, G); else flat_connection(r, m, G);
+#endif
 }
 
 S5_DEV void raytrace_prepare(double bh_spin, const double x[4], const double k[4], double precision,
