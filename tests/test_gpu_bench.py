@@ -58,8 +58,9 @@ def test_single_gpu_line_carries_every_config():
     assert fu["1024_x128"]["roofline_frac"] > 0.40 and fu["4096_x128"]["roofline_frac"] > 0.48, fu
     assert fu["1024_x128"]["job_ms"] < 0.85 * x["f3_spectrum_1024_x128"]["job_ms"]
     assert abs(fu["4096_x128"]["spectrum_sum"] / (16 * fu["1024_x128"]["spectrum_sum"]) - 1) < 1e-3
-    # round 6: the march kernel with the loads of its store phase issued together (measured 0.257; round 5: 0.2525)
-    assert x["c4_1024_torus_verlet"]["roofline_frac"] > 0.24
+    # round 6: the march kernel with the loads of its store phase issued together and the connection in compact form
+    # (measured 0.282; round 5: 0.2525)
+    assert x["c4_1024_torus_verlet"]["roofline_frac"] > 0.265
     # round 6: raytrace() one call at a time through the scalar API (host-side; skipped without gcc): the look-ahead's records
     # against one launch per call, and the same call counts as the same program over the reference library
     rt = x["scalar_api_raytrace_loop"]
