@@ -67,6 +67,41 @@ S5_DEV double surface_height(const double* sR, const double* sH, int n, double R
     return sH[lo] + w * (sH[hi] - sH[lo]);
 }
 
+// The same value with the segment GUESSED first (round 6).  The segment of R -- the one pair of neighbours with sR[lo] < R <=
+// sR[lo + 1]; unique, the table is strictly ascending -- is looked for where a table in equal steps would have it (index from
+// (R - R_0) (n - 1) / (R_(n-1) - R_0)): two table reads in one round trip, and one more read for the neighbour on the side the
+// comparison points to.  Where neither holds R (a table in unequal steps) the bisection above decides.  Whatever finds the
+// segment, the interpolation is the same expression on the same nodes: the same bits.  Why: the bisection is eight DEPENDENT
+// LDS round trips, and a walk step of some lane of a wave ends at almost every sub-step of the wave -- the walk kernel's
+// waves waited on these reads (VALU busy 69 % at three waves per SIMD: profiles/r05_jobs_summary.json; the job 4.00 -> 3.80 ms
+// in one call, profiles/r06_surface_guess_ab.txt).
+S5_DEV double surface_height_guess(const double* sR, const double* sH, int n, double R, double R_first, double steps_per_R)
+{
+    if (!(R > R_first)) return sH[0];
+    const double R_last = sR[n - 1];
+    if (R >= R_last) return sH[n - 1] * (R / R_last);
+    int g = (int)((R - R_first) * steps_per_R);
+    g = g > n - 3 ? n - 3 : g; g = g < 1 ? 1 : g;                     // candidates g - 1, g, g + 1: nodes g - 1 .. g + 2
+    int lo = g;
+    double xl = sR[g], xh = sR[g + 1];
+    if (!(xl < R)) { lo = g - 1; xh = xl; xl = sR[g - 1]; }
+    else if (!(R <= xh)) { lo = g + 1; xl = xh; xh = sR[g + 2]; }
+    if (n < 4 || !(xl < R && R <= xh)) {                              // a table in unequal steps (or too short to guess in): the bisection
+        int hi;
+        surface_segment(sR, n, R, lo, hi);
+        xl = sR[lo]; xh = sR[hi];
+    }
+    const double w = (R - xl) / (xh - xl);
+    const double hl = sH[lo], hh = sH[lo + 1];
+    return hl + w * (hh - hl);
+}
+
+S5_DEV double surface_height_guess(const double* sR, const double* sH, int n, double R)
+{
+    const double R_first = sR[0];
+    return surface_height_guess(sR, sH, n, R, R_first, (double)(n - 1) / (sR[n - 1] - R_first));
+}
+
 // The two ladders of a lane take 2 x 2 x rungs x 8 B of LDS.  The set-up kernel keeps all 8 rungs a double-precision
 // modulus can need (64 KB per workgroup; it runs once).  The walk kernel keeps 6 -- enough unless a modulus is within
 // 3e-6 of 1, i.e. the ray within ~1e-6 of the critical curve -- so that three workgroups (48 KB + table each) share a
@@ -129,19 +164,44 @@ S5_DEV void grow_step(WalkState& w, double Pe, double re, double me, const doubl
 {
     const double R1 = re * sqrt(1. - me * me);
     w.H1 = re * me;
-    w.Hd = surface_height(sR, sH, n_table, R1);
+    w.Hd = surface_height_guess(sR, sH, n_table, R1);
     if ((w.Hd < w.H1) || (w.r0 > 5e6) || (w.grow + 1 >= 64)) {
         if (!(w.Hd < w.H1)) w.state = ST_DONE;                                // :283 (Hd >= H1, or NaN): failed
         else { w.P = Pe; w.r = re; w.m = me; w.step_factor = 1.0; w.walk_it = 0; begin_forward(w); }
     } else { w.r0 = 2.0 * w.r0; ++w.grow; }
 }
 
+// a wave-uniform double in scalar registers (its two halves through v_readfirstlane)
+S5_DEV double scalar_copy(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// The radius a retry starts from (ref py :325 -> :265): max(200, 1.1 rp, (0.5 + iteration) sqrt(alpha^2 + beta^2) / cos(view)).
+// A ray retries at most three times in a walk of thousands of sub-steps, and the walk sits at its register bound: the
+// ray's own terms (rp, alpha, beta) are read from its record when the retry comes instead of being kept in registers
+// through the walk; cos(view) is the same for every ray of a job and lives in scalar registers.
+struct RetryRadius {
+    const Geod* records;       // the job's geodesic records (ray i = blockIdx.x * SURF_BLOCK + threadIdx.x)
+    double cos_view;           // wave-uniform
+    S5_DEV double operator()(int iteration) const
+    {
+        const Geod* g = records + ((size_t)blockIdx.x * SURF_BLOCK + threadIdx.x);
+        const double alpha = g->alpha, beta = g->beta, rp = g->rp;
+        return fmax(fmax(200.0, 1.1 * rp), (0.5 + iteration) * sqrt(alpha * alpha + beta * beta) / cos_view);
+    }
+};
+
 // The walk: sub-steps of geodesic_follow (ref c :903-924) and the decisions after each call (ref py :296-331) until
 // the ray leaves it -- found, failed, equatorial crossing or retry from further out.  `ev` supplies r(P) and mu(P).
 template <class Eval>
-S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clamped, double twoRpc, double rp,
-                        double alpha_beta, double cos_view, const double* sR, const double* sH, int n_table)
+S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clamped, double twoRpc, const RetryRadius& retry_radius,
+                        const double* sR, const double* sH, int n_table)
 {
+    // where a table in equal steps has the segment of R: first node and segments per unit of R (wave-uniform: scalar registers)
+    const double R_first = scalar_copy(sR[0]);
+    const double steps_per_R = scalar_copy((double)(n_table - 1) / (sR[n_table - 1] - sR[0]));
     const double accuracy = 1e-2;                                            // ref py :268
     const double rbh = r_horizon(a_in);
     const double rbh_follow = 1.01 * r_horizon(a_clamped);                   // geodesic_follow's own limit, ref c :913
@@ -194,7 +254,7 @@ S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clam
                 else {
                     const double R1 = w.r * sqrt(1. - w.m * w.m);
                     w.H1 = w.r * w.m;
-                    w.Hd = surface_height(sR, sH, n_table, R1);
+                    w.Hd = surface_height_guess(sR, sH, n_table, R1, R_first, steps_per_R);
                     if (w.H1 <= w.Hd) {                                               // surface hit? :307
                         if (w.step < accuracy) { w.fstep = -w.step / 2.; w.purpose = BACK_HALF; }
                         else { w.fstep = -w.step; w.purpose = BACK_FULL; }
@@ -205,13 +265,7 @@ S5_DEV void follow_loop(WalkState& w, const Eval& ev, double a_in, double a_clam
                     else if (w.r > 1.1 * w.r0) {                                      // :325 retry from further out
                         ++w.iteration;
                         if (w.iteration > 3) w.state = ST_DONE;
-#if S5_FAST
-                        // (the caller passes alpha_beta / cos_view in alpha_beta and max(200, 1.1 rp) in rp: two doubles kept
-                        // through the walk instead of three -- the walk sits one register under its occupancy bound)
-                        else { w.r0 = fmax(rp, (0.5 + w.iteration) * alpha_beta); w.grow = 0; w.state = ST_GROW; }
-#else
-                        else { w.r0 = fmax(fmax(200.0, 1.1 * rp), (0.5 + w.iteration) * alpha_beta / cos_view); w.grow = 0; w.state = ST_GROW; }
-#endif
+                        else { w.r0 = retry_radius(w.iteration); w.grow = 0; w.state = ST_GROW; }
                     }
                     else if (w.m < 0.0) w.state = ST_DONE;                            // :326
                     else if (w.step < accuracy / 2.) w.state = ST_DONE;               // :327
@@ -291,20 +345,18 @@ void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restri
 
     WalkState w = wk.ws[i];
     GeodTrack<SURF_BLOCK, NST> trk;
-    double a_clamped, alpha_beta, cos_view;
+    double a_clamped;
+    RetryRadius retry_radius;
     {
         const Geod gd = wk.gd[i];
         trk.build(gd, sLad + threadIdx.x);
-        a_clamped = gd.a;
+        // the clamped spin and the inclination are the job's, the same in every record: scalar registers
+        a_clamped = scalar_copy(gd.a);
         const double disk_theta = atan(surface_height(sR, sH, p.n_table, 1e6) / 1e6);
-        alpha_beta = sqrt(gd.alpha * gd.alpha + gd.beta * gd.beta);
-        cos_view = cos(gd.incl + disk_theta);
+        retry_radius.records = wk.gd;
+        retry_radius.cos_view = scalar_copy(cos(gd.incl + disk_theta));
     }
-#if S5_FAST
-    follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, fmax(200.0, 1.1 * trk.rp), alpha_beta / cos_view, 1.0, sR, sH, p.n_table);
-#else
-    follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, trk.rp, alpha_beta, cos_view, sR, sH, p.n_table);
-#endif
+    follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, retry_radius, sR, sH, p.n_table);
     wk.ws[i] = w;
     // (the rays this walk hands to the slow steps are NOT counted here: the walk sits at its register bound -- 168 for three waves
     // per SIMD -- and a ballot at its end spilled four registers and cost 7 % of the job; the slow kernel still sweeps)

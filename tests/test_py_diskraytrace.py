@@ -274,6 +274,33 @@ def test_surface_table_of_maximum_size_and_bad_tables(golden, capi, strict):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+def test_surface_height_lookup_on_any_spacing(capi, strict):
+    """The walk looks the segment of R up where a table in equal steps has it (k_surface.hip surface_height_guess) and
+    falls back to the bisection where that guess and its neighbours do not hold R.  One straight surface H = (R - 2) / 4
+    given on 256 equal steps (the guess holds), on 2 and on 3 nodes (too short to guess in), in geometric steps and in
+    steps that grow as a power (the neighbours or the bisection decide) is the same surface up to the rounding of the
+    interpolation: the same rays hit it, at the same points."""
+    a, inc, rmax, n = 0.9, 70.0, 20.0, 128
+    ax = ((np.arange(n) + .5) / n - .5) * 2 * rmax
+    al, be = np.meshgrid(ax, ax)
+    tables = {"equal": np.linspace(2.0, 60.0, 256), "two": np.array([2.0, 60.0]), "three": np.array([2.0, 7.0, 60.0]),
+              "geometric": np.geomspace(2.0, 60.0, 200), "power": 2.0 + 58.0 * np.linspace(0, 1, 300) ** 1.7,
+              "nearly_equal": np.linspace(2.0, 60.0, 256) + 0.2 * np.sin(np.arange(256.0))}
+    tables["nearly_equal"][[0, -1]] = 2.0, 60.0
+    res = {k: capi.disk_surface_rays(a, math.radians(inc), t, 0.25 * (t - 2.0), al.ravel(), be.ravel(), strict=strict)
+           for k, t in tables.items()}
+    base = res["equal"]
+    ok = base["status"] == 1
+    assert ok.sum() > 0.8 * n * n
+    for k, s in res.items():
+        assert (s["status"] == base["status"]).mean() > 0.9995, k
+        both = ok & (s["status"] == 1)
+        d = np.abs(s["r"][both] - base["r"][both])
+        assert np.max(d) < 2e-2 and np.median(d) < 1e-9, (k, np.max(d), np.median(d))
+
+
+@pytest.mark.gpu
 def test_thick_disk_image(golden, capi):
     """DiskRaytrace.image() for a disk with a tabulated photosphere (surface search kernel + surface tetrad,
     g-factor and emission angle through the batch calls) against the reference's own Python class run on the
