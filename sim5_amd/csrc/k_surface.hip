@@ -358,8 +358,7 @@ void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restri
     }
     follow_loop(w, trk, p.a, a_clamped, 2. * trk.Rpc, retry_radius, sR, sH, p.n_table);
     wk.ws[i] = w;
-    // (the rays this walk hands to the slow steps are NOT counted here: the walk sits at its register bound -- 168 for three waves
-    // per SIMD -- and a ballot at its end spilled four registers and cost 7 % of the job; the slow kernel still sweeps)
+    // (the rays this walk hands to the slow steps are NOT counted here: see surface_slow_kernel)
 }
 
 // the rare steps: equatorial crossing (ref py :317-320) and a new search for the starting radius after the ray
@@ -367,6 +366,12 @@ void surface_walk_kernel(SurfaceParams p, SurfaceWork wk, const double* __restri
 __global__ __launch_bounds__(SURF_BLOCK)
 void surface_slow_kernel(SurfaceParams p, SurfaceWork wk, const double* __restrict__ tabR, const double* __restrict__ tabH, const int round)
 {
+    // Only a walk leaves rays for the slow steps (the set-up and the slow steps themselves leave FOLLOW or DONE): when no ray
+    // walked in this round -- one word each, counted by whoever put the rays into FOLLOW -- there is nothing to look for.
+    // (Rounds 1-3 of a job without retries: 19 us each for reading the state of every ray.  The walk itself does not count
+    // what it hands over: any use of the state after its loop changes the loop's register allocation -- a ballot or a second
+    // store cost 40 moves per sub-step, 14 % of the kernel, measured in round 6.)
+    if (wk.counters[CNT_WALK + round] == 0u && wk.counters[CNT_DEEP + round] == 0u) return;
     extern __shared__ double lds[];
     double* sR = lds;
     double* sH = sR + p.n_table;
