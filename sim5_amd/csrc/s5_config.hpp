@@ -102,6 +102,17 @@
 // constant address space (kernel-argument segment, read-only tables): loads through such a pointer are scalar loads
 #define S5_AS4 __attribute__((address_space(4)))
 
+// A floating-point literal as a value in SCALAR registers.  A 64-bit literal cannot be an operand of a vector instruction; left
+// to itself the compiler often materialises it in a vector register pair right before its use (two v_mov_b32, then v_fmac with
+// the constant as the tied accumulator): three vector issue slots for one fused multiply-add in a Horner step, in kernels that
+// are bound by vector issue.  Through this (pure, CSE-able) asm the constant is two s_mov_b32 -- the scalar unit, which has slack
+// -- and the multiply-add reads it as its one scalar operand.  The VALUE is the literal: results are the same bits.
+__device__ __forceinline__ double sconst(double c)
+{
+    asm("" : "+s"(c));
+    return c;
+}
+
 // Parameters behind a constant-address-space reference: the same object through a pointer the optimiser cannot see through,
 // so the loads that follow are issued from here on (not hoisted to the kernel's head and held -- spilled -- in SGPRs).  A
 // by-value argument block passes through unchanged.

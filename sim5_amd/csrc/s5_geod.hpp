@@ -554,11 +554,11 @@ struct GeodTrack {
     static S5_DEV double sqrt_one_minus(double x)
     {
         double p;
-        if (TINY) p = fma(x, -0.0625, -0.125);
+        if (TINY) p = fma(x, sconst(-0.0625), -0.125);
         else {
-            p = fma(x, -0.02734375, -0.0390625);
-            p = fma(x, p, -0.0625);
-            p = fma(x, p, -0.125);
+            p = fma(x, sconst(-0.02734375), -0.0390625);
+            p = fma(x, p, sconst(-0.0625));
+            p = fma(x, p, sconst(-0.125));
         }
         p = fma(x, p, -0.5);
         return fma(x, p, 1.0);
