@@ -1,7 +1,7 @@
 import sys, math, numpy as np
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import sim5_amd.capi as capi
-n=1024; a=0.9; inc=70/180*math.pi; rmax=20.0
+n=int(sys.argv[1]) if len(sys.argv)>1 else 1024; a=0.9; inc=70/180*math.pi; rmax=20.0
 ax=((np.arange(n)+.5)/n-.5)*2*rmax
 al,be=np.meshgrid(ax,ax); al=al.ravel().copy(); be=be.ravel().copy()
 tR=np.linspace(2.0,60.0,256); tH=0.25*(tR-2.0)
@@ -17,4 +17,4 @@ for strict in (0,1):
     e1.record(); ms=e0.elapsed_ms(e1)/3
     st=o["st"].to_numpy(np.int32,(N,)); r=o["r"].to_numpy(np.float64,(N,))
     out.append("%s %.3f ms hits %d sum_r %.10e"%("strict" if strict else "fast",ms,int((st==1).sum()),float(r[st==1].sum())))
-print(" | ".join(out))
+print("n=%d: "%n + " | ".join(out))
