@@ -161,10 +161,15 @@ S5_DEV void polar_m2_host_rounding(double q, double l2, double a2, double& m2m, 
     m2p = (q + q) / X;
 }
 
-// the two range tests on m2p that the last bit can decide: m2p against 1 (ref :1140) and |m| against sqrt(m2p) (ref :1153)
-S5_DEV bool polar_tests_marginal(double m2p, double s_m2p, double m)
+// The two range tests on m2p that rounding can decide: m2p against 1 (ref :1140) and |m| against sqrt(m2p) (ref :1153).
+// How far rounding moves m2p depends on the sum X = sqrt(qla^2 + 4 q a^2) + qla: with qla < 0 and |q| << a^2 it cancels, and X --
+// with it m2p = 2q / X -- carries a relative error of ~ulp |qla| / |X| (found by the campaign of round 6: alpha = 0 and
+// beta^2 ~ a^2 cos^2 i gave the reference m2p = 1 + 1.4e-12 -- rejected -- and this arithmetic 1 - 3e-12).  The margin is
+// 1e-12 scaled by that factor; l = 0 (m2p = 1 in real arithmetic) is marginal whatever came out.
+S5_DEV bool polar_tests_marginal(double m2p, double s_m2p, double m, double l2, double qla, double X)
 {
-    return (fabs(m2p - 1.0) < 1e-12) || (fabs(s_m2p - fabs(m)) < 1e-12);
+    const double wide = 1e-12 * fmax(fabs(X), fabs(qla));           // 1e-12 max(1, |qla| / |X|), times |X|
+    return (l2 == 0.0) || (fabs(m2p - 1.0) * fabs(X) < wide) || (fabs(s_m2p - fabs(m)) * fabs(X) < wide);
 }
 
 // Carter's constant of a ray from infinity (ref :77; the caller's spin, not the clamped one), in the reference's roundings
@@ -200,7 +205,7 @@ S5_DEV bool polar_roots(Geod& g, double m, int& err)
     g.m2m = mdiv(X, a2 + a2);
     g.m2p = mdiv(q + q, X);
     double s_m2p = msqrt(g.m2p);
-    if (polar_tests_marginal(g.m2p, s_m2p, m)) {             // the last bit decides: the reference's roundings, an IEEE root
+    if (polar_tests_marginal(g.m2p, s_m2p, m, l2, qla, X)) {  // rounding decides: the reference's roundings, an IEEE root
         polar_m2_host_rounding(q, l2, a2, g.m2m, g.m2p);
         s_m2p = sqrt(g.m2p);
     }

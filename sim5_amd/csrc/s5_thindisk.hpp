@@ -117,7 +117,7 @@ S5_DEV void thin_disk_owed_flux(const PRM& p, ThinRay& out, ThinRay& out2)
 // pair kernel: SGPR spills 44 -> 28, -1.2 % time; the same pointer made in the kernel and handed down: +3 %).
 // iy: the image row of (alpha, beta_in) when the caller made them with pixel_alpha / pixel_beta, -1 for a caller's own ray.
 // Used by the fast variant's cold re-trace alone.  For a height that is not a power of two pixel_beta gives a row of the LOWER
-// half minus its mirror row's value -- within an ulp of the reference's own quotient, and that ulp decides the polar range
+// half minus its mirror row's value -- the reference's own value to the rounding of its quotient (iy + .5) / ny, and that last place decides the polar range
 // tests of the rays for which they are marginal (the central column of an odd width: polar_tests_marginal).  So the direct
 // routine is handed the reference's own beta of such a row -- beta_test0 for this ray, beta_test1 for the mirror ray of a pair,
 // NaN where the ray's beta is the reference's already -- and forms the q of THOSE TESTS from it, per ray; everything else of
@@ -347,8 +347,8 @@ S5_DEV void thin_disk_finish_direct(const PRM& p, ThinRay& out, ThinRay& out2, c
     // power of two -- has its OWN q in those tests: err_m[]; where the given beta's roots fail them and a ray's own pass, the
     // shared polar roots are the passing ray's, an ulp away)
     int err_m[2] = {-1, -1};                                // >= 0: this member's own verdict of the polar range tests
-    if (S5_ANY(polar_tests_marginal(m2p, s_m2p, p.cos_i))) {
-        if (polar_tests_marginal(m2p, s_m2p, p.cos_i)) {
+    if (S5_ANY(polar_tests_marginal(m2p, s_m2p, p.cos_i, l2, qla, XT))) {
+        if (polar_tests_marginal(m2p, s_m2p, p.cos_i, l2, qla, XT)) {
             polar_m2_host_rounding(q, l2, a2, m2m, m2p);
             s_m2p = sqrt(m2p);
             const bool own0 = (beta_test0 == beta_test0), own1 = PAIR && (beta_test1 == beta_test1);
@@ -679,11 +679,19 @@ S5_DEV void thin_disk_finish(const PRM& p_in, ThinRay& out, ThinRay& out2, const
     // either threshold is left to the direct routine, which forms m2p with the reference's own roundings (s5_geod.hpp
     // polar_m2_host_rounding) -- as an error code of its own: the lane idles through this routine like any rejected ray, both
     // rays of a pair (they share the polar roots).  One subtraction more than the exact tests.
+    // l = 0 exactly (alpha = 0: the central column) is left to the direct routine whatever m2p came out as: m2p = 1 there in
+    // real arithmetic, but with |q| << a^2 the sum XT cancels and the computed m2p is rounding noise well away from 1 (found by
+    // the campaign of round 6: 2 pixels in 40 000 jobs with beta^2 ~ a^2 cos^2 i on that column -- the reference rejects the
+    // ray, this routine called it a miss; the image is the same, the class plane was not).
+    // The margin is 1e-12 times max(1, |qla| / |XT|): where XT cancels (qla < 0, |q| << a^2) the computed m2p carries that much
+    // more rounding noise (s5_geod.hpp polar_tests_marginal).
     double mmT = 0.0, mK = 0.0;
     if (err == GD_OK) {
-        const double s_near = s_m2p - 1e-12;
-        if (m2p <= 0.0) err = GD_E_MUPLUS;
-        else if (m2p >= 1.0 - 1e-12) err = GD_E_LAST_BIT;
+        const double margin = 1e-12 * fmax(1.0, fabs(qla) * fabs(mdiv(1.0, XT)));
+        const double s_near = s_m2p - margin;
+        if (l2 == 0.0) err = GD_E_LAST_BIT;
+        else if (m2p <= 0.0) err = GD_E_MUPLUS;
+        else if (m2p >= 1.0 - margin) err = GD_E_LAST_BIT;
         else if (q > 0.0) {
             // mK = 1/sqrt(a^2 (m2p + m2m)) first; the modulus m2p/(m2p + m2m) is then m2p a^2 mK^2
             const double rk = rsqrt_pos(a2 * (m2p + m2m));
@@ -937,7 +945,11 @@ S5_DEV double pixel_beta(const PRM& p, int iy)
     // Other heights: the reference's own expression for the rows of the upper half, and for a row of the lower half MINUS the
     // value of its mirror row -- the two rows of a mirrored pair must get opposite beta exactly (the reference's quotients of
     // rows iy and ny-1-iy are not always each other's complement in the last bit), so the upper half has the reference's
-    // number and the lower half is within an ulp of it
+    // number and the lower half has it to the rounding of the quotient: (iy + .5) / ny - 0.5 cancels, so the two rows' values
+    // round apart by up to 2^-53 / |iy / ny - 0.5| relative (5 and 15 units in the last place in the two cases looked at).  What
+    // that costs: r(beta) of the REFERENCE has steps of 1e-9 .. 2e-7 where the iteration count of its own sn / cn changes
+    // (CA = 1e-8, src/sim5elliptic.c:544); a lower-half pixel whose beta falls across such a step from the reference's differs
+    // from it by the step.  Seen at 3 pixels in 80 000 random jobs (2e9 pixels): 1.7e-7 .. 2.3e-7, DESIGN.md section 5.
     if ((p.ny & (p.ny - 1)) == 0) return ((double)(2 * iy + 1 - p.ny) * (0.5 * p.inv_ny)) * 2.0 * p.rmax * p.ny_over_nx;
     const bool lower = (2 * iy + 1 > p.ny);
     const int jy = lower ? p.ny - 1 - iy : iy;

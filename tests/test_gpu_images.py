@@ -236,7 +236,11 @@ def test_random_image_shapes_and_parameters(capi):
 
 DEGENERATE_JOBS = [(0.9, 60.0, 201, 128), (0.998, 70.0, 301, 200), (0.5, 30.0, 151, 100), (0.0, 45.0, 99, 64),
                    (0.9, 60.0, 128, 201), (0.998, 70.0, 200, 301), (0.5, 30.0, 100, 151), (0.0, 45.0, 64, 99), (0.7, 80.0, 255, 255),
-                   (0.2610441040764561, 7.6689822933994, 85, 253)]      # (found by tests/tools/fuzz_images.py 1500 5001, case 89)
+                   (0.2610441040764561, 7.6689822933994, 85, 253),      # (found by tests/tools/fuzz_images.py 1500 5001, case 89)
+                   # fuzz_images.py 40000 8101, case 21925: alpha = 0 and beta^2 ~ a^2 cos^2 i, so |q| << a^2 and the sum under the polar
+                   # roots cancels -- the reference has m2p = 1 + 1.4e-12 there and rejects the ray; the fast variant's own m2p was
+                   # further than its margin of 1e-12 from 1 and it called the ray a miss (s5_geod.hpp polar_tests_marginal)
+                   (0.9, 76.46772616849847, 49, 26)]
 
 
 def degenerate_sets_report(capi):
@@ -301,6 +305,17 @@ def test_degenerate_sets_against_the_live_reference(capi):
             # round 5: the reference's class on EVERY pixel of both sets as well -- also where the reference itself flips under
             # an ulp of its inputs (same inputs, same roundings: s5_x87.hpp)
             assert rec[v]["elsewhere_differs"] == 0 and rec[v]["column_differs"] == 0 and rec[v]["row_differs"] == 0, rec
+
+
+def test_central_pixel_with_cancelling_polar_roots(capi):
+    """alpha = 0 AND beta = 0 (the centre of an odd x odd image) at spin 1e-5: q = 1.6e-13 against a^2 = 1e-10, the sum under the
+    polar roots cancels and m2p is rounding noise around 1.  The reference's loop does not take this field of view, so the
+    strict variant (the reference's operation order, x87 roundings included) stands in: the fast variant must hand the ray to
+    the same routine and give the same class on every pixel (fuzz_images.py 40000 8101, case 32282)."""
+    a, inc, nx, ny, rmax = 1e-05, 84.73166605663945, 255, 105, 6.692265192804282
+    f = capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), rmax=rmax), full=True)
+    s = capi.disk_image(capi.image_desc(nx, ny, a, deg2rad(inc), rmax=rmax, strict=True), full=True)
+    assert np.array_equal(f["cls"], s["cls"]), np.argwhere(f["cls"] != s["cls"]).tolist()
 
 
 def test_fast_and_strict_variants_agree(capi):

@@ -20,7 +20,8 @@ c = ol.cpu_disk_image("port", nx, ny, a, inc, nthreads=8, full=True) if (order =
 print("classes of fast and strict equal:", bool(np.array_equal(f["cls"], s["cls"])))
 same = (f["cls"] == s["cls"]) & np.isfinite(s["r"])
 er = np.where(same, np.abs(f["r"] / s["r"] - 1), 0)
-for (iy, ix) in np.argwhere(er > 1e-10)[:12]:
+worst_first = sorted(map(tuple, np.argwhere(er > 1e-10)), key=lambda t: -er[t])
+for (iy, ix) in worst_first[:12]:
     print("pixel (%d,%d) cls %d gtype %d  r fast %.15g strict %.15g %s  rel %.2e | g fast %.12g strict %.12g" % (
         iy, ix, f["cls"][iy, ix], f["gtype"][iy, ix], f["r"][iy, ix], s["r"][iy, ix],
         ("oracle %.15g (strict-oracle %.1e, fast-oracle %.1e)" % (c["r"][iy, ix], abs(s["r"][iy, ix] / c["r"][iy, ix] - 1), abs(f["r"][iy, ix] / c["r"][iy, ix] - 1))) if c is not None else "",
@@ -41,8 +42,12 @@ if len(bad):
     be = ((iy + .5) / ny - 0.5) * 2.0 * rm * (ny / nx)
     r0 = o.disk_pixel(deg2rad(inc), a, rms, al, be).r
     print("checker at the reference's (alpha, beta): r = %.15g" % r0)
-    for name, da, db in (("beta + 1 ulp", 0, 1), ("beta - 1 ulp", 0, -1), ("alpha + 1 ulp", 1, 0), ("alpha - 1 ulp", -1, 0)):
-        a2 = np.nextafter(al, math.inf if da > 0 else -math.inf) if da else al
-        b2 = np.nextafter(be, math.inf if db > 0 else -math.inf) if db else be
+    def ulps(x, k):
+        for _ in range(abs(k)):
+            x = float(np.nextafter(x, math.inf if k > 0 else -math.inf))
+        return x
+    for name, da, db in (("beta + 1 ulp", 0, 1), ("beta - 1 ulp", 0, -1), ("beta + 2 ulp", 0, 2), ("beta - 2 ulp", 0, -2), ("alpha + 1 ulp", 1, 0), ("alpha - 1 ulp", -1, 0)):
+        a2 = ulps(al, da)
+        b2 = ulps(be, db)
         r1 = o.disk_pixel(deg2rad(inc), a, rms, float(a2), float(b2)).r
         print("  %-14s r = %.15g   moved by %.2e (relative)" % (name, r1, abs(r1 / r0 - 1)))

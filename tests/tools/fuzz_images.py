@@ -76,10 +76,26 @@ for case in range(ncases):
             rm_ = rmax if rmax > 0.0 else rms + 8.0
             al0 = ((wx + .5) / nx - 0.5) * 2.0 * rm_; be0 = ((wy + .5) / ny - 0.5) * 2.0 * rm_ * (ny / nx)
             r0 = orc.disk_pixel(deg2rad(inc), a, rms, al0, be0).r
-            moved = max(abs(orc.disk_pixel(deg2rad(inc), a, rms, float(np.nextafter(al0, al0 + da)), float(np.nextafter(be0, be0 + db))).r / r0 - 1)
-                        for da, db in ((0, 1), (0, -1), (1, 0), (-1, 0)))
+            # (TWO units for beta: the fast variant gives a row of the lower half minus the value of its mirror row, and the two
+            # quotients can round apart by two -- case 1610 of the 40 000-job campaign of round 6, profiles/r06_fuzz_summary.txt)
+            def ulps(x, k):
+                for _ in range(abs(k)):
+                    x = float(np.nextafter(x, x + k))
+                return x
+            moved = max(abs(orc.disk_pixel(deg2rad(inc), a, rms, ulps(al0, da), ulps(be0, db)).r / r0 - 1)
+                        for da, db in ((0, 1), (0, -1), (1, 0), (-1, 0), (0, 2), (0, -2)))
             if moved >= 0.5 * er_map[wy, wx]:
-                explained = " [pixel (%d,%d): the CHECKER's r moves by %.1e for one ulp of alpha / beta -- the difference is the input's]" % (wy, wx, moved)
+                explained = " [pixel (%d,%d): the CHECKER's r moves by %.1e for one or two ulp of alpha / beta -- the difference is the input's]" % (wy, wx, moved)
+            elif 2 * wy + 1 > ny and (ny & (ny - 1)) != 0:
+                # a row of the lower half of a height that is not a power of two: the fast variant's beta is MINUS the value of the
+                # mirror row (s5_thindisk.hpp pixel_beta).  (iy + .5) / ny - 0.5 cancels, so the two rows' values round apart by up to
+                # 2^-53 / |iy / ny - 0.5| relative -- a few to a few hundred units in the last place.  The checker AT THAT beta:
+                be_img = -((((ny - 1 - wy) + .5) / ny - 0.5) * 2.0 * rm_ * (ny / nx))
+                r_own = orc.disk_pixel(deg2rad(inc), a, rms, al0, be_img).r
+                if abs(r_own / sym["r"][wy, wx] - 1) < 1e-9:
+                    explained = (" [pixel (%d,%d): at the fast variant's own beta, %d ulp from the reference's, the CHECKER has the fast variant's r to %.1e"
+                                 " and its r at the reference's beta is %.1e away: a step of the reference's own r(beta)]" % (
+                                     wy, wx, int(round((be_img - be0) / np.spacing(be0))), abs(r_own / sym["r"][wy, wx] - 1), abs(r_own / r0 - 1)))
         if explained:
             note_in = explained
         elif er > 1e-7 or eg > 1e-7 or ef > 1e-6:
