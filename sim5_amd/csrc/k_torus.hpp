@@ -28,6 +28,8 @@ struct TorusAux {
 } // namespace s5abi
 
 namespace s5 { int launch_torus_strict(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream);
-               size_t release_torus_workspace_strict(); }
+               size_t release_torus_workspace_strict();
+               // the strict variant's start kernel over the rays the fast job marked (k_torus.hip START_AGAIN)
+               hipError_t launch_torus_start_again_strict(const s5abi::TorusParams& p, double* cols, size_t cap, int* ok, hipStream_t stream); }
 namespace s5f { int launch_torus_fast(const s5abi::TorusParams& p, sim5gpu_stokes* out, const s5abi::TorusAux& aux, hipStream_t stream);
                 size_t release_torus_workspace_fast(); }

@@ -15,6 +15,7 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 bad = 0
 tot_rays = {"strict": 0, "fast": 0}; tot_diff = {"strict": 0, "fast": 0}; degenerate_diff = {"strict": 0, "fast": 0}
+above_1e6 = {"strict": 0, "fast": 0}; excused = {"strict": 0, "fast": 0}
 t0 = time.time()
 for case in range(ncases):
     a = float(rng.choice([0.1, 0.3, 0.9, 0.998, rng.uniform(0.01, 0.99)]))
@@ -49,15 +50,25 @@ for case in range(ncases):
         tot_rays[tag] += same.size; tot_diff[tag] += int((~same).sum())
         m = same & (steps > 0) & regular
         if m.any():
-            er = np.abs(xe[m, 1] / ref["x_end"][m, 1] - 1).max()
-            eI = (np.abs(S[m, 0] - ref["I"][m]) / max(float(ref["I"].max()), 1e-300)).max()
-            if er > (1e-6 if strict else 1e-5) or eI > 1e-5:
-                w = np.nonzero(m)[0][np.argmax(np.abs(xe[m, 1] / ref["x_end"][m, 1] - 1))]
-                msg.append("%s: r_end %.1e I %.1e (ray alpha %.3f beta %.3f: %d steps, median %d)" % (
-                    tag, er, eI, al[w], be[w], steps[w], int(np.median(ref["steps"]))))
+            # every component of the end state, I and tau at 1e-6 in BOTH variants (the suite's bar: test_gpu_raytrace.py
+            # compare_rays); a ray above it passes only if the CHECKER's own result moves by as much for +-1 ulp of its start state
+            errs = T.ray_errors({"x_end": xe, "k_end": ke, "I": S[:, 0], "tau": S[:, 4]}, ref)
+            tot = np.max(np.stack(list(errs.values())), axis=0)
+            over = np.nonzero(m & (tot > 1e-6))[0]
+            if over.size:
+                kap = T.oracle_sensitivity(ol.ORACLE_SO, "orc_", a, deg2rad(inc), al[over], be[over],
+                                           {k: v[over] for k, v in ref.items()}, r0=r0, precision=prec, absorb0=absorb0, torus_r=tr, torus_w=tw)
+                above_1e6[tag] += int(over.size); excused[tag] += int((tot[over] <= kap).sum())
+                bad_rays = over[tot[over] > kap]
+                if bad_rays.size:
+                    w = bad_rays[np.argmax(tot[bad_rays])]
+                    msg.append("%s: %d ray(s) above 1e-6 that the checker's own sensitivity does not cover, worst %.1e (ray %d alpha %.3f beta %.3f: %d steps, median %d; %s)" % (
+                        tag, bad_rays.size, tot[w], w, al[w], be[w], steps[w], int(np.median(ref["steps"])),
+                        ", ".join("%s %.1e" % (kk, vv[w]) for kk, vv in errs.items() if vv[w] > 1e-7)))
     print("case %3d a=%.4g inc=%.1f n=%d r0=%.0f prec=%g absorb=%g torus(%.1f,%.1f) mean steps %.0f : %s" % (
         case, a, inc, n, r0, prec, absorb0, tr, tw, ref["steps"].mean(), "ok" if not msg else "; ".join(msg)), flush=True)
     bad += bool(msg)
 print("%d cases, %d with findings, %.0f s; rays with another step count than the CPU loop: strict %d of %d, fast %d of %d" % (
     ncases, bad, time.time() - t0, tot_diff["strict"], tot_rays["strict"], tot_diff["fast"], tot_rays["fast"]))
 print("alpha = 0 rays with another count (left out above): strict %d, fast %d" % (degenerate_diff["strict"], degenerate_diff["fast"]))
+print("rays above 1e-6 in some component: strict %d (%d covered by the checker's own +-1 ulp sensitivity), fast %d (%d)" % (above_1e6["strict"], excused["strict"], above_1e6["fast"], excused["fast"]))
