@@ -217,6 +217,44 @@ def test_thick_disk_surface_search(golden, capi, strict):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fast"])
+def test_thick_disk_surface_search_over_tables_spins_and_fields(golden, capi, strict):
+    """sim5gpu_disk_surface_rays against the reference's Python __find_surface over what the six cases above hold fixed
+    (oracle/gen_golden_surface.py: 60 jobs, 11 760 rays): tables in equal, logarithmic and growing steps with 2 .. 256 nodes --
+    flat, thin, steep, with a bump --, spins 0 .. 0.998, inclinations 8 .. 85 degrees (one job with the observer below the
+    disk's surface: no ray arrives), fields of view from 12 to 150 (the wide ones have rays that go through the reference's
+    retries).  The same rays succeed, at the same points."""
+    g = golden("py_surface_more.npz")
+    rays = hits = 0
+    worst = {"r": 0.0, "m": 0.0, "k": 0.0}
+    for ci, (a, inc, rmax, ti) in enumerate(g["cases"]):
+        a = max(float(a), 1e-4)          # the reference's class works with this spin throughout (python/sim5diskraytrace.py:32), as does sim5_amd/diskraytrace.py
+        s = capi.disk_surface_rays(float(a), math.radians(float(inc)), g["c%d_R" % ci], g["c%d_H" % ci],
+                                   g["c%d_alpha" % ci], g["c%d_beta" % ci], strict=strict)
+        ok = g["c%d_ok" % ci] == 1
+        assert np.array_equal(s["status"] == 1, ok), (ci, str(g["table_names"][int(ti)]), float(a), float(inc), int(((s["status"] == 1) != ok).sum()))
+        rays += ok.size; hits += int(ok.sum())
+        if not ok.any():
+            continue
+        r_ref, m_ref, k_ref = g["c%d_r" % ci][ok], g["c%d_m" % ci][ok], g["c%d_k" % ci][ok]
+        worst["r"] = max(worst["r"], float(np.max(np.abs(s["r"][ok] / r_ref - 1))))
+        worst["m"] = max(worst["m"], float(np.max(np.abs(s["m"][ok] - m_ref))))
+        # (a component of k next to a turning point of the ray is the root of a difference that cancels -- photon_momentum,
+        # src/sim5kerr.c:1176-1177 -- and r within 5e-10 moves it by far more than its own size: each component is held to
+        # 1e-5 of itself or of 1e-3 of the ray's largest component, whichever is larger)
+        kscale = np.maximum(np.abs(k_ref), 1e-3 * np.max(np.abs(k_ref), axis=1, keepdims=True))
+        ek = np.abs(s["k"][ok] - k_ref) / kscale
+        if ek.max() > worst["k"]:
+            j = np.unravel_index(int(np.argmax(ek)), ek.shape)
+            worst["k_where"] = "job %d ray %d component %d: k %s reference %s" % (ci, int(np.nonzero(ok)[0][j[0]]), j[1], s["k"][ok][j[0]].tolist(), k_ref[j[0]].tolist())
+        worst["k"] = max(worst["k"], float(ek.max()))
+    print("surface search, %d jobs, %d rays (%d on the surface), %s: worst r %.1e m %.1e k %.1e" % (
+        len(g["cases"]), rays, hits, "strict" if strict else "fast", worst["r"], worst["m"], worst["k"]))
+    assert hits > 0.8 * rays
+    assert worst["r"] < 1e-6 and worst["m"] < 1e-6 and worst["k"] < 1e-5, worst
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(0.9, 70.0, 20.0), (0.998, 30.0, 12.0), (0.2, 60.0, 40.0)], ids=["a0.9", "a0.998", "a0.2"])
 def test_surface_walk_increments_match_full_evaluation(capi, case):
     """The fast variant walks with the addition theorems of sn, cn, dn between full evaluations (s5_geod.hpp, GeodTrack::
