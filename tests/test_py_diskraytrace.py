@@ -123,6 +123,29 @@ def test_fused_spectrum_kernel(golden, capi):
 
 
 @pytest.mark.gpu
+def test_fused_spectrum_kernel_over_disks_and_grids(golden, capi):
+    """sim5gpu_disk_spectrum against the reference's Python classes over what the six cases above hold fixed
+    (oracle/gen_golden_spectrum.py, 36 jobs): image sizes 12 .. 28, spins 0 .. 0.998, inclinations 5 .. 86 degrees, masses 5 ..
+    1e8 and accretion rates 0.01 .. 1 (spectra that peak from the optical to hard X-rays), fields of view r_ms + 8 / 20 / 60,
+    energy grids in logarithmic and in EQUAL steps (24 .. 100 energies: the general loop and the recurrence), every
+    combination of limb darkening and hardening.  Both variants, every bin within 1e-6 (bins below 1e-9 of the peak: of
+    that)."""
+    g = golden("py_spectrum_more.npz")
+    worst = {False: 0.0, True: 0.0}
+    for ci, (a, inc, N, mass, mdot, rmax, limb, hard, equal) in enumerate(g["cases"]):
+        E, ref = g["c%d_E" % ci], g["c%d_spec" % ci]
+        assert ref.max() > 0
+        for strict in (False, True):
+            d = capi.image_desc(int(N), int(N), max(float(a), 1e-4), math.radians(float(inc)), rmax=float(rmax), disk_spin=float(a),
+                                bh_mass=float(mass), mdot=float(mdot), alpha_visc=0.1, strict=strict)
+            got = capi.disk_spectrum(d, E, hardening=float(hard), limb_darkening=int(limb))
+            err = float(np.max(np.abs(got - ref) / np.maximum(ref, 1e-9 * ref.max())))
+            worst[strict] = max(worst[strict], err)
+            assert err < 1e-6, (ci, "strict" if strict else "fast", err, [float(x) for x in g["cases"][ci]])
+    print("spectrum against the reference's Python classes, %d jobs: worst bin fast %.1e strict %.1e" % (len(g["cases"]), worst[False], worst[True]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_energies,lo,hi", [(128, -1.0, 1.5), (64, -2.0, 2.0), (256, -3.0, 3.0), (300, -2.0, 2.0), (17, -1.0, 1.0),
                                               (128, -3.0, 12.0), (40, -6.0, 13.0), (1, 0.0, 0.0)],
                          ids=["128", "64", "256", "300-two-passes", "17-run-time-stride", "128-to-1e12-keV", "40-to-1e13-keV", "one"])
