@@ -383,3 +383,35 @@ def test_thick_disk_image(golden, capi):
                 err = np.max(np.abs(img[k][have] - ref[k][have]) / np.maximum(np.abs(ref[k][have]), 1e-3 * np.abs(ref[k][have]).max()))
                 assert err < tol, (ci, fused, k, err)
             assert np.max(np.abs(img["mue"][have] - ref["mue"][have])) < 1e-3          # degrees
+
+
+@pytest.mark.gpu
+def test_thick_disk_image_over_tables_flows_and_disks(golden, capi):
+    """DiskRaytrace.image() of a disk with a tabulated photosphere against the reference's own Python class over what the six
+    cases above hold fixed (oracle/gen_golden_thick.py, 30 jobs of 12 x 12 pixels): six surface tables (equal, logarithmic and
+    growing steps; thin, steep, flaring, with a bump), no / slow / fast radial inflow, spins 0 .. 0.998, inclinations 8 .. 80
+    degrees (at 80 most rays end in the disk's flank), masses 10 and 1e6, two accretion rates, fields of view 15 / 30 / 80.  The
+    one kernel (sim5gpu_disk_surface_frame) and the call-by-call path: the same pixels lit, every plane within the
+    tolerances of test_thick_disk_image."""
+    from sim5_amd.diskraytrace import DiskModel_Surface, DiskRaytrace
+    g = golden("py_thick_more.npz")
+    worst = {}
+    for ci, (a, inc, rmax, Ns, mass, mdot, ti, vkind) in enumerate(g["cases"]):
+        disk = DiskModel_Surface(float(mass), float(a), float(mdot), 0.1, g["c%d_tR" % ci], g["c%d_tH" % ci], table_vr=g["c%d_tV" % ci])
+        ref = {k: g["c%d_%s" % (ci, k)] for k in ("flux", "gfactor", "mue", "T", "R", "H", "V")}
+        have = np.isfinite(ref["flux"])
+        for fused in (True, False):
+            img = DiskRaytrace(float(mass), float(a), 10.0, disk).image(float(inc), float(rmax), int(Ns), fused=fused)
+            assert np.array_equal(np.isfinite(img["flux"]), have), (ci, fused, int((np.isfinite(img["flux"]) != have).sum()))
+            if not have.any():
+                continue
+            for k, tol in (("R", 1e-6), ("H", 1e-5), ("gfactor", 1e-6), ("T", 1e-6), ("V", 1e-6), ("flux", 1e-5)):
+                scale = np.maximum(np.abs(ref[k][have]), 1e-3 * max(float(np.abs(ref[k][have]).max()), 1e-300))
+                err = float(np.max(np.abs(img[k][have] - ref[k][have]) / scale))
+                worst[k] = max(worst.get(k, 0.0), err)
+                assert err < tol, (ci, fused, k, err, [float(x) for x in g["cases"][ci]])
+            emu = float(np.max(np.abs(img["mue"][have] - ref["mue"][have])))
+            worst["mue_deg"] = max(worst.get("mue_deg", 0.0), emu)
+            assert emu < 1e-3, (ci, fused, emu)          # degrees
+    print("thick-disk images against the reference's Python class, %d jobs: worst %s" % (len(g["cases"]), {k: "%.1e" % v for k, v in worst.items()}))
+
