@@ -203,7 +203,7 @@ def test_vectors(capi, golden):
     assert_close(capi.dotprod(g["v1"], g["v2"], None), g["dot_flat"], floor=1e-12, what="dotprod flat")
     vn = capi.vector_norm_to(g["v1"], g["norm"], met)
     bad = np.isnan(g["vn"]).any(axis=1)
-    assert np.array_equal(np.isnan(vn).any(axis=1), bad) and bad.sum() < 40
+    assert np.array_equal(np.isnan(vn).any(axis=1), bad) and bad.sum() < 0.05 * bad.size          # (40 of the fixture's 800)
     assert_close(vn[~bad], g["vn"][~bad], floor=1e-12, what="vector_norm_to")
     # the scaled vectors do have the norm asked for
     chk = capi.dotprod(vn[~bad], vn[~bad], met[~bad])
