@@ -18,8 +18,11 @@ src = open(os.path.join(root, "oracle", "gen_golden.py")).read()
 src, k = re.subn(r"^(    n = )(\d+)$", lambda m: m.group(1) + str(int(m.group(2)) * scale), src, flags=re.M)
 src, k2 = re.subn(r"for _ in range\(110\):", "for _ in range(%d):" % (110 * min(scale, 20)), src)
 assert k >= 5 and k2 == 1, (k, k2)
-src = src.replace("np.random.default_rng(20261003)", "np.random.default_rng(%d)" % (20261003 + seed))
-src = src.replace("np.random.default_rng(20261004)", "np.random.default_rng(%d)" % (20261004 + seed))
+src, k3 = re.subn(r"for _ in range\(300\)\]", "for _ in range(%d)]" % (300 * min(scale, 50)), src)        # arguments per azimuth integral
+src, k4 = re.subn(r"for _ in range\(160\):", "for _ in range(%d):" % (160 * min(scale, 20)), src)       # rays per (spin, inclination), azimuth / time delay
+src, k5 = re.subn(r"for j in range\(8\):", "for j in range(%d):" % (8 * min(scale, 4)), src)             # rays of the raytrace() step sequences
+assert k3 == 1 and k4 == 1 and k5 == 1, (k3, k4, k5)
+src = re.sub(r"np\.random\.default_rng\((\d+)\)", lambda m: "np.random.default_rng(%d)" % (int(m.group(1)) + seed), src)
 mod = types.ModuleType("gen_golden_campaign")
 mod.__file__ = os.path.join(root, "oracle", "gen_golden.py")
 sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
@@ -37,11 +40,17 @@ try:
     mod.kat_kerr(ref, rng)
     mod.kat_polar(ref, rng)
     mod.kat_vectors(ref)
+    mod.kat_azimuth(ref)
+    mod.kat_boundary()
+    mod.kat_kerr_newman()
+    mod.kat_raytrace(ref, rng)
 finally:
     os.dup2(saved, 2)
 env = dict(os.environ, SIM5_GOLDEN_DIR=out)
 tests = ["tests/test_gpu_kat.py::test_elliptic", "tests/test_gpu_kat.py::test_geodesic_init_inf_records", "tests/test_gpu_kat.py::test_kerr",
-         "tests/test_gpu_kat.py::test_vectors", "tests/test_gpu_kat.py::test_polarization_and_blackbody", "tests/test_gpu_kat.py::test_geodesic_chain_records_both_arithmetics"]
+         "tests/test_gpu_kat.py::test_vectors", "tests/test_gpu_kat.py::test_polarization_and_blackbody", "tests/test_gpu_kat.py::test_geodesic_chain_records_both_arithmetics",
+         "tests/test_gpu_kat.py::test_azimuth_integrals", "tests/test_gpu_kat.py::test_position_azm_and_timedelay", "tests/test_gpu_kat.py::test_boundary_prototypes",
+         "tests/test_gpu_kat.py::test_kerr_newman_prototypes", "tests/test_gpu_raytrace.py::test_prepare_and_single_step", "tests/test_gpu_raytrace.py::test_step_sequences_follow_reference"]
 rc = subprocess.call([sys.executable, "-m", "pytest", "-q", "-s"] + tests, cwd=root, env=env)
 shutil.rmtree(out, ignore_errors=True)
 print("fuzz_kat: scale %d seed %d: pytest rc %d" % (scale, seed, rc))
