@@ -44,13 +44,17 @@ try:
     mod.kat_boundary()
     mod.kat_kerr_newman()
     mod.kat_raytrace(ref, rng)
+    mod.kat_init_src()
+    mod.kat_disk_edge()
+    mod.kat_disk_model()
 finally:
     os.dup2(saved, 2)
 env = dict(os.environ, SIM5_GOLDEN_DIR=out)
 tests = ["tests/test_gpu_kat.py::test_elliptic", "tests/test_gpu_kat.py::test_geodesic_init_inf_records", "tests/test_gpu_kat.py::test_kerr",
          "tests/test_gpu_kat.py::test_vectors", "tests/test_gpu_kat.py::test_polarization_and_blackbody", "tests/test_gpu_kat.py::test_geodesic_chain_records_both_arithmetics",
          "tests/test_gpu_kat.py::test_azimuth_integrals", "tests/test_gpu_kat.py::test_position_azm_and_timedelay", "tests/test_gpu_kat.py::test_boundary_prototypes",
-         "tests/test_gpu_kat.py::test_kerr_newman_prototypes", "tests/test_gpu_raytrace.py::test_prepare_and_single_step", "tests/test_gpu_raytrace.py::test_step_sequences_follow_reference"]
+         "tests/test_gpu_kat.py::test_kerr_newman_prototypes", "tests/test_gpu_kat.py::test_geodesic_init_src_records", "tests/test_gpu_kat.py::test_disk_flux_inner_edge_band", "tests/test_gpu_kat.py::test_disk_model_rest",
+         "tests/test_gpu_raytrace.py::test_prepare_and_single_step", "tests/test_gpu_raytrace.py::test_step_sequences_follow_reference"]
 rc = subprocess.call([sys.executable, "-m", "pytest", "-q", "-s"] + tests, cwd=root, env=env)
 shutil.rmtree(out, ignore_errors=True)
 print("fuzz_kat: scale %d seed %d: pytest rc %d" % (scale, seed, rc))
