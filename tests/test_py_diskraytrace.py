@@ -44,6 +44,15 @@ def test_host_logic_with_oracle_backend(golden, monkeypatch):
     check_against_golden(drt, golden("py_diskraytrace.npz"), rtol=1e-12)
 
 
+def test_host_logic_with_oracle_backend_over_spins_sizes_and_fields(golden, monkeypatch):
+    """The same over 30 more jobs of the reference's class (oracle/gen_golden_thin.py: spins 0 .. 0.998, inclinations 5 .. 86
+    degrees, image sizes 10 .. 22 -- odd ones included --, fields of view r_ms + 8 / 20 / 50)."""
+    import oracle_capi
+    import sim5_amd.diskraytrace as drt
+    monkeypatch.setattr(drt, "_c", oracle_capi)
+    check_against_golden(drt, golden("py_thin_more.npz"), rtol=1e-12)
+
+
 def test_sim5lib_module_has_the_swig_names():
     import sim5_amd.sim5lib as s
     need = """r_ms r_bh disk_nt_setup disk_nt_r_min disk_nt_flux disk_nt_ell geodesic intp doublep doubleArray
@@ -58,6 +67,7 @@ def test_sim5lib_module_has_the_swig_names():
 def test_batched_diskraytrace_on_gpu(golden, capi):
     import sim5_amd.diskraytrace as drt
     check_against_golden(drt, golden("py_diskraytrace.npz"), rtol=1e-6)
+    check_against_golden(drt, golden("py_thin_more.npz"), rtol=1e-6)          # 30 more jobs: oracle/gen_golden_thin.py
 
 
 @pytest.mark.gpu
