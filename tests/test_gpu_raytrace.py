@@ -512,6 +512,49 @@ def test_workspaces_can_be_released(capi):
         assert np.array_equal(s1[k], s2[k], equal_nan=True)
 
 
+def _c4_rows_on_the_cpu(args):
+    n, rows, absorb0 = args
+    c = ((np.arange(n) + .5) / n - 0.5) * 2.0 * (ol.Oracle().r_ms(0.998) + 8.0)
+    o = gga.torus_rays(ol.ORACLE_SO, "orc_", 0.998, deg2rad(70.0), np.tile(c, len(rows)), np.repeat(c[rows], n), r0=100.0, absorb0=absorb0)
+    return rows[0], {k: o[k] for k in ("steps", "x_end", "k_end", "I", "tau")}
+
+
+def test_c4_every_ray_of_a_256_image(capi):
+    """The C4 job at 256 x 256 with EVERY ray held to the CPU checker's raytrace() loop (the 1024^2 job the same way:
+    tests/tools/c4_all_rays.py, profiles/r06_c4_all_rays.json -- the golden sample of test_c4_full_size is every 16th pixel and
+    never sees the two columns next to the image's vertical axis).  What holds: call counts identical on every ray in both
+    variants; the strict variant within 1e-6 on every ray; the fast variant within 1e-6 on every ray EXCEPT a handful in the two
+    columns next to alpha = 0 (|alpha| = half a pixel: the ray passes the polar axis at ~1e-3 rad, where the reference's own
+    integration amplifies a last-bit difference a few hundred times and may then take the other side of one of its accept / fall-back
+    decisions); Stokes I within 1e-6 on every ray in both.  The smaller the pixel the closer such rays pass: at 1024^2 they are
+    ~300 of 1 048 576 in the fast variant (a few ending AT the pole, where phi and k^phi are singular: 0.14) and 12 in the strict one."""
+    from multiprocessing import Pool
+    import os
+    n = 256
+    blocks = [np.arange(r, min(r + 16, n)) for r in range(0, n, 16)]
+    with Pool(min(16, os.cpu_count() or 1)) as pool:
+        parts = dict(pool.map(_c4_rows_on_the_cpu, [(n, b, 0.0) for b in blocks]))
+    ref = {k: np.concatenate([parts[b[0]][k] for b in blocks]) for k in ("steps", "x_end", "k_end", "I", "tau")}
+    for strict in (True, False):
+        d = torus_desc(capi, n, 0.998, 70.0, r0=100.0)
+        if strict:
+            d.img.flags = 1
+        S, steps, xe, ce, me, ke = run_torus(capi, d, full=True)
+        assert np.array_equal(steps, ref["steps"]), int((steps != ref["steps"]).sum())
+        m = steps > 0
+        errs = ray_errors({"x_end": xe, "k_end": ke, "I": S[:, 0], "tau": S[:, 4]}, ref)
+        tot = np.max(np.stack([np.nan_to_num(v, nan=0.0) for v in errs.values()]), axis=0)
+        over = np.nonzero(m & (tot > REL))[0]
+        print("C4 256^2, every ray, %s: %d rays above 1e-6 (worst %.1e), columns %s; worst Stokes I %.1e" % (
+            "strict" if strict else "fast", over.size, float(tot[m].max()), sorted(set((over % n).tolist())), float(np.nan_to_num(errs["Stokes I"][m]).max())))
+        assert np.nan_to_num(errs["Stokes I"][m]).max() < REL
+        if strict:
+            assert over.size == 0, (over[:8], tot[over][:8])
+        else:
+            assert over.size <= 12 and all(abs((i % n) - (n - 1) / 2.0) <= 2.0 for i in over), [(int(i % n), int(i // n), float(tot[i])) for i in over[:12]]
+            assert tot[over].max() < 1e-4 if over.size else True
+
+
 def test_zz_exemption_record(capi):
     """Not a comparison: writes what the comparisons above recorded -- per set the rays held to 1e-6 and how many of them used
     the ill-conditioned-ray exemption of compare_rays -- to gpurun_out/torus_exemptions.json (committed under profiles/), and

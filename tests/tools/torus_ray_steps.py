@@ -9,9 +9,14 @@ from gpuutil import deg2rad
 import oraclelib as ol
 import gen_golden_access as gga
 import test_gpu_raytrace as T
-seed, want, ray = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+if sys.argv[1] == "c4":            # the C4 job (a = 0.998, i = 70 deg, r0 = 100, torus (8, 2)):  c4 <n> <ray = iy * n + ix> [fast|strict] [m,m,...]
+    sys.argv[1:3] = ["0", "-1"] + [sys.argv[3]] if False else sys.argv[1:3]
+C4 = sys.argv[1] == "c4"
+seed, want, ray = (0, -1, int(sys.argv[3])) if C4 else (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
 strict = len(sys.argv) > 4 and sys.argv[4] == "strict"
 rng = np.random.default_rng(seed)
+if C4:
+    a, inc, n, r0, prec, absorb0, tr, tw = 0.998, 70.0, int(sys.argv[2]), 100.0, 1.0, 0.0, 8.0, 2.0
 for case in range(want + 1):
     a = float(rng.choice([0.1, 0.3, 0.9, 0.998, rng.uniform(0.01, 0.99)]))
     inc = float(rng.uniform(10.0, 85.0))
